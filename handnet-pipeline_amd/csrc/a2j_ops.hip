@@ -1,0 +1,163 @@
+// HBM-bound helpers of the A2J / ResNet path: 3x3/2 max pooling, depth -> NHWC packing
+// and the softmax-weighted anchor aggregation (a2j/anchor.py:57-82).
+#include "hn_common.h"
+
+#include <float.h>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// one thread = one output pixel x 4 channels; consecutive threads walk channels first,
+// so a wave reads/writes contiguous 16-B pieces (coalesced NHWC).
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           int n, int h, int w, int c4, int oh, int ow) {
+  const long total = (long)n * oh * ow * c4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c4);
+    long pix = i / c4;
+    const int x_ = (int)(pix % ow);
+    pix /= ow;
+    const int y_ = (int)(pix % oh);
+    const int img = (int)(pix / oh);
+    f32x4 m = {-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int iy = y_ * 2 - 1 + dy;
+      if ((unsigned)iy >= (unsigned)h) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int ix = x_ * 2 - 1 + dx;
+        if ((unsigned)ix >= (unsigned)w) continue;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((long)img * h + iy) * w + ix) * c4 * 4 + cc * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+      }
+    }
+    *reinterpret_cast<f32x4*>(y + i * 4) = m;
+  }
+}
+
+__global__ __launch_bounds__(256) void pack_depth_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                         long npix, int c4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix * c4; i += (long)gridDim.x * blockDim.x) {
+    const long pix = i / c4;
+    const int cc = (int)(i - pix * c4);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (cc == 0) v[0] = src[pix];
+    *reinterpret_cast<f32x4*>(dst + i * 4) = v;
+  }
+}
+
+// One workgroup per crop; thread c = a*J + j owns one (anchor-in-cell, joint) channel
+// and walks the fh*fw cells, so every cell read is one contiguous A*J-float run.
+// Pass 1: per-joint max of the logits (exact, order independent).
+// Pass 2: e = exp(x - max); running sums of e, e*(anchor+offset), e*depth.
+// The 16 per-anchor partials of a joint are then combined in fixed order through LDS.
+constexpr int kAnchorsPerCell = 16;
+
+__global__ __launch_bounds__(1024) void a2j_aggregate_kernel(const float* __restrict__ cls,
+                                                             const float* __restrict__ reg,
+                                                             const float* __restrict__ dep,
+                                                             const int* __restrict__ valid, int fh, int fw,
+                                                             int J, int stride, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [4][A*J]
+  const int k = blockIdx.x;
+  const int AJ = kAnchorsPerCell * J;
+  const int c = threadIdx.x;
+  const bool active = c < AJ;
+  const int a = active ? c / J : 0, j = active ? c - a * J : 0;
+  if (valid && valid[k] == 0) {  // uniform per workgroup
+    if (c < J * 3) out[(long)k * J * 3 + c] = 0.f;
+    return;
+  }
+  const int cells = fh * fw;
+  const float* clsk = cls + (long)k * cells * AJ;
+  const float* depk = dep + (long)k * cells * AJ;
+  const float* regk = reg + (long)k * cells * AJ * 2;
+
+  float mx = -FLT_MAX;
+  if (active)
+    for (int p = 0; p < cells; ++p) mx = fmaxf(mx, clsk[(long)p * AJ + c]);
+  if (active) lds[c] = mx;
+  __syncthreads();
+  float mj = -FLT_MAX;
+  if (active)
+    for (int aa = 0; aa < kAnchorsPerCell; ++aa) mj = fmaxf(mj, lds[aa * J + j]);
+  __syncthreads();
+
+  float s = 0.f, s0 = 0.f, s1 = 0.f, sd = 0.f;
+  if (active) {
+    const float p0 = 2.f + 4.f * (float)(a >> 2), p1 = 2.f + 4.f * (float)(a & 3);
+    for (int hh = 0; hh < fh; ++hh) {
+      const float a0 = (float)(hh * stride) + p0;
+      for (int ww = 0; ww < fw; ++ww) {
+        const long p = (long)hh * fw + ww;
+        const float e = expf(clsk[p * AJ + c] - mj);
+        const float2 r = *reinterpret_cast<const float2*>(regk + (p * AJ + c) * 2);
+        const float a1 = (float)(ww * stride) + p1;
+        s += e;
+        s0 += e * (a0 + r.x);
+        s1 += e * (a1 + r.y);
+        sd += e * depk[p * AJ + c];
+      }
+    }
+    lds[c] = s;
+    lds[AJ + c] = s0;
+    lds[2 * AJ + c] = s1;
+    lds[3 * AJ + c] = sd;
+  }
+  __syncthreads();
+  if (c < J) {
+    float t = 0.f, t0 = 0.f, t1 = 0.f, td = 0.f;
+    for (int aa = 0; aa < kAnchorsPerCell; ++aa) {
+      t += lds[aa * J + c];
+      t0 += lds[AJ + aa * J + c];
+      t1 += lds[2 * AJ + aa * J + c];
+      td += lds[3 * AJ + aa * J + c];
+    }
+    float* o = out + ((long)k * J + c) * 3;
+    o[0] = t0 / t;
+    o[1] = t1 / t;
+    o[2] = td / t;
+  }
+}
+
+}  // namespace
+
+extern "C" int hn_maxpool3x3s2_nhwc_f32(const float* x, float* y, int n, int h, int w, int c, int oh, int ow,
+                                        void* stream) {
+  HN_CHECK_ARG(x && y, "hn_maxpool3x3s2_nhwc_f32: null pointer");
+  HN_CHECK_ARG(n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "bad dims (c must be a multiple of 4)");
+  HN_CHECK_ARG(oh == (h + 2 - 3) / 2 + 1 && ow == (w + 2 - 3) / 2 + 1, "output size mismatch");
+  const long total = (long)n * oh * ow * (c / 4);
+  const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, n, h, w, c / 4, oh, ow);
+  HN_CHECK_LAUNCH("maxpool3x3s2_kernel");
+  return HN_OK;
+}
+
+extern "C" int hn_pack_depth_nhwc(const float* src, float* dst, int n, int hw, int cpad, void* stream) {
+  HN_CHECK_ARG(src && dst, "hn_pack_depth_nhwc: null pointer");
+  HN_CHECK_ARG(n > 0 && hw > 0 && cpad >= 4 && cpad % 4 == 0, "bad dims");
+  const long npix = (long)n * hw;
+  const long total = npix * (cpad / 4);
+  const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(pack_depth_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, dst, npix, cpad / 4);
+  HN_CHECK_LAUNCH("pack_depth_kernel");
+  return HN_OK;
+}
+
+extern "C" int hn_a2j_aggregate_f32(const float* cls, const float* reg, const float* dep, const int32_t* valid,
+                                    int k, int fh, int fw, int joints, int stride, float* out, void* stream) {
+  HN_CHECK_ARG(cls && reg && dep && out, "hn_a2j_aggregate_f32: null pointer");
+  HN_CHECK_ARG(k >= 0 && fh > 0 && fw > 0 && stride > 0, "bad dims");
+  HN_CHECK_ARG(joints > 0 && joints * kAnchorsPerCell <= 1024, "joints must be in [1, 64]");
+  if (k == 0) return HN_OK;
+  const int aj = kAnchorsPerCell * joints;
+  const int threads = ((aj + 63) / 64) * 64;
+  hipLaunchKernelGGL(a2j_aggregate_kernel, dim3(k), dim3(threads), 4 * aj * sizeof(float), (hipStream_t)stream,
+                     cls, reg, dep, valid, fh, fw, joints, stride, out);
+  HN_CHECK_LAUNCH("a2j_aggregate_kernel");
+  return HN_OK;
+}

@@ -1,0 +1,542 @@
+// FCOS pre/post-processing and the HandNet crop stage (all HBM/latency-bound, integer or
+// order-sensitive fp32 work -- built with -ffp-contract=off so every multiply and add
+// rounds separately, exactly like the reference's chain of torch ops).
+//
+//   hn_fcos_preprocess_f32 : torchvision GeneralizedRCNNTransform (fcos_utils/fcos.py:709)
+//   hn_fcos_candidates     : fcos_utils/fcos.py:591-628 + det_utils.py:266-294 +
+//                            anchor_utils.py:82-132 (anchors are generated in-kernel)
+//   hn_fcos_nms / hn_nms   : torchvision.ops.batched_nms / nms (call site fcos.py:635),
+//                            resize_boxes (fcos.py:770-783)
+//   hn_crop_resize         : handnet_pipeline/handnet_pipeline.py:74-105
+#include "hn_common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------
+// preprocess: normalize -> bilinear (align_corners=False, scale = in/out) -> zero pad
+// ---------------------------------------------------------------------------------------
+struct Norm3 {
+  float mean[3], stdv[3];
+};
+
+__device__ __forceinline__ void src_index(float scale, int dst, int in_size, int& i0, int& i1, float& l0, float& l1) {
+  float real = scale * ((float)dst + 0.5f) - 0.5f;
+  if (real < 0.f) real = 0.f;
+  i0 = min((int)floorf(real), in_size - 1);
+  l1 = fminf(fmaxf(real - (float)i0, 0.f), 1.f);
+  i1 = min(i0 + 1, in_size - 1);
+  l0 = 1.f - l1;
+}
+
+__global__ __launch_bounds__(256) void fcos_preprocess_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                              int n, int h, int w, int oh, int ow, int ph, int pw,
+                                                              float scale_h, float scale_w, Norm3 nm) {
+  const long total = (long)n * ph * pw;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % pw);
+    const long t = i / pw;
+    const int oy = (int)(t % ph);
+    const int img = (int)(t / ph);
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    if (oy < oh && ox < ow) {
+      int y0, y1, x0, x1;
+      float wy0, wy1, wx0, wx1;
+      src_index(scale_h, oy, h, y0, y1, wy0, wy1);
+      src_index(scale_w, ox, w, x0, x1, wx0, wx1);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float* pl = src + ((long)img * 3 + c) * h * w;
+        const float m = nm.mean[c], s = nm.stdv[c];
+        const float v00 = (pl[(long)y0 * w + x0] - m) / s, v01 = (pl[(long)y0 * w + x1] - m) / s;
+        const float v10 = (pl[(long)y1 * w + x0] - m) / s, v11 = (pl[(long)y1 * w + x1] - m) / s;
+        const float r0 = v00 * wx0 + v01 * wx1;
+        const float r1 = v10 * wx0 + v11 * wx1;
+        o[c] = r0 * wy0 + r1 * wy1;
+      }
+    }
+    *reinterpret_cast<f32x4*>(dst + i * 4) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// candidates: score / argmax / threshold / decode / ordered compaction
+// ---------------------------------------------------------------------------------------
+struct LevelTable {
+  int num_levels;
+  int h[HN_FCOS_MAX_LEVELS], w[HN_FCOS_MAX_LEVELS], stride[HN_FCOS_MAX_LEVELS];
+  int start[HN_FCOS_MAX_LEVELS + 1];  // first point index of each level
+  const float* cls_lr[HN_FCOS_MAX_LEVELS];
+  const float* reg_ctr[HN_FCOS_MAX_LEVELS];
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ __launch_bounds__(1024) void fcos_candidates_kernel(const LevelTable lt, int num_classes, float thresh,
+                                                               float* __restrict__ cand_boxes,
+                                                               float* __restrict__ cand_scores,
+                                                               int* __restrict__ cand_labels,
+                                                               int* __restrict__ cand_sides,
+                                                               int* __restrict__ cand_level,
+                                                               int* __restrict__ cand_count, int cap) {
+  __shared__ int wave_counts[16];
+  __shared__ int base_s;
+  const int img = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int P = lt.start[lt.num_levels];
+  const int cw = num_classes + 2;
+  if (tid == 0) base_s = 0;
+  __syncthreads();
+  for (int start = 0; start < P; start += blockDim.x) {
+    const int i = start + tid;
+    bool pass = false;
+    float score = 0.f, bx0 = 0.f, by0 = 0.f, bx1 = 0.f, by1 = 0.f;
+    int label = 0, side = 0, lvl = 0;
+    if (i < P) {
+      while (lvl + 1 < lt.num_levels && i >= lt.start[lvl + 1]) ++lvl;
+      const int q = i - lt.start[lvl];
+      const int hw = lt.h[lvl] * lt.w[lvl];
+      const float* pc = lt.cls_lr[lvl] + ((long)img * hw + q) * cw;
+      const float* pr = lt.reg_ctr[lvl] + ((long)img * hw + q) * 5;
+      const float sctr = sigmoidf_(pr[4]);
+      float best = -1.f;
+      for (int c = 0; c < num_classes; ++c) {
+        const float sc = sqrtf(sigmoidf_(pc[c]) * sctr);
+        if (sc > best) {  // ties keep the lowest class index (torch.max)
+          best = sc;
+          label = c;
+        }
+      }
+      score = best;
+      pass = score > thresh;
+      if (pass) {
+        const float s0 = sigmoidf_(pc[num_classes]), s1 = sigmoidf_(pc[num_classes + 1]);
+        side = s1 > s0 ? 1 : 0;
+        const int gy = q / lt.w[lvl], gx = q - gy * lt.w[lvl];
+        const float st = (float)lt.stride[lvl];
+        const float half = rintf(st * 0.5f);  // base anchor [-s/2, -s/2, s/2, s/2].round()
+        const float ax0 = (float)(gx * lt.stride[lvl]) - half, ay0 = (float)(gy * lt.stride[lvl]) - half;
+        const float ax1 = (float)(gx * lt.stride[lvl]) + half, ay1 = (float)(gy * lt.stride[lvl]) + half;
+        const float cx = 0.5f * (ax0 + ax1), cy = 0.5f * (ay0 + ay1);
+        const float bw = ax1 - ax0, bh = ay1 - ay0;
+        bx0 = cx - pr[0] * bw;
+        by0 = cy - pr[1] * bh;
+        bx1 = cx + pr[2] * bw;
+        by1 = cy + pr[3] * bh;
+      }
+    }
+    const unsigned long long bal = __ballot(pass);
+    const int lane_prefix = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_counts[wave] = __popcll(bal);
+    __syncthreads();
+    int wave_off = 0, total = 0;
+    const int nw = blockDim.x >> 6;
+    for (int k = 0; k < nw; ++k) {
+      if (k < wave) wave_off += wave_counts[k];
+      total += wave_counts[k];
+    }
+    const int base = base_s;
+    if (pass) {
+      const int pos = base + wave_off + lane_prefix;
+      if (pos < cap) {
+        const long o = (long)img * cap + pos;
+        cand_boxes[o * 4 + 0] = bx0;
+        cand_boxes[o * 4 + 1] = by0;
+        cand_boxes[o * 4 + 2] = bx1;
+        cand_boxes[o * 4 + 3] = by1;
+        cand_scores[o] = score;
+        cand_labels[o] = label;
+        cand_sides[o] = side;
+        cand_level[o] = lvl;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) base_s = base + total;
+    __syncthreads();
+  }
+  if (tid == 0) cand_count[img] = min(base_s, cap);
+}
+
+// ---------------------------------------------------------------------------------------
+// NMS
+// ---------------------------------------------------------------------------------------
+constexpr int kSortLds = 2048;  // keys sorted in LDS up to this many (padded) entries
+constexpr int kKeptRec = 6;     // x1 y1 x2 y2 area label(as float bits)
+
+__host__ __device__ inline int pow2_at_least(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+__device__ __forceinline__ unsigned long long make_key(float score, int idx) {
+  unsigned u = __float_as_uint(score);
+  u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;  // ascending-sortable
+  u = ~u;                                       // descending score
+  return ((unsigned long long)u << 32) | (unsigned)idx;
+}
+
+struct NmsArgs {
+  const float* boxes;    // [n][cap][4]
+  const float* scores;   // [n][cap]
+  const int* labels;     // [n][cap] or null (plain nms)
+  const int* sides;      // or null
+  const int* level;      // or null
+  const int* count;      // [n] or null (then k_fixed)
+  int k_fixed;
+  int cap;
+  float thr;
+  float ratio_h, ratio_w;
+  int rescale;           // multiply output boxes by the ratios
+  char* scratch;
+  long scratch_stride;   // bytes per image
+  int pad_cap;           // pow2 >= cap
+  float* det_boxes;
+  float* det_scores;
+  int* det_labels;
+  int* det_sides;
+  int* det_level;
+  int* det_keep;
+  int* det_count;
+};
+
+__device__ __forceinline__ bool iou_gt(float ax1, float ay1, float ax2, float ay2, float aarea, float bx1, float by1,
+                                       float bx2, float by2, float barea, double thr) {
+  const float xx1 = fmaxf(ax1, bx1), yy1 = fmaxf(ay1, by1);
+  const float xx2 = fminf(ax2, bx2), yy2 = fminf(ay2, by2);
+  const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
+  const float inter = w * h;
+  const float ovr = inter / (aarea + barea - inter);
+  return (double)ovr > thr;  // torchvision CPU kernel compares the fp32 IoU with a double threshold
+}
+
+__global__ __launch_bounds__(1024) void nms_kernel(const NmsArgs a) {
+  __shared__ unsigned long long keys_lds[kSortLds];
+  __shared__ float red[16];
+  __shared__ float maxc_s;
+  const int img = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = a.count ? min(a.count[img], a.cap) : a.k_fixed;
+  const float* boxes = a.boxes + (long)img * a.cap * 4;
+  const float* scores = a.scores + (long)img * a.cap;
+  const int* labels = a.labels ? a.labels + (long)img * a.cap : nullptr;
+  if (K <= 0) {
+    if (tid == 0 && a.det_count) a.det_count[img] = 0;
+    return;
+  }
+  char* scr = a.scratch + (long)img * a.scratch_stride;
+  unsigned long long* keys_g = reinterpret_cast<unsigned long long*>(scr);
+  float* kept = reinterpret_cast<float*>(scr + (long)a.pad_cap * 8);
+  const int npad = pow2_at_least(K);
+  unsigned long long* keys = npad <= kSortLds ? keys_lds : keys_g;
+
+  // keys + max coordinate (torchvision's coordinate trick needs boxes.max())
+  float mx = -3.402823466e38f;
+  for (int i = tid; i < npad; i += blockDim.x) {
+    keys[i] = i < K ? make_key(scores[i], i) : ~0ull;
+    if (i < K) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(boxes + (long)i * 4);
+      mx = fmaxf(fmaxf(fmaxf(mx, b[0]), fmaxf(b[1], b[2])), b[3]);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  if (tid == 0) {
+    float m = red[0];
+    for (int k = 1; k < (int)(blockDim.x >> 6); ++k) m = fmaxf(m, red[k]);
+    maxc_s = m;
+  }
+  // bitonic sort (ascending keys = descending score, ties by ascending index)
+  for (int k = 2; k <= npad; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      __syncthreads();
+      for (int i = tid; i < npad; i += blockDim.x) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long x = keys[i], y = keys[ixj];
+          const bool up = (i & k) == 0;
+          if ((x > y) == up) {
+            keys[i] = y;
+            keys[ixj] = x;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (wave != 0) return;  // the greedy pass is one wavefront; it uses no workgroup barrier below
+
+  // batched_nms: coordinate trick iff boxes.numel() <= 4000, else per-class on raw boxes
+  const bool classwise = labels != nullptr;
+  const bool trick = classwise && (4 * K <= 4000);
+  const float offs_unit = maxc_s + 1.0f;
+  const double thr = (double)a.thr;
+  int nk = 0;
+  for (int t0 = 0; t0 < K; t0 += 64) {
+    const int t = t0 + lane;
+    const bool has = t < K;
+    const int idx = has ? (int)(unsigned)(keys[t] & 0xFFFFFFFFull) : 0;
+    f32x4 raw = {0.f, 0.f, 0.f, 0.f};
+    int lab = 0;
+    if (has) {
+      raw = *reinterpret_cast<const f32x4*>(boxes + (long)idx * 4);
+      lab = labels ? labels[idx] : 0;
+    }
+    float x1 = raw[0], y1 = raw[1], x2 = raw[2], y2 = raw[3];
+    if (trick) {
+      const float off = (float)lab * offs_unit;
+      x1 = x1 + off;
+      y1 = y1 + off;
+      x2 = x2 + off;
+      y2 = y2 + off;
+    }
+    const float area = (x2 - x1) * (y2 - y1);
+    bool alive = has;
+    // against the boxes kept so far (wave-uniform reads of the kept list)
+    for (int q = 0; q < nk; ++q) {
+      const float* kr = kept + (long)q * kKeptRec;
+      const float kx1 = kr[0], ky1 = kr[1], kx2 = kr[2], ky2 = kr[3], ka = kr[4];
+      const int kl = __float_as_int(kr[5]);
+      if (alive && (trick || !classwise || kl == lab) && iou_gt(kx1, ky1, kx2, ky2, ka, x1, y1, x2, y2, area, thr))
+        alive = false;
+    }
+    // inside the tile: mask of later lanes this lane would suppress
+    unsigned long long mask = 0ull;
+    for (int j = 0; j < 64; ++j) {
+      const float jx1 = __shfl(x1, j), jy1 = __shfl(y1, j), jx2 = __shfl(x2, j), jy2 = __shfl(y2, j);
+      const float ja = __shfl(area, j);
+      const int jl = __shfl(lab, j);
+      const bool jhas = (t0 + j) < K;
+      if (j > lane && jhas && (trick || !classwise || jl == lab) &&
+          iou_gt(x1, y1, x2, y2, area, jx1, jy1, jx2, jy2, ja, thr))
+        mask |= 1ull << j;
+    }
+    unsigned long long alive_bits = __ballot(alive);
+    for (int i = 0; i < 64; ++i) {
+      const unsigned long long mi = __shfl(mask, i);
+      if ((alive_bits >> i) & 1ull) alive_bits &= ~mi;
+    }
+    const bool keep = (alive_bits >> lane) & 1ull;
+    if (keep) {
+      const int pos = nk + __popcll(alive_bits & ((1ull << lane) - 1ull));
+      float* kr = kept + (long)pos * kKeptRec;
+      kr[0] = x1; kr[1] = y1; kr[2] = x2; kr[3] = y2; kr[4] = area; kr[5] = __int_as_float(lab);
+      const long o = (long)img * a.cap + pos;
+      if (a.det_boxes) {
+        float ox1 = raw[0], oy1 = raw[1], ox2 = raw[2], oy2 = raw[3];
+        if (a.rescale) {
+          ox1 = ox1 * a.ratio_w; ox2 = ox2 * a.ratio_w;
+          oy1 = oy1 * a.ratio_h; oy2 = oy2 * a.ratio_h;
+        }
+        a.det_boxes[o * 4 + 0] = ox1; a.det_boxes[o * 4 + 1] = oy1;
+        a.det_boxes[o * 4 + 2] = ox2; a.det_boxes[o * 4 + 3] = oy2;
+      }
+      if (a.det_scores) a.det_scores[o] = scores[idx];
+      if (a.det_labels) a.det_labels[o] = lab;
+      if (a.det_sides) a.det_sides[o] = a.sides[(long)img * a.cap + idx];
+      if (a.det_level) a.det_level[o] = a.level[(long)img * a.cap + idx];
+      if (a.det_keep) a.det_keep[o] = idx;
+    }
+    nk += __popcll(alive_bits);
+    __threadfence_block();  // kept[] written above is read by every lane in the next tile
+  }
+  if (lane == 0 && a.det_count) a.det_count[img] = nk;
+}
+
+// ---------------------------------------------------------------------------------------
+// crop: top-1 hand box -> padded int box; nearest gather to out x out
+// ---------------------------------------------------------------------------------------
+__global__ void crop_box_kernel(const float* __restrict__ det_boxes, const int* __restrict__ det_labels,
+                                const int* __restrict__ det_count, int cap, int hand_label, int n, int h, int w,
+                                long long* __restrict__ crop_box, int* __restrict__ has_hand) {
+  const int img = blockIdx.x * blockDim.x + threadIdx.x;
+  if (img >= n) return;
+  const int cnt = min(det_count[img], cap);
+  int found = -1;
+  for (int i = 0; i < cnt; ++i)
+    if (det_labels[(long)img * cap + i] == hand_label) {
+      found = i;
+      break;
+    }
+  long long b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+  int ok = 0;
+  if (found >= 0) {
+    const float* b = det_boxes + ((long)img * cap + found) * 4;
+    b0 = (long long)b[0]; b1 = (long long)b[1]; b2 = (long long)b[2]; b3 = (long long)b[3];  // trunc toward 0
+    const long long bw = b2 - b0, bh = b3 - b1;
+    // python: box[0] = max(0, box[0] - 0.4 * w) on 0-d tensors: fp32 arithmetic, trunc on store
+    const float pw = 0.4f * (float)bw, phh = 0.4f * (float)bh;
+    const float t0 = (float)b0 - pw, t1 = (float)b1 - phh;
+    const float t2 = (float)b2 + pw, t3 = (float)b3 + phh;
+    b0 = t0 > 0.f ? (long long)t0 : 0;
+    b1 = t1 > 0.f ? (long long)t1 : 0;
+    b2 = t2 < (float)w ? (long long)t2 : (long long)w;
+    b3 = t3 < (float)h ? (long long)t3 : (long long)h;
+    // slice [b1 : b3+1, b0 : b2+1] clamped to the image must be non-empty
+    const long long ch = (b3 + 1 < h ? b3 + 1 : h) - b1, cwid = (b2 + 1 < w ? b2 + 1 : w) - b0;
+    ok = (ch > 0 && cwid > 0 && b1 >= 0 && b0 >= 0) ? 1 : 0;
+  }
+  if (!ok) b0 = b1 = b2 = b3 = 0;
+  crop_box[(long)img * 4 + 0] = b0;
+  crop_box[(long)img * 4 + 1] = b1;
+  crop_box[(long)img * 4 + 2] = b2;
+  crop_box[(long)img * 4 + 3] = b3;
+  has_hand[img] = ok;
+}
+
+__global__ __launch_bounds__(256) void crop_gather_kernel(const float* __restrict__ depth,
+                                                          const long long* __restrict__ crop_box,
+                                                          const int* __restrict__ has_hand, int n, int h, int w,
+                                                          int out, int c4, float* __restrict__ crops) {
+  const long total = (long)n * out * out;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % out);
+    const long t = i / out;
+    const int oy = (int)(t % out);
+    const int img = (int)(t / out);
+    float v = 0.f;
+    if (has_hand[img]) {
+      const long long* b = crop_box + (long)img * 4;
+      const int x1 = (int)b[0], y1 = (int)b[1];
+      const int cw = (int)((b[2] + 1 < w ? b[2] + 1 : w) - b[0]);
+      const int ch = (int)((b[3] + 1 < h ? b[3] + 1 : h) - b[1]);
+      // F.interpolate(mode='nearest'): src = min(floor(dst * (float)in / out), in - 1)
+      int sy, sx;
+      if (ch == out) sy = oy; else if (out == 2 * ch) sy = oy >> 1;
+      else sy = min((int)floorf((float)oy * ((float)ch / (float)out)), ch - 1);
+      if (cw == out) sx = ox; else if (out == 2 * cw) sx = ox >> 1;
+      else sx = min((int)floorf((float)ox * ((float)cw / (float)out)), cw - 1);
+      v = depth[((long)img * h + (y1 + sy)) * w + (x1 + sx)];
+    }
+    f32x4 o = {v, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(crops + i * c4 * 4) = o;
+    for (int q = 1; q < c4; ++q) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(crops + i * c4 * 4 + q * 4) = z;
+    }
+  }
+}
+
+int grid_for(long total, int block) {
+  const long g = (total + block - 1) / block;
+  return (int)(g < 8192 ? (g > 0 ? g : 1) : 8192);
+}
+
+long nms_scratch_stride(int cap) {
+  const long b = (long)pow2_at_least(cap) * 8 + (long)cap * kKeptRec * 4;
+  return (b + 255) / 256 * 256;
+}
+
+}  // namespace
+
+extern "C" int hn_fcos_preprocess_f32(const float* src, float* dst, int n, int h, int w, int oh, int ow, int ph,
+                                      int pw, const float mean[3], const float stdv[3], void* stream) {
+  HN_CHECK_ARG(src && dst && mean && stdv, "hn_fcos_preprocess_f32: null pointer");
+  HN_CHECK_ARG(n > 0 && h > 0 && w > 0 && oh > 0 && ow > 0 && ph >= oh && pw >= ow, "bad dims");
+  Norm3 nm;
+  for (int c = 0; c < 3; ++c) {
+    nm.mean[c] = mean[c];
+    nm.stdv[c] = stdv[c];
+  }
+  const float scale_h = (float)h / (float)oh, scale_w = (float)w / (float)ow;
+  const long total = (long)n * ph * pw;
+  hipLaunchKernelGGL(fcos_preprocess_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, src, dst,
+                     n, h, w, oh, ow, ph, pw, scale_h, scale_w, nm);
+  HN_CHECK_LAUNCH("fcos_preprocess_kernel");
+  return HN_OK;
+}
+
+extern "C" int hn_fcos_candidates(const hn_fcos_levels* lv, int n, int num_classes, float score_thresh,
+                                  float* cand_boxes, float* cand_scores, int32_t* cand_labels, int32_t* cand_sides,
+                                  int32_t* cand_level, int32_t* cand_count, int cap, void* stream) {
+  HN_CHECK_ARG(lv && cand_boxes && cand_scores && cand_labels && cand_sides && cand_level && cand_count,
+               "hn_fcos_candidates: null pointer");
+  HN_CHECK_ARG(lv->num_levels > 0 && lv->num_levels <= HN_FCOS_MAX_LEVELS, "bad level count");
+  HN_CHECK_ARG(n > 0 && num_classes > 0 && num_classes <= 64 && cap > 0, "bad dims");
+  LevelTable lt;
+  lt.num_levels = lv->num_levels;
+  lt.start[0] = 0;
+  for (int l = 0; l < lv->num_levels; ++l) {
+    HN_CHECK_ARG(lv->h[l] > 0 && lv->w[l] > 0 && lv->stride[l] > 0 && lv->cls_lr[l] && lv->reg_ctr[l], "bad level %d", l);
+    lt.h[l] = lv->h[l];
+    lt.w[l] = lv->w[l];
+    lt.stride[l] = lv->stride[l];
+    lt.cls_lr[l] = lv->cls_lr[l];
+    lt.reg_ctr[l] = lv->reg_ctr[l];
+    lt.start[l + 1] = lt.start[l] + lv->h[l] * lv->w[l];
+  }
+  for (int l = lv->num_levels; l < HN_FCOS_MAX_LEVELS; ++l) {
+    lt.h[l] = lt.w[l] = lt.stride[l] = 0;
+    lt.cls_lr[l] = lt.reg_ctr[l] = nullptr;
+    lt.start[l + 1] = lt.start[lv->num_levels];
+  }
+  hipLaunchKernelGGL(fcos_candidates_kernel, dim3(n), dim3(1024), 0, (hipStream_t)stream, lt, num_classes,
+                     score_thresh, cand_boxes, cand_scores, cand_labels, cand_sides, cand_level, cand_count, cap);
+  HN_CHECK_LAUNCH("fcos_candidates_kernel");
+  return HN_OK;
+}
+
+extern "C" int64_t hn_fcos_nms_scratch_bytes(int n, int cap) {
+  if (n <= 0 || cap <= 0) return 0;
+  return (int64_t)n * nms_scratch_stride(cap);
+}
+
+extern "C" int hn_fcos_nms(const float* cand_boxes, const float* cand_scores, const int32_t* cand_labels,
+                           const int32_t* cand_sides, const int32_t* cand_level, const int32_t* cand_count, int n,
+                           int cap, float iou_thresh, float ratio_h, float ratio_w, void* scratch, float* det_boxes,
+                           float* det_scores, int32_t* det_labels, int32_t* det_sides, int32_t* det_level,
+                           int32_t* det_keep, int32_t* det_count, void* stream) {
+  HN_CHECK_ARG(cand_boxes && cand_scores && cand_labels && cand_sides && cand_level && cand_count && scratch,
+               "hn_fcos_nms: null input");
+  HN_CHECK_ARG(det_boxes && det_scores && det_labels && det_sides && det_level && det_count, "hn_fcos_nms: null output");
+  HN_CHECK_ARG(n > 0 && cap > 0 && cap <= (1 << 24), "bad dims");
+  NmsArgs a;
+  a.boxes = cand_boxes; a.scores = cand_scores; a.labels = cand_labels; a.sides = cand_sides; a.level = cand_level;
+  a.count = cand_count; a.k_fixed = 0; a.cap = cap; a.thr = iou_thresh; a.ratio_h = ratio_h; a.ratio_w = ratio_w;
+  a.rescale = 1; a.scratch = (char*)scratch; a.scratch_stride = nms_scratch_stride(cap); a.pad_cap = pow2_at_least(cap);
+  a.det_boxes = det_boxes; a.det_scores = det_scores; a.det_labels = det_labels; a.det_sides = det_sides;
+  a.det_level = det_level; a.det_keep = det_keep; a.det_count = det_count;
+  hipLaunchKernelGGL(nms_kernel, dim3(n), dim3(1024), 0, (hipStream_t)stream, a);
+  HN_CHECK_LAUNCH("nms_kernel");
+  return HN_OK;
+}
+
+extern "C" int hn_nms(const float* boxes, const float* scores, int k, float iou_thresh, void* scratch, int32_t* keep,
+                      int32_t* num_keep, void* stream) {
+  HN_CHECK_ARG(boxes && scores && scratch && keep && num_keep, "hn_nms: null pointer");
+  HN_CHECK_ARG(k >= 0 && k <= (1 << 24), "bad k");
+  if (k == 0) {
+    HN_CHECK_HIP(hipMemsetAsync(num_keep, 0, sizeof(int32_t), (hipStream_t)stream));
+    return HN_OK;
+  }
+  NmsArgs a;
+  a.boxes = boxes; a.scores = scores; a.labels = nullptr; a.sides = nullptr; a.level = nullptr; a.count = nullptr;
+  a.k_fixed = k; a.cap = k; a.thr = iou_thresh; a.ratio_h = a.ratio_w = 1.f; a.rescale = 0;
+  a.scratch = (char*)scratch; a.scratch_stride = nms_scratch_stride(k); a.pad_cap = pow2_at_least(k);
+  a.det_boxes = nullptr; a.det_scores = nullptr; a.det_labels = nullptr; a.det_sides = nullptr; a.det_level = nullptr;
+  a.det_keep = keep; a.det_count = num_keep;
+  hipLaunchKernelGGL(nms_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+  HN_CHECK_LAUNCH("nms_kernel");
+  return HN_OK;
+}
+
+extern "C" int hn_crop_resize(const float* det_boxes, const int32_t* det_labels, const int32_t* det_count, int cap,
+                              int hand_label, const float* depth, int n, int h, int w, int out, int cpad,
+                              int64_t* crop_box, int32_t* has_hand, float* crops, void* stream) {
+  HN_CHECK_ARG(det_boxes && det_labels && det_count && depth && crop_box && has_hand && crops,
+               "hn_crop_resize: null pointer");
+  HN_CHECK_ARG(n > 0 && h > 0 && w > 0 && out > 0 && cap > 0 && cpad >= 4 && cpad % 4 == 0, "bad dims");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(crop_box_kernel, dim3((n + 63) / 64), dim3(64), 0, st, det_boxes, det_labels, det_count, cap,
+                     hand_label, n, h, w, (long long*)crop_box, has_hand);
+  HN_CHECK_LAUNCH("crop_box_kernel");
+  const long total = (long)n * out * out;
+  hipLaunchKernelGGL(crop_gather_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, depth,
+                     (const long long*)crop_box, has_hand, n, h, w, out, cpad / 4, crops);
+  HN_CHECK_LAUNCH("crop_gather_kernel");
+  return HN_OK;
+}

@@ -1,0 +1,106 @@
+// GroupNorm statistics -> per-(image, channel) scale/shift tables.
+//
+// The FCOS towers are conv3x3 -> GroupNorm(32,256) -> ReLU (fcos_utils/fcos.py:232-239,
+// 352-359).  The statistics span a whole feature level, so they cannot be folded into
+// the conv; instead the NEXT conv applies relu(x*scale + shift) while it stages its
+// input (hn_conv_desc.in_affine).  This file computes the tables:
+//   pass 1  gn_partial : one workgroup per (64-pixel chunk, image): fp32 sum / sumsq per
+//                        group, written to a [n][chunks][G][2] slab (no atomics ->
+//                        bitwise reproducible)
+//   pass 2  gn_finalize: per (image, channel): combine the chunk partials in fp64 in
+//                        fixed order, mean / biased var / rstd, then
+//                        scale = gamma*rstd, shift = beta - mean*scale.
+#include "hn_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kRowsPerChunk = 64;
+
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, int hw, int c, int groups,
+                                                         int chunks, float* __restrict__ partial) {
+  __shared__ float lds[2 * 256];
+  const int chunk = blockIdx.x, img = blockIdx.y;
+  const int cols = c >> 2;            // float4 columns; 256 % cols == 0 (checked on host)
+  const int rows_par = 256 / cols;
+  const int col = threadIdx.x % cols, rl = threadIdx.x / cols;
+  const int r0 = chunk * kRowsPerChunk;
+  const int r1 = min(r0 + kRowsPerChunk, hw);
+  float s = 0.f, ss = 0.f;
+  for (int r = r0 + rl; r < r1; r += rows_par) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((long)img * hw + r) * c + col * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      s += v[e];
+      ss += v[e] * v[e];
+    }
+  }
+  lds[threadIdx.x] = s;
+  lds[256 + threadIdx.x] = ss;
+  __syncthreads();
+  const int cpg4 = (c / groups) >> 2;  // float4 columns per group
+  if ((int)threadIdx.x < groups) {
+    const int g = threadIdx.x;
+    float ts = 0.f, tss = 0.f;
+    for (int rr = 0; rr < rows_par; ++rr)
+      for (int q = 0; q < cpg4; ++q) {
+        ts += lds[rr * cols + g * cpg4 + q];
+        tss += lds[256 + rr * cols + g * cpg4 + q];
+      }
+    float* o = partial + (((long)img * chunks + chunk) * groups + g) * 2;
+    o[0] = ts;
+    o[1] = tss;
+  }
+}
+
+__global__ __launch_bounds__(1024) void gn_finalize_kernel(const float* __restrict__ partial,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int hw, int c,
+                                                           int groups, int chunks, float eps,
+                                                           float* __restrict__ scale, float* __restrict__ shift) {
+  const int img = blockIdx.x;
+  const int ch = threadIdx.x;
+  if (ch >= c) return;
+  const int cpg = c / groups;
+  const int g = ch / cpg;
+  double s = 0.0, ss = 0.0;
+  for (int k = 0; k < chunks; ++k) {
+    const float* pp = partial + (((long)img * chunks + k) * groups + g) * 2;
+    s += (double)pp[0];
+    ss += (double)pp[1];
+  }
+  const double cnt = (double)hw * cpg;
+  const double mean = s / cnt;
+  double var = ss / cnt - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[ch] * rstd;
+  scale[(long)img * c + ch] = sc;
+  shift[(long)img * c + ch] = beta[ch] - (float)mean * sc;
+}
+
+}  // namespace
+
+extern "C" int64_t hn_groupnorm_scratch_floats(int n, int hw, int c, int groups) {
+  (void)c;
+  return (int64_t)n * hn::cdiv(hw, kRowsPerChunk) * groups * 2;
+}
+
+extern "C" int hn_groupnorm_affine_f32(const float* x, const float* gamma, const float* beta, int n, int hw, int c,
+                                       int groups, float eps, float* partial, float* scale, float* shift,
+                                       void* stream) {
+  HN_CHECK_ARG(x && gamma && beta && partial && scale && shift, "hn_groupnorm_affine_f32: null pointer");
+  HN_CHECK_ARG(n > 0 && hw > 0 && c > 0 && groups > 0 && c % groups == 0, "bad dims");
+  HN_CHECK_ARG((c / groups) % 4 == 0, "channels per group (%d) must be a multiple of 4", c / groups);
+  HN_CHECK_ARG(c <= 1024 && 256 % (c / 4) == 0, "c/4 (%d) must divide 256", c / 4);
+  HN_CHECK_ARG(groups <= 256, "too many groups");
+  const int chunks = hn::cdiv(hw, kRowsPerChunk);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, n), dim3(256), 0, st, x, hw, c, groups, chunks, partial);
+  HN_CHECK_LAUNCH("gn_partial_kernel");
+  const int threads = ((c + 63) / 64) * 64;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n), dim3(threads), 0, st, partial, gamma, beta, hw, c, groups, chunks,
+                     eps, scale, shift);
+  HN_CHECK_LAUNCH("gn_finalize_kernel");
+  return HN_OK;
+}

@@ -1,0 +1,38 @@
+// Shared helpers for libhandnet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/handnet_hip.h"
+
+namespace hn {
+
+// thread-local error text returned by hn_last_error()
+char* err_buf();
+int fail(int code, const char* fmt, ...);
+
+#define HN_CHECK_ARG(cond, ...)                          \
+  do {                                                   \
+    if (!(cond)) return hn::fail(HN_ERR_ARG, __VA_ARGS__); \
+  } while (0)
+
+#define HN_CHECK_HIP(expr)                                                         \
+  do {                                                                             \
+    hipError_t e_ = (expr);                                                        \
+    if (e_ != hipSuccess)                                                          \
+      return hn::fail(HN_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+// kernel launches report configuration errors through hipGetLastError
+#define HN_CHECK_LAUNCH(name)                                                          \
+  do {                                                                                 \
+    hipError_t e_ = hipGetLastError();                                                 \
+    if (e_ != hipSuccess)                                                              \
+      return hn::fail(HN_ERR_HIP, "launch of %s failed: %s", name, hipGetErrorString(e_)); \
+  } while (0)
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+}  // namespace hn

@@ -1,0 +1,108 @@
+"""ctypes binding of libhandnet_hip.so (the C ABI declared in include/handnet_hip.h).
+
+There is no CPU fallback: if the library is missing it is built with hipcc, and if that
+fails (or a call returns non-zero) a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import threading
+from pathlib import Path
+
+from . import build as _build
+
+ABI_VERSION = 4
+
+HN_PREC_F32, HN_PREC_F16 = 0, 1
+TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, TILE_256x128, TILE_64x128 = range(7)
+HN_FCOS_MAX_LEVELS = 5
+
+c_f32p = C.POINTER(C.c_float)
+c_i32p = C.POINTER(C.c_int32)
+c_i64p = C.POINTER(C.c_int64)
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in (
+        "n", "h", "w", "cin", "cout", "r", "s", "stride", "pad", "dil", "oh", "ow",
+        "relu_cols", "res_mode", "res_h", "res_w", "in_affine", "tile", "precision",
+        "stats", "stats_group", "in_pix_stride", "out_pix_stride")]
+
+
+class FcosLevels(C.Structure):
+    _fields_ = [("num_levels", C.c_int32),
+                ("h", C.c_int32 * HN_FCOS_MAX_LEVELS),
+                ("w", C.c_int32 * HN_FCOS_MAX_LEVELS),
+                ("stride", C.c_int32 * HN_FCOS_MAX_LEVELS),
+                ("cls_lr", C.c_void_p * HN_FCOS_MAX_LEVELS),
+                ("reg_ctr", C.c_void_p * HN_FCOS_MAX_LEVELS)]
+
+
+# name -> (restype, argtypes); every symbol of include/handnet_hip.h is listed here and
+# tests/test_abi.py checks the two stay in sync.
+VP = C.c_void_p
+SIGNATURES = {
+    "hn_abi_version": (C.c_int, []),
+    "hn_last_error": (C.c_char_p, []),
+    "hn_device_info": (C.c_int, [c_i32p, c_i32p, C.c_char_p, C.c_int]),
+    "hn_event_create": (C.c_int, [C.POINTER(VP)]),
+    "hn_event_destroy": (C.c_int, [VP]),
+    "hn_event_record": (C.c_int, [VP, VP]),
+    "hn_event_elapsed_ms": (C.c_int, [VP, VP, c_f32p]),
+    "hn_conv2d_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), VP, VP, VP, VP, VP, VP, VP, VP]),
+    "hn_conv2d_pick_tile": (C.c_int, [C.POINTER(ConvDesc)]),
+    "hn_maxpool3x3s2_nhwc_f32": (C.c_int, [VP, VP] + [C.c_int] * 6 + [VP]),
+    "hn_groupnorm_scratch_floats": (C.c_int64, [C.c_int] * 4),
+    "hn_groupnorm_affine_f32": (C.c_int, [VP, VP, VP] + [C.c_int] * 4 + [C.c_float, VP, VP, VP, VP]),
+    "hn_fcos_preprocess_f32": (C.c_int, [VP, VP] + [C.c_int] * 7 + [c_f32p, c_f32p, VP]),
+    "hn_fcos_candidates": (C.c_int, [C.POINTER(FcosLevels), C.c_int, C.c_int, C.c_float,
+                                     VP, VP, VP, VP, VP, VP, C.c_int, VP]),
+    "hn_fcos_nms_scratch_bytes": (C.c_int64, [C.c_int, C.c_int]),
+    "hn_fcos_nms": (C.c_int, [VP] * 6 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float] + [VP] * 9),
+    "hn_nms": (C.c_int, [VP, VP, C.c_int, C.c_float, VP, VP, VP, VP]),
+    "hn_crop_resize": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, VP] + [C.c_int] * 5 + [VP, VP, VP, VP]),
+    "hn_pack_depth_nhwc": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, VP]),
+    "hn_a2j_aggregate_f32": (C.c_int, [VP, VP, VP, VP] + [C.c_int] * 5 + [VP, VP]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def lib_path() -> Path:
+    return _build.LIB_PATH
+
+
+def load(build_if_missing: bool = True) -> C.CDLL:
+    """Load (building first if needed) the HIP library.  Raises on any failure."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = lib_path()
+        if not path.exists():
+            if not build_if_missing:
+                raise RuntimeError(f"{path} is missing; run `python __graft_entry__.py build`")
+            _build.build_library()
+        lib = C.CDLL(str(path))
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as e:
+                raise RuntimeError(f"{path} does not export {name}; rebuild it") from e
+            fn.restype, fn.argtypes = res, args
+        if lib.hn_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{path}: ABI {lib.hn_abi_version()} != expected {ABI_VERSION}; rebuild it")
+        _lib = lib
+        return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load().hn_last_error()
+        raise RuntimeError(f"{what} failed (status {status}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t) -> int | None:
+    """Device/host address of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()

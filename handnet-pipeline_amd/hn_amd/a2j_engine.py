@@ -1,0 +1,152 @@
+"""A2J pose network on MI355X: dilated ResNet-50 trunk + 3 conv heads + anchor aggregation.
+
+Mirrors (arithmetically) a2j/a2j.py:194-250 of the reference; every convolution runs as
+hn_conv2d_nhwc_f32 with BatchNorm folded, ReLU / residual fused in the epilogue, NHWC
+activations resident in HBM.  The regression and depth heads read the same x4, so their
+first layers run as ONE 2048 -> 512 conv (wider N tile, x4 gathered once).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .weights import ConvW, bn_scale_shift, concat_cout, pack_conv, strip_prefix
+
+# (planes, blocks, stride of first block, dilation of later blocks)  a2j/resnet.py:109-112
+_LAYERS = [(64, 3, 1, 1), (128, 4, 2, 1), (256, 6, 2, 1), (512, 3, 1, 2)]
+ANCHORS_PER_CELL = 16
+
+
+class A2JEngine:
+    def __init__(self, state_dict, num_joints: int = 21, rgbd: bool = False, device="cuda"):
+        sd = strip_prefix(state_dict, "a2j.")
+        self.device = torch.device(device)
+        self.joints = num_joints
+        self.rgbd = rgbd
+        p = "Backbone.model."
+        dev = self.device
+
+        def cbn(conv, bn, **kw):
+            return pack_conv(sd[conv + ".weight"], None, bn_scale_shift(sd, bn), **kw).to(dev)
+
+        # stem: depth replicated to 3 channels in the reference -> fold to one channel
+        self.stem = cbn(p + "conv1", p + "bn1", stride=2, pad=3, sum_cin=not rgbd)
+        self.blocks = []
+        for li, (planes, blocks, stride, dil) in enumerate(_LAYERS, start=1):
+            for b in range(blocks):
+                q = f"{p}layer{li}.{b}."
+                st = stride if b == 0 else 1
+                dl = 1 if b == 0 else dil
+                blk = {
+                    "c1": cbn(q + "conv1", q + "bn1"),
+                    "c2": cbn(q + "conv2", q + "bn2", stride=st, pad=dl, dil=dl),
+                    "c3": cbn(q + "conv3", q + "bn3"),
+                    "ds": cbn(q + "downsample.0", q + "downsample.1", stride=st)
+                    if (q + "downsample.0.weight") in sd else None,
+                    "tap": li,  # layer index, to tap x3 after layer3
+                }
+                self.blocks.append(blk)
+
+        def head(name):
+            convs = []
+            for i in range(1, 5):
+                convs.append(pack_conv(sd[f"{name}.conv{i}.weight"], sd[f"{name}.conv{i}.bias"],
+                                       bn_scale_shift(sd, f"{name}.bn{i}"), pad=1))
+            out = pack_conv(sd[f"{name}.output.weight"], sd[f"{name}.output.bias"], None, pad=1)
+            return convs, out
+
+        cls_c, cls_o = head("classificationModel")
+        reg_c, reg_o = head("regressionModel")
+        dep_c, dep_o = head("DepthRegressionModel")
+        self.cls_convs = [c.to(dev) for c in cls_c]
+        self.cls_out = cls_o.to(dev)
+        self.regdep_conv1 = concat_cout([reg_c[0], dep_c[0]]).to(dev)  # shared-input fusion
+        self.reg_convs = [c.to(dev) for c in reg_c[1:]]
+        self.dep_convs = [c.to(dev) for c in dep_c[1:]]
+        self.reg_out = reg_o.to(dev)
+        self.dep_out = dep_o.to(dev)
+        if self.cls_out.cout != ANCHORS_PER_CELL * num_joints:
+            raise ValueError("checkpoint does not match num_joints")
+
+    # -----------------------------------------------------------------------------------
+    @staticmethod
+    def _conv(x, cw: ConvW, relu=True, residual=None, tile=0):
+        return ops.conv2d_nhwc(x, cw.w, cw.bias, stride=cw.stride, pad=cw.pad, dil=cw.dil, relu=relu,
+                               residual=residual, tile=tile)
+
+    def trunk(self, x):
+        """x [K,H,W,4] NHWC -> (x3 [K,H/16,W/16,1024], x4 [K,H/16,W/16,2048])."""
+        x = self._conv(x, self.stem)
+        x = ops.maxpool3x3s2_nhwc(x)
+        x3 = None
+        for i, blk in enumerate(self.blocks):
+            o = self._conv(x, blk["c1"])
+            o = self._conv(o, blk["c2"])
+            idn = self._conv(x, blk["ds"], relu=False) if blk["ds"] is not None else x
+            x = self._conv(o, blk["c3"], relu=True, residual=idn)
+            last_of_layer = (i + 1 == len(self.blocks)) or (self.blocks[i + 1]["tap"] != blk["tap"])
+            if blk["tap"] == 3 and last_of_layer:
+                x3 = x
+        return x3, x
+
+    def heads(self, x3, x4):
+        c = x3
+        for cw in self.cls_convs:
+            c = self._conv(c, cw)
+        cls = self._conv(c, self.cls_out, relu=False)
+        rd = self._conv(x4, self.regdep_conv1)
+        # the fused tensor is [.., 512]: channels 0..255 regression tower, 256..511 depth tower
+        # (read in place as channel-slice views: no copy)
+        r = rd[..., :256]
+        d = rd[..., 256:]
+        for cw in self.reg_convs:
+            r = self._conv(r, cw)
+        for cw in self.dep_convs:
+            d = self._conv(d, cw)
+        reg = self._conv(r, self.reg_out, relu=False)
+        dep = self._conv(d, self.dep_out, relu=False)
+        return cls, reg, dep
+
+    def forward_nhwc(self, x, valid=None, return_heads=False):
+        x3, x4 = self.trunk(x)
+        cls, reg, dep = self.heads(x3, x4)
+        out = ops.a2j_aggregate(cls, reg, dep, joints=self.joints, stride=16, valid=valid)
+        if return_heads:
+            return out, (x3, x4), (cls, reg, dep)
+        return out
+
+    def forward(self, depth, valid=None):
+        """depth [K,1,H,W] (or [K,4,H,W] for RGBD) fp32 on the GPU -> [K,J,3] on the GPU."""
+        if depth.dim() != 4:
+            raise ValueError("expected [K,C,H,W]")
+        if not depth.is_cuda:
+            raise RuntimeError("A2JEngine needs GPU tensors (no CPU fallback)")
+        depth = depth.float().contiguous()
+        if self.rgbd:
+            x = depth[:, :4].permute(0, 2, 3, 1).contiguous()
+        else:
+            x = ops.pack_depth_nhwc(depth[:, 0:1].contiguous(), cpad=4)
+        return self.forward_nhwc(x, valid)
+
+    # -----------------------------------------------------------------------------------
+    def macs_per_crop(self, h=176, w=176) -> int:
+        """Algorithmic MACs exactly as the reference executes them (3-channel stem)."""
+        from .ops import conv_out_size
+
+        total = 0
+        oh, ow = conv_out_size(h, w, 7, 7, 2, 3, 1)
+        total += oh * ow * 64 * 49 * (4 if self.rgbd else 3)
+        oh, ow = (oh + 2 - 3) // 2 + 1, (ow + 2 - 3) // 2 + 1
+        for blk in self.blocks:
+            total += oh * ow * blk["c1"].macs_per_pixel()
+            c2 = blk["c2"]
+            oh2, ow2 = conv_out_size(oh, ow, 3, 3, c2.stride, c2.pad, c2.dil)
+            total += oh2 * ow2 * (c2.macs_per_pixel() + blk["c3"].macs_per_pixel())
+            if blk["ds"] is not None:
+                total += oh2 * ow2 * blk["ds"].macs_per_pixel()
+            oh, ow = oh2, ow2
+        px = oh * ow
+        for cw in self.cls_convs + [self.cls_out, self.regdep_conv1] + self.reg_convs + self.dep_convs + \
+                [self.reg_out, self.dep_out]:
+            total += px * cw.macs_per_pixel()
+        return total

@@ -1,0 +1,75 @@
+"""Build libhandnet_hip.so (gfx950) in-tree with hipcc.
+
+`python -m hn_amd.build` or `hn_amd.build.build_library()`.  Objects are rebuilt only
+when their source (or a header) is newer; the shared library lands next to the sources
+(`csrc/libhandnet_hip.so`) so that it travels with the repo snapshot to the GPU box.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+PKG_ROOT = Path(__file__).resolve().parent.parent          # handnet-pipeline_amd/
+CSRC = PKG_ROOT / "csrc"
+REPO_ROOT = PKG_ROOT.parent
+LIB_PATH = CSRC / "libhandnet_hip.so"
+ARCH = "gfx950"
+
+# decode / IoU arithmetic must round exactly like the reference's separate torch ops
+# (no FMA contraction), so that file is built with contraction off.
+EXTRA_FLAGS = {"fcos_post.hip": ["-ffp-contract=off"]}
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC)")
+
+
+def _newer(src_paths, target: Path) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(p.stat().st_mtime > t for p in src_paths)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> Path:
+    hipcc = _hipcc()
+    sources = sorted(CSRC.glob("*.hip"))
+    headers = sorted(CSRC.glob("*.h")) + sorted((REPO_ROOT / "include").glob("*.h"))
+    objdir = CSRC / "build"
+    objdir.mkdir(exist_ok=True)
+    base = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
+            "-Wall", "-Wno-unused-function", f"-I{REPO_ROOT / 'include'}"]
+
+    def compile_one(src: Path) -> Path:
+        obj = objdir / (src.stem + ".o")
+        if force or _newer([src] + headers, obj):
+            cmd = base + EXTRA_FLAGS.get(src.name, []) + ["-c", str(src), "-o", str(obj)]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed on {src.name}:\n{r.stdout}\n{r.stderr}")
+            if verbose and r.stderr.strip():
+                print(r.stderr, file=sys.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(6, len(sources) or 1)) as ex:
+        objs = list(ex.map(compile_one, sources))
+    if force or _newer(objs, LIB_PATH):
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB_PATH)] + [str(o) for o in objs]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    p = build_library(force="--force" in sys.argv, verbose=True)
+    print(p)

@@ -1,0 +1,94 @@
+"""Load-time weight transforms: BatchNorm folding and NCHW -> [Cout][R][S][Cin] repacking.
+
+Done once on the host in fp64 (then rounded to fp32) when a reference-layout state_dict
+is loaded; the device only ever sees folded, NHWC-ordered, channel-padded filters.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+
+BN_EPS = 1e-5
+
+
+@dataclass
+class ConvW:
+    """A packed convolution: w [Cout,R,S,Cin_pad] fp32, bias [Cout] fp32 or None."""
+    w: torch.Tensor
+    bias: torch.Tensor | None
+    stride: int = 1
+    pad: int = 0
+    dil: int = 1
+
+    def to(self, device):
+        return ConvW(self.w.to(device).contiguous(), None if self.bias is None else self.bias.to(device).contiguous(),
+                     self.stride, self.pad, self.dil)
+
+    @property
+    def cout(self):
+        return self.w.shape[0]
+
+    @property
+    def cin(self):
+        return self.w.shape[3]
+
+    def macs_per_pixel(self, real_cin=None):
+        r, s = self.w.shape[1], self.w.shape[2]
+        return self.cout * r * s * (real_cin or self.cin)
+
+
+def _pad_to(c: int, m: int) -> int:
+    return (c + m - 1) // m * m
+
+
+def bn_scale_shift(sd, name, eps=BN_EPS):
+    """(Frozen)BatchNorm2d eval: y = x*scale + shift (fp64)."""
+    w = sd[name + ".weight"].double()
+    b = sd[name + ".bias"].double()
+    rm = sd[name + ".running_mean"].double()
+    rv = sd[name + ".running_var"].double()
+    scale = w / torch.sqrt(rv + eps)
+    return scale, b - rm * scale
+
+
+def pack_conv(weight, bias=None, bn=None, stride=1, pad=0, dil=1, cin_pad_to=4, sum_cin=False) -> ConvW:
+    """weight [Cout,Cin,R,S] (torch layout) -> ConvW.
+
+    bn        (scale, shift) from bn_scale_shift, folded into weight/bias
+    sum_cin   collapse the input channels into one (the A2J stem sees the depth map
+              replicated 3x -- a2j/a2j.py:199 -- so conv(w, [d,d,d]) == conv(sum_c w_c, d))
+    """
+    w = weight.double()
+    b = bias.double() if bias is not None else None
+    if sum_cin:
+        w = w.sum(dim=1, keepdim=True)
+    if bn is not None:
+        scale, shift = bn
+        w = w * scale[:, None, None, None]
+        b = shift if b is None else b * scale + shift
+    cout, cin, r, s = w.shape
+    cp = _pad_to(cin, cin_pad_to)
+    packed = torch.zeros((cout, r, s, cp), dtype=torch.float64)
+    packed[..., :cin] = w.permute(0, 2, 3, 1)
+    return ConvW(packed.float().contiguous(), None if b is None else b.float().contiguous(), stride, pad, dil)
+
+
+def concat_cout(convs) -> ConvW:
+    """Stack several convs that read the same input along Cout (same geometry)."""
+    c0 = convs[0]
+    for c in convs[1:]:
+        assert c.w.shape[1:] == c0.w.shape[1:] and (c.stride, c.pad, c.dil) == (c0.stride, c0.pad, c0.dil)
+    w = torch.cat([c.w for c in convs], 0)
+    if all(c.bias is None for c in convs):
+        b = None
+    else:
+        b = torch.cat([c.bias if c.bias is not None else torch.zeros(c.cout) for c in convs], 0)
+    return ConvW(w.contiguous(), b, c0.stride, c0.pad, c0.dil)
+
+
+def strip_prefix(sd, prefix):
+    """Lightning checkpoints store A2J under 'a2j.' (a2j/a2j.py:277)."""
+    if any(k.startswith(prefix) for k in sd):
+        return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    return sd

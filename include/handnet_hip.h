@@ -1,0 +1,201 @@
+/*
+ * handnet_hip.h -- C ABI of libhandnet_hip.so (MI355X / gfx950).
+ *
+ * This is the drop-in boundary for the FCOS -> crop -> A2J inference hot path of
+ * IRVLUTD/handnet-pipeline.  The reference has NO FFI / plugin layer of its own
+ * (its only seam is the Python nn.Module callable handnet_pipeline.HandNet,
+ * handnet_pipeline/handnet_pipeline.py:38-116), so each entry point below names the
+ * reference Python call site whose arithmetic it replaces.  Host code
+ * (handnet-pipeline_amd/) binds these with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *  - every function returns 0 on success, non-zero on failure; hn_last_error()
+ *    returns a thread-local description of the last failure.
+ *  - all pointers are DEVICE pointers borrowed from the caller unless noted; no
+ *    function allocates, frees or synchronises; all work is enqueued on `stream`
+ *    (a hipStream_t passed as void*; NULL = default stream), so calls can be
+ *    captured into a hipGraph.
+ *  - activations are NHWC fp32; conv weights are [Cout][R][S][Cin] fp32
+ *    (Cin % 4 == 0; pad with zeros), already folded with their BatchNorm.
+ *  - "fp32" here is exact: f32-input MFMA accumulates as a k-ordered fmaf chain.
+ */
+#ifndef HANDNET_HIP_H
+#define HANDNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HN_OK 0
+#define HN_ERR_ARG 1
+#define HN_ERR_HIP 2
+
+/* ABI version; bumped whenever a struct below changes. */
+#define HN_ABI_VERSION 4
+int hn_abi_version(void);
+const char* hn_last_error(void);
+
+/* Device facts used by bench.py (no allocation; queries the current device). */
+int hn_device_info(int* cu_count, int* clock_khz, char* arch_name, int arch_name_len);
+
+/* ---- timing helper: HIP events on the caller's stream (bench.py roofline leg) ---- */
+int hn_event_create(void** ev);
+int hn_event_destroy(void* ev);
+int hn_event_record(void* ev, void* stream);
+int hn_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
+
+/* ------------------------------------------------------------------------------------
+ * Convolution (implicit GEMM on f32 / f16 MFMA), fused epilogue.
+ * Replaces: torch.nn.Conv2d + (Frozen)BatchNorm2d + ReLU + residual add at
+ *   a2j/resnet.py:78-96 (Bottleneck), a2j/a2j.py:70-89,116-135,162-181 (heads),
+ *   tv resnet34 BasicBlock / FPN called at fcos_utils/fcos.py:737,
+ *   fcos_utils/fcos.py:276-289,377-380 (FCOS towers / outputs; GroupNorm of the
+ *   PREVIOUS layer is applied on load via in_scale/in_shift).
+ * ------------------------------------------------------------------------------------ */
+typedef struct hn_conv_desc {
+  int32_t n, h, w, cin;      /* input  [n][h][w][cin], cin % 4 == 0                      */
+  int32_t cout;              /* output channels (any >= 1)                               */
+  int32_t r, s;              /* filter taps                                              */
+  int32_t stride, pad, dil;
+  int32_t oh, ow;            /* output spatial size (caller computes; checked)           */
+  int32_t relu_cols;         /* ReLU on output channels [0, relu_cols); 0 = none         */
+  int32_t res_mode;          /* 0 none | 1 residual[n][oh][ow][cout] |
+                                2 residual[n][res_h][res_w][cout] read at (oh*res_h/oh.., nearest) */
+  int32_t res_h, res_w;      /* residual spatial size for res_mode 2                     */
+  int32_t in_affine;         /* 1: x <- relu(x*in_scale[img][c] + in_shift[img][c]) on load */
+  int32_t tile;              /* 0 = auto; else one of HN_TILE_*                          */
+  int32_t precision;         /* HN_PREC_F32 | HN_PREC_F16 (see hn_conv2d_nhwc)          */
+  int32_t stats;             /* 1: also accumulate per-(img, group) sum / sumsq of the
+                                 OUTPUT into gn_partial (GroupNorm statistics)           */
+  int32_t stats_group;       /* channels per group for stats (8 for GroupNorm(32,256))  */
+  int32_t in_pix_stride;     /* floats between consecutive input pixels; 0 = cin.  Lets a
+                                 conv read a channel slice [c0, c0+cin) of a wider tensor
+                                 (pass x + c0); must be a multiple of 4                  */
+  int32_t out_pix_stride;    /* floats between consecutive output pixels; 0 = cout      */
+} hn_conv_desc;
+
+#define HN_PREC_F32 0
+#define HN_PREC_F16 1
+
+#define HN_TILE_AUTO 0
+#define HN_TILE_128x128 1
+#define HN_TILE_128x64 2
+#define HN_TILE_64x64 3
+#define HN_TILE_128x32 4
+#define HN_TILE_256x128 5
+#define HN_TILE_64x128 6
+
+int hn_conv2d_nhwc_f32(const hn_conv_desc* d, const float* x, const float* w,
+                       const float* bias /* [cout] or NULL */,
+                       const float* residual /* or NULL */,
+                       const float* in_scale, const float* in_shift /* [n][cin] or NULL */,
+                       float* y, void* stream);
+
+/* Number of workgroups the auto heuristic would launch (host-only; for tests/plans). */
+int hn_conv2d_pick_tile(const hn_conv_desc* d);
+
+/* 3x3 / stride-2 / pad-1 max pooling, NHWC fp32 (c % 4 == 0).
+ * Replaces nn.MaxPool2d at a2j/resnet.py:107,158 and tv resnet34 stem. */
+int hn_maxpool3x3s2_nhwc_f32(const float* x, float* y, int n, int h, int w, int c,
+                             int oh, int ow, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * GroupNorm statistics -> per-(image, channel) affine, consumed by the next conv's
+ * in_scale / in_shift.  Replaces nn.GroupNorm(32, 256) + ReLU at
+ * fcos_utils/fcos.py:232-239,352-359 (eps 1e-5, biased variance over group x H x W).
+ *   scale[img][c] = gamma[c] * rstd[img][g],  shift[img][c] = beta[c] - mean*scale
+ * `partial` is caller scratch of hn_groupnorm_scratch_floats(...) floats.
+ * ------------------------------------------------------------------------------------ */
+int64_t hn_groupnorm_scratch_floats(int n, int hw, int c, int groups);
+int hn_groupnorm_affine_f32(const float* x /* [n][hw][c] */, const float* gamma,
+                            const float* beta, int n, int hw, int c, int groups, float eps,
+                            float* partial, float* scale, float* shift, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * FCOS pre-processing: normalize + bilinear resize (align_corners=False, scale =
+ * in/out as with recompute_scale_factor=True) + zero pad, NCHW fp32 in -> NHWC(4) out.
+ * Replaces torchvision GeneralizedRCNNTransform called at fcos_utils/fcos.py:709.
+ * src [n][3][h][w], dst [n][ph][pw][4] (channel 3 = 0, rows >= oh / cols >= ow = 0).
+ * ------------------------------------------------------------------------------------ */
+int hn_fcos_preprocess_f32(const float* src, float* dst, int n, int h, int w,
+                           int oh, int ow, int ph, int pw,
+                           const float mean[3], const float stdv[3], void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * FCOS post-processing.  Replaces fcos_utils/fcos.py:572-659 (postprocess_detections),
+ * det_utils.py:266-294 (BoxLinearCoder.decode_single), anchor_utils.py:82-132,
+ * torchvision.ops.batched_nms (call site fcos.py:635) and resize_boxes fcos.py:770-783.
+ *
+ * Head tensors are the raw conv outputs per level, NHWC:
+ *   cls_lr[l]  [n][h_l][w_l][num_classes + 2]   (cls_logits then hand_lr)
+ *   reg_ctr[l] [n][h_l][w_l][5]                 (relu(bbox_reg)[4] then ctrness)
+ * Step 1 hn_fcos_candidates: score = sqrt(sigmoid(cls)*sigmoid(ctr)); max/argmax over
+ *   classes (ties -> lowest class); keep score > thresh; decode box; compact in anchor
+ *   order.  Output per image (capacity `cap` = total points): cand_* arrays + count.
+ * Step 2 hn_fcos_nms: sort candidates by (score desc, index asc), greedy NMS exactly as
+ *   torchvision 0.11.3 batched_nms (coordinate trick when 4*K <= 4000, per-class
+ *   otherwise; CPU-kernel rule: suppress iff (double)iou > iou_thresh), write kept
+ *   detections in score order, boxes rescaled by (ratio_h, ratio_w).
+ * ------------------------------------------------------------------------------------ */
+#define HN_FCOS_MAX_LEVELS 5
+typedef struct hn_fcos_levels {
+  int32_t num_levels;
+  int32_t h[HN_FCOS_MAX_LEVELS], w[HN_FCOS_MAX_LEVELS], stride[HN_FCOS_MAX_LEVELS];
+  const float* cls_lr[HN_FCOS_MAX_LEVELS];
+  const float* reg_ctr[HN_FCOS_MAX_LEVELS];
+} hn_fcos_levels;
+
+int hn_fcos_candidates(const hn_fcos_levels* lv, int n, int num_classes, float score_thresh,
+                       float* cand_boxes /* [n][cap][4] */, float* cand_scores /* [n][cap] */,
+                       int32_t* cand_labels, int32_t* cand_sides, int32_t* cand_level /* [n][cap] */,
+                       int32_t* cand_count /* [n] */, int cap, void* stream);
+
+int64_t hn_fcos_nms_scratch_bytes(int n, int cap);
+int hn_fcos_nms(const float* cand_boxes, const float* cand_scores, const int32_t* cand_labels,
+                const int32_t* cand_sides, const int32_t* cand_level, const int32_t* cand_count,
+                int n, int cap, float iou_thresh, float ratio_h, float ratio_w,
+                void* scratch,
+                float* det_boxes /* [n][cap][4] */, float* det_scores, int32_t* det_labels,
+                int32_t* det_sides, int32_t* det_level, int32_t* det_keep /* cand index */,
+                int32_t* det_count /* [n] */, void* stream);
+
+/* Stand-alone NMS with torchvision.ops.nms semantics (tests / callers with own boxes). */
+int hn_nms(const float* boxes, const float* scores, int k, float iou_thresh,
+           void* scratch /* hn_fcos_nms_scratch_bytes(1,k) */, int32_t* keep, int32_t* num_keep,
+           void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Crop: top-1 hand box -> int box -> pad 40 % -> clamp -> nearest resize to out x out.
+ * Replaces handnet_pipeline/handnet_pipeline.py:74-105.
+ * For each image: first detection (score order) with label == hand_label.  Writes
+ *   crop_box [n][4] int64 (x1,y1,x2,y2 after padding; zeros if none), has_hand [n] int32,
+ *   crops [n][out][out][cpad] fp32 NHWC with depth in channel 0, other channels 0.
+ * depth is [n][1][h][w] fp32.
+ * ------------------------------------------------------------------------------------ */
+int hn_crop_resize(const float* det_boxes, const int32_t* det_labels, const int32_t* det_count,
+                   int cap, int hand_label, const float* depth, int n, int h, int w,
+                   int out, int cpad, int64_t* crop_box, int32_t* has_hand, float* crops,
+                   void* stream);
+
+/* Pack [n][1][h][w] depth crops into NHWC(cpad) for the A2J stem (A2J-only entry). */
+int hn_pack_depth_nhwc(const float* src, float* dst, int n, int hw, int cpad, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * A2J anchor aggregation.  Replaces a2j/anchor.py:57-82 (post_process.forward).
+ * Inputs are the raw head conv outputs, NHWC over the 11x11 anchor grid:
+ *   cls [k][fh][fw][A*J], reg [k][fh][fw][A*J*2], dep [k][fh][fw][A*J], A = 16 anchors.
+ * out [k][J][3] = (sum w*(anchor_0 + reg_0), sum w*(anchor_1 + reg_1), sum w*depth),
+ * w = softmax over all fh*fw*A anchors per joint.  Anchor coords follow
+ * a2j/anchor.py:7-42: coordinate 0 = h*stride + P[a/4], coordinate 1 = w*stride + P[a%4].
+ * Rows with valid[k] == 0 (if valid != NULL) are written as zeros.
+ * ------------------------------------------------------------------------------------ */
+int hn_a2j_aggregate_f32(const float* cls, const float* reg, const float* dep,
+                         const int32_t* valid, int k, int fh, int fw, int joints, int stride,
+                         float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HANDNET_HIP_H */

@@ -1,0 +1,22 @@
+"""CPU oracle for the FCOS -> crop -> A2J hot path.  TEST INFRASTRUCTURE ONLY.
+
+This package restates, in plain PyTorch-CPU fp32 / numpy / C, the algorithm of the
+reference (IRVLUTD/handnet-pipeline) for the path named in BASELINE.json.  Only `tests/`,
+`__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` may import it -- as the
+checker, never as the thing measured or shipped.  The product (handnet-pipeline_amd/)
+never imports it and has no CPU fallback.
+
+Pinning status
+  * A2J (a2j_ref.py): pinned -- tests/golden/a2j_*.npz were produced by importing the
+    reference's own a2j/a2j.py, a2j/resnet.py, a2j/anchor.py in the build container
+    (tests/golden/make_golden.py) and the restatement reproduces them.
+  * HandNet glue (handnet_ref.py) and the in-repo FCOS pieces (heads, anchors, box
+    decode, score/threshold, dict assembly: fcos_ref.py): pinned the same way
+    (tests/golden/fcos_*.npz, handnet_*.npz).
+  * torchvision 0.11.3 pieces that the reference only CALLS (resnet34 body, FrozenBN,
+    FPN, GeneralizedRCNNTransform, batched_nms/nms): torchvision is absent from
+    /root/reference and from this image, the reference holds no tests or fixtures for
+    them => PARITY UNPINNED for those functions; they are restated from the published
+    torchvision-0.11.3 algorithm and anchored on the reference call sites
+    (fcos_utils/fcos.py:476,505,635,709,737).
+"""

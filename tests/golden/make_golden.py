@@ -1,0 +1,117 @@
+#!/usr/bin/env python3 -B
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference.
+
+Runs only in the build container (needs /root/reference; never on the GPU box, never at
+test time).  The reference is imported under a stub shim for its NON-arithmetic
+dependencies; the arithmetic that runs is the reference's own.
+
+    python -B tests/golden/make_golden.py [a2j] [anchor] [fcos] [handnet]
+
+Outputs are small .npz files holding seeded inputs (or their seeds) and the reference's
+outputs.  Weights are NOT stored: they are regenerated from hn_amd.synth (seeded).
+"""
+from __future__ import annotations
+
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+REPO = HERE.parent.parent
+REF = Path("/root/reference")
+sys.dont_write_bytecode = True
+sys.path.insert(0, str(REPO / "handnet-pipeline_amd"))
+sys.path.insert(0, str(REPO))
+
+from hn_amd import synth  # noqa: E402
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def install_a2j_shim():
+    """Stub the non-arithmetic imports of a2j/a2j.py:3,8-15."""
+    _mod("dex_ycb_toolkit")
+    _mod("dex_ycb_toolkit.hpe_eval", HPEEvaluator=object)
+    _mod("pytorch_lightning", LightningModule=torch.nn.Module, LightningDataModule=object)
+    _mod("datasets3d")
+    _mod("datasets3d.a2jdataset", uvd2xyz=None)
+    _mod("utils")
+    _mod("utils.utils", get_e2e_loaders=None, vis_minibatch=None)
+    _mod("utils.vistool", VisualUtil=None)
+    tv = _mod("torchvision")
+    tv.transforms = _mod("torchvision.transforms")
+    if str(REF) not in sys.path:
+        sys.path.insert(0, str(REF))
+    import a2j.resnet as R
+    orig = R.resnet50
+    R.resnet50 = lambda pretrained=False, **kw: orig(pretrained=False, **kw)  # no model-zoo download
+
+
+def gen_a2j():
+    install_a2j_shim()
+    from a2j.a2j import A2JModel
+    torch.manual_seed(0)
+    model = A2JModel(21, crop_height=176, crop_width=176, is_RGBD=False).eval()
+    sd = synth.make_a2j_state_dict(seed=0)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    # only the anchor buffers are allowed to be missing from the synthetic checkpoint
+    assert all(("all_anchors" in k or "thres" in k) for k in missing), missing
+    assert not unexpected, unexpected
+    x = synth.make_crops(2, 176, seed=3000)
+    feats = {}
+    with torch.inference_mode():
+        x3, x4 = model.Backbone(x)
+        cls = model.classificationModel(x3)
+        reg = model.regressionModel(x4)
+        dep = model.DepthRegressionModel(x4)
+        out = model(x)
+    assert out.device.type == "cpu" and out.shape == (2, 21, 3)
+    np.savez_compressed(
+        HERE / "a2j_forward.npz",
+        input_seed=np.int64(3000), weight_seed=np.int64(0),
+        keypoints=out.numpy(),
+        x3_probe=x3[:, :64, 5, 5].numpy(), x4_probe=x4[:, :64, 5, 5].numpy(),
+        x3_absmean=np.float32(x3.abs().mean().item()), x4_absmean=np.float32(x4.abs().mean().item()),
+        cls_probe=cls[:, :64, :].numpy(), reg_probe=reg[:, :64, :, :].numpy(), dep_probe=dep[:, :64, :].numpy(),
+        anchors=model.post_process.all_anchors.numpy(),
+    )
+    print("a2j_forward.npz: keypoints[0,:3] =", out[0, :3].tolist())
+
+
+def gen_anchor():
+    """Stand-alone post_process golden (a2j/anchor.py:57-82) incl. a spiked (peaked-softmax) case."""
+    install_a2j_shim()
+    from a2j.anchor import post_process
+    pp = post_process(shape=[11, 11], stride=16, P_h=None, P_w=None)
+    g = torch.Generator().manual_seed(4000)
+    cls = torch.randn((4, 1936, 21), generator=g) * 2.0
+    reg = torch.randn((4, 1936, 21, 2), generator=g) * 8.0
+    dep = 0.8 + 0.2 * torch.randn((4, 1936, 21), generator=g)
+    cls[3, 100, :] += 30.0  # one dominant anchor per joint
+    cls[2] *= 0.0           # perfectly flat softmax
+    out = pp((cls, reg, dep))
+    np.savez_compressed(HERE / "a2j_post_process.npz", seed=np.int64(4000), out=out.numpy())
+    print("a2j_post_process.npz:", out.shape)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["a2j", "anchor", "fcos", "handnet"]
+    if "a2j" in what:
+        gen_a2j()
+    if "anchor" in what:
+        gen_anchor()
+    if "fcos" in what or "handnet" in what:
+        from make_golden_fcos import gen_fcos, gen_handnet  # noqa: E402
+        if "fcos" in what:
+            gen_fcos()
+        if "handnet" in what:
+            gen_handnet()

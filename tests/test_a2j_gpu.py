@@ -1,0 +1,96 @@
+"""A2J on HIP vs the oracle and vs the golden vectors produced by the imported reference.
+
+Tolerance (BASELINE.json north_star): keypoints within 1e-3 of the fp32 reference
+(u, v in crop pixels, d in metres).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+KP_TOL = 1e-3
+
+
+def test_aggregate_matches_reference_post_process(golden_dir):
+    """hn_a2j_aggregate_f32 vs a2j/anchor.py post_process output (golden, incl. peaked + flat softmax)."""
+    from hn_amd import ops
+    g = np.load(golden_dir / "a2j_post_process.npz")
+    gen = torch.Generator().manual_seed(int(g["seed"]))
+    cls = torch.randn((4, 1936, 21), generator=gen) * 2.0
+    reg = torch.randn((4, 1936, 21, 2), generator=gen) * 8.0
+    dep = 0.8 + 0.2 * torch.randn((4, 1936, 21), generator=gen)
+    cls[3, 100, :] += 30.0
+    cls[2] *= 0.0
+    # reference layout [B, (w*11+h)*16+a, J] -> NHWC conv-output layout [B, h, w, a*J+j]
+    def to_nhwc(t, last):
+        return t.reshape(4, 11, 11, 16, *last).permute(0, 2, 1, 3, *range(4, 4 + len(last))).reshape(4, 11, 11, -1).contiguous()
+    out = ops.a2j_aggregate(to_nhwc(cls, (21,)).cuda(), to_nhwc(reg, (21, 2)).cuda(), to_nhwc(dep, (21,)).cuda())
+    err = np.abs(out.cpu().numpy() - g["out"]).max()
+    assert err < 2e-4, err
+
+
+def test_aggregate_valid_mask_and_empty():
+    from hn_amd import ops
+    cls = torch.randn((3, 11, 11, 336), device="cuda")
+    reg = torch.randn((3, 11, 11, 672), device="cuda")
+    dep = torch.randn((3, 11, 11, 336), device="cuda")
+    valid = torch.tensor([1, 0, 1], dtype=torch.int32, device="cuda")
+    full = ops.a2j_aggregate(cls, reg, dep)
+    masked = ops.a2j_aggregate(cls, reg, dep, valid=valid)
+    assert torch.equal(masked[0], full[0]) and torch.equal(masked[2], full[2])
+    assert float(masked[1].abs().max()) == 0.0
+    empty = ops.a2j_aggregate(cls[:0], reg[:0], dep[:0])
+    assert empty.shape == (0, 21, 3)
+
+
+def test_a2j_forward_matches_golden_and_oracle(golden_dir, a2j_sd):
+    from hn_amd import synth
+    from hn_amd.a2j_engine import A2JEngine
+    from oracle import a2j_ref
+    g = np.load(golden_dir / "a2j_forward.npz")
+    x = synth.make_crops(2, 176, seed=int(g["input_seed"]))
+    eng = A2JEngine(a2j_sd, device="cuda")
+    out, (x3, x4), (cls, reg, dep) = eng.forward_nhwc(
+        torch.nn.functional.pad(x.permute(0, 2, 3, 1), (0, 3)).contiguous().cuda(), return_heads=True)
+    ref, (rx3, rx4), (rcls, rreg, rdep) = a2j_ref.a2j_forward(x, a2j_sd, return_heads=True)
+    # stage-by-stage (NCHW oracle vs NHWC engine)
+    for name, a, b, tol in (("x3", x3, rx3, 2e-4), ("x4", x4, rx4, 2e-4), ("cls", cls, rcls, 5e-4),
+                            ("reg", reg, rreg, 2e-3), ("dep", dep, rdep, 2e-4)):
+        d = (a.cpu() - b.permute(0, 2, 3, 1)).abs().max().item()
+        s = b.abs().max().item()
+        assert d <= tol * max(1.0, s), f"{name}: max diff {d} (scale {s})"
+    kp = out.cpu().numpy()
+    assert np.abs(kp - ref.numpy()).max() < KP_TOL
+    assert np.abs(kp - g["keypoints"]).max() < KP_TOL  # the imported reference's own output
+
+
+def test_a2jmodel_dropin_contract(a2j_sd):
+    """Reference call pattern of a2j_infer.py:25-28,58-60."""
+    from a2j.a2j import A2JModel
+    from hn_amd import synth
+    from oracle import a2j_ref
+    model = A2JModel(21, crop_height=176, crop_width=176, is_RGBD=False).cuda().eval()
+    missing, unexpected = model.load_state_dict(a2j_sd, strict=False)
+    assert not missing and not unexpected
+    x = synth.make_crops(3, 176, seed=7)
+    with torch.inference_mode():
+        out = model(x.cuda())
+    assert out.device.type == "cpu" and out.dtype == torch.float32 and out.shape == (3, 21, 3)
+    ref = a2j_ref.a2j_forward(x, a2j_sd)
+    assert (out - ref).abs().max().item() < KP_TOL
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        A2JModel(21, 176, 176)(x)  # still on the CPU -> must fail loudly, not fall back
+
+
+def test_a2j_batch64_properties(a2j_sd):
+    """BASELINE config 2 size: per-crop independence (batch result == single-crop result)."""
+    from hn_amd import synth
+    from hn_amd.a2j_engine import A2JEngine
+    eng = A2JEngine(a2j_sd, device="cuda")
+    x = synth.make_crops(64, 176, seed=3000).cuda()
+    out = eng.forward(x)
+    assert torch.isfinite(out).all()
+    one = eng.forward(x[17:18])
+    assert (out[17:18] - one).abs().max().item() < 1e-4
+    assert out[..., :2].min() > -50 and out[..., :2].max() < 226

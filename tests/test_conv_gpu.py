@@ -1,0 +1,124 @@
+"""HIP implicit-GEMM conv / pool / GroupNorm vs the plain-torch CPU reference (oracle/ops_ref.py).
+
+Tolerance: fp32 with a different accumulation order -> |err| <= 2e-5 * sqrt(K) * rms(term),
+tested as rtol 1e-4 / atol 1e-4 * max|y| (values are O(1)).
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def _check(y_gpu, y_ref, what=""):
+    y = y_gpu.cpu()
+    assert y.shape == y_ref.shape, (what, y.shape, y_ref.shape)
+    scale = max(1.0, float(y_ref.abs().max()))
+    err = float((y - y_ref).abs().max())
+    assert err <= 1e-4 * scale, f"{what}: max err {err} vs scale {scale}"
+
+
+# (n, h, w, cin, cout, r, stride, pad, dil)  -- shapes taken from the A2J / FCOS tables
+CASES = [
+    (2, 44, 44, 64, 256, 1, 1, 0, 1),     # bottleneck 1x1 expand
+    (2, 44, 44, 64, 64, 3, 1, 1, 1),      # 3x3
+    (2, 44, 44, 128, 128, 3, 2, 1, 1),    # 3x3 stride 2
+    (3, 11, 11, 512, 512, 3, 1, 2, 2),    # layer4 dilated 3x3, ragged M (363 rows)
+    (2, 44, 44, 256, 512, 1, 2, 0, 1),    # 1x1 stride-2 downsample
+    (2, 64, 48, 4, 64, 7, 2, 3, 1),       # stem, Cin padded to 4 (small-C gather)
+    (2, 11, 11, 256, 336, 3, 1, 1, 1),    # head output, Cout not a tile multiple
+    (1, 25, 34, 256, 5, 3, 1, 1, 1),      # FCOS head output, Cout = 5
+    (1, 13, 17, 32, 48, 3, 1, 1, 1),      # odd sizes, Cin = 32
+    (1, 9, 9, 8, 16, 3, 1, 1, 1),         # Cin = 8 (small-C path with 2 chunks per tap)
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 6])
+def test_conv_matches_reference(case, tile):
+    from hn_amd import ops
+    from oracle import ops_ref
+    n, h, w, cin, cout, r, stride, pad, dil = case
+    x = _rand((n, h, w, cin), 1)
+    wt = _rand((cout, r, r, cin), 2, scale=(2.0 / (cin * r * r)) ** 0.5)
+    b = _rand((cout,), 3, 0.1)
+    ref = ops_ref.conv2d_nhwc(x, wt, b, stride, pad, dil, relu_cols=cout)
+    y = ops.conv2d_nhwc(x.cuda(), wt.cuda(), b.cuda(), stride=stride, pad=pad, dil=dil, relu=True, tile=tile)
+    _check(y, ref, f"case {case} tile {tile}")
+
+
+def test_conv_residual_and_partial_relu():
+    from hn_amd import ops
+    from oracle import ops_ref
+    x = _rand((2, 22, 22, 128), 4)
+    wt = _rand((512, 1, 1, 128), 5, 0.1)
+    res = _rand((2, 22, 22, 512), 6)
+    ref = ops_ref.conv2d_nhwc(x, wt, None, relu_cols=100, residual=res)
+    y = ops.conv2d_nhwc(x.cuda(), wt.cuda(), None, relu_cols=100, residual=res.cuda())
+    _check(y, ref, "residual + relu_cols")
+
+
+def test_conv_fpn_upsample_add():
+    from hn_amd import ops
+    from oracle import ops_ref
+    x = _rand((2, 50, 68, 64), 7)
+    wt = _rand((256, 1, 1, 64), 8, 0.1)
+    b = _rand((256,), 9, 0.1)
+    top = _rand((2, 25, 34, 256), 10)
+    ref = ops_ref.conv2d_nhwc(x, wt, b, residual=top, res_upsample=True)
+    y = ops.conv2d_nhwc(x.cuda(), wt.cuda(), b.cuda(), residual=top.cuda(), res_upsample=True)
+    _check(y, ref, "fpn lateral + nearest 2x add")
+
+
+def test_conv_groupnorm_on_load():
+    """conv(relu(GN(x))) with GN folded into per-(image, channel) scale/shift applied on load."""
+    from hn_amd import ops
+    from oracle import ops_ref
+    x = _rand((2, 25, 34, 256), 11, 2.0) + 0.3
+    gamma = 1.0 + 0.2 * _rand((256,), 12)
+    beta = 0.1 * _rand((256,), 13)
+    wt = _rand((256, 3, 3, 256), 14, (2.0 / 2304) ** 0.5)
+    b = _rand((256,), 15, 0.1)
+    sc_ref, sh_ref = ops_ref.groupnorm_affine(x, gamma, beta)
+    sc, sh = ops.groupnorm_affine(x.cuda(), gamma.cuda(), beta.cuda())
+    _check(sc, sc_ref, "gn scale")
+    _check(sh, sh_ref, "gn shift")
+    xn = ops_ref.groupnorm_relu_nhwc(x, gamma, beta)
+    ref = ops_ref.conv2d_nhwc(xn, wt, b, pad=1)
+    y = ops.conv2d_nhwc(x.cuda(), wt.cuda(), b.cuda(), pad=1, in_scale=sc, in_shift=sh)
+    _check(y, ref, "conv with GroupNorm+ReLU on load")
+
+
+def test_conv_channel_slice_views():
+    from hn_amd import ops
+    from oracle import ops_ref
+    wide = _rand((2, 11, 11, 512), 16)
+    wt = _rand((256, 3, 3, 256), 17, 0.05)
+    ref = ops_ref.conv2d_nhwc(wide[..., 256:].contiguous(), wt, None, pad=1)
+    wg = wide.cuda()
+    out_wide = torch.zeros((2, 11, 11, 512), device="cuda")
+    ops.conv2d_nhwc(wg[..., 256:], wt.cuda(), None, pad=1, out=out_wide[..., :256])
+    _check(out_wide[..., :256].contiguous(), ref, "slice in / slice out")
+    assert float(out_wide[..., 256:].abs().max()) == 0.0
+
+
+def test_maxpool():
+    from hn_amd import ops
+    from oracle import ops_ref
+    x = _rand((2, 89, 67, 64), 18)
+    y = ops.maxpool3x3s2_nhwc(x.cuda())
+    assert torch.equal(y.cpu(), ops_ref.maxpool3x3s2_nhwc(x))
+
+
+def test_bad_arguments_fail_loudly():
+    from hn_amd import ops
+    x = torch.zeros((1, 8, 8, 6), device="cuda")  # cin not a multiple of 4
+    w = torch.zeros((8, 3, 3, 6), device="cuda")
+    with pytest.raises(RuntimeError, match="multiple of 4"):
+        ops.conv2d_nhwc(x, w, None, pad=1)
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.conv2d_nhwc(torch.zeros((1, 8, 8, 4)), torch.zeros((8, 3, 3, 4), device="cuda"))
