@@ -271,6 +271,8 @@ def a2j_aggregate(cls, reg, dep, joints=21, stride=16, valid=None, out=None):
         raise ValueError("bad head shapes")
     if out is None:
         out = torch.empty((k, joints, 3), device=cls.device, dtype=torch.float32)
+    if k == 0:
+        return out
     if valid is not None:
         _req(valid, torch.int32, "valid")
     check(lib.hn_a2j_aggregate_f32(ptr(cls), ptr(reg), ptr(dep), ptr(valid), k, fh, fw, joints, stride, ptr(out),

@@ -120,16 +120,26 @@ def make_fcos_state_dict(seed: int = 0, num_classes: int = 3, ext: bool = False)
             g = f"{tower}.conv.{3 * i + 1}"
             sd[g + ".weight"] = _uniform(seed, g + ".weight", (256,), 0.8, 1.2)
             sd[g + ".bias"] = _normal(seed, g + ".bias", (256,), std=0.1)
+    # Output layers use ZERO-SUM 3x3 kernels per (output, input) channel pair: they ignore
+    # each tower channel's (unknown) mean and respond only to spatial variation, so every
+    # logit's spatial mean equals its bias by construction and all classes are equally
+    # likely.  Wide class logits (sigma ~ 2) keep the fraction above the hard-coded 0.7
+    # score threshold at a few percent without calibration.
+    def out_conv(name, tower, cout, gain, target_mean):
+        _conv(sd, seed, name, cout, 256, 3, gain=gain, bias=False)
+        w = sd[name + ".weight"]
+        sd[name + ".weight"] = (w - w.mean(dim=(2, 3), keepdim=True)).contiguous()
+        sd[name + ".bias"] = torch.as_tensor(target_mean, dtype=torch.float32).expand(cout).clone()
+
     h = "head.classification_head."
-    # GN+ReLU tower output has E[x^2] ~ 0.5; gain 4 -> logits with sigma ~ 1.4
-    _conv(sd, seed, h + "cls_logits", num_classes, 256, 3, gain=4.0, bias=True, bias_std=0.0, bias_mean=-0.6)
-    _conv(sd, seed, h + "hand_lr_layer", 2, 256, 3, gain=2.0, bias=True)
+    out_conv(h + "cls_logits", "head.classification_head", num_classes, 38.0, -3.4)
+    out_conv(h + "hand_lr_layer", "head.classification_head", 2, 4.0, 0.0)
     if ext:
-        _conv(sd, seed, h + "hand_contact_state_layer", 5, 256, 3, gain=2.0, bias=True)
-        _conv(sd, seed, h + "hand_dydx_layer", 3, 256, 3, gain=2.0, bias=True)
+        out_conv(h + "hand_contact_state_layer", "head.classification_head", 5, 4.0, 0.0)
+        out_conv(h + "hand_dydx_layer", "head.classification_head", 3, 4.0, 0.5)
     r = "head.regression_head."
-    _conv(sd, seed, r + "bbox_reg", 4, 256, 3, gain=1.0, bias=True, bias_std=0.5, bias_mean=4.0)
-    _conv(sd, seed, r + "bbox_ctrness", 1, 256, 3, gain=4.0, bias=True, bias_std=0.0, bias_mean=1.0)
+    out_conv(r + "bbox_reg", "head.regression_head", 4, 4.0, [3.5, 4.0, 5.5, 3.5])
+    out_conv(r + "bbox_ctrness", "head.regression_head", 1, 4.0, 1.5)
     return sd
 
 

@@ -1,0 +1,52 @@
+"""CPU tests: the C-ABI library builds for gfx950, loads, and exports exactly the symbols
+that include/handnet_hip.h declares (no compute calls without a GPU)."""
+import re
+import subprocess
+
+from hn_amd import _lib, build
+
+
+def _declared_symbols():
+    text = (build.REPO_ROOT / "include" / "handnet_hip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_builds_and_loads():
+    path = build.build_library()
+    assert path.exists()
+    lib = _lib.load()
+    assert lib.hn_abi_version() == _lib.ABI_VERSION
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    out = subprocess.run(["nm", "-D", "--defined-only", str(_lib.lib_path())], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (hn_[a-z0-9_]+)", out))
+    missing = [s for s in declared if s not in exported]
+    assert not missing, f"declared in handnet_hip.h but not exported: {missing}"
+    unbound = [s for s in declared if s not in _lib.SIGNATURES]
+    assert not unbound, f"declared but not bound in hn_amd/_lib.py: {unbound}"
+    extra = [s for s in _lib.SIGNATURES if s not in declared]
+    assert not extra, f"bound but not declared in the header: {extra}"
+
+
+def test_conv_desc_struct_matches_header():
+    text = (build.REPO_ROOT / "include" / "handnet_hip.h").read_text()
+    body = re.search(r"typedef struct hn_conv_desc \{(.*?)\} hn_conv_desc;", text, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in re.findall(r"int32_t\s+([^;]+);", body):
+        fields += [f.strip() for f in decl.split(",")]
+    assert fields == [f for f, _ in _lib.ConvDesc._fields_]
+
+
+def test_argument_errors_do_not_need_a_gpu():
+    import ctypes as C
+    lib = _lib.load()
+    d = _lib.ConvDesc(n=1, h=8, w=8, cin=6, cout=8, r=3, s=3, stride=1, pad=1, dil=1, oh=8, ow=8)
+    st = lib.hn_conv2d_nhwc_f32(C.byref(d), 1, 1, None, None, None, None, 1, None)
+    assert st == 1 and b"multiple of 4" in lib.hn_last_error()
+    assert lib.hn_fcos_nms_scratch_bytes(2, 1000) > 2 * 1024 * 8
+    assert lib.hn_groupnorm_scratch_floats(2, 13600, 256, 32) == 2 * 213 * 32 * 2
