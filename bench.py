@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the FCOS -> crop -> A2J hot path on MI355X (driver contract).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of HandNet (FCOS detector, top-1 hand crop, A2J) over one batch of
+synthetic 640x480 RGB-D frames already resident in HBM, plus -- for N > 1 -- the all-gather
+of the per-frame results (RCCL).  Weak scaling: every rank processes its own `--batch`
+frames (BASELINE.json config 4: 32 frames on one GPU; config 5: 8 x 32).  Rank 0 prints ONE
+JSON line; `value` is whole-job frames/s = N * batch * K / max-over-ranks(time).
+
+Extra objects in the line:
+  roofline      dominant kernel (an instantiation of conv_igemm_f32_kernel): algorithmic
+                FLOP per launch / average launch duration, both measured live with HIP events
+                on the launch stream over K instrumented steps, vs the 157.3 TFLOP/s
+                f32-MFMA peak (MI355X_MICROARCH.md).
+  cpu_baseline  the oracle (CPU restatement, kind "port") timed on this box's host cores on a
+                bounded sample of the same workload (rank 0, N == 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO / "handnet-pipeline_amd"))
+sys.path.insert(0, str(REPO))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=None, help="frames (or crops) per GPU; default 32 (a2j: 64)")
+    ap.add_argument("--workload", choices=["pipeline", "a2j", "fcos"], default="pipeline")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=4, help="frames in the bounded CPU sample")
+    return ap.parse_args()
+
+
+def build_workload(args, dev, rank):
+    from hn_amd import synth
+    from hn_amd.a2j_engine import A2JEngine
+    from hn_amd.fcos_engine import FCOSEngine
+    from hn_amd.pipeline import HandNetEngine
+
+    wl = args.workload
+    batch = args.batch or (64 if wl == "a2j" else 32 if wl == "pipeline" else 16)
+    a2j_sd = synth.make_a2j_state_dict(0)
+    fcos_sd = synth.make_fcos_state_dict(0, 3)
+    info = {"batch_per_gpu": batch}
+    if wl == "a2j":
+        eng = A2JEngine(a2j_sd, device=dev)
+        x = synth.make_crops(batch, 176, seed=3000 + rank).to(dev)
+        step = lambda: eng.forward(x)  # noqa: E731
+        info.update(unit="crops/s", gflop_per_unit=2 * eng.macs_per_crop() / 1e9,
+                    name="A2J-only inference, 176x176 depth crops (BASELINE config 2)")
+        return step, info, None
+    fcos = FCOSEngine(fcos_sd, 3, device=dev)
+    rgb = synth.make_rgb(batch, seed=1000 + rank).to(dev)
+    if wl == "fcos":
+        step = lambda: fcos.detect(rgb)  # noqa: E731
+        info.update(unit="frames/s", gflop_per_unit=2 * fcos.macs_per_frame() / 1e9,
+                    name="FCOS ResNet34-FPN detector, 640x480 RGB (BASELINE config 3)")
+        return step, info, None
+    a2j = A2JEngine(a2j_sd, device=dev)
+    depth = synth.make_depth(batch, seed=2000 + rank).to(dev)
+    eng = HandNetEngine(fcos, a2j, 3)
+    info.update(unit="frames/s", gflop_per_unit=2 * (fcos.macs_per_frame() + a2j.macs_per_crop()) / 1e9,
+                name="Full HandNet pipeline (FCOS -> crop -> A2J), 640x480 RGB-D (BASELINE config 4)")
+    if args.graph:
+        run, _, _, out = eng.graphed(rgb, depth)
+
+        def step():
+            run()
+            return out
+    else:
+        step = lambda: eng.forward_device(rgb, depth)  # noqa: E731
+    return step, info, (fcos_sd, a2j_sd)
+
+
+def roofline_leg(step, steps):
+    """Bracket every conv launch with HIP events (on the launch stream) for `steps` steps."""
+    from hn_amd import ops
+    ops.CONV_PROFILE = []
+    try:
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        recs = ops.CONV_PROFILE
+    finally:
+        ops.CONV_PROFILE = None
+    groups = {}
+    for tile, macs, timer, _shape in recs:
+        g = groups.setdefault(tile, {"ms": 0.0, "flop": 0.0, "launches": 0})
+        g["ms"] += timer.elapsed_ms()
+        g["flop"] += 2.0 * macs
+        g["launches"] += 1
+    if not groups:
+        return None
+    tile, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
+    tot_ms = sum(v["ms"] for v in groups.values())
+    tot_flop = sum(v["flop"] for v in groups.values())
+    achieved = g["flop"] / (g["ms"] * 1e-3) / 1e12
+    return {
+        "bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+        "kernel": f"conv_igemm_f32_kernel<{ops.TILE_NAMES.get(tile, tile)}>",
+        "avg_launch_us": round(1e3 * g["ms"] / g["launches"], 2),
+        "gflop_per_launch": round(g["flop"] / g["launches"] / 1e9, 3),
+        "launches_per_step": g["launches"] // steps,
+        "share_of_conv_time": round(g["ms"] / tot_ms, 3),
+        "all_conv_achieved": round(tot_flop / (tot_ms * 1e-3) / 1e12, 2),
+        "conv_ms_per_step": round(tot_ms / steps, 3),
+    }
+
+
+def cpu_baseline(args, sds):
+    """Oracle (CPU restatement of the reference path) on a bounded sample, all host cores."""
+    from hn_amd import synth
+    from oracle import a2j_ref, handnet_ref
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    n = args.cpu_frames
+    if args.workload == "a2j":
+        x = synth.make_crops(16, 176, seed=3000)
+        sd = synth.make_a2j_state_dict(0)
+        a2j_ref.a2j_forward(x[:2], sd)
+        t0 = time.time()
+        reps = 3
+        for _ in range(reps):
+            a2j_ref.a2j_forward(x, sd)
+        dt = time.time() - t0
+        return {"value": round(16 * reps / dt, 2), "unit": "crops/s", "cores": threads, "kind": "port",
+                "sample": f"{reps} x batch-16 A2J oracle forward (torch CPU fp32)"}
+    fcos_sd, a2j_sd = sds
+    rgb = synth.make_rgb(n, seed=1000)
+    depth = synth.make_depth(n, seed=2000)
+    imgs = [rgb[i] for i in range(n)]
+    handnet_ref.handnet_forward(imgs[:1], depth[:1], fcos_sd, a2j_sd, 3)  # warm-up
+    t0 = time.time()
+    reps = 2
+    for _ in range(reps):
+        handnet_ref.handnet_forward(imgs, depth, fcos_sd, a2j_sd, 3)
+    dt = time.time() - t0
+    return {"value": round(n * reps / dt, 3), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{reps} x batch-{n} full-pipeline oracle forward (torch CPU fp32, FCOS+crop+A2J)"}
+
+
+def main():
+    args = parse()
+    from hn_amd import dist as hdist
+    rank, local, world = hdist.init_from_env("nccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    step, info, sds = build_workload(args, dev, rank)
+    batch = info["batch_per_gpu"]
+
+    def full_step():
+        out = step()
+        if world > 1 and args.workload == "pipeline":
+            hdist.gather_results(out.keypoints, out.crop_box, out.has_hand, per_rank=batch)
+        return out
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        full_step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        full_step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    roof = None
+    if not args.no_roofline and not args.graph:
+        roof = roofline_leg(step, max(1, min(args.steps, 3)))
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, sds)
+
+    if rank == 0:
+        units = world * batch * args.steps
+        value = units / elapsed
+        line = {
+            "metric": "end-to-end frames/sec (FCOS+A2J, 640x480)" if args.workload == "pipeline"
+            else f"{args.workload} throughput",
+            "value": round(value, 2), "unit": info["unit"], "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (seeded uniform RGB in [0,1), depth 0.3-1.5 m; random-init weights of the "
+                    "reference architectures, hn_amd.synth seed 0)",
+            "config": {"workload": info["name"], "batch_per_gpu": batch, "global_batch": batch * world,
+                       "frame": "640x480 RGB-D" if args.workload != "a2j" else "176x176 depth crop",
+                       "parallelism": f"frames sharded over {world} GPU(s), all-gather of per-frame results",
+                       "gflop_per_unit": round(info["gflop_per_unit"], 3), "hipgraph": bool(args.graph)},
+            "algorithmic_tflops": round(value * info["gflop_per_unit"] / 1e3, 2),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -36,6 +36,7 @@ struct ConvParams {
   int M, Ktot, ktiles;
   int relu_cols, res_mode, res_h, res_w, in_affine;
   int xs, ys;  // pixel strides (floats) of x and y: channel-slice views of wider tensors
+  int as;      // row stride (floats) of the in_scale / in_shift tables
   int tiles_m, tiles_n, nblocks;
 };
 
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
       if (ok) {
         v = *reinterpret_cast<const f32x4*>(p.x + a_base[it] + ((long)ih * p.W + iw) * p.xs + c);
         if (p.in_affine) {
-          const long o = (long)a_img[it] * p.Cin + c;
+          const long o = (long)a_img[it] * p.as + c;
           const f32x4 sc = *reinterpret_cast<const f32x4*>(p.in_scale + o);
           const f32x4 sh = *reinterpret_cast<const f32x4*>(p.in_shift + o);
 #pragma unroll
@@ -285,6 +286,7 @@ extern "C" int hn_conv2d_nhwc_f32(const hn_conv_desc* d, const float* x, const f
   HN_CHECK_ARG(!d->in_affine || (in_scale && in_shift), "in_affine set but scale/shift null");
   HN_CHECK_ARG(d->in_pix_stride == 0 || (d->in_pix_stride >= d->cin && d->in_pix_stride % 4 == 0), "bad in_pix_stride");
   HN_CHECK_ARG(d->out_pix_stride == 0 || d->out_pix_stride >= d->cout, "bad out_pix_stride");
+  HN_CHECK_ARG(d->in_affine_stride == 0 || (d->in_affine_stride >= d->cin && d->in_affine_stride % 4 == 0), "bad in_affine_stride");
   HN_CHECK_ARG(d->precision == HN_PREC_F32, "hn_conv2d_nhwc_f32 handles HN_PREC_F32 only");
   HN_CHECK_ARG((int64_t)d->n * d->h * d->w * d->cin < (int64_t)1 << 40, "input too large");
   HN_CHECK_ARG((int64_t)d->n * d->oh * d->ow < (int64_t)1 << 31, "too many output pixels");
@@ -300,6 +302,7 @@ extern "C" int hn_conv2d_nhwc_f32(const hn_conv_desc* d, const float* x, const f
   p.in_affine = d->in_affine;
   p.xs = d->in_pix_stride ? d->in_pix_stride : d->cin;
   p.ys = d->out_pix_stride ? d->out_pix_stride : d->cout;
+  p.as = d->in_affine_stride ? d->in_affine_stride : d->cin;
   p.tiles_m = p.tiles_n = p.nblocks = 0;
   const bool smallc = (d->cin % BK) != 0;
   hipStream_t st = (hipStream_t)stream;

@@ -24,7 +24,9 @@ struct Norm3 {
 };
 
 __device__ __forceinline__ void src_index(float scale, int dst, int in_size, int& i0, int& i1, float& l0, float& l1) {
-  float real = scale * ((float)dst + 0.5f) - 0.5f;
+  // ATen's area_pixel_compute_source_index; its builds (AVX2 host code and nvcc device code
+  // alike) contract scale*(dst+0.5)-0.5 into one fused multiply-add, so do the same here
+  float real = fmaf(scale, (float)dst + 0.5f, -0.5f);
   if (real < 0.f) real = 0.f;
   i0 = min((int)floorf(real), in_size - 1);
   l1 = fminf(fmaxf(real - (float)i0, 0.f), 1.f);
@@ -188,7 +190,7 @@ struct NmsArgs {
   const int* count;      // [n] or null (then k_fixed)
   int k_fixed;
   int cap;
-  float thr;
+  double thr;  // torchvision passes iou_threshold as a C++ double (0.3, not 0.3f)
   float ratio_h, ratio_w;
   int rescale;           // multiply output boxes by the ratios
   char* scratch;
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(1024) void nms_kernel(const NmsArgs a) {
   const bool classwise = labels != nullptr;
   const bool trick = classwise && (4 * K <= 4000);
   const float offs_unit = maxc_s + 1.0f;
-  const double thr = (double)a.thr;
+  const double thr = a.thr;
   int nk = 0;
   for (int t0 = 0; t0 < K; t0 += 64) {
     const int t = t0 + lane;
@@ -487,7 +489,7 @@ extern "C" int64_t hn_fcos_nms_scratch_bytes(int n, int cap) {
 
 extern "C" int hn_fcos_nms(const float* cand_boxes, const float* cand_scores, const int32_t* cand_labels,
                            const int32_t* cand_sides, const int32_t* cand_level, const int32_t* cand_count, int n,
-                           int cap, float iou_thresh, float ratio_h, float ratio_w, void* scratch, float* det_boxes,
+                           int cap, double iou_thresh, float ratio_h, float ratio_w, void* scratch, float* det_boxes,
                            float* det_scores, int32_t* det_labels, int32_t* det_sides, int32_t* det_level,
                            int32_t* det_keep, int32_t* det_count, void* stream) {
   HN_CHECK_ARG(cand_boxes && cand_scores && cand_labels && cand_sides && cand_level && cand_count && scratch,
@@ -505,7 +507,7 @@ extern "C" int hn_fcos_nms(const float* cand_boxes, const float* cand_scores, co
   return HN_OK;
 }
 
-extern "C" int hn_nms(const float* boxes, const float* scores, int k, float iou_thresh, void* scratch, int32_t* keep,
+extern "C" int hn_nms(const float* boxes, const float* scores, int k, double iou_thresh, void* scratch, int32_t* keep,
                       int32_t* num_keep, void* stream) {
   HN_CHECK_ARG(boxes && scores && scratch && keep && num_keep, "hn_nms: null pointer");
   HN_CHECK_ARG(k >= 0 && k <= (1 << 24), "bad k");

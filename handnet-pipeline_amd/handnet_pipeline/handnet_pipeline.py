@@ -1,0 +1,96 @@
+"""Drop-in `handnet_pipeline.handnet_pipeline.HandNet` (alias `HandNetPipeline`) on MI355X.
+
+Constructor and call contract of handnet_pipeline/handnet_pipeline.py:38-116:
+
+    net = HandNet(args, reload_detector=True, num_classes=3, reload_a2j=True, RGBD=False).cuda().eval()
+    keypoints, depth_batch, crops = net(images, depth_images=depth)        # ros_demo.py:270,388
+
+  keypoints   FloatTensor [N,21,3] on the CPU (zero rows for frames without a hand)
+  depth_batch [K,1,176,176] on the model device, K = frames with a hand
+  crops       [K,4] int64 on the model device (padded, clamped x1,y1,x2,y2)
+  no frame with a hand: (zeros[N,21,3], zeros_like(depth_images), zeros[N,4] float32)
+  is_detect or is_3D: returns None (the reference has no such branch either).
+
+Documented deviations: a batch that MIXES frames with and without a hand raises in the
+reference (torch.stack of a list containing None, :82,111) and an empty crop slice reuses
+the previous frame's crop (:100-105); here such frames simply count as "no hand".
+"""
+from __future__ import annotations
+
+import torch
+
+from a2j.a2j import A2JModel
+from fcos_utils.fcos import FCOS
+from hn_amd.pipeline import HandNetEngine
+from hn_amd.state import EngineOwner
+from hn_amd.weights import strip_prefix
+
+
+def load_pretrained_fcos(args, reload_detector=False, num_classes=2):
+    detector = FCOS(num_classes=num_classes, ext=False, nms_thresh=0.5)
+    if reload_detector:
+        checkpoint = torch.load(args.pretrained_fcos, map_location="cpu")
+        detector.load_state_dict(checkpoint["model"], strict=False)
+    for p in detector.parameters():
+        p.requires_grad = False
+    return detector
+
+
+def load_pretrained_a2j(args, reload_a2j=False, RGBD=False):
+    if RGBD:
+        raise NotImplementedError("the RGBD A2J variant (4-channel stem) is not built yet (SURVEY 8f #3)")
+    a2j = A2JModel(21, crop_height=176, crop_width=176, is_RGBD=False)
+    if reload_a2j:
+        checkpoint = torch.load(args.pretrained_a2j, map_location="cpu")
+        if "ckpt" in str(args.pretrained_a2j) or "state_dict" in checkpoint:
+            # Lightning checkpoint: weights live under state_dict with an 'a2j.' prefix (a2j/a2j.py:277)
+            a2j.load_state_dict(strip_prefix(checkpoint["state_dict"], "a2j."), strict=False)
+        else:
+            a2j.load_state_dict(checkpoint["model"], strict=False)
+    for p in a2j.parameters():
+        p.requires_grad = False
+    return a2j
+
+
+class HandNet(EngineOwner):
+    """End-to-End HandNet: FCOS hand detector -> depth crop -> A2J keypoints."""
+
+    def __init__(self, args, reload_detector: bool = False, num_classes: int = 2, reload_a2j: bool = False,
+                 RGBD: bool = False):
+        super().__init__()
+        self.detector = load_pretrained_fcos(args, reload_detector, num_classes)
+        self.detector.eval()
+        self.a2j = load_pretrained_a2j(args, reload_a2j, RGBD)
+        self.RGBD = RGBD
+        self.num_classes = num_classes
+
+    def engine(self) -> HandNetEngine:
+        self._require_gpu()
+        if self._engine is None:
+            self._engine = HandNetEngine(self.detector.engine(), self.a2j.engine(), self.num_classes)
+        return self._engine
+
+    def forward_device(self, images, depth_images):
+        """Sync-free variant: returns hn_amd.pipeline.HandNetOutput with everything on the GPU."""
+        batch = images if torch.is_tensor(images) else torch.stack([i.float() for i in images])
+        return self.engine().forward_device(batch, depth_images)
+
+    def forward(self, images, depth_images=None, is_3D: bool = False, is_detect: bool = False):
+        if is_detect or is_3D:
+            return None
+        if depth_images is None:
+            raise ValueError("depth_images is required for the ensemble inference branch")
+        n = len(images)
+        out = self.forward_device(images, depth_images)
+        mask = out.has_hand.bool()
+        final_results = out.keypoints.cpu()          # the reference returns keypoints on the CPU
+        mask_cpu = mask.cpu()
+        if not bool(mask_cpu.any()):
+            return (torch.zeros((n, 21, 3)), torch.zeros_like(depth_images),
+                    torch.zeros((n, 4), device=depth_images.device))
+        depth_batch = out.crops_nhwc[mask][..., 0].unsqueeze(1).contiguous()
+        crops = out.crop_box[mask]
+        return final_results, depth_batch, crops
+
+
+HandNetPipeline = HandNet

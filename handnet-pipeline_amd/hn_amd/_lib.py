@@ -11,7 +11,7 @@ from pathlib import Path
 
 from . import build as _build
 
-ABI_VERSION = 4
+ABI_VERSION = 6
 
 HN_PREC_F32, HN_PREC_F16 = 0, 1
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, TILE_256x128, TILE_64x128 = range(7)
@@ -26,7 +26,7 @@ class ConvDesc(C.Structure):
     _fields_ = [(k, C.c_int32) for k in (
         "n", "h", "w", "cin", "cout", "r", "s", "stride", "pad", "dil", "oh", "ow",
         "relu_cols", "res_mode", "res_h", "res_w", "in_affine", "tile", "precision",
-        "stats", "stats_group", "in_pix_stride", "out_pix_stride")]
+        "stats", "stats_group", "in_pix_stride", "out_pix_stride", "in_affine_stride")]
 
 
 class FcosLevels(C.Structure):
@@ -58,8 +58,8 @@ SIGNATURES = {
     "hn_fcos_candidates": (C.c_int, [C.POINTER(FcosLevels), C.c_int, C.c_int, C.c_float,
                                      VP, VP, VP, VP, VP, VP, C.c_int, VP]),
     "hn_fcos_nms_scratch_bytes": (C.c_int64, [C.c_int, C.c_int]),
-    "hn_fcos_nms": (C.c_int, [VP] * 6 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float] + [VP] * 9),
-    "hn_nms": (C.c_int, [VP, VP, C.c_int, C.c_float, VP, VP, VP, VP]),
+    "hn_fcos_nms": (C.c_int, [VP] * 6 + [C.c_int, C.c_int, C.c_double, C.c_float, C.c_float] + [VP] * 9),
+    "hn_nms": (C.c_int, [VP, VP, C.c_int, C.c_double, VP, VP, VP, VP]),
     "hn_crop_resize": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, VP] + [C.c_int] * 5 + [VP, VP, VP, VP]),
     "hn_pack_depth_nhwc": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, VP]),
     "hn_a2j_aggregate_f32": (C.c_int, [VP, VP, VP, VP] + [C.c_int] * 5 + [VP, VP]),

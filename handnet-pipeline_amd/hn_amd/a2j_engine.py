@@ -70,13 +70,13 @@ class A2JEngine:
 
     # -----------------------------------------------------------------------------------
     @staticmethod
-    def _conv(x, cw: ConvW, relu=True, residual=None, tile=0):
+    def _conv(x, cw: ConvW, relu=True, residual=None, tile=0, algo_cin=None):
         return ops.conv2d_nhwc(x, cw.w, cw.bias, stride=cw.stride, pad=cw.pad, dil=cw.dil, relu=relu,
-                               residual=residual, tile=tile)
+                               residual=residual, tile=tile, algo_cin=algo_cin)
 
     def trunk(self, x):
         """x [K,H,W,4] NHWC -> (x3 [K,H/16,W/16,1024], x4 [K,H/16,W/16,2048])."""
-        x = self._conv(x, self.stem)
+        x = self._conv(x, self.stem, algo_cin=4 if self.rgbd else 3)
         x = ops.maxpool3x3s2_nhwc(x)
         x3 = None
         for i, blk in enumerate(self.blocks):

@@ -1,0 +1,189 @@
+"""FCOS hand detector on MI355X: ResNet-34-FPN + GroupNorm towers + on-device post-process.
+
+Arithmetic follows fcos_utils/fcos.py:675-767 of the reference (eval branch):
+  transform (torchvision GeneralizedRCNNTransform)   -> hn_fcos_preprocess_f32 (NHWC, C=4)
+  resnet34 body + FrozenBatchNorm (folded) + FPN      -> hn_conv2d_nhwc_f32 (+ residual /
+                                                         nearest-2x top-down add epilogues)
+  4 x (conv3x3 + GroupNorm(32) + ReLU) towers          -> conv writes raw output, GN statistics
+                                                         become per-(image,channel) scale/shift
+                                                         applied by the NEXT conv on load
+  cls_logits+hand_lr / bbox_reg+ctrness               -> one Cout=C+2 and one Cout=5 conv
+  score/threshold/decode/compaction, batched NMS      -> hn_fcos_candidates, hn_fcos_nms
+Everything stays on the device; nothing here synchronises with the host.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import ops
+from .weights import ConvW, bn_scale_shift, concat_cout, pack_conv
+
+IMAGE_MEAN = (0.485, 0.456, 0.406)
+IMAGE_STD = (0.229, 0.224, 0.225)
+SCORE_THRESH = 0.7  # hard-coded in the reference, fcos_utils/fcos.py:600 (ctor args are ignored)
+NMS_THRESH = 0.3    # hard-coded, fcos_utils/fcos.py:635
+_R34 = [(64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)]
+
+
+def resized_size(h: int, w: int, min_size: int = 800, max_size: int = 1333):
+    """Size after GeneralizedRCNNTransform.resize.  torchvision evaluates
+    `float / tensor` = tensor.reciprocal() * float in fp32, then floor(size * scale) in fp64."""
+    inv_min = torch.tensor(float(min(h, w))).reciprocal()
+    inv_max = torch.tensor(float(max(h, w))).reciprocal()
+    scale = torch.min(inv_min * float(min_size), inv_max * float(max_size)).item()
+    return int(h * scale), int(w * scale)
+
+
+class FCOSEngine:
+    def __init__(self, state_dict, num_classes: int, device="cuda", min_size=800, max_size=1333):
+        sd = state_dict
+        dev = torch.device(device)
+        self.device = dev
+        self.num_classes = num_classes
+        self.min_size, self.max_size = min_size, max_size
+        p = "backbone.body."
+
+        def cbn(conv, bn, **kw):
+            return pack_conv(sd[conv + ".weight"], None, bn_scale_shift(sd, bn), **kw).to(dev)
+
+        self.stem = cbn(p + "conv1", p + "bn1", stride=2, pad=3)  # Cin 3 -> padded to 4
+        self.blocks = []
+        for li, (planes, blocks, stride) in enumerate(_R34, start=1):
+            for b in range(blocks):
+                q = f"{p}layer{li}.{b}."
+                st = stride if b == 0 else 1
+                self.blocks.append({
+                    "c1": cbn(q + "conv1", q + "bn1", stride=st, pad=1),
+                    "c2": cbn(q + "conv2", q + "bn2", pad=1),
+                    "ds": cbn(q + "downsample.0", q + "downsample.1", stride=st)
+                    if (q + "downsample.0.weight") in sd else None,
+                    "layer": li, "last": b == blocks - 1,
+                })
+        f = "backbone.fpn."
+        self.inner = [pack_conv(sd[f"{f}inner_blocks.{i}.weight"], sd[f"{f}inner_blocks.{i}.bias"]).to(dev)
+                      for i in range(3)]
+        self.layer = [pack_conv(sd[f"{f}layer_blocks.{i}.weight"], sd[f"{f}layer_blocks.{i}.bias"], pad=1).to(dev)
+                      for i in range(3)]
+        c, r = "head.classification_head", "head.regression_head"
+
+        def tconv(t, i):
+            return pack_conv(sd[f"{t}.conv.{3 * i}.weight"], sd[f"{t}.conv.{3 * i}.bias"], pad=1)
+
+        # layer 0 of both towers reads the same FPN level -> one 256->512 conv, one GN(64 groups)
+        self.tower0 = concat_cout([tconv(c, 0), tconv(r, 0)]).to(dev)
+        self.cls_tower = [tconv(c, i).to(dev) for i in range(1, 4)]
+        self.reg_tower = [tconv(r, i).to(dev) for i in range(1, 4)]
+        gn = lambda t, i, k: sd[f"{t}.conv.{3 * i + 1}.{k}"].float()  # noqa: E731
+        self.gn0_gamma = torch.cat([gn(c, 0, "weight"), gn(r, 0, "weight")]).to(dev)
+        self.gn0_beta = torch.cat([gn(c, 0, "bias"), gn(r, 0, "bias")]).to(dev)
+        self.cls_gn = [(gn(c, i, "weight").to(dev), gn(c, i, "bias").to(dev)) for i in range(1, 4)]
+        self.reg_gn = [(gn(r, i, "weight").to(dev), gn(r, i, "bias").to(dev)) for i in range(1, 4)]
+        self.cls_out = concat_cout([
+            pack_conv(sd[c + ".cls_logits.weight"], sd[c + ".cls_logits.bias"], pad=1),
+            pack_conv(sd[c + ".hand_lr_layer.weight"], sd[c + ".hand_lr_layer.bias"], pad=1)]).to(dev)
+        self.reg_out = concat_cout([
+            pack_conv(sd[r + ".bbox_reg.weight"], sd[r + ".bbox_reg.bias"], pad=1),
+            pack_conv(sd[r + ".bbox_ctrness.weight"], sd[r + ".bbox_ctrness.bias"], pad=1)]).to(dev)
+        if self.cls_out.cout != num_classes + 2:
+            raise ValueError("checkpoint does not match num_classes")
+        self._gn_scratch = None
+
+    # -----------------------------------------------------------------------------------
+    @staticmethod
+    def _conv(x, cw: ConvW, relu=False, **kw):
+        return ops.conv2d_nhwc(x, cw.w, cw.bias, stride=cw.stride, pad=cw.pad, dil=cw.dil, relu=relu, **kw)
+
+    def geometry(self, h, w):
+        oh, ow = resized_size(h, w, self.min_size, self.max_size)
+        ph, pw = int(math.ceil(oh / 32) * 32), int(math.ceil(ow / 32) * 32)
+        return oh, ow, ph, pw
+
+    def backbone(self, x):
+        """x [N,PH,PW,4] -> [P3, P4, P5] (256 channels, strides 8/16/32)."""
+        x = self._conv(x, self.stem, relu=True, algo_cin=3)
+        x = ops.maxpool3x3s2_nhwc(x)
+        feats = []
+        for blk in self.blocks:
+            o = self._conv(x, blk["c1"], relu=True)
+            idn = self._conv(x, blk["ds"]) if blk["ds"] is not None else x
+            x = self._conv(o, blk["c2"], relu=True, residual=idn)
+            if blk["last"] and blk["layer"] >= 2:
+                feats.append(x)
+        c3, c4, c5 = feats
+        lat5 = self._conv(c5, self.inner[2])
+        lat4 = self._conv(c4, self.inner[1], residual=lat5, res_upsample=True)
+        lat3 = self._conv(c3, self.inner[0], residual=lat4, res_upsample=True)
+        return [self._conv(lat3, self.layer[0]), self._conv(lat4, self.layer[1]), self._conv(lat5, self.layer[2])]
+
+    def _gn(self, x, gamma, beta, groups):
+        n, h, w, c = x.shape
+        need = ops._lib.load().hn_groupnorm_scratch_floats(n, h * w, c, groups)
+        if self._gn_scratch is None or self._gn_scratch.numel() < need:
+            self._gn_scratch = torch.empty((need,), device=x.device, dtype=torch.float32)
+        return ops.groupnorm_affine(x, gamma, beta, groups=groups, scratch=self._gn_scratch)
+
+    def head_level(self, feat):
+        """One FPN level -> (cls_lr [N,h,w,C+2], reg_ctr [N,h,w,5]) raw conv outputs."""
+        t0 = self._conv(feat, self.tower0)                       # [N,h,w,512], pre-GN
+        sc, sh = self._gn(t0, self.gn0_gamma, self.gn0_beta, 64)  # 2 x GroupNorm(32,256)
+        xc, sc_c, sh_c = t0[..., :256], sc[:, :256], sh[:, :256]
+        xr, sc_r, sh_r = t0[..., 256:], sc[:, 256:], sh[:, 256:]
+        for cw, (g, b) in zip(self.cls_tower, self.cls_gn):
+            xc = self._conv(xc, cw, in_scale=sc_c, in_shift=sh_c)
+            sc_c, sh_c = self._gn(xc, g, b, 32)
+        for cw, (g, b) in zip(self.reg_tower, self.reg_gn):
+            xr = self._conv(xr, cw, in_scale=sc_r, in_shift=sh_r)
+            sc_r, sh_r = self._gn(xr, g, b, 32)
+        cls_lr = self._conv(xc, self.cls_out, in_scale=sc_c, in_shift=sh_c)
+        reg_ctr = self._conv(xr, self.reg_out, relu_cols=4, in_scale=sc_r, in_shift=sh_r)
+        return cls_lr, reg_ctr
+
+    def forward_heads(self, images):
+        """images [N,3,H,W] fp32 0..1 on the GPU -> per-level head tensors + geometry."""
+        if images.dim() != 4 or images.shape[1] != 3:
+            raise ValueError("expected [N,3,H,W]")
+        n, _, h, w = images.shape
+        oh, ow, ph, pw = self.geometry(h, w)
+        x = ops.fcos_preprocess(images.float().contiguous(), oh, ow, ph, pw, IMAGE_MEAN, IMAGE_STD)
+        feats = self.backbone(x)
+        outs = [self.head_level(f) for f in feats]
+        strides = [ph // f.shape[1] for f in feats]
+        return [o[0] for o in outs], [o[1] for o in outs], strides, (oh, ow, ph, pw)
+
+    def detect(self, images, cand=None, det=None, nms_scratch=None):
+        """Full detector on the device -> ops.Detections (fixed capacity, score-ordered)."""
+        n, _, h, w = images.shape
+        cls_lr, reg_ctr, strides, (oh, ow, ph, pw) = self.forward_heads(images)
+        cand = ops.fcos_candidates(cls_lr, reg_ctr, strides, self.num_classes, SCORE_THRESH, out=cand)
+        # resize_boxes (fcos.py:770-783): fp32 tensor / fp32 tensor
+        ratio_h = (torch.tensor(float(h)) / torch.tensor(float(oh))).item()
+        ratio_w = (torch.tensor(float(w)) / torch.tensor(float(ow))).item()
+        det = ops.fcos_nms(cand, NMS_THRESH, ratio_h, ratio_w, scratch=nms_scratch, out=det)
+        return det, cand
+
+    # -----------------------------------------------------------------------------------
+    def macs_per_frame(self, h=480, w=640) -> int:
+        """Algorithmic conv MACs exactly as the reference executes them (3-channel stem, padded canvas)."""
+        _, _, ph, pw = self.geometry(h, w)
+        total = 0
+        sh, sw = ph // 2, pw // 2
+        total += sh * sw * 64 * 49 * 3
+        sh, sw = sh // 2, sw // 2
+        sizes = {}
+        for blk in self.blocks:
+            st = blk["c1"].stride
+            sh, sw = sh // st, sw // st
+            total += sh * sw * (blk["c1"].macs_per_pixel() + blk["c2"].macs_per_pixel())
+            if blk["ds"] is not None:
+                total += sh * sw * blk["ds"].macs_per_pixel()
+            sizes[blk["layer"]] = (sh, sw)
+        pts = 0
+        for i, li in enumerate((2, 3, 4)):
+            a, b = sizes[li]
+            total += a * b * (self.inner[i].macs_per_pixel() + self.layer[i].macs_per_pixel())
+            pts += a * b
+        per_pt = self.tower0.macs_per_pixel() + sum(c.macs_per_pixel() for c in self.cls_tower + self.reg_tower)
+        per_pt += self.cls_out.macs_per_pixel() + self.reg_out.macs_per_pixel()
+        return total + pts * per_pt

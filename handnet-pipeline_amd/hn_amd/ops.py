@@ -51,12 +51,22 @@ def make_conv_desc(n, h, w, cin, cout, r, s, stride=1, pad=0, dil=1, relu_cols=0
     return ConvDesc(n=n, h=h, w=w, cin=cin, cout=cout, r=r, s=s, stride=stride, pad=pad, dil=dil,
                     oh=oh, ow=ow, relu_cols=relu_cols, res_mode=res_mode, res_h=res_h, res_w=res_w,
                     in_affine=in_affine, tile=tile, precision=precision, stats=0, stats_group=0,
-                    in_pix_stride=in_pix_stride, out_pix_stride=out_pix_stride)
+                    in_pix_stride=in_pix_stride, out_pix_stride=out_pix_stride, in_affine_stride=0)
+
+
+# bench.py's roofline leg: when set to a list, every conv launch is bracketed by HIP events
+# on the launch stream and (tile id, algorithmic MACs, timer) is appended.
+CONV_PROFILE = None
+TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x64", 4: "128x32", 6: "64x128"}
 
 
 def conv2d_nhwc(x, w, bias=None, *, stride=1, pad=0, dil=1, relu=False, relu_cols=None,
-                residual=None, res_upsample=False, in_scale=None, in_shift=None, out=None, tile=0):
-    """x [N,H,W,Cin] fp32, w [Cout,R,S,Cin] fp32 -> y [N,OH,OW,Cout]."""
+                residual=None, res_upsample=False, in_scale=None, in_shift=None, out=None, tile=0,
+                algo_cin=None):
+    """x [N,H,W,Cin] fp32, w [Cout,R,S,Cin] fp32 -> y [N,OH,OW,Cout].
+
+    algo_cin: input channels the reference's conv really has when Cin is zero-padded
+    (only used for FLOP accounting)."""
     lib = _lib.load()
     _req(w, name="w")
     if not x.is_cuda or x.dtype != torch.float32:
@@ -89,11 +99,25 @@ def conv2d_nhwc(x, w, bias=None, *, stride=1, pad=0, dil=1, relu=False, relu_col
         raise ValueError("residual shape mismatch")
     if res_mode == 2 and (residual.shape[0] != n or residual.shape[3] != cout):
         raise ValueError("residual shape mismatch")
-    for t, nm in ((bias, "bias"), (in_scale, "in_scale"), (in_shift, "in_shift")):
-        if t is not None:
-            _req(t, name=nm)
+    if bias is not None:
+        _req(bias, name="bias")
+    if in_scale is not None:
+        # [N, Cin] tables, possibly column slices of a wider [N, C] table
+        for t in (in_scale, in_shift):
+            if (not t.is_cuda or t.dtype != torch.float32 or tuple(t.shape) != (n, cin) or t.stride(1) != 1
+                    or t.stride(0) != in_scale.stride(0)):
+                raise ValueError("in_scale / in_shift must be fp32 GPU [N, Cin] tables with equal row stride")
+        d.in_affine_stride = 0 if in_scale.stride(0) == cin else in_scale.stride(0)
+    prof = CONV_PROFILE
+    if prof is not None:
+        timer = HipTimer()
+        timer.start()
     check(lib.hn_conv2d_nhwc_f32(C.byref(d), ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(in_scale),
                                  ptr(in_shift), ptr(out), _stream()), "hn_conv2d_nhwc_f32")
+    if prof is not None:
+        timer.stop()
+        macs = n * d.oh * d.ow * cout * r * s * (algo_cin or cin)
+        prof.append((lib.hn_conv2d_pick_tile(C.byref(d)), macs, timer, (n, h, wd, cin, cout, r, stride, dil)))
     return out
 
 

@@ -1,0 +1,66 @@
+"""End-to-end HandNet on the device: FCOS -> top-1 hand box -> depth crop -> A2J.
+
+Restates handnet_pipeline/handnet_pipeline.py:58-116 without its per-image Python loop
+and its ~10 device->host syncs per frame: box selection, int truncation, 40 % padding,
+clamping and the nearest-neighbour 176x176 gather run in hn_crop_resize; A2J then runs on
+ALL N frames with a validity mask (frames without a hand produce zero rows), so the whole
+step has a static launch sequence and can be captured into a hipGraph.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+
+from . import ops
+from .a2j_engine import A2JEngine
+from .fcos_engine import FCOSEngine
+
+CROP = 176
+
+
+@dataclass
+class HandNetOutput:
+    keypoints: torch.Tensor   # [N,21,3] fp32 device; zero rows where has_hand == 0
+    crops_nhwc: torch.Tensor  # [N,176,176,4] fp32 device; channel 0 = cropped depth
+    crop_box: torch.Tensor    # [N,4] int64 device (x1,y1,x2,y2 after padding)
+    has_hand: torch.Tensor    # [N] int32 device
+    detections: ops.Detections
+    candidates: ops.Candidates
+
+
+class HandNetEngine:
+    def __init__(self, fcos: FCOSEngine, a2j: A2JEngine, num_classes: int):
+        self.fcos, self.a2j, self.num_classes = fcos, a2j, num_classes
+        self._graphs = {}
+
+    def forward_device(self, images: torch.Tensor, depth: torch.Tensor) -> HandNetOutput:
+        """images [N,3,H,W] 0..1, depth [N,1,H,W] metres, both fp32 on the GPU."""
+        if depth.dim() != 4 or depth.shape[1] != 1 or depth.shape[0] != images.shape[0]:
+            raise ValueError("depth must be [N,1,H,W] matching images")
+        det, cand = self.fcos.detect(images)
+        crop_box, has_hand, crops = ops.crop_resize(det, self.num_classes - 1, depth.float().contiguous(), CROP, 4)
+        kp = self.a2j.forward_nhwc(crops, valid=has_hand)
+        return HandNetOutput(kp, crops, crop_box, has_hand, det, cand)
+
+    # -------------------------------------------------------------------------------
+    # hipGraph replay for a fixed batch shape (launch-bound at small batch)
+    # -------------------------------------------------------------------------------
+    def graphed(self, images: torch.Tensor, depth: torch.Tensor):
+        """Returns (run, static_images, static_depth, static_output): copy new inputs into the
+        static tensors and call run() to replay the captured step."""
+        key = (tuple(images.shape), tuple(depth.shape))
+        if key not in self._graphs:
+            s_img, s_dep = images.clone(), depth.clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):  # warm-up (allocator, lazy module load) outside capture
+                    self.forward_device(s_img, s_dep)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self.forward_device(s_img, s_dep)
+            self._graphs[key] = (g, s_img, s_dep, out)
+        g, s_img, s_dep, out = self._graphs[key]
+        return g.replay, s_img, s_dep, out

@@ -33,7 +33,7 @@ extern "C" {
 #define HN_ERR_HIP 2
 
 /* ABI version; bumped whenever a struct below changes. */
-#define HN_ABI_VERSION 4
+#define HN_ABI_VERSION 6
 int hn_abi_version(void);
 const char* hn_last_error(void);
 
@@ -74,6 +74,7 @@ typedef struct hn_conv_desc {
                                  conv read a channel slice [c0, c0+cin) of a wider tensor
                                  (pass x + c0); must be a multiple of 4                  */
   int32_t out_pix_stride;    /* floats between consecutive output pixels; 0 = cout      */
+  int32_t in_affine_stride;  /* floats between rows of in_scale / in_shift; 0 = cin     */
 } hn_conv_desc;
 
 #define HN_PREC_F32 0
@@ -155,14 +156,14 @@ int hn_fcos_candidates(const hn_fcos_levels* lv, int n, int num_classes, float s
 int64_t hn_fcos_nms_scratch_bytes(int n, int cap);
 int hn_fcos_nms(const float* cand_boxes, const float* cand_scores, const int32_t* cand_labels,
                 const int32_t* cand_sides, const int32_t* cand_level, const int32_t* cand_count,
-                int n, int cap, float iou_thresh, float ratio_h, float ratio_w,
+                int n, int cap, double iou_thresh, float ratio_h, float ratio_w,
                 void* scratch,
                 float* det_boxes /* [n][cap][4] */, float* det_scores, int32_t* det_labels,
                 int32_t* det_sides, int32_t* det_level, int32_t* det_keep /* cand index */,
                 int32_t* det_count /* [n] */, void* stream);
 
 /* Stand-alone NMS with torchvision.ops.nms semantics (tests / callers with own boxes). */
-int hn_nms(const float* boxes, const float* scores, int k, float iou_thresh,
+int hn_nms(const float* boxes, const float* scores, int k, double iou_thresh,
            void* scratch /* hn_fcos_nms_scratch_bytes(1,k) */, int32_t* keep, int32_t* num_keep,
            void* stream);
 

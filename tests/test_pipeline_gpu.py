@@ -1,0 +1,132 @@
+"""Crop stage and the end-to-end HandNet callable on HIP vs the oracle / reference goldens."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dets_from_boxes(boxes, labels):
+    """Pack per-image (boxes [k,4], labels [k]) lists into an ops.Detections."""
+    from hn_amd import ops
+    n = len(boxes)
+    cap = max(8, max(len(b) for b in boxes))
+    det = ops.alloc_detections(n, cap, "cuda")
+    for i, (b, l) in enumerate(zip(boxes, labels)):
+        k = len(b)
+        if k:
+            det.boxes[i, :k] = torch.as_tensor(b, dtype=torch.float32).cuda()
+            det.labels[i, :k] = torch.as_tensor(l, dtype=torch.int32).cuda()
+        det.count[i] = k
+    return det
+
+
+def test_crop_resize_matches_reference_rule():
+    """Boxes incl. negative / out-of-range / tiny / full-frame; hand = first label-2 box in score order."""
+    from hn_amd import ops
+    from oracle import handnet_ref
+    g = torch.Generator().manual_seed(9)
+    depth = 0.3 + torch.rand((6, 1, 480, 640), generator=g)
+    boxes = [
+        [[100.7, 50.2, 300.9, 400.5]],
+        [[5.0, 5.0, 9.0, 9.0], [-30.5, 200.2, 40.9, 260.0]],       # first is label 0; second (negative x1) is the hand
+        [[600.1, 440.3, 700.0, 500.0]],                              # sticks out bottom/right
+        [[0.0, 0.0, 639.9, 479.9]],                                  # full frame
+        [[10.0, 10.0, 11.5, 11.2]],                                  # 1x1 px box
+        [[50.0, 60.0, 70.0, 80.0]],                                  # no hand label at all
+    ]
+    labels = [[2], [0, 2], [2], [2], [2], [1]]
+    det = _dets_from_boxes(boxes, labels)
+    crop_box, has_hand, crops = ops.crop_resize(det, 2, depth.cuda(), 176, 4)
+    assert has_hand.cpu().tolist() == [1, 1, 1, 1, 1, 0]
+    for i in range(6):
+        if not has_hand[i]:
+            assert crop_box[i].cpu().tolist() == [0, 0, 0, 0] and float(crops[i].abs().max()) == 0.0
+            continue
+        hb = torch.tensor([b for b, l in zip(boxes[i], labels[i]) if l == 2][:1])
+        ref_box = handnet_ref.crop_box(hb, 640, 480)
+        assert crop_box[i].cpu().tolist() == ref_box.tolist()          # int64, bit-exact
+        ref_crop = handnet_ref.crop_depth(depth[i], ref_box)
+        assert torch.equal(crops[i, :, :, 0].cpu(), ref_crop[0])         # pure gather, bit-exact
+        assert float(crops[i, :, :, 1:].abs().max()) == 0.0
+
+
+def test_crop_degenerate_box_counts_as_no_hand():
+    from hn_amd import ops
+    depth = torch.ones((1, 1, 480, 640))
+    det = _dets_from_boxes([[[700.0, 100.0, 760.0, 200.0]]], [[2]])  # entirely right of the image
+    crop_box, has_hand, crops = ops.crop_resize(det, 2, depth.cuda(), 176, 4)
+    assert has_hand.cpu().tolist() == [0] and float(crops.abs().max()) == 0.0
+
+
+@pytest.fixture(scope="module")
+def handnet(fcos_sd, a2j_sd):
+    from handnet_pipeline.handnet_pipeline import HandNet
+    args = types.SimpleNamespace(pretrained_fcos="unused.pth", pretrained_a2j="unused.pth")
+    net = HandNet(args, reload_detector=False, num_classes=3, reload_a2j=False, RGBD=False)
+    net.detector.load_state_dict(fcos_sd, strict=False)
+    net.a2j.load_state_dict(a2j_sd, strict=False)
+    return net.cuda().eval()
+
+
+def test_handnet_matches_reference_golden(handnet, golden_dir):
+    """Same call as ros_demo.py:270; compared with what the imported reference returned."""
+    from hn_amd import synth
+    g = np.load(golden_dir / "handnet_forward.npz")
+    rgb = synth.make_rgb(2, seed=int(g["rgb_seed"])).cuda()
+    depth = synth.make_depth(2, seed=int(g["depth_seed"])).cuda()
+    with torch.inference_mode():
+        kp, depth_batch, crops = handnet([rgb[0], rgb[1]], depth_images=depth)
+    assert kp.device.type == "cpu" and kp.shape == (2, 21, 3) and kp.dtype == torch.float32
+    assert crops.dtype == torch.int64 and crops.is_cuda and depth_batch.is_cuda
+    assert depth_batch.shape == (2, 1, 176, 176)
+    assert np.array_equal(crops.cpu().numpy(), g["crops"])                       # int boxes bit-exact
+    assert np.array_equal(depth_batch[:, 0, ::16, ::16].cpu().numpy(), g["depth_batch_probe"])
+    assert abs(depth_batch.double().sum().item() - float(g["depth_batch_sum"])) < 1e-6
+    assert np.abs(kp.numpy() - g["keypoints"]).max() < 1e-3                      # north_star tolerance
+
+
+def test_handnet_contract_branches(handnet):
+    from handnet_pipeline import HandNetPipeline
+    from hn_amd import synth
+    assert HandNetPipeline is type(handnet)
+    rgb = synth.make_rgb(1, seed=5).cuda()
+    depth = synth.make_depth(1, seed=6).cuda()
+    assert handnet([rgb[0]], depth_images=depth, is_detect=True) is None
+    assert handnet([rgb[0]], depth_images=depth, is_3D=True) is None
+    # no detection: a black frame scores below 0.7 everywhere?  force it by demanding a class that never wins
+    old = handnet.num_classes
+    handnet._invalidate_all()
+    handnet.num_classes = 99
+    try:
+        kp, db, cr = handnet([rgb[0]], depth_images=depth)
+    finally:
+        handnet.num_classes = old
+        handnet._invalidate_all()
+    assert kp.shape == (1, 21, 3) and float(kp.abs().max()) == 0.0
+    assert db.shape == depth.shape and float(db.abs().max()) == 0.0
+    assert cr.shape == (1, 4) and cr.dtype == torch.float32
+
+
+def test_pipeline_batch_consistency_and_graph(handnet):
+    """Frames are independent: a batch-8 run equals per-frame runs (the property the multi-GPU
+    sharding relies on), and a hipGraph replay equals the eager run."""
+    from hn_amd import synth
+    rgb = synth.make_rgb(8, seed=1000).cuda()
+    depth = synth.make_depth(8, seed=2000).cuda()
+    eng = handnet.engine()
+    full = eng.forward_device(rgb, depth)
+    assert int(full.has_hand.sum()) >= 6
+    for i in (0, 5):
+        one = eng.forward_device(rgb[i:i + 1], depth[i:i + 1])
+        assert torch.equal(one.crop_box[0], full.crop_box[i])
+        assert (one.keypoints[0] - full.keypoints[i]).abs().max().item() < 1e-4
+    run, s_img, s_dep, out = eng.graphed(rgb, depth)
+    s_img.copy_(rgb)
+    s_dep.copy_(depth)
+    run()
+    torch.cuda.synchronize()
+    assert torch.equal(out.crop_box, full.crop_box)
+    assert (out.keypoints - full.keypoints).abs().max().item() < 1e-5
