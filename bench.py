@@ -132,7 +132,9 @@ def cpu_baseline(args, sds):
     """Oracle (CPU restatement of the reference path) on a bounded sample, all host cores."""
     from hn_amd import synth
     from oracle import a2j_ref, handnet_ref
-    threads = os.cpu_count() or 1
+    # one GPU's share of the host is 16 cores on the benchmark boxes; more threads than that
+    # makes torch's CPU convolutions slower, not faster (measured: 256 threads = 50x slower)
+    threads = int(os.environ.get("HN_CPU_THREADS", min(os.cpu_count() or 1, 16)))
     torch.set_num_threads(threads)
     n = args.cpu_frames
     if args.workload == "a2j":

@@ -1,0 +1,88 @@
+"""N > 1 path on CPU: two gloo ranks shard a batch, run the (CPU oracle) per-frame stage on
+their shard, all-gather the fixed-size records with hn_amd.dist.gather_results, and every
+rank must end up with exactly the single-process result in global frame order."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+REPO = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_stage(frames: torch.Tensor):
+    """Deterministic per-frame function standing in for the GPU pipeline (frames are independent)."""
+    n = frames.shape[0]
+    kp = torch.stack([torch.arange(63, dtype=torch.float32).reshape(21, 3) * 0.01 + frames[i].sum() for i in range(n)])
+    box = torch.stack([torch.tensor([int(frames[i, 0] * 100), 2, 30 + int(frames[i, 1] * 50), 40], dtype=torch.int64)
+                       for i in range(n)])
+    has = (frames[:, 0] > 0.2).to(torch.int32)
+    return kp, box, has
+
+
+def _worker(rank, world, port, total, out_dir):
+    for p in (str(REPO), str(REPO / "handnet-pipeline_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from hn_amd import dist as hdist
+    r, _, w = hdist.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    g = torch.Generator().manual_seed(123)
+    frames = torch.rand((total, 4), generator=g)
+    lo, hi = hdist.shard_bounds(total, rank, world)
+    per_rank = -(-total // world)
+    kp, box, has = _fake_stage(frames[lo:hi])
+    gk, gb, gh, valid = hdist.gather_results(kp, box, has, per_rank=per_rank)
+    ck, cb, ch = hdist.compact_gathered(gk, gb, gh, valid)
+    torch.save((ck, cb, ch), os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [8, 7])
+def test_two_rank_gather_equals_single_process(tmp_path, total):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, total, str(tmp_path)), nprocs=2, join=True)
+    g = torch.Generator().manual_seed(123)
+    frames = torch.rand((total, 4), generator=g)
+    kp, box, has = _fake_stage(frames)
+    for rank in range(2):
+        ck, cb, ch = torch.load(tmp_path / f"rank{rank}.pt")
+        assert torch.equal(ck, kp) and torch.equal(cb, box) and torch.equal(ch, has)
+        assert cb.dtype == torch.int64 and ch.dtype == torch.int32
+
+
+def test_shard_bounds_cover_batch():
+    from hn_amd.dist import shard_bounds
+    for total in (1, 7, 32, 255, 256):
+        for world in (1, 2, 4, 8):
+            spans = [shard_bounds(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_single_process_gather_is_identity():
+    from hn_amd.dist import compact_gathered, gather_results
+    kp = torch.rand((3, 21, 3))
+    box = torch.randint(0, 600, (3, 4))
+    has = torch.tensor([1, 0, 1], dtype=torch.int32)
+    gk, gb, gh, valid = gather_results(kp, box, has, per_rank=5)
+    assert gk.shape == (5, 21, 3) and valid.tolist() == [True, True, True, False, False]
+    ck, cb, ch = compact_gathered(gk, gb, gh, valid)
+    assert torch.equal(ck, kp) and torch.equal(cb, box) and torch.equal(ch, has)
