@@ -11,7 +11,7 @@ from pathlib import Path
 
 from . import build as _build
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 HN_PREC_F32, HN_PREC_F16 = 0, 1
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, TILE_256x128, TILE_64x128 = range(7)
@@ -51,6 +51,8 @@ SIGNATURES = {
     "hn_event_elapsed_ms": (C.c_int, [VP, VP, c_f32p]),
     "hn_conv2d_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), VP, VP, VP, VP, VP, VP, VP, VP]),
     "hn_conv2d_pick_tile": (C.c_int, [C.POINTER(ConvDesc)]),
+    "hn_conv2d_nhwc_f16x3": (C.c_int, [C.POINTER(ConvDesc), VP, VP, VP, VP, VP, VP, VP, VP]),
+    "hn_conv2d_f16x3_pick_tile": (C.c_int, [C.POINTER(ConvDesc)]),
     "hn_maxpool3x3s2_nhwc_f32": (C.c_int, [VP, VP] + [C.c_int] * 6 + [VP]),
     "hn_groupnorm_scratch_floats": (C.c_int64, [C.c_int] * 4),
     "hn_groupnorm_affine_f32": (C.c_int, [VP, VP, VP] + [C.c_int] * 4 + [C.c_float, VP, VP, VP, VP]),

@@ -18,7 +18,12 @@ ANCHORS_PER_CELL = 16
 
 
 class A2JEngine:
-    def __init__(self, state_dict, num_joints: int = 21, rgbd: bool = False, device="cuda"):
+    def __init__(self, state_dict, num_joints: int = 21, rgbd: bool = False, device="cuda", precision="f16x3"):
+        """precision: "f16x3" (split-fp16 operands on the f16 MFMA, fp32-grade results; default)
+        or "f32" (exact f32 MFMA).  Layers with Cin % 32 != 0 (the stem) always run in f32."""
+        if precision not in ("f32", "f16x3"):
+            raise ValueError("precision must be 'f32' or 'f16x3'")
+        self.precision = precision
         sd = strip_prefix(state_dict, "a2j.")
         self.device = torch.device(device)
         self.joints = num_joints
@@ -69,10 +74,10 @@ class A2JEngine:
             raise ValueError("checkpoint does not match num_joints")
 
     # -----------------------------------------------------------------------------------
-    @staticmethod
-    def _conv(x, cw: ConvW, relu=True, residual=None, tile=0, algo_cin=None):
+    def _conv(self, x, cw: ConvW, relu=True, residual=None, tile=0, algo_cin=None):
         return ops.conv2d_nhwc(x, cw.w, cw.bias, stride=cw.stride, pad=cw.pad, dil=cw.dil, relu=relu,
-                               residual=residual, tile=tile, algo_cin=algo_cin)
+                               residual=residual, tile=tile, algo_cin=algo_cin,
+                               w16=cw.w16 if self.precision == "f16x3" else None)
 
     def trunk(self, x):
         """x [K,H,W,4] NHWC -> (x3 [K,H/16,W/16,1024], x4 [K,H/16,W/16,2048])."""

@@ -37,7 +37,12 @@ def resized_size(h: int, w: int, min_size: int = 800, max_size: int = 1333):
 
 
 class FCOSEngine:
-    def __init__(self, state_dict, num_classes: int, device="cuda", min_size=800, max_size=1333):
+    def __init__(self, state_dict, num_classes: int, device="cuda", min_size=800, max_size=1333,
+                 precision="f16x3"):
+        """precision: "f16x3" (split-fp16 operands, fp32-grade; default) or "f32" (exact f32 MFMA)."""
+        if precision not in ("f32", "f16x3"):
+            raise ValueError("precision must be 'f32' or 'f16x3'")
+        self.precision = precision
         sd = state_dict
         dev = torch.device(device)
         self.device = dev
@@ -91,9 +96,9 @@ class FCOSEngine:
         self._gn_scratch = None
 
     # -----------------------------------------------------------------------------------
-    @staticmethod
-    def _conv(x, cw: ConvW, relu=False, **kw):
-        return ops.conv2d_nhwc(x, cw.w, cw.bias, stride=cw.stride, pad=cw.pad, dil=cw.dil, relu=relu, **kw)
+    def _conv(self, x, cw: ConvW, relu=False, **kw):
+        return ops.conv2d_nhwc(x, cw.w, cw.bias, stride=cw.stride, pad=cw.pad, dil=cw.dil, relu=relu,
+                               w16=cw.w16 if self.precision == "f16x3" else None, **kw)
 
     def geometry(self, h, w):
         oh, ow = resized_size(h, w, self.min_size, self.max_size)

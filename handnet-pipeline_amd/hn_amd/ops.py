@@ -62,11 +62,13 @@ TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x64", 4: "128x32", 6: "64x128"}
 
 def conv2d_nhwc(x, w, bias=None, *, stride=1, pad=0, dil=1, relu=False, relu_cols=None,
                 residual=None, res_upsample=False, in_scale=None, in_shift=None, out=None, tile=0,
-                algo_cin=None):
+                algo_cin=None, w16=None):
     """x [N,H,W,Cin] fp32, w [Cout,R,S,Cin] fp32 -> y [N,OH,OW,Cout].
 
     algo_cin: input channels the reference's conv really has when Cin is zero-padded
-    (only used for FLOP accounting)."""
+    (only used for FLOP accounting).
+    w16: split-fp16 filter bank (weights.split_f16x3); when given the conv runs on the f16
+    MFMA with split operands (hn_conv2d_nhwc_f16x3) instead of the f32 MFMA."""
     lib = _lib.load()
     _req(w, name="w")
     if not x.is_cuda or x.dtype != torch.float32:
@@ -112,12 +114,23 @@ def conv2d_nhwc(x, w, bias=None, *, stride=1, pad=0, dil=1, relu=False, relu_col
     if prof is not None:
         timer = HipTimer()
         timer.start()
-    check(lib.hn_conv2d_nhwc_f32(C.byref(d), ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(in_scale),
-                                 ptr(in_shift), ptr(out), _stream()), "hn_conv2d_nhwc_f32")
+    if w16 is not None:
+        if (not w16.is_cuda or w16.dtype != torch.float16 or not w16.is_contiguous()
+                or w16.numel() != 2 * w.numel()):
+            raise ValueError("w16 must be the contiguous fp16 GPU tensor produced by weights.split_f16x3(w)")
+        check(lib.hn_conv2d_nhwc_f16x3(C.byref(d), ptr(x), ptr(w16), ptr(bias), ptr(residual), ptr(in_scale),
+                                       ptr(in_shift), ptr(out), _stream()), "hn_conv2d_nhwc_f16x3")
+    else:
+        check(lib.hn_conv2d_nhwc_f32(C.byref(d), ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(in_scale),
+                                     ptr(in_shift), ptr(out), _stream()), "hn_conv2d_nhwc_f32")
     if prof is not None:
         timer.stop()
         macs = n * d.oh * d.ow * cout * r * s * (algo_cin or cin)
-        prof.append((lib.hn_conv2d_pick_tile(C.byref(d)), macs, timer, (n, h, wd, cin, cout, r, stride, dil)))
+        if w16 is not None:
+            kind = ("f16x3", lib.hn_conv2d_f16x3_pick_tile(C.byref(d)))
+        else:
+            kind = ("f32", lib.hn_conv2d_pick_tile(C.byref(d)))
+        prof.append((kind, macs, timer, (n, h, wd, cin, cout, r, stride, dil)))
     return out
 
 

@@ -20,10 +20,12 @@ class ConvW:
     stride: int = 1
     pad: int = 0
     dil: int = 1
+    w16: torch.Tensor | None = None  # split-fp16 filter bank for hn_conv2d_nhwc_f16x3 (Cin % 32 == 0 only)
 
     def to(self, device):
+        w16 = split_f16x3(self.w).to(device) if self.w.shape[3] % 32 == 0 else None
         return ConvW(self.w.to(device).contiguous(), None if self.bias is None else self.bias.to(device).contiguous(),
-                     self.stride, self.pad, self.dil)
+                     self.stride, self.pad, self.dil, w16)
 
     @property
     def cout(self):
@@ -36,6 +38,18 @@ class ConvW:
     def macs_per_pixel(self, real_cin=None):
         r, s = self.w.shape[1], self.w.shape[2]
         return self.cout * r * s * (real_cin or self.cin)
+
+
+def split_f16x3(w: torch.Tensor) -> torch.Tensor:
+    """[Cout,R,S,Cin] fp32 -> fp16 [Cout, R*S*Cin/32, 2, 32]: per 32-k tile the hi run then the
+    lo run, hi = fp16(w), lo = fp16(w - hi) (hi + lo carries 22 significant bits of w)."""
+    cout = w.shape[0]
+    flat = w.reshape(cout, -1).float()
+    if flat.shape[1] % 32:
+        raise ValueError("split_f16x3 needs R*S*Cin to be a multiple of 32")
+    hi = flat.half()
+    lo = (flat - hi.float()).half()
+    return torch.stack([hi.reshape(cout, -1, 32), lo.reshape(cout, -1, 32)], dim=2).contiguous()
 
 
 def _pad_to(c: int, m: int) -> int:

@@ -33,7 +33,7 @@ extern "C" {
 #define HN_ERR_HIP 2
 
 /* ABI version; bumped whenever a struct below changes. */
-#define HN_ABI_VERSION 6
+#define HN_ABI_VERSION 7
 int hn_abi_version(void);
 const char* hn_last_error(void);
 
@@ -94,8 +94,19 @@ int hn_conv2d_nhwc_f32(const hn_conv_desc* d, const float* x, const float* w,
                        const float* in_scale, const float* in_shift /* [n][cin] or NULL */,
                        float* y, void* stream);
 
-/* Number of workgroups the auto heuristic would launch (host-only; for tests/plans). */
+/* Tile id (HN_TILE_*) the auto heuristic picks for this shape (host-only; for tests/plans). */
 int hn_conv2d_pick_tile(const hn_conv_desc* d);
+
+/* Same convolution on the f16 MFMA with SPLIT operands: every fp32 value v = hi + lo,
+ * hi = fp16(v), lo = fp16(v - hi); a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi accumulated in
+ * fp32 (fp32-grade result, 16/3 x the f32-MFMA rate).  x / y / bias / residual stay fp32.
+ * w16 is the filter bank split on the host: fp16 [cout][r*s*cin/32][2][32] (hi run, lo run
+ * of each 32-k tile; k = (r, s, c) with c fastest).  Requires cin % 32 == 0. */
+int hn_conv2d_nhwc_f16x3(const hn_conv_desc* d, const float* x, const void* w16,
+                         const float* bias, const float* residual,
+                         const float* in_scale, const float* in_shift,
+                         float* y, void* stream);
+int hn_conv2d_f16x3_pick_tile(const hn_conv_desc* d);
 
 /* 3x3 / stride-2 / pad-1 max pooling, NHWC fp32 (c % 4 == 0).
  * Replaces nn.MaxPool2d at a2j/resnet.py:107,158 and tv resnet34 stem. */

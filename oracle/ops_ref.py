@@ -12,7 +12,8 @@ import torch.nn.functional as F
 def conv2d_nhwc(x, w, bias=None, stride=1, pad=0, dil=1, relu_cols=0, residual=None, res_upsample=False,
                 in_scale=None, in_shift=None):
     """x [N,H,W,Cin], w [Cout,R,S,Cin] (packed layout) -> [N,OH,OW,Cout]."""
-    x = x.float()
+    # dtype follows the inputs: fp32 for the per-op parity tests, fp64 where a test wants an
+    # "exact" value to measure fp32-grade error against
     if in_scale is not None:
         x = torch.relu(x * in_scale[:, None, None, :] + in_shift[:, None, None, :])
     y = F.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), bias, stride=stride, padding=pad, dilation=dil)

@@ -122,3 +122,77 @@ def test_bad_arguments_fail_loudly():
         ops.conv2d_nhwc(x, w, None, pad=1)
     with pytest.raises(RuntimeError, match="GPU"):
         ops.conv2d_nhwc(torch.zeros((1, 8, 8, 4)), torch.zeros((8, 3, 3, 4), device="cuda"))
+
+
+# ---- split-fp16 ("f16x3") convolution: fp32-grade results on the f16 MFMA ----
+F16X3_CASES = [
+    (2, 44, 44, 64, 256, 1, 1, 0, 1),
+    (2, 44, 44, 64, 64, 3, 1, 1, 1),
+    (2, 44, 44, 128, 128, 3, 2, 1, 1),
+    (3, 11, 11, 512, 512, 3, 1, 2, 2),
+    (2, 44, 44, 256, 512, 1, 2, 0, 1),
+    (2, 11, 11, 256, 336, 3, 1, 1, 1),
+    (1, 25, 34, 256, 5, 3, 1, 1, 1),
+    (1, 13, 17, 32, 48, 3, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", F16X3_CASES)
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6])
+def test_conv_f16x3_matches_fp64_reference(case, tile):
+    """Error budget: operands carry 22 bits (hi+lo), products exact, fp32 accumulate =>
+    same 1e-4*scale bar as the exact-f32 kernel, checked against an fp64 convolution."""
+    from hn_amd import ops
+    from hn_amd.weights import split_f16x3
+    from oracle import ops_ref
+    n, h, w, cin, cout, r, stride, pad, dil = case
+    x = _rand((n, h, w, cin), 21)
+    wt = _rand((cout, r, r, cin), 22, scale=(2.0 / (cin * r * r)) ** 0.5)
+    b = _rand((cout,), 23, 0.1)
+    ref = ops_ref.conv2d_nhwc(x.double(), wt.double(), b.double(), stride, pad, dil, relu_cols=cout).float()
+    y = ops.conv2d_nhwc(x.cuda(), wt.cuda(), b.cuda(), stride=stride, pad=pad, dil=dil, relu=True, tile=tile,
+                        w16=split_f16x3(wt).cuda())
+    _check(y, ref, f"f16x3 case {case} tile {tile}")
+    # and it must be fp32-grade, not fp16-grade: two orders below the fp16 rounding level
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((y.cpu() - ref).abs().max()) <= 2e-5 * scale
+
+
+def test_conv_f16x3_small_magnitudes_keep_precision():
+    """lo parts of O(1e-2) activations / weights are fp16 SUBNORMALS (~1e-5 < 6.1e-5): they must
+    not be flushed by the MFMA (relative error stays ~3e-6; a flush would give ~5e-4)."""
+    from hn_amd import ops
+    from hn_amd.weights import split_f16x3
+    from oracle import ops_ref
+    x = _rand((2, 22, 22, 128), 31, 2e-2)
+    wt = _rand((128, 3, 3, 128), 32, 1e-2)
+    ref = ops_ref.conv2d_nhwc(x.double(), wt.double(), None, 1, 1, 1).float()
+    y = ops.conv2d_nhwc(x.cuda(), wt.cuda(), None, pad=1, w16=split_f16x3(wt).cuda()).cpu()
+    rel = float((y - ref).abs().max() / ref.abs().max())
+    assert rel <= 2e-5, rel
+
+
+def test_conv_f16x3_fused_paths():
+    """GroupNorm-on-load + channel-slice views + FPN upsample-add, as the FCOS engine uses them."""
+    from hn_amd import ops
+    from hn_amd.weights import split_f16x3
+    from oracle import ops_ref
+    wide = _rand((2, 25, 34, 512), 41, 2.0) + 0.3
+    gamma = 1.0 + 0.2 * _rand((512,), 42)
+    beta = 0.1 * _rand((512,), 43)
+    wt = _rand((256, 3, 3, 256), 44, (2.0 / 2304) ** 0.5)
+    b = _rand((256,), 45, 0.1)
+    sc, sh = ops.groupnorm_affine(wide.cuda(), gamma.cuda(), beta.cuda(), groups=64)
+    xs = wide[..., 256:].contiguous()
+    xn = ops_ref.groupnorm_relu_nhwc(xs, gamma[256:], beta[256:])
+    ref = ops_ref.conv2d_nhwc(xn, wt, b, pad=1)
+    y = ops.conv2d_nhwc(wide.cuda()[..., 256:], wt.cuda(), b.cuda(), pad=1, in_scale=sc[:, 256:], in_shift=sh[:, 256:],
+                        w16=split_f16x3(wt).cuda())
+    _check(y, ref, "f16x3 GN-on-load over a channel slice")
+    x2 = _rand((2, 50, 68, 64), 46)
+    w2 = _rand((256, 1, 1, 64), 47, 0.1)
+    top = _rand((2, 25, 34, 256), 48)
+    ref2 = ops_ref.conv2d_nhwc(x2, w2, b, residual=top, res_upsample=True)
+    y2 = ops.conv2d_nhwc(x2.cuda(), w2.cuda(), b.cuda(), residual=top.cuda(), res_upsample=True,
+                         w16=split_f16x3(w2).cuda())
+    _check(y2, ref2, "f16x3 fpn lateral")

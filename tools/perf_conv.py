@@ -1,0 +1,40 @@
+"""Time one conv shape (development aid).  usage: perf_conv.py prec tile n h w cin cout r [stride dil iters affine]"""
+import sys
+from pathlib import Path
+R = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(R / "handnet-pipeline_amd"))
+import torch
+from hn_amd import ops
+from hn_amd.weights import split_f16x3
+
+a = sys.argv[1:]
+prec, tile = a[0], int(a[1])
+n, h, w, cin, cout, r = map(int, a[2:8])
+stride = int(a[8]) if len(a) > 8 else 1
+dil = int(a[9]) if len(a) > 9 else 1
+iters = int(a[10]) if len(a) > 10 else 20
+affine = int(a[11]) if len(a) > 11 else 0
+pad = dil * (r // 2)
+g = torch.Generator().manual_seed(0)
+x = torch.randn((n, h, w, cin), generator=g).cuda()
+wt = (torch.randn((cout, r, r, cin), generator=g) * (2.0 / (cin * r * r)) ** 0.5).cuda()
+b = torch.randn((cout,), generator=g).cuda()
+w16 = split_f16x3(wt.cpu()).cuda() if prec == "f16x3" else None
+sc = sh = None
+if affine:
+    sc = torch.rand((n, cin), generator=g).cuda() + 0.5
+    sh = torch.randn((n, cin), generator=g).cuda() * 0.1
+oh, ow = ops.conv_out_size(h, w, r, r, stride, pad, dil)
+y = torch.empty((n, oh, ow, cout), device="cuda")
+kw = dict(stride=stride, pad=pad, dil=dil, relu=True, tile=tile, w16=w16, out=y, in_scale=sc, in_shift=sh)
+for _ in range(3):
+    ops.conv2d_nhwc(x, wt, b, **kw)
+torch.cuda.synchronize()
+t = ops.HipTimer()
+t.start()
+for _ in range(iters):
+    ops.conv2d_nhwc(x, wt, b, **kw)
+t.stop()
+ms = t.elapsed_ms() / iters
+fl = 2.0 * n * oh * ow * cout * r * r * cin
+print(f"{prec} tile={tile} {n}x{h}x{w}x{cin}->{cout} r{r} s{stride} d{dil} aff{affine}: {ms*1e3:.1f} us  {fl/ms/1e9:.1f} TFLOP/s")
