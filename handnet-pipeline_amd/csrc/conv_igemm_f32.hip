@@ -37,6 +37,7 @@ struct ConvParams {
   int relu_cols, res_mode, res_h, res_w, in_affine;
   int xs, ys;  // pixel strides (floats) of x and y: channel-slice views of wider tensors
   int as;      // row stride (floats) of the in_scale / in_shift tables
+  int out_split;  // write y as an S32 split tensor (ys is then in halfs)
   int tiles_m, tiles_n, nblocks;
 };
 
@@ -233,7 +234,14 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
         if (p.bias) v += p.bias[n];
         if (p.res_mode) v += p.res[rbase + n];
         if (n < p.relu_cols) v = fmaxf(v, 0.f);
-        p.y[(long)m * p.ys + n] = v;
+        if (p.out_split) {
+          _Float16* q = reinterpret_cast<_Float16*>(p.y) + (long)m * p.ys + (n >> 5) * 64 + (n & 31);
+          const _Float16 h = (_Float16)v;
+          q[0] = h;
+          q[32] = (_Float16)(v - (float)h);
+        } else {
+          p.y[(long)m * p.ys + n] = v;
+        }
       }
     }
   }
@@ -285,9 +293,10 @@ extern "C" int hn_conv2d_nhwc_f32(const hn_conv_desc* d, const float* x, const f
   HN_CHECK_ARG(d->res_mode != 2 || (d->res_h > 0 && d->res_w > 0), "res_mode 2 needs res_h/res_w");
   HN_CHECK_ARG(!d->in_affine || (in_scale && in_shift), "in_affine set but scale/shift null");
   HN_CHECK_ARG(d->in_pix_stride == 0 || (d->in_pix_stride >= d->cin && d->in_pix_stride % 4 == 0), "bad in_pix_stride");
-  HN_CHECK_ARG(d->out_pix_stride == 0 || d->out_pix_stride >= d->cout, "bad out_pix_stride");
+  HN_CHECK_ARG(d->out_pix_stride == 0 || d->out_pix_stride >= (d->out_split ? 2 : 1) * d->cout, "bad out_pix_stride");
   HN_CHECK_ARG(d->in_affine_stride == 0 || (d->in_affine_stride >= d->cin && d->in_affine_stride % 4 == 0), "bad in_affine_stride");
-  HN_CHECK_ARG(d->precision == HN_PREC_F32, "hn_conv2d_nhwc_f32 handles HN_PREC_F32 only");
+  HN_CHECK_ARG(!d->out_split || d->cout % 32 == 0, "S32 output needs cout %% 32 == 0 (got %d)", d->cout);
+  HN_CHECK_ARG(!d->res_split, "the f32 kernel takes fp32 residuals only");
   HN_CHECK_ARG((int64_t)d->n * d->h * d->w * d->cin < (int64_t)1 << 40, "input too large");
   HN_CHECK_ARG((int64_t)d->n * d->oh * d->ow < (int64_t)1 << 31, "too many output pixels");
 
@@ -301,7 +310,8 @@ extern "C" int hn_conv2d_nhwc_f32(const hn_conv_desc* d, const float* x, const f
   p.relu_cols = d->relu_cols; p.res_mode = d->res_mode; p.res_h = d->res_h; p.res_w = d->res_w;
   p.in_affine = d->in_affine;
   p.xs = d->in_pix_stride ? d->in_pix_stride : d->cin;
-  p.ys = d->out_pix_stride ? d->out_pix_stride : d->cout;
+  p.out_split = d->out_split;
+  p.ys = d->out_pix_stride ? d->out_pix_stride : (d->out_split ? 2 : 1) * d->cout;
   p.as = d->in_affine_stride ? d->in_affine_stride : d->cin;
   p.tiles_m = p.tiles_n = p.nblocks = 0;
   const bool smallc = (d->cin % BK) != 0;

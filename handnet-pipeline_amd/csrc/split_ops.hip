@@ -1,0 +1,188 @@
+// HBM-bound producers / consumers of the "S32" split activation format used by the f16x3
+// convolutions (conv_igemm_f16x3.hip):   fp16 [N][H][W][C/32][2][32], per pixel and 32-channel
+// block a 128-byte run hi[32] | lo[32] with hi = fp16(v), lo = fp16(v - hi).
+//
+//   hn_affine_split_f32   fp32 NHWC -> S32, optionally y = relu(x*scale[img][c] + shift[img][c])
+//                         first: this is the GroupNorm(32,256)+ReLU of the FCOS towers
+//                         (fcos_utils/fcos.py:232-239,352-359) applied between two convs
+//   hn_unsplit_f32        S32 -> fp32 (hi + lo is exact in fp32)
+//   hn_maxpool3x3s2_s32   3x3/2 max pooling on S32 (the max element's (hi, lo) pair is copied,
+//                         so pooling commutes with the split exactly)
+#include "hn_common.h"
+
+#include <float.h>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, f16x8& hi, f16x8& lo) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const _Float16 h0 = (_Float16)a[e], h1 = (_Float16)b[e];
+    hi[e] = h0;
+    hi[4 + e] = h1;
+    lo[e] = (_Float16)(a[e] - (float)h0);
+    lo[4 + e] = (_Float16)(b[e] - (float)h1);
+  }
+}
+
+// one thread = one pixel x 8 channels: reads 32 B fp32, writes 16 B hi + 16 B lo
+__global__ __launch_bounds__(256) void affine_split_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, int relu, long npix,
+                                                           int hw, int c, int xs, int as,
+                                                           _Float16* __restrict__ y, int ys) {
+  const int c8 = c >> 3;
+  const long total = npix * c8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long pix = i / c8;
+    const int ch = (int)(i - pix * c8) * 8;
+    const float* src = x + pix * xs + ch;
+    f32x4 a = *reinterpret_cast<const f32x4*>(src);
+    f32x4 b = *reinterpret_cast<const f32x4*>(src + 4);
+    if (scale) {
+      const long o = (pix / hw) * as + ch;
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale + o), s1 = *reinterpret_cast<const f32x4*>(scale + o + 4);
+      const f32x4 t0 = *reinterpret_cast<const f32x4*>(shift + o), t1 = *reinterpret_cast<const f32x4*>(shift + o + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a[e] = a[e] * s0[e] + t0[e];
+        b[e] = b[e] * s1[e] + t1[e];
+      }
+    }
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a[e] = fmaxf(a[e], 0.f);
+        b[e] = fmaxf(b[e], 0.f);
+      }
+    }
+    f16x8 hi, lo;
+    split8(a, b, hi, lo);
+    _Float16* dst = y + pix * ys + (ch >> 5) * 64 + (ch & 31);
+    *reinterpret_cast<f16x8*>(dst) = hi;
+    *reinterpret_cast<f16x8*>(dst + 32) = lo;
+  }
+}
+
+__global__ __launch_bounds__(256) void unsplit_kernel(const _Float16* __restrict__ x, long npix, int c, int xs,
+                                                      float* __restrict__ y, int ys) {
+  const int c8 = c >> 3;
+  const long total = npix * c8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long pix = i / c8;
+    const int ch = (int)(i - pix * c8) * 8;
+    const _Float16* src = x + pix * xs + (ch >> 5) * 64 + (ch & 31);
+    const f16x8 hi = *reinterpret_cast<const f16x8*>(src);
+    const f16x8 lo = *reinterpret_cast<const f16x8*>(src + 32);
+    f32x4 a, b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      a[e] = (float)hi[e] + (float)lo[e];
+      b[e] = (float)hi[4 + e] + (float)lo[4 + e];
+    }
+    float* dst = y + pix * ys + ch;
+    *reinterpret_cast<f32x4*>(dst) = a;
+    *reinterpret_cast<f32x4*>(dst + 4) = b;
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool_s32_kernel(const _Float16* __restrict__ x, _Float16* __restrict__ y,
+                                                          int n, int h, int w, int c, int oh, int ow) {
+  const int c8 = c >> 3;
+  const long total = (long)n * oh * ow * c8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c8) * 8;
+    long pix = i / c8;
+    const long opix = pix;
+    const int x_ = (int)(pix % ow);
+    pix /= ow;
+    const int y_ = (int)(pix % oh);
+    const int img = (int)(pix / oh);
+    const int off = (cc >> 5) * 64 + (cc & 31);
+    float best[8];
+    f16x8 bh, bl;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      best[e] = -FLT_MAX;
+      bh[e] = (_Float16)0;
+      bl[e] = (_Float16)0;
+    }
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int iy = y_ * 2 - 1 + dy;
+      if ((unsigned)iy >= (unsigned)h) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int ix = x_ * 2 - 1 + dx;
+        if ((unsigned)ix >= (unsigned)w) continue;
+        const _Float16* src = x + (((long)img * h + iy) * w + ix) * (2 * c) + off;
+        const f16x8 hi = *reinterpret_cast<const f16x8*>(src);
+        const f16x8 lo = *reinterpret_cast<const f16x8*>(src + 32);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float v = (float)hi[e] + (float)lo[e];
+          if (v > best[e]) {
+            best[e] = v;
+            bh[e] = hi[e];
+            bl[e] = lo[e];
+          }
+        }
+      }
+    }
+    _Float16* dst = y + opix * (2 * c) + off;
+    *reinterpret_cast<f16x8*>(dst) = bh;
+    *reinterpret_cast<f16x8*>(dst + 32) = bl;
+  }
+}
+
+int grid_for(long total) {
+  const long g = (total + 255) / 256;
+  return (int)(g < 16384 ? (g > 0 ? g : 1) : 16384);
+}
+
+}  // namespace
+
+extern "C" int hn_affine_split_f32(const float* x, const float* scale, const float* shift, int relu, int n, int hw,
+                                   int c, int in_pix_stride, int affine_stride, void* y16, int out_pix_stride,
+                                   void* stream) {
+  HN_CHECK_ARG(x && y16, "hn_affine_split_f32: null pointer");
+  HN_CHECK_ARG((scale == nullptr) == (shift == nullptr), "scale and shift must be given together");
+  HN_CHECK_ARG(n > 0 && hw > 0 && c > 0 && c % 32 == 0, "bad dims (c must be a multiple of 32)");
+  const int xs = in_pix_stride ? in_pix_stride : c;
+  const int as = affine_stride ? affine_stride : c;
+  const int ys = out_pix_stride ? out_pix_stride : 2 * c;
+  HN_CHECK_ARG(xs >= c && xs % 4 == 0 && as >= c && as % 4 == 0 && ys >= 2 * c && ys % 64 == 0, "bad strides");
+  const long npix = (long)n * hw;
+  hipLaunchKernelGGL(affine_split_kernel, dim3(grid_for(npix * (c / 8))), dim3(256), 0, (hipStream_t)stream, x, scale,
+                     shift, relu, npix, hw, c, xs, as, (_Float16*)y16, ys);
+  HN_CHECK_LAUNCH("affine_split_kernel");
+  return HN_OK;
+}
+
+extern "C" int hn_unsplit_f32(const void* x16, int n, int hw, int c, int in_pix_stride, float* y, int out_pix_stride,
+                              void* stream) {
+  HN_CHECK_ARG(x16 && y, "hn_unsplit_f32: null pointer");
+  HN_CHECK_ARG(n > 0 && hw > 0 && c > 0 && c % 32 == 0, "bad dims (c must be a multiple of 32)");
+  const int xs = in_pix_stride ? in_pix_stride : 2 * c;
+  const int ys = out_pix_stride ? out_pix_stride : c;
+  HN_CHECK_ARG(xs >= 2 * c && xs % 64 == 0 && ys >= c && ys % 4 == 0, "bad strides");
+  const long npix = (long)n * hw;
+  hipLaunchKernelGGL(unsplit_kernel, dim3(grid_for(npix * (c / 8))), dim3(256), 0, (hipStream_t)stream,
+                     (const _Float16*)x16, npix, c, xs, y, ys);
+  HN_CHECK_LAUNCH("unsplit_kernel");
+  return HN_OK;
+}
+
+extern "C" int hn_maxpool3x3s2_s32(const void* x16, void* y16, int n, int h, int w, int c, int oh, int ow,
+                                   void* stream) {
+  HN_CHECK_ARG(x16 && y16, "hn_maxpool3x3s2_s32: null pointer");
+  HN_CHECK_ARG(n > 0 && h > 0 && w > 0 && c > 0 && c % 32 == 0, "bad dims (c must be a multiple of 32)");
+  HN_CHECK_ARG(oh == (h + 2 - 3) / 2 + 1 && ow == (w + 2 - 3) / 2 + 1, "output size mismatch");
+  const long total = (long)n * oh * ow * (c / 8);
+  hipLaunchKernelGGL(maxpool_s32_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const _Float16*)x16, (_Float16*)y16, n, h, w, c, oh, ow);
+  HN_CHECK_LAUNCH("maxpool_s32_kernel");
+  return HN_OK;
+}

@@ -11,9 +11,8 @@ from pathlib import Path
 
 from . import build as _build
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
-HN_PREC_F32, HN_PREC_F16 = 0, 1
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, TILE_256x128, TILE_64x128 = range(7)
 HN_FCOS_MAX_LEVELS = 5
 
@@ -25,8 +24,8 @@ c_i64p = C.POINTER(C.c_int64)
 class ConvDesc(C.Structure):
     _fields_ = [(k, C.c_int32) for k in (
         "n", "h", "w", "cin", "cout", "r", "s", "stride", "pad", "dil", "oh", "ow",
-        "relu_cols", "res_mode", "res_h", "res_w", "in_affine", "tile", "precision",
-        "stats", "stats_group", "in_pix_stride", "out_pix_stride", "in_affine_stride")]
+        "relu_cols", "res_mode", "res_h", "res_w", "in_affine", "tile", "out_split", "res_split",
+        "res_pix_stride", "in_pix_stride", "out_pix_stride", "in_affine_stride")]
 
 
 class FcosLevels(C.Structure):
@@ -51,7 +50,10 @@ SIGNATURES = {
     "hn_event_elapsed_ms": (C.c_int, [VP, VP, c_f32p]),
     "hn_conv2d_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), VP, VP, VP, VP, VP, VP, VP, VP]),
     "hn_conv2d_pick_tile": (C.c_int, [C.POINTER(ConvDesc)]),
-    "hn_conv2d_nhwc_f16x3": (C.c_int, [C.POINTER(ConvDesc), VP, VP, VP, VP, VP, VP, VP, VP]),
+    "hn_conv2d_nhwc_f16x3": (C.c_int, [C.POINTER(ConvDesc), VP, VP, VP, VP, VP, VP]),
+    "hn_affine_split_f32": (C.c_int, [VP, VP, VP] + [C.c_int] * 6 + [VP, C.c_int, VP]),
+    "hn_unsplit_f32": (C.c_int, [VP] + [C.c_int] * 4 + [VP, C.c_int, VP]),
+    "hn_maxpool3x3s2_s32": (C.c_int, [VP, VP] + [C.c_int] * 6 + [VP]),
     "hn_conv2d_f16x3_pick_tile": (C.c_int, [C.POINTER(ConvDesc)]),
     "hn_maxpool3x3s2_nhwc_f32": (C.c_int, [VP, VP] + [C.c_int] * 6 + [VP]),
     "hn_groupnorm_scratch_floats": (C.c_int64, [C.c_int] * 4),

@@ -74,13 +74,16 @@ class A2JEngine:
             raise ValueError("checkpoint does not match num_joints")
 
     # -----------------------------------------------------------------------------------
-    def _conv(self, x, cw: ConvW, relu=True, residual=None, tile=0, algo_cin=None):
+    def _conv(self, x, cw: ConvW, relu=True, residual=None, tile=0, algo_cin=None, out_f32=False):
+        """f16x3 mode: activations travel in the S32 split format (written by each epilogue, read by
+        LDS-DMA); only the stem (Cin = 4) runs on the f32 kernel and only head outputs are fp32."""
+        s16 = self.precision == "f16x3"
         return ops.conv2d_nhwc(x, cw.w, cw.bias, stride=cw.stride, pad=cw.pad, dil=cw.dil, relu=relu,
                                residual=residual, tile=tile, algo_cin=algo_cin,
-                               w16=cw.w16 if self.precision == "f16x3" else None)
+                               w16=cw.w16 if s16 else None, out_split=s16 and not out_f32)
 
     def trunk(self, x):
-        """x [K,H,W,4] NHWC -> (x3 [K,H/16,W/16,1024], x4 [K,H/16,W/16,2048])."""
+        """x [K,H,W,4] NHWC fp32 -> (x3 [K,H/16,W/16,1024], x4 [K,H/16,W/16,2048]) (S32 in f16x3 mode)."""
         x = self._conv(x, self.stem, algo_cin=4 if self.rgbd else 3)
         x = ops.maxpool3x3s2_nhwc(x)
         x3 = None
@@ -98,18 +101,20 @@ class A2JEngine:
         c = x3
         for cw in self.cls_convs:
             c = self._conv(c, cw)
-        cls = self._conv(c, self.cls_out, relu=False)
+        cls = self._conv(c, self.cls_out, relu=False, out_f32=True)
         rd = self._conv(x4, self.regdep_conv1)
-        # the fused tensor is [.., 512]: channels 0..255 regression tower, 256..511 depth tower
+        # the fused tensor has 512 channels: 0..255 regression tower, 256..511 depth tower
         # (read in place as channel-slice views: no copy)
-        r = rd[..., :256]
-        d = rd[..., 256:]
+        if ops.is_split(rd):
+            r, d = rd[:, :, :, :8], rd[:, :, :, 8:]
+        else:
+            r, d = rd[..., :256], rd[..., 256:]
         for cw in self.reg_convs:
             r = self._conv(r, cw)
         for cw in self.dep_convs:
             d = self._conv(d, cw)
-        reg = self._conv(r, self.reg_out, relu=False)
-        dep = self._conv(d, self.dep_out, relu=False)
+        reg = self._conv(r, self.reg_out, relu=False, out_f32=True)
+        dep = self._conv(d, self.dep_out, relu=False, out_f32=True)
         return cls, reg, dep
 
     def forward_nhwc(self, x, valid=None, return_heads=False):
@@ -117,6 +122,8 @@ class A2JEngine:
         cls, reg, dep = self.heads(x3, x4)
         out = ops.a2j_aggregate(cls, reg, dep, joints=self.joints, stride=16, valid=valid)
         if return_heads:
+            if ops.is_split(x3):
+                x3, x4 = ops.from_split(x3), ops.from_split(x4)
             return out, (x3, x4), (cls, reg, dep)
         return out
 

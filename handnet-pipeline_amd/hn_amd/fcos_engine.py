@@ -96,9 +96,13 @@ class FCOSEngine:
         self._gn_scratch = None
 
     # -----------------------------------------------------------------------------------
-    def _conv(self, x, cw: ConvW, relu=False, **kw):
+    def _conv(self, x, cw: ConvW, relu=False, out_f32=False, **kw):
+        """f16x3 mode: activations travel in the S32 split format (written by each epilogue, read by
+        LDS-DMA); the stem (Cin = 4) runs on the f32 kernel; tower outputs that feed GroupNorm and
+        the final head outputs are fp32."""
+        s16 = self.precision == "f16x3"
         return ops.conv2d_nhwc(x, cw.w, cw.bias, stride=cw.stride, pad=cw.pad, dil=cw.dil, relu=relu,
-                               w16=cw.w16 if self.precision == "f16x3" else None, **kw)
+                               w16=cw.w16 if s16 else None, out_split=s16 and not out_f32, **kw)
 
     def geometry(self, h, w):
         oh, ow = resized_size(h, w, self.min_size, self.max_size)
@@ -106,7 +110,7 @@ class FCOSEngine:
         return oh, ow, ph, pw
 
     def backbone(self, x):
-        """x [N,PH,PW,4] -> [P3, P4, P5] (256 channels, strides 8/16/32)."""
+        """x [N,PH,PW,4] fp32 -> [P3, P4, P5] (256 channels, strides 8/16/32; S32 in f16x3 mode)."""
         x = self._conv(x, self.stem, relu=True, algo_cin=3)
         x = ops.maxpool3x3s2_nhwc(x)
         feats = []
@@ -130,19 +134,32 @@ class FCOSEngine:
         return ops.groupnorm_affine(x, gamma, beta, groups=groups, scratch=self._gn_scratch)
 
     def head_level(self, feat):
-        """One FPN level -> (cls_lr [N,h,w,C+2], reg_ctr [N,h,w,5]) raw conv outputs."""
-        t0 = self._conv(feat, self.tower0)                       # [N,h,w,512], pre-GN
+        """One FPN level -> (cls_lr [N,h,w,C+2], reg_ctr [N,h,w,5]) raw fp32 conv outputs.
+
+        conv -> GroupNorm -> ReLU -> conv: each tower conv writes its raw fp32 output, the
+        statistics pass turns GroupNorm into a per-(image, channel) affine, and
+          f16x3: one hn_affine_split_f32 pass applies affine + ReLU and emits the S32 input of
+                 the next conv (whose hot loop is then pure DMA + MFMA);
+          f32  : the next conv applies the affine + ReLU while staging its input (in_affine)."""
+        s16 = self.precision == "f16x3"
+        t0 = self._conv(feat, self.tower0, out_f32=True)          # [N,h,w,512] raw
         sc, sh = self._gn(t0, self.gn0_gamma, self.gn0_beta, 64)  # 2 x GroupNorm(32,256)
         xc, sc_c, sh_c = t0[..., :256], sc[:, :256], sh[:, :256]
         xr, sc_r, sh_r = t0[..., 256:], sc[:, 256:], sh[:, 256:]
+
+        def nxt(x, cw, scale, shift, **kw):
+            if s16:
+                return self._conv(ops.to_split(x, scale, shift, relu=True), cw, out_f32=True, **kw)
+            return self._conv(x, cw, in_scale=scale, in_shift=shift, **kw)
+
         for cw, (g, b) in zip(self.cls_tower, self.cls_gn):
-            xc = self._conv(xc, cw, in_scale=sc_c, in_shift=sh_c)
+            xc = nxt(xc, cw, sc_c, sh_c)
             sc_c, sh_c = self._gn(xc, g, b, 32)
         for cw, (g, b) in zip(self.reg_tower, self.reg_gn):
-            xr = self._conv(xr, cw, in_scale=sc_r, in_shift=sh_r)
+            xr = nxt(xr, cw, sc_r, sh_r)
             sc_r, sh_r = self._gn(xr, g, b, 32)
-        cls_lr = self._conv(xc, self.cls_out, in_scale=sc_c, in_shift=sh_c)
-        reg_ctr = self._conv(xr, self.reg_out, relu_cols=4, in_scale=sc_r, in_shift=sh_r)
+        cls_lr = nxt(xc, self.cls_out, sc_c, sh_c)
+        reg_ctr = nxt(xr, self.reg_out, sc_r, sh_r, relu_cols=4)
         return cls_lr, reg_ctr
 
     def forward_heads(self, images):

@@ -35,72 +35,154 @@ def conv_out_size(h, w, r, s, stride, pad, dil):
             (w + 2 * pad - dil * (s - 1) - 1) // stride + 1)
 
 
+def is_split(t) -> bool:
+    """S32 split activation tensor: fp16 [N,H,W,C/32,2,32] (hi[32] | lo[32] per 32-channel block)."""
+    return t is not None and t.dtype == torch.float16 and t.dim() == 6 and t.shape[4] == 2 and t.shape[5] == 32
+
+
+def channels(t) -> int:
+    return t.shape[3] * 32 if is_split(t) else t.shape[3]
+
+
 def _pixel_stride(t: torch.Tensor, name: str) -> int:
-    """Accept a dense NHWC tensor or a channel slice of one (x[..., c0:c1])."""
-    n, h, w, c = t.shape
+    """Accept a dense NHWC tensor (fp32 or S32) or a channel slice of one (x[..., c0:c1] /
+    xs[:, :, :, b0:b1]).  Returns the pixel stride in elements (floats or halfs)."""
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (no CPU fallback in handnet-pipeline_amd)")
+    n, h, w = t.shape[:3]
     ps = t.stride(2)
-    if t.stride(3) != 1 or t.stride(1) != w * ps or t.stride(0) != h * w * ps or ps < c:
+    if is_split(t):
+        inner_ok = t.stride(5) == 1 and t.stride(4) == 32 and t.stride(3) == 64 and ps >= 64 * t.shape[3]
+    elif t.dtype == torch.float32 and t.dim() == 4:
+        inner_ok = t.stride(3) == 1 and ps >= t.shape[3]
+    else:
+        raise TypeError(f"{name}: expected fp32 [N,H,W,C] or fp16 S32 [N,H,W,C/32,2,32], got {t.dtype} {tuple(t.shape)}")
+    if not inner_ok or t.stride(1) != w * ps or t.stride(0) != h * w * ps:
         raise ValueError(f"{name} must be NHWC-dense or a channel slice of an NHWC-dense tensor")
     return ps
 
 
 def make_conv_desc(n, h, w, cin, cout, r, s, stride=1, pad=0, dil=1, relu_cols=0, res_mode=0,
-                   res_h=0, res_w=0, in_affine=0, tile=0, precision=0, in_pix_stride=0,
-                   out_pix_stride=0) -> ConvDesc:
+                   res_h=0, res_w=0, in_affine=0, tile=0, in_pix_stride=0, out_pix_stride=0) -> ConvDesc:
     oh, ow = conv_out_size(h, w, r, s, stride, pad, dil)
     return ConvDesc(n=n, h=h, w=w, cin=cin, cout=cout, r=r, s=s, stride=stride, pad=pad, dil=dil,
                     oh=oh, ow=ow, relu_cols=relu_cols, res_mode=res_mode, res_h=res_h, res_w=res_w,
-                    in_affine=in_affine, tile=tile, precision=precision, stats=0, stats_group=0,
+                    in_affine=in_affine, tile=tile, out_split=0, res_split=0, res_pix_stride=0,
                     in_pix_stride=in_pix_stride, out_pix_stride=out_pix_stride, in_affine_stride=0)
 
 
+def to_split(x, scale=None, shift=None, relu=False, out=None):
+    """fp32 [N,H,W,C] -> S32 [N,H,W,C/32,2,32]; optional per-(image, channel) affine (+ReLU) first
+    (GroupNorm-apply of the FCOS towers)."""
+    lib = _lib.load()
+    xs = _pixel_stride(x, "x")
+    if is_split(x):
+        raise TypeError("x is already split")
+    n, h, w, c = x.shape
+    if c % 32:
+        raise ValueError("the S32 format needs C % 32 == 0")
+    if out is None:
+        out = torch.empty((n, h, w, c // 32, 2, 32), device=x.device, dtype=torch.float16)
+    ys = _pixel_stride(out, "out")
+    a_stride = 0
+    if scale is not None:
+        for t in (scale, shift):
+            if (not t.is_cuda or t.dtype != torch.float32 or tuple(t.shape) != (n, c) or t.stride(1) != 1
+                    or t.stride(0) != scale.stride(0)):
+                raise ValueError("scale / shift must be fp32 GPU [N, C] tables with equal row stride")
+        a_stride = scale.stride(0)
+    check(lib.hn_affine_split_f32(ptr(x), ptr(scale), ptr(shift), 1 if relu else 0, n, h * w, c, xs, a_stride,
+                                  ptr(out), ys, _stream()), "hn_affine_split_f32")
+    return out
+
+
+def from_split(xs16, out=None):
+    """S32 -> fp32 [N,H,W,C] (exact)."""
+    lib = _lib.load()
+    ps = _pixel_stride(xs16, "x")
+    if not is_split(xs16):
+        raise TypeError("x is not an S32 tensor")
+    n, h, w, nb = xs16.shape[:4]
+    if out is None:
+        out = torch.empty((n, h, w, nb * 32), device=xs16.device, dtype=torch.float32)
+    check(lib.hn_unsplit_f32(ptr(xs16), n, h * w, nb * 32, ps, ptr(out), _pixel_stride(out, "out"), _stream()),
+          "hn_unsplit_f32")
+    return out
+
+
 # bench.py's roofline leg: when set to a list, every conv launch is bracketed by HIP events
-# on the launch stream and (tile id, algorithmic MACs, timer) is appended.
+# on the launch stream and ((precision, tile id), algorithmic MACs, timer, shape) is appended.
 CONV_PROFILE = None
-TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x64", 4: "128x32", 6: "64x128"}
+TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x64", 4: "128x32", 5: "256x128", 6: "64x128"}
 
 
 def conv2d_nhwc(x, w, bias=None, *, stride=1, pad=0, dil=1, relu=False, relu_cols=None,
                 residual=None, res_upsample=False, in_scale=None, in_shift=None, out=None, tile=0,
-                algo_cin=None, w16=None):
-    """x [N,H,W,Cin] fp32, w [Cout,R,S,Cin] fp32 -> y [N,OH,OW,Cout].
+                algo_cin=None, w16=None, out_split=False):
+    """Convolution with fused epilogue.  x: fp32 [N,H,W,Cin] or S32 split; w [Cout,R,S,Cin] fp32.
 
-    algo_cin: input channels the reference's conv really has when Cin is zero-padded
-    (only used for FLOP accounting).
-    w16: split-fp16 filter bank (weights.split_f16x3); when given the conv runs on the f16
-    MFMA with split operands (hn_conv2d_nhwc_f16x3) instead of the f32 MFMA."""
+    w16 given  -> f16x3 kernel (split-fp16 operands on the f16 MFMA, fp32-grade results); an fp32
+                  x (and a GroupNorm-on-load affine in_scale/in_shift) is first converted with
+                  one hn_affine_split_f32 pass.  Otherwise the exact f32-MFMA kernel runs.
+    out_split  -> y is written in the S32 format (Cout % 32 == 0), ready for the next f16x3 conv.
+    residual   -> fp32 or S32 tensor added before the ReLU; res_upsample = nearest-neighbour
+                  read of a coarser map (FPN top-down path).
+    algo_cin   -> input channels the reference's conv really has when Cin is zero-padded
+                  (FLOP accounting only)."""
     lib = _lib.load()
     _req(w, name="w")
-    if not x.is_cuda or x.dtype != torch.float32:
-        raise RuntimeError("x must be an fp32 GPU tensor (no CPU fallback in handnet-pipeline_amd)")
+    cout, r, s, cin = w.shape
+    use16 = w16 is not None
+    if use16:
+        if is_split(x):
+            if in_scale is not None:
+                raise ValueError("apply the affine with to_split() before an S32-input convolution")
+        else:
+            x = to_split(x, in_scale, in_shift, relu=in_scale is not None)
+            in_scale = in_shift = None
+    elif is_split(x):
+        raise TypeError("the f32 kernel needs an fp32 input (use from_split)")
     xs = _pixel_stride(x, "x")
-    n, h, wd, cin = x.shape
-    cout, r, s, cin_w = w.shape
-    if cin_w != cin:
-        raise ValueError(f"weight Cin {cin_w} != input Cin {cin}")
+    n, h, wd = x.shape[:3]
+    if channels(x) != cin:
+        raise ValueError(f"weight Cin {cin} != input channels {channels(x)}")
     rc = cout if relu else 0
     if relu_cols is not None:
         rc = relu_cols
     res_mode, rh, rw = 0, 0, 0
     if residual is not None:
-        _req(residual, name="residual")
+        if channels(residual) != cout or residual.shape[0] != n:
+            raise ValueError("residual shape mismatch")
+        if is_split(residual) and not use16:
+            raise TypeError("the f32 kernel takes fp32 residuals only")
         if res_upsample:
             res_mode, rh, rw = 2, residual.shape[1], residual.shape[2]
         else:
             res_mode = 1
+    dense_in = xs == (2 * cin if is_split(x) else cin)
     d = make_conv_desc(n, h, wd, cin, cout, r, s, stride, pad, dil, rc, res_mode, rh, rw,
-                       1 if in_scale is not None else 0, tile, in_pix_stride=0 if xs == cin else xs)
+                       1 if in_scale is not None else 0, tile, in_pix_stride=0 if dense_in else xs)
     if out is None:
-        out = torch.empty((n, d.oh, d.ow, cout), device=x.device, dtype=torch.float32)
-    else:
-        if tuple(out.shape) != (n, d.oh, d.ow, cout) or not out.is_cuda or out.dtype != torch.float32:
-            raise ValueError("out has the wrong shape / dtype / device")
-        ys = _pixel_stride(out, "out")
-        d.out_pix_stride = 0 if ys == cout else ys
-    if res_mode == 1 and tuple(residual.shape) != tuple(out.shape):
-        raise ValueError("residual shape mismatch")
-    if res_mode == 2 and (residual.shape[0] != n or residual.shape[3] != cout):
-        raise ValueError("residual shape mismatch")
+        if out_split:
+            if cout % 32:
+                raise ValueError("out_split needs Cout % 32 == 0")
+            out = torch.empty((n, d.oh, d.ow, cout // 32, 2, 32), device=x.device, dtype=torch.float16)
+        else:
+            out = torch.empty((n, d.oh, d.ow, cout), device=x.device, dtype=torch.float32)
+    if tuple(out.shape[:3]) != (n, d.oh, d.ow) or channels(out) != cout:
+        raise ValueError("out has the wrong shape")
+    ys = _pixel_stride(out, "out")
+    d.out_split = 1 if is_split(out) else 0
+    d.out_pix_stride = 0 if ys == (2 * cout if d.out_split else cout) else ys
+    if residual is not None:
+        rs = _pixel_stride(residual, "residual")
+        d.res_split = 1 if is_split(residual) else 0
+        if res_mode == 1 and tuple(residual.shape[:3]) != (n, d.oh, d.ow):
+            raise ValueError("residual shape mismatch")
+        if use16:
+            d.res_pix_stride = rs
+        elif rs != cout:
+            raise ValueError("the f32 kernel needs a dense residual")
     if bias is not None:
         _req(bias, name="bias")
     if in_scale is not None:
@@ -114,19 +196,19 @@ def conv2d_nhwc(x, w, bias=None, *, stride=1, pad=0, dil=1, relu=False, relu_col
     if prof is not None:
         timer = HipTimer()
         timer.start()
-    if w16 is not None:
+    if use16:
         if (not w16.is_cuda or w16.dtype != torch.float16 or not w16.is_contiguous()
                 or w16.numel() != 2 * w.numel()):
             raise ValueError("w16 must be the contiguous fp16 GPU tensor produced by weights.split_f16x3(w)")
-        check(lib.hn_conv2d_nhwc_f16x3(C.byref(d), ptr(x), ptr(w16), ptr(bias), ptr(residual), ptr(in_scale),
-                                       ptr(in_shift), ptr(out), _stream()), "hn_conv2d_nhwc_f16x3")
+        check(lib.hn_conv2d_nhwc_f16x3(C.byref(d), ptr(x), ptr(w16), ptr(bias), ptr(residual), ptr(out), _stream()),
+              "hn_conv2d_nhwc_f16x3")
     else:
         check(lib.hn_conv2d_nhwc_f32(C.byref(d), ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(in_scale),
                                      ptr(in_shift), ptr(out), _stream()), "hn_conv2d_nhwc_f32")
     if prof is not None:
         timer.stop()
         macs = n * d.oh * d.ow * cout * r * s * (algo_cin or cin)
-        if w16 is not None:
+        if use16:
             kind = ("f16x3", lib.hn_conv2d_f16x3_pick_tile(C.byref(d)))
         else:
             kind = ("f32", lib.hn_conv2d_pick_tile(C.byref(d)))
@@ -136,6 +218,15 @@ def conv2d_nhwc(x, w, bias=None, *, stride=1, pad=0, dil=1, relu=False, relu_col
 
 def maxpool3x3s2_nhwc(x, out=None):
     lib = _lib.load()
+    if is_split(x):
+        if not x.is_contiguous():
+            raise ValueError("x must be contiguous")
+        n, h, w, nb = x.shape[:4]
+        oh, ow = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+        if out is None:
+            out = torch.empty((n, oh, ow, nb, 2, 32), device=x.device, dtype=torch.float16)
+        check(lib.hn_maxpool3x3s2_s32(ptr(x), ptr(out), n, h, w, nb * 32, oh, ow, _stream()), "hn_maxpool3x3s2_s32")
+        return out
     _req(x, name="x")
     n, h, w, c = x.shape
     oh, ow = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1

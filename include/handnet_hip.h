@@ -33,7 +33,7 @@ extern "C" {
 #define HN_ERR_HIP 2
 
 /* ABI version; bumped whenever a struct below changes. */
-#define HN_ABI_VERSION 7
+#define HN_ABI_VERSION 8
 int hn_abi_version(void);
 const char* hn_last_error(void);
 
@@ -64,21 +64,19 @@ typedef struct hn_conv_desc {
   int32_t res_mode;          /* 0 none | 1 residual[n][oh][ow][cout] |
                                 2 residual[n][res_h][res_w][cout] read at (oh*res_h/oh.., nearest) */
   int32_t res_h, res_w;      /* residual spatial size for res_mode 2                     */
-  int32_t in_affine;         /* 1: x <- relu(x*in_scale[img][c] + in_shift[img][c]) on load */
+  int32_t in_affine;         /* 1: x <- relu(x*in_scale[img][c] + in_shift[img][c]) on load
+                                 (f32 kernel only)                                        */
   int32_t tile;              /* 0 = auto; else one of HN_TILE_*                          */
-  int32_t precision;         /* HN_PREC_F32 | HN_PREC_F16 (see hn_conv2d_nhwc)          */
-  int32_t stats;             /* 1: also accumulate per-(img, group) sum / sumsq of the
-                                 OUTPUT into gn_partial (GroupNorm statistics)           */
-  int32_t stats_group;       /* channels per group for stats (8 for GroupNorm(32,256))  */
-  int32_t in_pix_stride;     /* floats between consecutive input pixels; 0 = cin.  Lets a
-                                 conv read a channel slice [c0, c0+cin) of a wider tensor
-                                 (pass x + c0); must be a multiple of 4                  */
-  int32_t out_pix_stride;    /* floats between consecutive output pixels; 0 = cout      */
+  int32_t out_split;         /* 1: write y in the S32 split format (cout % 32 == 0)      */
+  int32_t res_split;         /* 1: residual is an S32 tensor (f16x3 kernel only)         */
+  int32_t res_pix_stride;    /* elements between residual pixels; 0 = dense              */
+  int32_t in_pix_stride;     /* elements between consecutive input pixels; 0 = dense.  Lets a
+                                 conv read a channel slice of a wider tensor (pass the slice's
+                                 first element).  fp32: floats (multiple of 4); S32: halfs
+                                 (2 x parent channels)                                     */
+  int32_t out_pix_stride;    /* elements between consecutive output pixels; 0 = dense    */
   int32_t in_affine_stride;  /* floats between rows of in_scale / in_shift; 0 = cin     */
 } hn_conv_desc;
-
-#define HN_PREC_F32 0
-#define HN_PREC_F16 1
 
 #define HN_TILE_AUTO 0
 #define HN_TILE_128x128 1
@@ -99,14 +97,27 @@ int hn_conv2d_pick_tile(const hn_conv_desc* d);
 
 /* Same convolution on the f16 MFMA with SPLIT operands: every fp32 value v = hi + lo,
  * hi = fp16(v), lo = fp16(v - hi); a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi accumulated in
- * fp32 (fp32-grade result, 16/3 x the f32-MFMA rate).  x / y / bias / residual stay fp32.
- * w16 is the filter bank split on the host: fp16 [cout][r*s*cin/32][2][32] (hi run, lo run
- * of each 32-k tile; k = (r, s, c) with c fastest).  Requires cin % 32 == 0. */
-int hn_conv2d_nhwc_f16x3(const hn_conv_desc* d, const float* x, const void* w16,
-                         const float* bias, const float* residual,
-                         const float* in_scale, const float* in_shift,
-                         float* y, void* stream);
+ * fp32 (fp32-grade result, 16/3 x the f32-MFMA rate).  The input is an S32 split tensor
+ * (below), written once by its producer; w16 is the filter bank split on the host the same
+ * way: fp16 [cout][r*s*cin/32][2][32] (k = (r, s, c), c fastest).  Requires cin % 32 == 0.
+ * GroupNorm-on-load (in_affine) is not available here: run hn_affine_split_f32 in between. */
+int hn_conv2d_nhwc_f16x3(const hn_conv_desc* d, const void* x16 /* S32 */, const void* w16,
+                         const float* bias, const void* residual /* fp32 or S32 */,
+                         void* y /* fp32 or S32 (d->out_split) */, void* stream);
 int hn_conv2d_f16x3_pick_tile(const hn_conv_desc* d);
+
+/* ---- S32 split activation format: fp16 [N][H][W][C/32][2][32] (hi[32] | lo[32] per block) ----
+ * hn_affine_split_f32: fp32 NHWC -> S32; with scale/shift [n][c] it first applies
+ *   y = x*scale[img][c] + shift[img][c] (the GroupNorm(32,256) of fcos_utils/fcos.py:232-239,
+ *   352-359 expressed as a per-(image, channel) affine) and, if relu, max(y, 0).
+ * hn_unsplit_f32: S32 -> fp32 (exact: hi + lo).   hn_maxpool3x3s2_s32: pooling on S32. */
+int hn_affine_split_f32(const float* x, const float* scale, const float* shift, int relu,
+                        int n, int hw, int c, int in_pix_stride, int affine_stride,
+                        void* y16, int out_pix_stride, void* stream);
+int hn_unsplit_f32(const void* x16, int n, int hw, int c, int in_pix_stride,
+                   float* y, int out_pix_stride, void* stream);
+int hn_maxpool3x3s2_s32(const void* x16, void* y16, int n, int h, int w, int c,
+                        int oh, int ow, void* stream);
 
 /* 3x3 / stride-2 / pad-1 max pooling, NHWC fp32 (c % 4 == 0).
  * Replaces nn.MaxPool2d at a2j/resnet.py:107,158 and tv resnet34 stem. */

@@ -196,3 +196,62 @@ def test_conv_f16x3_fused_paths():
     y2 = ops.conv2d_nhwc(x2.cuda(), w2.cuda(), b.cuda(), residual=top.cuda(), res_upsample=True,
                          w16=split_f16x3(w2).cuda())
     _check(y2, ref2, "f16x3 fpn lateral")
+
+
+# ---- S32 split activation format (producers / consumers of the f16x3 convolutions) ----
+def test_split_roundtrip_and_affine():
+    from hn_amd import ops
+    x = _rand((2, 9, 7, 64), 51, 3.0)
+    xs = ops.to_split(x.cuda())
+    assert ops.is_split(xs) and tuple(xs.shape) == (2, 9, 7, 2, 2, 32)
+    back = ops.from_split(xs).cpu()
+    # hi + lo carries 22 bits: |error| <= 2^-21 |x| (+ half an fp16 subnormal step for tiny lo parts)
+    assert bool(((back - x).abs() <= 2 ** -21 * x.abs() + 3.0e-8).all())
+    hi = xs[..., 0, :].reshape(2, 9, 7, 64).float().cpu()
+    assert torch.equal(hi, x.half().float())                      # hi plane = fp16(x), channel order kept
+    sc, sh = _rand((2, 64), 52) * 0.5 + 1.0, _rand((2, 64), 53, 0.2)
+    ya = ops.from_split(ops.to_split(x.cuda(), sc.cuda(), sh.cuda(), relu=True)).cpu()
+    ref = torch.relu(x * sc[:, None, None, :] + sh[:, None, None, :])
+    assert float((ya - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    # channel-slice input (fp32 slice of a wider tensor, sliced affine table)
+    wide = _rand((2, 5, 5, 128), 54)
+    scw, shw = _rand((2, 128), 55) + 2.0, _rand((2, 128), 56)
+    ys = ops.from_split(ops.to_split(wide.cuda()[..., 64:], scw.cuda()[:, 64:], shw.cuda()[:, 64:], relu=False)).cpu()
+    refs = wide[..., 64:] * scw[:, None, None, 64:] + shw[:, None, None, 64:]
+    assert float((ys - refs).abs().max()) <= 2e-6 * float(refs.abs().max())
+
+
+def test_maxpool_split_is_exact():
+    from hn_amd import ops
+    from oracle import ops_ref
+    x = _rand((2, 45, 33, 64), 57)
+    xs = ops.to_split(x.cuda())
+    y = ops.from_split(ops.maxpool3x3s2_nhwc(xs)).cpu()
+    assert torch.equal(y, ops_ref.maxpool3x3s2_nhwc(ops.from_split(xs).cpu()))
+
+
+def test_conv_f16x3_split_in_out_residual():
+    """Bottleneck tail as the engines run it: S32 input, S32 residual, ReLU, S32 output, channel slices."""
+    from hn_amd import ops
+    from hn_amd.weights import split_f16x3
+    from oracle import ops_ref
+    x = _rand((2, 22, 22, 256), 58)
+    wt = _rand((512, 1, 1, 128), 59, 0.1)
+    b = _rand((512,), 60, 0.1)
+    res = _rand((2, 22, 22, 512), 61)
+    xs = ops.to_split(x.cuda())                 # 8 blocks; the conv reads blocks 4..7 = channels 128..255
+    rs = ops.to_split(res.cuda())
+    y = ops.conv2d_nhwc(xs[:, :, :, 4:], wt.cuda(), b.cuda(), relu=True, residual=rs, w16=split_f16x3(wt).cuda(),
+                        out_split=True)
+    assert ops.is_split(y)
+    # reference on the values the kernel actually sees (hi + lo of x and of the residual)
+    ref = ops_ref.conv2d_nhwc(ops.from_split(xs).cpu()[..., 128:].contiguous(), wt, b, relu_cols=512,
+                              residual=ops.from_split(rs).cpu())
+    _check(ops.from_split(y), ref, "S32 in / S32 residual / S32 out")
+    # fp32 residual + fp32 output into a channel slice of a wider tensor
+    wide_out = torch.zeros((2, 22, 22, 1024), device="cuda")
+    ops.conv2d_nhwc(xs[:, :, :, 4:], wt.cuda(), b.cuda(), residual=res.cuda(), w16=split_f16x3(wt).cuda(),
+                    out=wide_out[..., 512:])
+    ref2 = ops_ref.conv2d_nhwc(ops.from_split(xs).cpu()[..., 128:].contiguous(), wt, b, residual=res)
+    _check(wide_out[..., 512:].contiguous(), ref2, "fp32 residual / sliced fp32 out")
+    assert float(wide_out[..., :512].abs().max()) == 0.0

@@ -47,13 +47,15 @@ def test_backbone_and_heads_match_oracle(oracle_run, engine):
     x = ops.fcos_preprocess(rgb.cuda(), 800, 1066, 800, 1088, IMAGE_MEAN, IMAGE_STD)
     feats = engine.backbone(x)
     for f, rf in zip(feats, inter["features"]):
-        d = (f.cpu() - rf.permute(0, 2, 3, 1)).abs().max().item()
+        f32 = ops.from_split(f) if ops.is_split(f) else f
+        d = (f32.cpu() - rf.permute(0, 2, 3, 1)).abs().max().item()
         assert d <= 2e-4 * max(1.0, rf.abs().max().item()), d
     ho = inter["head"]
     start = 0
     for f in feats:
         cls_lr, reg_ctr = engine.head_level(f)
         n, h, w, _ = cls_lr.shape
+        assert cls_lr.dtype == torch.float32 and reg_ctr.dtype == torch.float32
         sl = slice(start, start + h * w)
         got_cls = cls_lr.cpu().reshape(n, h * w, 5)
         got_reg = reg_ctr.cpu().reshape(n, h * w, 5)

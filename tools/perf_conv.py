@@ -26,6 +26,12 @@ if affine:
     sh = torch.randn((n, cin), generator=g).cuda() * 0.1
 oh, ow = ops.conv_out_size(h, w, r, r, stride, pad, dil)
 y = torch.empty((n, oh, ow, cout), device="cuda")
+osplit = int(a[12]) if len(a) > 12 else 0
+if prec == "f16x3":
+    x = ops.to_split(x, sc, sh, relu=bool(affine))   # S32 input, produced once (as the engines do)
+    sc = sh = None
+    if osplit:
+        y = torch.empty((n, oh, ow, cout // 32, 2, 32), device="cuda", dtype=torch.float16)
 kw = dict(stride=stride, pad=pad, dil=dil, relu=True, tile=tile, w16=w16, out=y, in_scale=sc, in_shift=sh)
 for _ in range(3):
     ops.conv2d_nhwc(x, wt, b, **kw)
@@ -37,4 +43,4 @@ for _ in range(iters):
 t.stop()
 ms = t.elapsed_ms() / iters
 fl = 2.0 * n * oh * ow * cout * r * r * cin
-print(f"{prec} tile={tile} {n}x{h}x{w}x{cin}->{cout} r{r} s{stride} d{dil} aff{affine}: {ms*1e3:.1f} us  {fl/ms/1e9:.1f} TFLOP/s")
+print(f"{prec} tile={tile} {n}x{h}x{w}x{cin}->{cout} r{r} s{stride} d{dil} aff{affine} osplit{osplit}: {ms*1e3:.1f} us  {fl/ms/1e9:.1f} TFLOP/s")
