@@ -38,6 +38,7 @@ struct ConvParams {
   int xs, ys;  // pixel strides (floats) of x and y: channel-slice views of wider tensors
   int as;      // row stride (floats) of the in_scale / in_shift tables
   int out_split;  // write y as an S32 split tensor (ys is then in halfs)
+  int vec_epi;    // 1: 16-byte epilogue through LDS (Cout % 8 == 0 and aligned strides)
   int tiles_m, tiles_n, nblocks;
 };
 
@@ -207,7 +208,96 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
     __syncthreads();
   }
 
-  // ---- epilogue: bias, residual, ReLU, NHWC store (128-B runs per pixel row) ----
+  // ---- epilogue: bias, residual, ReLU, NHWC store ----
+  constexpr bool kPatchFits = 4 * 32 * (TN * 32) <= 2 * (BM + BN) * LDK;  // 4 wave patches inside smem
+  if (kPatchFits && p.vec_epi) {
+    // Vector path (Cout % 8 == 0): each wave transposes its accumulators through a private LDS
+    // patch (32 rows x TN*32 columns per pass) so that a lane owns 8 consecutive channels of
+    // one pixel: 16-byte bias / residual reads and fp32 or S32 (hi|lo) stores.
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    constexpr int PW = TN * 32, GROUPS = PW / 8;
+    __syncthreads();
+    float* patch = smem + wave * (32 * PW);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int prow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) patch[prow * PW + j * 32 + (lane & 31)] = acc[i][j][r];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < (32 * GROUPS) / 64; ++k) {
+        const int q = lane + 64 * k;
+        const int prow = q / GROUPS, g = q - prow * GROUPS;
+        const int m = m0 + wm * (BM / WM) + i * 32 + prow;
+        const int n = n0 + wn * (BN / WN) + g * 8;
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(&patch[prow * PW + g * 8]);
+        const f32x4 c1 = *reinterpret_cast<const f32x4*>(&patch[prow * PW + g * 8 + 4]);
+        if (m >= p.M || n >= p.Cout) continue;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = c0[e];
+          v[4 + e] = c1[e];
+        }
+        if (p.bias) {
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] += b0[e];
+            v[4 + e] += b1[e];
+          }
+        }
+        if (p.res_mode) {
+          long rpix = m;
+          if (p.res_mode == 2) {
+            const int img = m / ohow;
+            const int rem = m - img * ohow;
+            const int oh = rem / p.OW, ow = rem - oh * p.OW;
+            const int sh_ = (int)(((long)oh * p.res_h) / p.OH), sw_ = (int)(((long)ow * p.res_w) / p.OW);
+            rpix = ((long)img * p.res_h + sh_) * p.res_w + sw_;
+          }
+          const float* q32 = p.res + rpix * p.Cout + n;
+          const f32x4 r0 = *reinterpret_cast<const f32x4*>(q32), r1 = *reinterpret_cast<const f32x4*>(q32 + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] += r0[e];
+            v[4 + e] += r1[e];
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (n + e < p.relu_cols) v[e] = fmaxf(v[e], 0.f);
+        if (p.out_split) {
+          f16x8 hi, lo;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const _Float16 h = (_Float16)v[e];
+            hi[e] = h;
+            lo[e] = (_Float16)(v[e] - (float)h);
+          }
+          _Float16* q16 = reinterpret_cast<_Float16*>(p.y) + (long)m * p.ys + (n >> 5) * 64 + (n & 31);
+          *reinterpret_cast<f16x8*>(q16) = hi;
+          *reinterpret_cast<f16x8*>(q16 + 32) = lo;
+        } else {
+          float* q32 = p.y + (long)m * p.ys + n;
+          f32x4 o0, o1;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            o0[e] = v[e];
+            o1[e] = v[4 + e];
+          }
+          *reinterpret_cast<f32x4*>(q32) = o0;
+          *reinterpret_cast<f32x4*>(q32 + 4) = o1;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    return;
+  }
+  // Scalar path (ragged Cout or unaligned strides)
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -313,6 +403,8 @@ extern "C" int hn_conv2d_nhwc_f32(const hn_conv_desc* d, const float* x, const f
   p.out_split = d->out_split;
   p.ys = d->out_pix_stride ? d->out_pix_stride : (d->out_split ? 2 : 1) * d->cout;
   p.as = d->in_affine_stride ? d->in_affine_stride : d->cin;
+  p.vec_epi = (d->cout % 8 == 0) && (p.out_split || p.ys % 4 == 0) && ((uintptr_t)y % 16 == 0) &&
+              (bias == nullptr || (uintptr_t)bias % 16 == 0) && (residual == nullptr || (uintptr_t)residual % 16 == 0);
   p.tiles_m = p.tiles_n = p.nblocks = 0;
   const bool smallc = (d->cin % BK) != 0;
   hipStream_t st = (hipStream_t)stream;

@@ -7,7 +7,7 @@
 //   pass 1  gn_partial : one workgroup per (64-pixel chunk, image): fp32 sum / sumsq per
 //                        group, written to a [n][chunks][G][2] slab (no atomics ->
 //                        bitwise reproducible)
-//   pass 2  gn_finalize: per (image, channel): combine the chunk partials in fp64 in
+//   pass 2  gn_finalize: one wave per (image, group): combine the chunk partials in fp64 in
 //                        fixed order, mean / biased var / rstd, then
 //                        scale = gamma*rstd, shift = beta - mean*scale.
 #include "hn_common.h"
@@ -53,30 +53,40 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
   }
 }
 
-__global__ __launch_bounds__(1024) void gn_finalize_kernel(const float* __restrict__ partial,
-                                                           const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, int hw, int c,
-                                                           int groups, int chunks, float eps,
-                                                           float* __restrict__ scale, float* __restrict__ shift) {
-  const int img = blockIdx.x;
-  const int ch = threadIdx.x;
-  if (ch >= c) return;
+// one wave per (image, group): lanes stride over the chunk partials (fixed assignment ->
+// bitwise reproducible), fp64 butterfly reduction, then lanes 0..cpg-1 write the group's
+// per-channel scale / shift.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int hw, int c,
+                                                          int groups, int chunks, float eps,
+                                                          float* __restrict__ scale, float* __restrict__ shift) {
+  const int img = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (g >= groups) return;
   const int cpg = c / groups;
-  const int g = ch / cpg;
   double s = 0.0, ss = 0.0;
-  for (int k = 0; k < chunks; ++k) {
+  for (int k = lane; k < chunks; k += 64) {
     const float* pp = partial + (((long)img * chunks + k) * groups + g) * 2;
     s += (double)pp[0];
     ss += (double)pp[1];
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o);
+    ss += __shfl_xor(ss, o);
   }
   const double cnt = (double)hw * cpg;
   const double mean = s / cnt;
   double var = ss / cnt - mean * mean;
   if (var < 0.0) var = 0.0;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-  const float sc = gamma[ch] * rstd;
-  scale[(long)img * c + ch] = sc;
-  shift[(long)img * c + ch] = beta[ch] - (float)mean * sc;
+  for (int e = lane; e < cpg; e += 64) {
+    const int ch = g * cpg + e;
+    const float sc = gamma[ch] * rstd;
+    scale[(long)img * c + ch] = sc;
+    shift[(long)img * c + ch] = beta[ch] - (float)mean * sc;
+  }
 }
 
 }  // namespace
@@ -98,9 +108,8 @@ extern "C" int hn_groupnorm_affine_f32(const float* x, const float* gamma, const
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, n), dim3(256), 0, st, x, hw, c, groups, chunks, partial);
   HN_CHECK_LAUNCH("gn_partial_kernel");
-  const int threads = ((c + 63) / 64) * 64;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n), dim3(threads), 0, st, partial, gamma, beta, hw, c, groups, chunks,
-                     eps, scale, shift);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((groups + 3) / 4, n), dim3(256), 0, st, partial, gamma, beta, hw, c,
+                     groups, chunks, eps, scale, shift);
   HN_CHECK_LAUNCH("gn_finalize_kernel");
   return HN_OK;
 }
