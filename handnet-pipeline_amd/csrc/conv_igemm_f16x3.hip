@@ -3,7 +3,7 @@
 // Every fp32 value v is represented as hi + lo with hi = fp16(v), lo = fp16(v - hi)
 // (22 significant bits) and each product a*b is evaluated as
 //      a_hi*b_hi + a_hi*b_lo + a_lo*b_hi          (a_lo*b_lo ~ 2^-22 |ab| is dropped)
-// by three v_mfma_f32_32x32x16_f16 accumulating in ONE fp32 accumulator.  fp16 x fp16
+// by three v_mfma_f32_16x16x32_f16 accumulating in ONE fp32 accumulator.  fp16 x fp16
 // products are exact in fp32, so the result carries fp32-grade error (A2J keypoints move by
 // <= 2e-4 vs the fp32 reference, bound 1e-3) at 16/3 = 5.3x the f32-MFMA rate; plain fp16 /
 // bf16 operands miss the bound by two orders.
@@ -23,15 +23,18 @@
 //     and so is the bank swizzle (the DMA destination is wave-linear): chunk cc of row r
 //     lands at position cc ^ ((r >> 1) & 7), which makes every ds_read_b128 conflict-free;
 //   * 2 LDS buffers, DMA issued a full step ahead, ONE barrier per 32-deep k tile placed
-//     MID-step so that MFMAs sit on both sides of it; k-step fragments are read 12 MFMAs
-//     before use;  s_waitcnt / s_barrier are raw (a __syncthreads() would drain the DMA).
+//     MID-step so that MFMAs sit on both sides of it; operand fragments are read 24 MFMAs
+//     before use;  s_waitcnt / s_barrier are raw (a __syncthreads() would drain the DMA);
+//   * MFMA shape 16x16x32 (v4): a register-only probe (tools/probes/mfma_peak*.hip) sustains
+//     1.65-1.9 PFLOP/s with it on this chip against 1.2-1.45 PFLOP/s for 32x32x16 (the chip
+//     holds a higher clock); one ds_read_b128 then covers a 16-row tile's whole 32-deep k run,
+//     so LDS traffic per MFMA FLOP is unchanged.  A step is split by output-column halves.
 // Epilogue: bias, residual (fp32 or S32), ReLU on a column prefix, output fp32 or S32.
 // Requires Cin % 32 == 0 (the 4-channel stems stay on the f32 kernel).
 #include "hn_common.h"
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void;
@@ -65,8 +68,9 @@ __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const ConvParams16 p) {
   constexpr int NT = WM * WN * 64;
-  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;  // 16x16 MFMA tiles per wave
+  static_assert(TM >= 2 && TM % 2 == 0 && TN >= 2 && TN % 2 == 0, "wave tile must be a multiple of 32x32");
+  constexpr int TH = TN / 2;                            // column tiles per half step
   constexpr int ROWS_PASS = NT / 8;  // 8 lanes (16 B each) cover one 128-byte row
   static_assert(BM % ROWS_PASS == 0 && BN % ROWS_PASS == 0, "tile rows must be a multiple of NT/8");
   constexpr int A_IT = BM / ROWS_PASS, B_IT = BN / ROWS_PASS;
@@ -155,62 +159,66 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
     }
   };
 
-  f32x16 acc[TM][TN];
+  f32x4 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
-  // fragment read offsets (halfs): lane (r = lane&31, h = lane>>5) reads chunk pl*4 + 2*s + h
-  const int lh = lane >> 5;
-  int a_rd[TM][2][2], b_rd[TN][2][2];  // [tile][plane][k step]
+  // fragment read offsets (halfs): 16x16x32 operand map -- lane (r = lane&15, g = lane>>4) holds
+  // row r of the tile and k = 8g..8g+7, i.e. chunk pl*4 + g of its LDS row
+  const int lg = lane >> 4;
+  int a_rd[TM][2], b_rd[TN][2];  // [tile][plane]
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int row = wm * (BM / WM) + i * 32 + (lane & 31);
-        a_rd[i][pl][s] = row * ROWH + (((pl * 4 + 2 * s + lh) ^ swz(row)) << 3);
-      }
+    for (int pl = 0; pl < 2; ++pl) {
+      const int row = wm * (BM / WM) + i * 16 + (lane & 15);
+      a_rd[i][pl] = row * ROWH + (((pl * 4 + lg) ^ swz(row)) << 3);
+    }
 #pragma unroll
   for (int j = 0; j < TN; ++j)
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int row = wn * (BN / WN) + j * 32 + (lane & 31);
-        b_rd[j][pl][s] = row * ROWH + (((pl * 4 + 2 * s + lh) ^ swz(row)) << 3);
-      }
+    for (int pl = 0; pl < 2; ++pl) {
+      const int row = wn * (BN / WN) + j * 16 + (lane & 15);
+      b_rd[j][pl] = row * ROWH + (((pl * 4 + lg) ^ swz(row)) << 3);
+    }
 
-  struct Frags {
-    f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+  struct AFrag {
+    f16x8 h[TM], l[TM];
   };
-  auto read_frags = [&](Frags& f, int buf, int s) {
+  struct BFrag {
+    f16x8 h[TH], l[TH];
+  };
+  auto read_a = [&](AFrag& f, int buf) {
     const _Float16* Ab = As + buf * A_BUF;
-    const _Float16* Bb = Bs + buf * B_BUF;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      f.ah[i] = *reinterpret_cast<const f16x8*>(&Ab[a_rd[i][0][s]]);
-      f.al[i] = *reinterpret_cast<const f16x8*>(&Ab[a_rd[i][1][s]]);
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      f.bh[j] = *reinterpret_cast<const f16x8*>(&Bb[b_rd[j][0][s]]);
-      f.bl[j] = *reinterpret_cast<const f16x8*>(&Bb[b_rd[j][1][s]]);
+      f.h[i] = *reinterpret_cast<const f16x8*>(&Ab[a_rd[i][0]]);
+      f.l[i] = *reinterpret_cast<const f16x8*>(&Ab[a_rd[i][1]]);
     }
   };
-  // the TM*TN*3 MFMAs of one 16-deep k step (small cross terms first, dominant hi*hi last)
-  auto mfma_step = [&](const Frags& f) {
+  auto read_b = [&](BFrag& f, int buf, int half) {
+    const _Float16* Bb = Bs + buf * B_BUF;
+#pragma unroll
+    for (int jj = 0; jj < TH; ++jj) {
+      f.h[jj] = *reinterpret_cast<const f16x8*>(&Bb[b_rd[half * TH + jj][0]]);
+      f.l[jj] = *reinterpret_cast<const f16x8*>(&Bb[b_rd[half * TH + jj][1]]);
+    }
+  };
+  // TM*TH*3 MFMAs: all row tiles x one half of the column tiles, full 32-deep k
+  // (small cross terms first, dominant hi*hi last)
+  auto mma_half = [&](const AFrag& a, const BFrag& b, int half) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+      for (int jj = 0; jj < TH; ++jj) {
+        const int j = half * TH + jj;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.l[i], b.h[jj], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h[i], b.l[jj], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h[i], b.h[jj], acc[i][j], 0, 0, 0);
       }
   };
   // all of this wave's DMA has landed and all of its LDS reads have returned; then rendezvous
@@ -221,25 +229,34 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
   };
 
   const int T = p.ktiles;
+  BFrag b0, b1;
+  // one step = tile t (LDS buffer t&1), A fragments in `ac`, column-half-0 W fragments in b0:
+  //   first half : MFMAs of column half 0 || W fragments of half 1 are read
+  //   barrier    : tile t+1 (DMA issued one step ago) is complete for every wave, buffer t&1 free
+  //   second half: MFMAs of column half 1 || DMA of tile t+2 is issued || A and half-0 W
+  //                fragments of tile t+1 are read (into the other A set)
+  auto step = [&](const AFrag& ac, AFrag& an, int t) {
+    const int buf = t & 1;
+    read_b(b1, buf, 1);
+    mma_half(ac, b0, 0);
+    if (t + 1 < T) {
+      drain_and_barrier();
+      if (t + 2 < T) dma_tile(buf);  // tile t+2 overwrites tile t
+      read_a(an, buf ^ 1);
+      read_b(b0, buf ^ 1, 0);
+    }
+    mma_half(ac, b1, 1);
+  };
   // prologue: tile 0 -> buffer 0; tile 1 -> buffer 1 is put in flight right behind it
   dma_tile(0);
   drain_and_barrier();
   if (T > 1) dma_tile(1);
-  Frags f0, f1;
-  read_frags(f0, 0, 0);
+  AFrag a0, a1;
+  read_a(a0, 0);
+  read_b(b0, 0, 0);
   for (int t = 0; t < T; ++t) {
-    const int buf = t & 1;
-    // first half: k step 0 of tile t (fragments already in registers)
-    read_frags(f1, buf, 1);
-    mfma_step(f0);
-    if (t + 1 < T) {
-      // tile t+1 (DMA issued one step ago) is complete for every wave; buffer `buf` is free
-      drain_and_barrier();
-      if (t + 2 < T) dma_tile(buf);  // tile t+2 overwrites tile t
-      read_frags(f0, buf ^ 1, 0);    // k step 0 of tile t+1
-    }
-    // second half: k step 1 of tile t
-    mfma_step(f1);
+    step(a0, a1, t);
+    a0 = a1;  // register copies (2*TM*4 v_mov per step) keep the loop body single and the accumulators pinned
   }
 
   // ---- epilogue: bias, residual, ReLU, NHWC store ----
@@ -249,30 +266,33 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
   _Float16* y16 = reinterpret_cast<_Float16*>(p.y);
   if (p.vec_epi) {
     // Vector path (Cout % 8 == 0): every wave transposes its accumulators through a private
-    // LDS patch (32 rows x TN*32 columns per pass) so that each lane then owns 8 consecutive
+    // LDS patch (32 rows x TN*16 columns per pass) so that each lane then owns 8 consecutive
     // channels of one pixel: bias / residual are read and the result is written with 16-byte
     // accesses (the raw MFMA layout would need 2-byte stores for S32 outputs).
-    constexpr int PW = TN * 32;       // patch width in floats
+    constexpr int PW = TN * 16;       // patch width in floats
+    constexpr int PWP = PW + 4;       // padded pitch: the four 16-lane groups hit disjoint banks
     constexpr int GROUPS = PW / 8;    // 8-channel groups per row
     __syncthreads();                  // every wave is done with the operand tiles in LDS
-    float* patch = reinterpret_cast<float*>(smem) + wave * (32 * PW);
+    float* patch = reinterpret_cast<float*>(smem) + wave * (32 * PWP);
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; i += 2) {  // 32 rows (two 16-row tiles) per pass
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int prow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) patch[prow * PW + j * 32 + (lane & 31)] = acc[i][j][r];
-      }
+        for (int r = 0; r < 4; ++r) {
+          const int prow = ii * 16 + lg * 4 + r;  // C/D map: row = 4*(lane>>4) + reg, col = lane&15
+#pragma unroll
+          for (int j = 0; j < TN; ++j) patch[prow * PWP + j * 16 + (lane & 15)] = acc[i + ii][j][r];
+        }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
       for (int k = 0; k < (32 * GROUPS) / 64; ++k) {
         const int q = lane + 64 * k;
         const int prow = q / GROUPS, g = q - prow * GROUPS;
-        const int m = m0 + wm * (BM / WM) + i * 32 + prow;
+        const int m = m0 + wm * (BM / WM) + i * 16 + prow;
         const int n = n0 + wn * (BN / WN) + g * 8;
-        const f32x4 c0 = *reinterpret_cast<const f32x4*>(&patch[prow * PW + g * 8]);
-        const f32x4 c1 = *reinterpret_cast<const f32x4*>(&patch[prow * PW + g * 8 + 4]);
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(&patch[prow * PWP + g * 8]);
+        const f32x4 c1 = *reinterpret_cast<const f32x4*>(&patch[prow * PWP + g * 8 + 4]);
         if (m >= p.M || n >= p.Cout) continue;
         float v[8];
 #pragma unroll
@@ -346,8 +366,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    for (int r = 0; r < 4; ++r) {
+      const int row = wm * (BM / WM) + i * 16 + lg * 4 + r;
       const int m = m0 + row;
       if (m >= p.M) continue;
       long rpix = 0;
@@ -362,7 +382,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
+        const int n = n0 + wn * (BN / WN) + j * 16 + (lane & 15);
         if (n >= p.Cout) continue;
         float v = acc[i][j][r];
         if (p.bias) v += p.bias[n];
