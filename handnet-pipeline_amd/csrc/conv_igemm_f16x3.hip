@@ -12,7 +12,8 @@
 //   activations  fp16 [N][H][W][C/32][2][32]  -- per pixel and 32-channel block a 128-byte run:
 //                hi[32] | lo[32].  Written ONCE by the producer (conv epilogue, max-pool,
 //                GroupNorm-apply pass), so consumers never convert.
-//   weights      fp16 [Cout][R*S*Cin/32][2][32] -- the same run structure along k = (r,s,c).
+//   weights      fp16 [Cout][(Cin/32)*R*S][2][32] -- the same run structure along k; k tiles are
+//                ordered channel block OUTER, tap (r,s) INNER (weights.split_f16x3).
 //
 // Kernel (v3).  rocprof ablations of v2 (fp32 activations split in the loader; kept for
 // reference in conv_igemm_f16x3_v2.hip.txt) showed the loader's conversion VALU (+27 %) and
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
   // ---- DMA geometry: lane -> (row = tid >> 3 within a pass, LDS position pos = tid & 7) ----
   const int drow = tid >> 3, dpos = tid & 7;
   int a_ih0[A_IT], a_iw0[A_IT], a_cc[A_IT];
-  long a_base[A_IT];
+  const _Float16* a_row[A_IT];  // address of (img, ih0, iw0, channel 0) + swizzled chunk; may lie outside the image
 #pragma unroll
   for (int it = 0; it < A_IT; ++it) {
     const int row = drow + it * ROWS_PASS;
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
     a_ih0[it] = oh * p.stride - p.pad;
     a_iw0[it] = ow * p.stride - p.pad;
     a_cc[it] = (dpos ^ swz(row)) * 8;  // source chunk (halfs) that belongs at this LDS position
-    a_base[it] = (long)img * p.H * p.W * p.xs + a_cc[it];
+    a_row[it] = p.x + ((long)img * p.H * p.W + (long)a_ih0[it] * p.W + a_iw0[it]) * p.xs + a_cc[it];
   }
   const _Float16* b_ptr[B_IT];
 #pragma unroll
@@ -119,29 +120,23 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
   // wave-uniform LDS row base of this wave's 8-row group inside a pass
   const int grp_row = __builtin_amdgcn_readfirstlane(wave) * 8;
 
-  // per-row source pointers of the CURRENT tap, advanced by one 32-channel block (64 halfs)
-  // per tile; padding taps point into the zero page and do not advance.
-  const _Float16* a_ptr[A_IT];
-  int a_inc[A_IT];
-  int cur_r = 0, cur_s = 0, cur_c = 0, load_t = 0;
+  // K order: 32-channel block OUTER, filter taps INNER.  Consecutive k tiles then re-read almost
+  // the same pixels (shifted by one tap), so the re-use distance across the ~64 workgroups of an
+  // XCD is ~1 MB instead of ~8 MB and the 4 MB L2 serves it (tap-outer order re-fetched the
+  // input 3-7x over the fabric: FETCH_SIZE, profiles/).  Per step the tap offset is wave-uniform
+  // (SALU); per lane only the two bounds checks and one 64-bit add remain.
+  int cur_r = 0, cur_s = 0, cur_cb = 0, load_t = 0;
 
   auto dma_tile = [&](int buf) {
-    if (cur_c == 0) {  // wave-uniform: first channel block of a new tap
-#pragma unroll
-      for (int it = 0; it < A_IT; ++it) {
-        const int ih = a_ih0[it] + cur_r * p.dil, iw = a_iw0[it] + cur_s * p.dil;
-        const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-        a_ptr[it] = ok ? p.x + a_base[it] + ((long)ih * p.W + iw) * p.xs : g_zero_page16 + a_cc[it];
-        a_inc[it] = ok ? 2 * BK : 0;
-      }
-    }
+    const int dr = cur_r * p.dil, ds = cur_s * p.dil;
+    const long uoff = ((long)dr * p.W + ds) * p.xs + (long)cur_cb * (2 * BK);  // wave-uniform
     _Float16* Ad = As + buf * A_BUF;
     _Float16* Bd = Bs + buf * B_BUF;
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
-      __builtin_amdgcn_global_load_lds((gbl_void*)a_ptr[it], (lds_void*)(Ad + (it * ROWS_PASS + grp_row) * ROWH), 16, 0,
-                                       0);
-      a_ptr[it] += a_inc[it];
+      const bool ok = (unsigned)(a_ih0[it] + dr) < (unsigned)p.H && (unsigned)(a_iw0[it] + ds) < (unsigned)p.W;
+      const _Float16* src = ok ? a_row[it] + uoff : g_zero_page16 + a_cc[it];  // padding taps read zeros
+      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(Ad + (it * ROWS_PASS + grp_row) * ROWH), 16, 0, 0);
     }
     const long boff = (long)load_t * (2 * BK);
 #pragma unroll
@@ -149,12 +144,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
       __builtin_amdgcn_global_load_lds((gbl_void*)(b_ptr[it] + boff),
                                        (lds_void*)(Bd + (it * ROWS_PASS + grp_row) * ROWH), 16, 0, 0);
     ++load_t;
-    cur_c += BK;
-    if (cur_c >= p.Cin) {
-      cur_c = 0;
-      if (++cur_s == p.S) {
-        cur_s = 0;
-        ++cur_r;
+    if (++cur_s == p.S) {
+      cur_s = 0;
+      if (++cur_r == p.R) {
+        cur_r = 0;
+        ++cur_cb;
       }
     }
   };

@@ -41,15 +41,16 @@ class ConvW:
 
 
 def split_f16x3(w: torch.Tensor) -> torch.Tensor:
-    """[Cout,R,S,Cin] fp32 -> fp16 [Cout, R*S*Cin/32, 2, 32]: per 32-k tile the hi run then the
-    lo run, hi = fp16(w), lo = fp16(w - hi) (hi + lo carries 22 significant bits of w)."""
-    cout = w.shape[0]
-    flat = w.reshape(cout, -1).float()
-    if flat.shape[1] % 32:
-        raise ValueError("split_f16x3 needs R*S*Cin to be a multiple of 32")
-    hi = flat.half()
-    lo = (flat - hi.float()).half()
-    return torch.stack([hi.reshape(cout, -1, 32), lo.reshape(cout, -1, 32)], dim=2).contiguous()
+    """[Cout,R,S,Cin] fp32 -> fp16 [Cout, (Cin/32)*R*S, 2, 32]: k tiles ordered 32-channel block
+    OUTER / filter tap INNER (the order the f16x3 kernel walks K, chosen for L2 reuse of the input);
+    per tile the hi run then the lo run, hi = fp16(w), lo = fp16(w - hi) (22 significant bits)."""
+    cout, r, s, cin = w.shape
+    if cin % 32:
+        raise ValueError("split_f16x3 needs Cin to be a multiple of 32")
+    tiles = w.float().reshape(cout, r * s, cin // 32, 32).permute(0, 2, 1, 3).reshape(cout, -1, 32)
+    hi = tiles.half()
+    lo = (tiles - hi.float()).half()
+    return torch.stack([hi, lo], dim=2).contiguous()
 
 
 def _pad_to(c: int, m: int) -> int:

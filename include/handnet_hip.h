@@ -99,7 +99,8 @@ int hn_conv2d_pick_tile(const hn_conv_desc* d);
  * hi = fp16(v), lo = fp16(v - hi); a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi accumulated in
  * fp32 (fp32-grade result, 16/3 x the f32-MFMA rate).  The input is an S32 split tensor
  * (below), written once by its producer; w16 is the filter bank split on the host the same
- * way: fp16 [cout][r*s*cin/32][2][32] (k = (r, s, c), c fastest).  Requires cin % 32 == 0.
+ * way: fp16 [cout][(cin/32)*r*s][2][32] (k tiles: 32-channel block outer, tap (r,s) inner;
+ * hi run | lo run per tile).  Requires cin % 32 == 0.
  * GroupNorm-on-load (in_affine) is not available here: run hn_affine_split_f32 in between. */
 int hn_conv2d_nhwc_f16x3(const hn_conv_desc* d, const void* x16 /* S32 */, const void* w16,
                          const float* bias, const void* residual /* fp32 or S32 */,
