@@ -107,11 +107,14 @@ def roofline_leg(step, steps):
     finally:
         ops.CONV_PROFILE = None
     groups = {}
-    for kind, macs, timer, _shape in recs:
-        g = groups.setdefault(kind, {"ms": 0.0, "flop": 0.0, "launches": 0})
+    for kind, macs, timer, shape in recs:
+        g = groups.setdefault(kind, {"ms": 0.0, "flop": 0.0, "launches": 0, "bytes": 0.0})
         g["ms"] += timer.elapsed_ms()
         g["flop"] += 2.0 * macs
         g["launches"] += 1
+        n, h, w, cin, cout, r, stride, _dil = shape
+        # algorithmic bytes: input + filters + output, 4 bytes per value (fp32 or S32 hi+lo)
+        g["bytes"] += 4.0 * (n * h * w * cin + cout * r * r * cin + n * (h // stride) * (w // stride) * cout)
     if not groups:
         return None
     (prec, tile), g = max(groups.items(), key=lambda kv: kv[1]["ms"])
@@ -123,7 +126,8 @@ def roofline_leg(step, steps):
     peak = F16_MFMA_PEAK_TFLOPS if prec == "f16x3" else F32_MFMA_PEAK_TFLOPS
     return {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-        "frac": round(achieved / peak, 4), "traffic": None,
+        "frac": round(achieved / peak, 4), "traffic": measured_traffic(prec, tile),
+        "algorithmic_bytes_per_launch": int(g["bytes"] / g["launches"]),
         "kernel": f"conv_igemm_{prec}_kernel<{ops.TILE_NAMES.get(tile, tile)}>",
         "mfma_issued_tflops": round(achieved * (3 if prec == "f16x3" else 1), 2),
         "mfma_issued_frac": round(achieved * (3 if prec == "f16x3" else 1) / peak, 4),
@@ -134,6 +138,21 @@ def roofline_leg(step, steps):
         "all_conv_achieved": round(tot_flop / (tot_ms * 1e-3) / 1e12, 2),
         "conv_ms_per_step": round(tot_ms / steps, 3),
     }
+
+
+def measured_traffic(prec, tile):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
+    same command (profiles/traffic_latest.json, written by tools/save_profiles.py); None if absent."""
+    from hn_amd import ops
+    f = REPO / "profiles" / "traffic_latest.json"
+    if not f.exists():
+        return None
+    bm, bn = ops.TILE_NAMES.get(tile, "0x0").split("x")
+    want = f"conv_igemm_{prec}_kernel<{bm}, {bn},"
+    for name, rec in json.loads(f.read_text())["kernels"].items():
+        if want in name:
+            return rec["hbm_bytes_per_launch"]
+    return None
 
 
 def cpu_baseline(args, sds):
