@@ -205,15 +205,18 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
   // TM*TH*3 MFMAs: all row tiles x one half of the column tiles, full 32-deep k
   // (small cross terms first, dominant hi*hi last)
   auto mma_half = [&](const AFrag& a, const BFrag& b, int half) {
+    // term-major order: the three MFMAs that chain through one accumulator are TM*TH issues
+    // apart, so no MFMA waits on the result of its predecessor (16x16x32 has a 4-pass latency)
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int term = 0; term < 3; ++term)
 #pragma unroll
-      for (int jj = 0; jj < TH; ++jj) {
-        const int j = half * TH + jj;
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.l[i], b.h[jj], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h[i], b.l[jj], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h[i], b.h[jj], acc[i][j], 0, 0, 0);
-      }
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jj = 0; jj < TH; ++jj) {
+          const int j = half * TH + jj;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(term == 0 ? a.l[i] : a.h[i], term == 1 ? b.l[jj] : b.h[jj],
+                                                             acc[i][j], 0, 0, 0);
+        }
   };
   // all of this wave's DMA has landed and all of its LDS reads have returned; then rendezvous
   auto drain_and_barrier = [&]() {
