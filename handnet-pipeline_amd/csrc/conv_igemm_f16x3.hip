@@ -23,7 +23,9 @@
 //     (im2col row, zero page for padding taps) is expressed in the per-lane SOURCE address,
 //     and so is the bank swizzle (the DMA destination is wave-linear): chunk cc of row r
 //     lands at position cc ^ ((r >> 1) & 7), which makes every ds_read_b128 conflict-free;
-//   * 2 LDS buffers, DMA issued a full step ahead, ONE barrier per 32-deep k tile placed
+//   * NBUF LDS stages (2 for the 128x128 tile, 3-4 for the small tiles whose steps are shorter
+//     than the memory latency), DMA issued NBUF-1 steps ahead and retired with COUNTED vmcnt
+//     waits, ONE barrier per 32-deep k tile placed
 //     MID-step so that MFMAs sit on both sides of it; operand fragments are read 24 MFMAs
 //     before use;  s_waitcnt / s_barrier are raw (a __syncthreads() would drain the DMA);
 //   * MFMA shape 16x16x32 (v4): a register-only probe (tools/probes/mfma_peak*.hip) sustains
@@ -66,8 +68,9 @@ constexpr int ROWH = 64;  // halfs per LDS row (hi 32 | lo 32) = 128 bytes
 
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NBUF>
 __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const ConvParams16 p) {
+  static_assert(NBUF >= 2 && NBUF <= 6, "2..6 LDS stages");
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;  // 16x16 MFMA tiles per wave
   static_assert(TM >= 2 && TM % 2 == 0 && TN >= 2 && TN % 2 == 0, "wave tile must be a multiple of 32x32");
@@ -76,9 +79,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
   static_assert(BM % ROWS_PASS == 0 && BN % ROWS_PASS == 0, "tile rows must be a multiple of NT/8");
   constexpr int A_IT = BM / ROWS_PASS, B_IT = BN / ROWS_PASS;
   constexpr int A_BUF = BM * ROWH, B_BUF = BN * ROWH;  // halfs per buffer
-  __shared__ __attribute__((aligned(1024))) _Float16 smem[2 * (A_BUF + B_BUF)];
-  _Float16* As = smem;              // [buf][BM][64]
-  _Float16* Bs = smem + 2 * A_BUF;  // [buf][BN][64]
+  __shared__ __attribute__((aligned(1024))) _Float16 smem[NBUF * (A_BUF + B_BUF)];
+  _Float16* As = smem;                 // [stage][BM][64]
+  _Float16* Bs = smem + NBUF * A_BUF;  // [stage][BN][64]
 
   int lid;
   {
@@ -227,33 +230,46 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
 
   const int T = p.ktiles;
   BFrag b0, b1;
-  // one step = tile t (LDS buffer t&1), A fragments in `ac`, column-half-0 W fragments in b0:
+  constexpr int DPT = A_IT + B_IT;  // DMA instructions each wave issues per k tile
+  // one step = tile t in LDS stage `cs`; its A fragments are in `ac`, its column-half-0 W
+  // fragments in b0; tiles t+1 .. t+NBUF-1 are in flight or landed (stage `ns` holds t+1):
   //   first half : MFMAs of column half 0 || W fragments of half 1 are read
-  //   barrier    : tile t+1 (DMA issued one step ago) is complete for every wave, buffer t&1 free
-  //   second half: MFMAs of column half 1 || DMA of tile t+2 is issued || A and half-0 W
-  //                fragments of tile t+1 are read (into the other A set)
-  auto step = [&](const AFrag& ac, AFrag& an, int t) {
-    const int buf = t & 1;
-    read_b(b1, buf, 1);
+  //   wait       : counted vmcnt -- only tile t+1 has to be complete, the NBUF-2 younger tiles
+  //                stay in flight across the barrier (small tiles have ~200-cycle steps, far
+  //                shorter than the L2/HBM latency, so they prefetch 2-3 steps ahead)
+  //   barrier    : tile t+1 is complete for every wave and nobody reads stage `cs` any more
+  //   second half: MFMAs of column half 1 || DMA of tile t+NBUF into stage `cs` || A and
+  //                half-0 W fragments of tile t+1 are read (into the other A set)
+  auto step = [&](const AFrag& ac, AFrag& an, int t, int cs, int ns) {
+    read_b(b1, cs, 1);
     mma_half(ac, b0, 0);
     if (t + 1 < T) {
-      drain_and_barrier();
-      if (t + 2 < T) dma_tile(buf);  // tile t+2 overwrites tile t
-      read_a(an, buf ^ 1);
-      read_b(b0, buf ^ 1, 0);
+      if (t + NBUF - 1 <= T - 1)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NBUF - 2) * DPT) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // tail: fewer tiles in flight
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (t + NBUF < T) dma_tile(cs);  // tile t+NBUF overwrites tile t
+      read_a(an, ns);
+      read_b(b0, ns, 0);
     }
     mma_half(ac, b1, 1);
   };
-  // prologue: tile 0 -> buffer 0; tile 1 -> buffer 1 is put in flight right behind it
+  // prologue: tile 0 -> stage 0 (waited for); tiles 1..NBUF-1 are put in flight behind it
   dma_tile(0);
   drain_and_barrier();
-  if (T > 1) dma_tile(1);
+  for (int i = 1; i < NBUF; ++i)
+    if (i < T) dma_tile(i);
   AFrag a0, a1;
   read_a(a0, 0);
   read_b(b0, 0, 0);
+  int cs = 0, ns = 1;
   for (int t = 0; t < T; ++t) {
-    step(a0, a1, t);
+    step(a0, a1, t, cs, ns);
     a0 = a1;  // register copies (2*TM*4 v_mov per step) keep the loop body single and the accumulators pinned
+    cs = ns;
+    ns = ns + 1 == NBUF ? 0 : ns + 1;
   }
 
   // ---- epilogue: bias, residual, ReLU, NHWC store ----
@@ -405,13 +421,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
   }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NBUF>
 int launch16(const ConvParams16& p0, hipStream_t st) {
   ConvParams16 p = p0;
   p.tiles_m = hn::cdiv(p.M, BM);
   p.tiles_n = hn::cdiv(p.Cout, BN);
   p.nblocks = p.tiles_m * p.tiles_n;
-  hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN>), dim3(p.nblocks), dim3(WM * WN * 64), 0, st, p);
+  hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, NBUF>), dim3(p.nblocks), dim3(WM * WN * 64), 0, st, p);
   HN_CHECK_LAUNCH("conv_igemm_f16x3_kernel");
   return HN_OK;
 }
@@ -427,7 +443,9 @@ extern "C" int hn_conv2d_f16x3_pick_tile(const hn_conv_desc* d) {
   if (!d) return HN_TILE_64x64;
   if (d->tile != HN_TILE_AUTO) return d->tile;
   if (d->cout <= 32) return HN_TILE_128x32;
-  const int64_t want = 2 * 256;
+  // measured (tools/perf_conv.py tile sweep): the largest tile wins as soon as it yields one
+  // workgroup per CU; below that the small-M A2J layers prefer more, smaller workgroups
+  const int64_t want = 256;
   if (d->cout > 64 && nblocks16(d, 128, 128) >= want) return HN_TILE_128x128;
   if (nblocks16(d, 128, 64) >= want) return HN_TILE_128x64;
   return HN_TILE_64x64;
@@ -470,12 +488,15 @@ extern "C" int hn_conv2d_nhwc_f16x3(const hn_conv_desc* d, const void* x16, cons
   p.tiles_m = p.tiles_n = p.nblocks = 0;
   hipStream_t st = (hipStream_t)stream;
   switch (hn_conv2d_f16x3_pick_tile(d)) {
-    case HN_TILE_128x128: return launch16<128, 128, 2, 2>(p, st);
-    case HN_TILE_128x64: return launch16<128, 64, 2, 2>(p, st);
-    case HN_TILE_64x64: return launch16<64, 64, 2, 2>(p, st);
-    case HN_TILE_128x32: return launch16<128, 32, 4, 1>(p, st);
-    case HN_TILE_64x128: return launch16<64, 128, 2, 2>(p, st);
-    case HN_TILE_256x128: return launch16<256, 128, 4, 2>(p, st);
+    case HN_TILE_128x128: return launch16<128, 128, 2, 2, 2>(p, st);
+    // LDS stage counts from an in-pipeline sweep (tools/stage_sweep.py): extra stages only pay
+    // where they do not cost occupancy
+    case HN_TILE_128x64: return launch16<128, 64, 2, 2, 2>(p, st);
+    case HN_TILE_64x64: return launch16<64, 64, 2, 2, 3>(p, st);
+    case HN_TILE_128x32: return launch16<128, 32, 4, 1, 3>(p, st);
+    case HN_TILE_64x128: return launch16<64, 128, 2, 2, 3>(p, st);
+    case HN_TILE_256x128: return launch16<256, 128, 4, 2, 2>(p, st);
+    case HN_TILE_32x64: return launch16<32, 64, 1, 2, 4>(p, st);
     default: return hn::fail(HN_ERR_ARG, "unknown tile id %d", d->tile);
   }
 }
