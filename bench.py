@@ -51,6 +51,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=4, help="frames in the bounded CPU sample")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo = rehearsal of the N > 1 plumbing on a box with fewer GPUs than ranks "
+                         "(results are gathered through host memory; not a performance mode)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     return ap.parse_args()
 
 
@@ -192,7 +196,9 @@ def cpu_baseline(args, sds):
 def main():
     args = parse()
     from hn_amd import dist as hdist
-    rank, local, world = hdist.init_from_env("nccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    if args.share_gpu:
+        os.environ["LOCAL_RANK"] = "0"
+    rank, local, world = hdist.init_from_env(args.dist_backend if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
@@ -206,7 +212,10 @@ def main():
     def full_step():
         out = step()
         if world > 1 and args.workload == "pipeline":
-            hdist.gather_results(out.keypoints, out.crop_box, out.has_hand, per_rank=batch)
+            if args.dist_backend == "gloo":  # rehearsal only: gloo gathers host tensors
+                hdist.gather_results(out.keypoints.cpu(), out.crop_box.cpu(), out.has_hand.cpu(), per_rank=batch)
+            else:
+                hdist.gather_results(out.keypoints, out.crop_box, out.has_hand, per_rank=batch)
         return out
 
     def fence():
@@ -224,7 +233,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
