@@ -123,7 +123,51 @@ __global__ __launch_bounds__(1024) void a2j_aggregate_kernel(const float* __rest
   }
 }
 
+// crop-(u,v,d) -> image (u,v,d) -> camera xyz in millimetres (a2j/a2j.py:17-34 convert_joints +
+// datasets3d/a2jdataset.py:31-38 uvd2xyz), one thread per joint
+__global__ __launch_bounds__(256) void convert_joints_kernel(const float* __restrict__ kp,
+                                                             const long long* __restrict__ box,
+                                                             const int* __restrict__ valid, int n, int J,
+                                                             float crop_w, float crop_h, int has_paras, float fx,
+                                                             float fy, float cx, float cy, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * J) return;
+  const int img = i / J;
+  float* o = out + (long)i * 3;
+  if (valid && valid[img] == 0) {
+    o[0] = o[1] = o[2] = 0.f;
+    return;
+  }
+  const float x0 = (float)box[img * 4 + 0], y0 = (float)box[img * 4 + 1];
+  const float x1 = (float)box[img * 4 + 2], y1 = (float)box[img * 4 + 3];
+  const float u = kp[(long)i * 3 + 0] * (x1 - x0) / crop_w + x0;
+  const float v = kp[(long)i * 3 + 1] * (y1 - y0) / crop_h + y0;
+  const float d = kp[(long)i * 3 + 2];
+  if (has_paras) {
+    o[0] = (u - cx) * d / fx * 1000.f;
+    o[1] = (v - cy) * d / fy * 1000.f;
+    o[2] = d * 1000.f;
+  } else {
+    o[0] = u;
+    o[1] = v;
+    o[2] = d;
+  }
+}
+
 }  // namespace
+
+extern "C" int hn_convert_joints_f32(const float* kp, const int64_t* crop_box, const int32_t* valid, int n, int joints,
+                                     float crop_w, float crop_h, const float* paras, float* out, void* stream) {
+  HN_CHECK_ARG(kp && crop_box && out, "hn_convert_joints_f32: null pointer");
+  HN_CHECK_ARG(n >= 0 && joints > 0 && crop_w > 0.f && crop_h > 0.f, "bad dims");
+  if (n == 0) return HN_OK;
+  const int total = n * joints;
+  hipLaunchKernelGGL(convert_joints_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, kp,
+                     (const long long*)crop_box, valid, n, joints, crop_w, crop_h, paras ? 1 : 0, paras ? paras[0] : 1.f,
+                     paras ? paras[1] : 1.f, paras ? paras[2] : 0.f, paras ? paras[3] : 0.f, out);
+  HN_CHECK_LAUNCH("convert_joints_kernel");
+  return HN_OK;
+}
 
 extern "C" int hn_maxpool3x3s2_nhwc_f32(const float* x, float* y, int n, int h, int w, int c, int oh, int ow,
                                         void* stream) {

@@ -393,14 +393,15 @@ __global__ void crop_box_kernel(const float* __restrict__ det_boxes, const int* 
 __global__ __launch_bounds__(256) void crop_gather_kernel(const float* __restrict__ depth,
                                                           const long long* __restrict__ crop_box,
                                                           const int* __restrict__ has_hand, int n, int h, int w,
-                                                          int out, int c4, float* __restrict__ crops) {
+                                                          int in_ch, int reorder, int out, int c4,
+                                                          float* __restrict__ crops) {
   const long total = (long)n * out * out;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int ox = (int)(i % out);
     const long t = i / out;
     const int oy = (int)(t % out);
     const int img = (int)(t / out);
-    float v = 0.f;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
     if (has_hand[img]) {
       const long long* b = crop_box + (long)img * 4;
       const int x1 = (int)b[0], y1 = (int)b[1];
@@ -412,9 +413,13 @@ __global__ __launch_bounds__(256) void crop_gather_kernel(const float* __restric
       else sy = min((int)floorf((float)oy * ((float)ch / (float)out)), ch - 1);
       if (cw == out) sx = ox; else if (out == 2 * cw) sx = ox >> 1;
       else sx = min((int)floorf((float)ox * ((float)cw / (float)out)), cw - 1);
-      v = depth[((long)img * h + (y1 + sy)) * w + (x1 + sx)];
+      const long pix = (long)(y1 + sy) * w + (x1 + sx);
+      for (int c = 0; c < in_ch; ++c) {
+        // RGBD: depth_crop[[2,1,0,3]] (handnet_pipeline.py:102): output channel c reads input channel perm[c]
+        const int src_c = (reorder && c < 3) ? 2 - c : c;
+        o[c] = depth[((long)img * in_ch + src_c) * h * w + pix];
+      }
     }
-    f32x4 o = {v, 0.f, 0.f, 0.f};
     *reinterpret_cast<f32x4*>(crops + i * c4 * 4) = o;
     for (int q = 1; q < c4; ++q) {
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -527,18 +532,20 @@ extern "C" int hn_nms(const float* boxes, const float* scores, int k, double iou
 }
 
 extern "C" int hn_crop_resize(const float* det_boxes, const int32_t* det_labels, const int32_t* det_count, int cap,
-                              int hand_label, const float* depth, int n, int h, int w, int out, int cpad,
+                              int hand_label, const float* depth, int n, int in_ch, int reorder_bgr, int h, int w,
+                              int out, int cpad,
                               int64_t* crop_box, int32_t* has_hand, float* crops, void* stream) {
   HN_CHECK_ARG(det_boxes && det_labels && det_count && depth && crop_box && has_hand && crops,
                "hn_crop_resize: null pointer");
   HN_CHECK_ARG(n > 0 && h > 0 && w > 0 && out > 0 && cap > 0 && cpad >= 4 && cpad % 4 == 0, "bad dims");
+  HN_CHECK_ARG(in_ch >= 1 && in_ch <= 4, "depth image must have 1..4 channels (got %d)", in_ch);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(crop_box_kernel, dim3((n + 63) / 64), dim3(64), 0, st, det_boxes, det_labels, det_count, cap,
                      hand_label, n, h, w, (long long*)crop_box, has_hand);
   HN_CHECK_LAUNCH("crop_box_kernel");
   const long total = (long)n * out * out;
   hipLaunchKernelGGL(crop_gather_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, depth,
-                     (const long long*)crop_box, has_hand, n, h, w, out, cpad / 4, crops);
+                     (const long long*)crop_box, has_hand, n, h, w, in_ch, reorder_bgr, out, cpad / 4, crops);
   HN_CHECK_LAUNCH("crop_gather_kernel");
   return HN_OK;
 }

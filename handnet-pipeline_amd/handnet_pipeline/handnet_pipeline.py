@@ -37,16 +37,21 @@ def load_pretrained_fcos(args, reload_detector=False, num_classes=2):
 
 
 def load_pretrained_a2j(args, reload_a2j=False, RGBD=False):
-    if RGBD:
-        raise NotImplementedError("the RGBD A2J variant (4-channel stem) is not built yet (SURVEY 8f #3)")
-    a2j = A2JModel(21, crop_height=176, crop_width=176, is_RGBD=False)
-    if reload_a2j:
-        checkpoint = torch.load(args.pretrained_a2j, map_location="cpu")
-        if "ckpt" in str(args.pretrained_a2j) or "state_dict" in checkpoint:
-            # Lightning checkpoint: weights live under state_dict with an 'a2j.' prefix (a2j/a2j.py:277)
-            a2j.load_state_dict(strip_prefix(checkpoint["state_dict"], "a2j."), strict=False)
-        else:
-            a2j.load_state_dict(checkpoint["model"], strict=False)
+    """Reference (handnet_pipeline.py:25-36): RGBD or a '.ckpt' path -> Lightning checkpoint (weights under
+    state_dict with prefix 'a2j.', a2j/a2j.py:277), always loaded; else A2JModel + optional {"model": sd}."""
+    path = str(getattr(args, "pretrained_a2j", ""))
+    checkpoint = None
+    if "ckpt" in path or (RGBD and reload_a2j):
+        # Lightning restores the constructor arguments saved in the file (a2j/a2j.py:276), so the
+        # checkpoint, not the RGBD flag, decides the stem width
+        checkpoint = torch.load(path, map_location="cpu")
+        RGBD = bool(checkpoint.get("hyper_parameters", {}).get("is_RGBD", RGBD))
+    a2j = A2JModel(21, crop_height=176, crop_width=176, is_RGBD=RGBD)
+    if checkpoint is not None:
+        a2j.load_state_dict(strip_prefix(checkpoint["state_dict"], "a2j."), strict=False)
+    elif reload_a2j:
+        checkpoint = torch.load(path, map_location="cpu")
+        a2j.load_state_dict(checkpoint["model"], strict=False)
     for p in a2j.parameters():
         p.requires_grad = False
     return a2j
@@ -61,7 +66,7 @@ class HandNet(EngineOwner):
         self.detector = load_pretrained_fcos(args, reload_detector, num_classes)
         self.detector.eval()
         self.a2j = load_pretrained_a2j(args, reload_a2j, RGBD)
-        self.RGBD = RGBD
+        self.RGBD = bool(self.a2j.is_RGBD)
         self.num_classes = num_classes
 
     def engine(self) -> HandNetEngine:
@@ -88,7 +93,8 @@ class HandNet(EngineOwner):
         if not bool(mask_cpu.any()):
             return (torch.zeros((n, 21, 3)), torch.zeros_like(depth_images),
                     torch.zeros((n, 4), device=depth_images.device))
-        depth_batch = out.crops_nhwc[mask][..., 0].unsqueeze(1).contiguous()
+        sel = out.crops_nhwc[mask]
+        depth_batch = (sel.permute(0, 3, 1, 2) if self.RGBD else sel[..., 0].unsqueeze(1)).contiguous()
         crops = out.crop_box[mask]
         return final_results, depth_batch, crops
 

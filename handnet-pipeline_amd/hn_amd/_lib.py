@@ -11,7 +11,7 @@ from pathlib import Path
 
 from . import build as _build
 
-ABI_VERSION = 8
+ABI_VERSION = 10
 
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, TILE_256x128, TILE_64x128 = range(7)
 HN_FCOS_MAX_LEVELS = 5
@@ -64,9 +64,10 @@ SIGNATURES = {
     "hn_fcos_nms_scratch_bytes": (C.c_int64, [C.c_int, C.c_int]),
     "hn_fcos_nms": (C.c_int, [VP] * 6 + [C.c_int, C.c_int, C.c_double, C.c_float, C.c_float] + [VP] * 9),
     "hn_nms": (C.c_int, [VP, VP, C.c_int, C.c_double, VP, VP, VP, VP]),
-    "hn_crop_resize": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, VP] + [C.c_int] * 5 + [VP, VP, VP, VP]),
+    "hn_crop_resize": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, VP] + [C.c_int] * 7 + [VP, VP, VP, VP]),
     "hn_pack_depth_nhwc": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, VP]),
     "hn_a2j_aggregate_f32": (C.c_int, [VP, VP, VP, VP] + [C.c_int] * 5 + [VP, VP]),
+    "hn_convert_joints_f32": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_float, C.c_float, c_f32p, VP, VP]),
 }
 
 _lock = threading.Lock()

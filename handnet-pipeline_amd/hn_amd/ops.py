@@ -357,13 +357,15 @@ def nms(boxes, scores, iou_thresh):
     return keep[: int(cnt.item())].to(torch.int64)
 
 
-def crop_resize(det: Detections, hand_label, depth, out_size=176, cpad=4, crop_box=None, has_hand=None, crops=None):
-    """depth [N,1,H,W] -> (crop_box [N,4] int64, has_hand [N] int32, crops [N,out,out,cpad])."""
+def crop_resize(det: Detections, hand_label, depth, out_size=176, cpad=4, crop_box=None, has_hand=None, crops=None,
+                reorder_bgr=False):
+    """depth [N,C,H,W] (C = 1 depth, or 4 RGB-D) -> (crop_box [N,4] int64, has_hand [N] int32,
+    crops [N,out,out,cpad] NHWC).  reorder_bgr applies the RGBD channel permutation [2,1,0,3]."""
     lib = _lib.load()
     _req(depth, name="depth")
     n, c, h, w = depth.shape
-    if c != 1:
-        raise ValueError("depth must be [N,1,H,W]")
+    if c not in (1, 4):
+        raise ValueError("depth must be [N,1,H,W] or [N,4,H,W]")
     cap = det.scores.shape[1]
     dev = depth.device
     if crop_box is None:
@@ -372,8 +374,9 @@ def crop_resize(det: Detections, hand_label, depth, out_size=176, cpad=4, crop_b
         has_hand = torch.empty((n,), device=dev, dtype=torch.int32)
     if crops is None:
         crops = torch.empty((n, out_size, out_size, cpad), device=dev, dtype=torch.float32)
-    check(lib.hn_crop_resize(ptr(det.boxes), ptr(det.labels), ptr(det.count), cap, int(hand_label), ptr(depth), n, h, w,
-                             out_size, cpad, ptr(crop_box), ptr(has_hand), ptr(crops), _stream()), "hn_crop_resize")
+    check(lib.hn_crop_resize(ptr(det.boxes), ptr(det.labels), ptr(det.count), cap, int(hand_label), ptr(depth), n, c,
+                             1 if reorder_bgr else 0, h, w, out_size, cpad, ptr(crop_box), ptr(has_hand), ptr(crops),
+                             _stream()), "hn_crop_resize")
     return crop_box, has_hand, crops
 
 
@@ -405,6 +408,25 @@ def a2j_aggregate(cls, reg, dep, joints=21, stride=16, valid=None, out=None):
         _req(valid, torch.int32, "valid")
     check(lib.hn_a2j_aggregate_f32(ptr(cls), ptr(reg), ptr(dep), ptr(valid), k, fh, fw, joints, stride, ptr(out),
                                    _stream()), "hn_a2j_aggregate_f32")
+    return out
+
+
+def convert_joints(kp, crop_box, valid=None, paras=None, crop=176, out=None):
+    """kp [N,J,3] crop-(u,v,d), crop_box [N,4] int64 -> image (u,v,d), or camera xyz in mm when
+    paras = (fx, fy, cx, cy) is given (convert_joints + uvd2xyz of the reference, on the device)."""
+    lib = _lib.load()
+    _req(kp, name="kp")
+    _req(crop_box, torch.int64, "crop_box")
+    n, j, _ = kp.shape
+    if out is None:
+        out = torch.empty_like(kp)
+    if valid is not None:
+        _req(valid, torch.int32, "valid")
+    pp = None
+    if paras is not None:
+        pp = (C.c_float * 4)(*[float(v) for v in paras])
+    check(lib.hn_convert_joints_f32(ptr(kp), ptr(crop_box), ptr(valid), n, j, float(crop), float(crop), pp, ptr(out),
+                                    _stream()), "hn_convert_joints_f32")
     return out
 
 

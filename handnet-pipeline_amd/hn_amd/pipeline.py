@@ -35,11 +35,14 @@ class HandNetEngine:
         self._graphs = {}
 
     def forward_device(self, images: torch.Tensor, depth: torch.Tensor) -> HandNetOutput:
-        """images [N,3,H,W] 0..1, depth [N,1,H,W] metres, both fp32 on the GPU."""
-        if depth.dim() != 4 or depth.shape[1] != 1 or depth.shape[0] != images.shape[0]:
-            raise ValueError("depth must be [N,1,H,W] matching images")
+        """images [N,3,H,W] 0..1, depth [N,1,H,W] metres (RGBD model: [N,4,H,W] = RGB + depth), fp32 on the GPU."""
+        want_c = 4 if self.a2j.rgbd else 1
+        if depth.dim() != 4 or depth.shape[1] != want_c or depth.shape[0] != images.shape[0]:
+            raise ValueError(f"depth_images must be [N,{want_c},H,W] matching images"
+                             + (" (RGB + depth, ros_demo.py:268-270)" if self.a2j.rgbd else ""))
         det, cand = self.fcos.detect(images)
-        crop_box, has_hand, crops = ops.crop_resize(det, self.num_classes - 1, depth.float().contiguous(), CROP, 4)
+        crop_box, has_hand, crops = ops.crop_resize(det, self.num_classes - 1, depth.float().contiguous(), CROP, 4,
+                                                    reorder_bgr=self.a2j.rgbd)
         kp = self.a2j.forward_nhwc(crops, valid=has_hand)
         return HandNetOutput(kp, crops, crop_box, has_hand, det, cand)
 

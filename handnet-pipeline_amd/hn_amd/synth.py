@@ -158,3 +158,8 @@ def make_depth(n: int, h: int = 480, w: int = 640, seed: int = 2000) -> torch.Te
 
 def make_crops(n: int, size: int = 176, seed: int = 3000) -> torch.Tensor:
     return make_depth(n, size, size, seed)
+
+
+def make_rgbd_crops(n: int, size: int = 176, seed: int = 3100) -> torch.Tensor:
+    """[n,4,size,size]: three colour channels in 0..1 and a depth channel in metres."""
+    return torch.cat([make_rgb(n, size, size, seed), make_depth(n, size, size, seed + 1)], dim=1)

@@ -33,7 +33,7 @@ extern "C" {
 #define HN_ERR_HIP 2
 
 /* ABI version; bumped whenever a struct below changes. */
-#define HN_ABI_VERSION 8
+#define HN_ABI_VERSION 10
 int hn_abi_version(void);
 const char* hn_last_error(void);
 
@@ -197,11 +197,12 @@ int hn_nms(const float* boxes, const float* scores, int k, double iou_thresh,
  * For each image: first detection (score order) with label == hand_label.  Writes
  *   crop_box [n][4] int64 (x1,y1,x2,y2 after padding; zeros if none), has_hand [n] int32,
  *   crops [n][out][out][cpad] fp32 NHWC with depth in channel 0, other channels 0.
- * depth is [n][1][h][w] fp32.
+ * depth is [n][in_ch][h][w] fp32, in_ch = 1 (depth) or 4 (RGB-D; reorder_bgr = 1 applies the
+ * reference's channel permutation [2,1,0,3], handnet_pipeline.py:102); crops channel c = image channel.
  * ------------------------------------------------------------------------------------ */
 int hn_crop_resize(const float* det_boxes, const int32_t* det_labels, const int32_t* det_count,
-                   int cap, int hand_label, const float* depth, int n, int h, int w,
-                   int out, int cpad, int64_t* crop_box, int32_t* has_hand, float* crops,
+                   int cap, int hand_label, const float* depth, int n, int in_ch, int reorder_bgr,
+                   int h, int w, int out, int cpad, int64_t* crop_box, int32_t* has_hand, float* crops,
                    void* stream);
 
 /* Pack [n][1][h][w] depth crops into NHWC(cpad) for the A2J stem (A2J-only entry). */
@@ -219,6 +220,15 @@ int hn_pack_depth_nhwc(const float* src, float* dst, int n, int hw, int cpad, vo
 int hn_a2j_aggregate_f32(const float* cls, const float* reg, const float* dep,
                          const int32_t* valid, int k, int fh, int fw, int joints, int stride,
                          float* out, void* stream);
+
+/* crop-(u,v,d) keypoints -> image (u,v,d) or, with paras = host array (fx, fy, cx, cy), camera
+ * xyz in millimetres.  Replaces convert_joints (a2j/a2j.py:17-34) + uvd2xyz
+ * (datasets3d/a2jdataset.py:31-38), the step every caller runs right after the path
+ * (ros_demo.py:289,329-330).  kp [n][joints][3], crop_box [n][4] int64 (x1,y1,x2,y2),
+ * valid [n] or NULL (rows with valid == 0 are written as zeros). */
+int hn_convert_joints_f32(const float* kp, const int64_t* crop_box, const int32_t* valid,
+                          int n, int joints, float crop_w, float crop_h,
+                          const float* paras /* host, 4 floats, or NULL */, float* out, void* stream);
 
 #ifdef __cplusplus
 }

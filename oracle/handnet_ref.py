@@ -1,5 +1,5 @@
 """Oracle for the end-to-end HandNet glue (handnet_pipeline/handnet_pipeline.py:58-116).
-Test infrastructure only.  Pinned by tests/golden/handnet_forward.npz.
+Test infrastructure only.  Pinned by tests/golden/handnet_forward.npz and handnet_rgbd_forward.npz.
 """
 from __future__ import annotations
 
@@ -30,7 +30,7 @@ def crop_depth(depth_img, box, size=176):
     return F.interpolate(sl.unsqueeze(0), size=(size, size)).squeeze(0)
 
 
-def select_and_crop(dets, depth_images, num_classes):
+def select_and_crop(dets, depth_images, num_classes, rgbd=False):
     """handnet_pipeline.py:74-105.  Returns (image_mask, crops list, depth crops list).
 
     Deviation from the reference (documented in DESIGN.md): a frame without a hand-class
@@ -48,22 +48,24 @@ def select_and_crop(dets, depth_images, num_classes):
         dc = crop_depth(depth_images[i], box)
         if dc is None:
             continue
+        if rgbd:
+            dc = dc[[2, 1, 0, 3], :, :]  # handnet_pipeline.py:102
         mask[i] = True
         boxes.append(box)
         dcrops.append(dc)
     return mask, boxes, dcrops
 
 
-def handnet_forward(images, depth_images, fcos_sd, a2j_sd, num_classes=3):
-    """images: list of [3,H,W]; depth_images [N,1,H,W] -> (keypoints [N,21,3], depth_batch, crops)."""
+def handnet_forward(images, depth_images, fcos_sd, a2j_sd, num_classes=3, rgbd=False):
+    """images: list of [3,H,W]; depth_images [N,1,H,W] (rgbd: [N,4,H,W]) -> (keypoints [N,21,3], depth_batch, crops)."""
     with torch.no_grad():
         n = len(images)
         final = torch.zeros((n, 21, 3))
         dets = fcos_ref.fcos_forward(images, fcos_sd, num_classes)
-        mask, boxes, dcrops = select_and_crop(dets, depth_images, num_classes)
+        mask, boxes, dcrops = select_and_crop(dets, depth_images, num_classes, rgbd)
         if not dcrops:
             return final, torch.zeros_like(depth_images), torch.zeros((n, 4))
         depth_batch = torch.stack(dcrops)
         crops = torch.stack(boxes)
-        final[mask] = a2j_ref.a2j_forward(depth_batch, a2j_sd)
+        final[mask] = a2j_ref.a2j_forward(depth_batch, a2j_sd, channel_in=4 if rgbd else 1)
     return final, depth_batch, crops

@@ -47,6 +47,12 @@ def a2j_sd():
 
 
 @pytest.fixture(scope="session")
+def a2j_rgbd_sd():
+    from hn_amd import synth
+    return synth.make_a2j_state_dict(seed=0, rgbd=True)
+
+
+@pytest.fixture(scope="session")
 def fcos_sd():
     from hn_amd import synth
     return synth.make_fcos_state_dict(seed=0, num_classes=3)

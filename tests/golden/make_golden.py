@@ -5,7 +5,7 @@ Runs only in the build container (needs /root/reference; never on the GPU box, n
 test time).  The reference is imported under a stub shim for its NON-arithmetic
 dependencies; the arithmetic that runs is the reference's own.
 
-    python -B tests/golden/make_golden.py [a2j] [anchor] [fcos] [handnet]
+    python -B tests/golden/make_golden.py [a2j] [a2j_rgbd] [anchor] [fcos] [handnet] [handnet_rgbd]
 
 Outputs are small .npz files holding seeded inputs (or their seeds) and the reference's
 outputs.  Weights are NOT stored: they are regenerated from hn_amd.synth (seeded).
@@ -87,6 +87,26 @@ def gen_a2j():
     print("a2j_forward.npz: keypoints[0,:3] =", out[0, :3].tolist())
 
 
+def gen_a2j_rgbd():
+    """RGB-D variant (a2j/a2j.py:191-199,216: 4-channel stem, no channel expand) on [2,4,176,176] crops."""
+    install_a2j_shim()
+    from a2j.a2j import A2JModel
+    model = A2JModel(21, crop_height=176, crop_width=176, is_RGBD=True).eval()
+    sd = synth.make_a2j_state_dict(seed=0, rgbd=True)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert all(("all_anchors" in k or "thres" in k) for k in missing), missing
+    assert not unexpected, unexpected
+    x = synth.make_rgbd_crops(2, 176, seed=3100)
+    with torch.inference_mode():
+        x3, x4 = model.Backbone(x)
+        out = model(x)
+    np.savez_compressed(
+        HERE / "a2j_rgbd_forward.npz", input_seed=np.int64(3100), weight_seed=np.int64(0), keypoints=out.numpy(),
+        x3_probe=x3[:, :64, 5, 5].numpy(), x4_probe=x4[:, :64, 5, 5].numpy(),
+    )
+    print("a2j_rgbd_forward.npz: keypoints[0,:3] =", out[0, :3].tolist())
+
+
 def gen_anchor():
     """Stand-alone post_process golden (a2j/anchor.py:57-82) incl. a spiked (peaked-softmax) case."""
     install_a2j_shim()
@@ -104,13 +124,17 @@ def gen_anchor():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["a2j", "anchor", "fcos", "handnet"]
+    what = sys.argv[1:] or ["a2j", "a2j_rgbd", "anchor", "fcos", "handnet", "handnet_rgbd"]
     if "a2j" in what:
         gen_a2j()
+    if "a2j_rgbd" in what:
+        gen_a2j_rgbd()
     if "anchor" in what:
         gen_anchor()
-    if "fcos" in what or "handnet" in what:
-        from make_golden_fcos import gen_fcos, gen_handnet  # noqa: E402
+    if "fcos" in what or "handnet" in what or "handnet_rgbd" in what:
+        from make_golden_fcos import gen_fcos, gen_handnet, gen_handnet_rgbd  # noqa: E402
+        if "handnet_rgbd" in what:
+            gen_handnet_rgbd()
         if "fcos" in what:
             gen_fcos()
         if "handnet" in what:

@@ -67,6 +67,10 @@ class _Backbone(nn.Module):
 def install_fcos_shim():
     from make_golden import install_a2j_shim
     install_a2j_shim()
+    # the reference must win over this repo's same-named drop-in packages
+    while str(REF) in sys.path:
+        sys.path.remove(str(REF))
+    sys.path.insert(0, str(REF))
     tv = sys.modules["torchvision"]
     boxes_ns = types.SimpleNamespace(batched_nms=fcos_ref.batched_nms)
     tv.ops = _mod("torchvision.ops", sigmoid_focal_loss=None, boxes=boxes_ns)
@@ -141,4 +145,34 @@ def gen_handnet():
         keypoints=kp.numpy(), crops=crops.numpy(),
         depth_batch_probe=depth_batch[:, 0, ::16, ::16].numpy(),
         depth_batch_sum=depth_batch.double().sum().item(),
+    )
+
+
+def gen_handnet_rgbd():
+    """RGBD=True glue (handnet_pipeline.py:101-102: 4-channel crop + channel permutation [2,1,0,3]).
+    The reference builds this model through a Lightning checkpoint (handnet_pipeline.py:28-29); offline the
+    same A2JModel(is_RGBD=True) is constructed directly and given the synthetic RGBD weights."""
+    install_fcos_shim()
+    from handnet_pipeline.handnet_pipeline import HandNet
+    from a2j.a2j import A2JModel
+    fsd = synth.make_fcos_state_dict(seed=0, num_classes=3)
+    asd = synth.make_a2j_state_dict(seed=0, rgbd=True)
+    _FCOS_SD["sd"] = fsd
+    args = types.SimpleNamespace(pretrained_fcos="none.pth", pretrained_a2j="none.pth")
+    net = HandNet(args, reload_detector=False, num_classes=3, reload_a2j=False, RGBD=False).eval()
+    net.detector.load_state_dict(fsd, strict=False)
+    net.RGBD = True
+    net.a2j = A2JModel(21, crop_height=176, crop_width=176, is_RGBD=True).eval()
+    net.a2j.load_state_dict(asd, strict=False)
+    rgb = synth.make_rgb(2, seed=1000)
+    depth = synth.make_depth(2, seed=2000)
+    rgbd = torch.cat([rgb, depth], dim=1)                     # ros_demo.py:268-270 (RGB + depth)
+    with torch.inference_mode():
+        kp, depth_batch, crops = net([rgb[0], rgb[1]], depth_images=rgbd)
+    print("handnet rgbd golden: crops", crops.tolist(), "kp[0,0]", kp[0, 0].tolist())
+    np.savez_compressed(
+        HERE / "handnet_rgbd_forward.npz", rgb_seed=np.int64(1000), depth_seed=np.int64(2000),
+        keypoints=kp.numpy(), crops=crops.numpy(),
+        depth_batch_probe=depth_batch[:, :, ::16, ::16].numpy(),
+        depth_batch_sum=depth_batch.double().sum(dim=(0, 2, 3)).numpy(),
     )

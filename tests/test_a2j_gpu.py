@@ -94,3 +94,17 @@ def test_a2j_batch64_properties(a2j_sd):
     one = eng.forward(x[17:18])
     assert (out[17:18] - one).abs().max().item() < 1e-4
     assert out[..., :2].min() > -50 and out[..., :2].max() < 226
+
+
+def test_a2j_rgbd_forward_matches_golden(golden_dir, a2j_rgbd_sd):
+    """SURVEY 8f #3: is_RGBD=True model (4-channel 7x7 stem, a2j/a2j.py:191-199) vs the imported reference."""
+    from a2j.a2j import A2JModel
+    from hn_amd import synth
+    g = np.load(golden_dir / "a2j_rgbd_forward.npz")
+    model = A2JModel(21, crop_height=176, crop_width=176, is_RGBD=True)
+    model.load_state_dict(a2j_rgbd_sd, strict=False)
+    model = model.cuda().eval()
+    x = synth.make_rgbd_crops(2, 176, seed=int(g["input_seed"])).cuda()
+    out = model(x)
+    assert out.device.type == "cpu" and out.shape == (2, 21, 3)
+    assert np.abs(out.numpy() - g["keypoints"]).max() < 1e-3

@@ -92,6 +92,25 @@ def test_handnet_oracle_reproduces_reference_golden(golden_dir, fcos_sd, a2j_sd)
     assert np.abs(kp.numpy() - g["keypoints"]).max() <= 1e-4
 
 
+def test_rgbd_oracles_reproduce_reference_goldens(golden_dir, fcos_sd, a2j_rgbd_sd):
+    """SURVEY 8f #3: 4-channel stem (a2j/a2j.py:191-199) and the RGBD crop permutation (handnet_pipeline.py:102)."""
+    g = np.load(golden_dir / "a2j_rgbd_forward.npz")
+    x = synth.make_rgbd_crops(2, 176, seed=int(g["input_seed"]))
+    out, (x3, x4), _ = a2j_ref.a2j_forward(x, a2j_rgbd_sd, channel_in=4, return_heads=True)
+    assert np.abs(out.numpy() - g["keypoints"]).max() <= 1e-5
+    assert np.abs(x3[:, :64, 5, 5].numpy() - g["x3_probe"]).max() <= 1e-5
+    assert np.abs(x4[:, :64, 5, 5].numpy() - g["x4_probe"]).max() <= 1e-5
+    g = np.load(golden_dir / "handnet_rgbd_forward.npz")
+    rgb = synth.make_rgb(2, seed=int(g["rgb_seed"]))
+    depth = synth.make_depth(2, seed=int(g["depth_seed"]))
+    kp, depth_batch, crops = handnet_ref.handnet_forward([rgb[0], rgb[1]], torch.cat([rgb, depth], 1), fcos_sd,
+                                                         a2j_rgbd_sd, 3, rgbd=True)
+    assert np.array_equal(crops.numpy(), g["crops"])
+    assert np.array_equal(depth_batch[:, :, ::16, ::16].numpy(), g["depth_batch_probe"])
+    assert np.abs(depth_batch.double().sum(dim=(0, 2, 3)).numpy() - g["depth_batch_sum"]).max() < 1e-6
+    assert np.abs(kp.numpy() - g["keypoints"]).max() <= 1e-4
+
+
 def test_crop_box_rule():
     """SURVEY A.8: trunc, pad 0.4, clamp to [0,W]/[0,H]."""
     b = handnet_ref.crop_box(torch.tensor([[10.9, 20.2, 110.7, 220.9]]), 640, 480)

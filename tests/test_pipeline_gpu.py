@@ -130,3 +130,68 @@ def test_pipeline_batch_consistency_and_graph(handnet):
     torch.cuda.synchronize()
     assert torch.equal(out.crop_box, full.crop_box)
     assert (out.keypoints - full.keypoints).abs().max().item() < 1e-5
+
+
+def test_rgbd_crop_reorders_channels():
+    """handnet_pipeline.py:101-102: 4-channel crop, output channels = input channels [2,1,0,3]."""
+    from hn_amd import ops
+    from oracle import handnet_ref
+    g = torch.Generator().manual_seed(11)
+    rgbd = torch.rand((2, 4, 480, 640), generator=g)
+    boxes = [[[100.7, 50.2, 300.9, 400.5]], [[600.1, 440.3, 700.0, 500.0]]]
+    det = _dets_from_boxes(boxes, [[2], [2]])
+    crop_box, has_hand, crops = ops.crop_resize(det, 2, rgbd.cuda(), 176, 4, reorder_bgr=True)
+    for i in range(2):
+        ref_box = handnet_ref.crop_box(torch.tensor(boxes[i]), 640, 480)
+        ref = handnet_ref.crop_depth(rgbd[i], ref_box)[[2, 1, 0, 3]]
+        assert crop_box[i].cpu().tolist() == ref_box.tolist()
+        assert torch.equal(crops[i].permute(2, 0, 1).cpu(), ref)
+    _, _, plain = ops.crop_resize(det, 2, rgbd.cuda(), 176, 4, reorder_bgr=False)
+    assert torch.equal(plain[..., [2, 1, 0, 3]], crops)
+
+
+def test_handnet_rgbd_matches_reference_golden(fcos_sd, a2j_rgbd_sd, golden_dir, tmp_path):
+    """RGBD=True through the drop-in, loading A2J from a Lightning-style .ckpt (handnet_pipeline.py:28-29:
+    weights under state_dict['a2j.*'])."""
+    from handnet_pipeline.handnet_pipeline import HandNet
+    from hn_amd import synth
+    ckpt = tmp_path / "a2j_rgbd.ckpt"
+    torch.save({"state_dict": {"a2j." + k: v for k, v in a2j_rgbd_sd.items()},
+                "hyper_parameters": {"num_classes": 21, "is_RGBD": True}}, ckpt)
+    args = types.SimpleNamespace(pretrained_fcos="unused.pth", pretrained_a2j=str(ckpt))
+    net = HandNet(args, reload_detector=False, num_classes=3, reload_a2j=True, RGBD=True)
+    net.detector.load_state_dict(fcos_sd, strict=False)
+    net = net.cuda().eval()
+    g = np.load(golden_dir / "handnet_rgbd_forward.npz")
+    rgb = synth.make_rgb(2, seed=int(g["rgb_seed"])).cuda()
+    depth = synth.make_depth(2, seed=int(g["depth_seed"])).cuda()
+    with torch.inference_mode():
+        kp, depth_batch, crops = net([rgb[0], rgb[1]], depth_images=torch.cat([rgb, depth], 1))
+    assert depth_batch.shape == (2, 4, 176, 176)
+    assert np.array_equal(crops.cpu().numpy(), g["crops"])
+    assert np.array_equal(depth_batch[:, :, ::16, ::16].cpu().numpy(), g["depth_batch_probe"])
+    assert np.abs(kp.numpy() - g["keypoints"]).max() < 1e-3
+    with pytest.raises(ValueError):
+        net([rgb[0], rgb[1]], depth_images=depth)      # an RGBD model needs the 4-channel tensor
+
+
+def test_convert_joints_matches_reference_formula():
+    """crop-uvd -> image-uvd -> camera xyz (mm) on the device vs the oracle's restatement of
+    a2j/a2j.py:17-34 + datasets3d/a2jdataset.py:31-38.  Tolerance 1e-2 mm on O(100-1000) mm values."""
+    from hn_amd import ops
+    from oracle import a2j_ref
+    g = torch.Generator().manual_seed(3)
+    kp = torch.rand((5, 21, 3), generator=g) * torch.tensor([176.0, 176.0, 1.2]) + torch.tensor([0.0, 0.0, 0.3])
+    box = torch.tensor([[0, 200, 49, 266], [192, 0, 264, 46], [100, 50, 420, 430], [0, 0, 640, 480], [7, 9, 8, 10]])
+    valid = torch.tensor([1, 1, 0, 1, 1], dtype=torch.int32)
+    paras = (617.343, 617.343, 312.42, 241.42)
+    xyz = ops.convert_joints(kp.cuda(), box.cuda(), valid.cuda(), paras).cpu()
+    uvd = ops.convert_joints(kp.cuda(), box.cuda(), None, None).cpu()
+    for i in range(5):
+        ref_xyz = a2j_ref.convert_joints(kp[i].numpy(), box[i].numpy(), paras)
+        ref_uvd = a2j_ref.convert_joints(kp[i].numpy(), box[i].numpy(), None)
+        assert np.abs(uvd[i].numpy() - ref_uvd).max() < 1e-3
+        if valid[i]:
+            assert np.abs(xyz[i].numpy() - ref_xyz).max() < 1e-2
+        else:
+            assert float(xyz[i].abs().max()) == 0.0
