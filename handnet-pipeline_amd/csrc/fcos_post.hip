@@ -83,6 +83,7 @@ __global__ __launch_bounds__(1024) void fcos_candidates_kernel(const LevelTable 
                                                                int* __restrict__ cand_labels,
                                                                int* __restrict__ cand_sides,
                                                                int* __restrict__ cand_level,
+                                                               int* __restrict__ cand_point,
                                                                int* __restrict__ cand_count, int cap) {
   __shared__ int wave_counts[16];
   __shared__ int base_s;
@@ -153,6 +154,7 @@ __global__ __launch_bounds__(1024) void fcos_candidates_kernel(const LevelTable 
         cand_labels[o] = label;
         cand_sides[o] = side;
         cand_level[o] = lvl;
+        if (cand_point) cand_point[o] = i;
       }
     }
     __syncthreads();
@@ -160,6 +162,47 @@ __global__ __launch_bounds__(1024) void fcos_candidates_kernel(const LevelTable 
     __syncthreads();
   }
   if (tid == 0) cand_count[img] = min(base_s, cap);
+}
+
+// ext=True outputs of the kept detections (fcos.py:299-320 head maths, :605-607,631-647 gather):
+//   ext[l] [n][h][w][8] = relu(hand_dydx_layer)[3] then hand_contact_state_layer[5], raw conv outputs
+//   dxdymags = [mag, 0.1 * dx / max(||(dx,dy)||, 1e-12), 0.1 * dy / ...]; contacts = argmax sigmoid (first max)
+struct ExtTable {
+  int num_levels;
+  int hw[HN_FCOS_MAX_LEVELS];
+  int start[HN_FCOS_MAX_LEVELS + 1];
+  const float* ext[HN_FCOS_MAX_LEVELS];
+};
+
+__global__ __launch_bounds__(256) void fcos_ext_gather_kernel(const ExtTable et, const int* __restrict__ det_keep,
+                                                               const int* __restrict__ cand_point,
+                                                               const int* __restrict__ det_count, int n, int cap,
+                                                               int* __restrict__ contacts,
+                                                               float* __restrict__ dxdymags) {
+  const long total = (long)n * cap;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int img = (int)(i / cap), d = (int)(i - (long)img * cap);
+    if (d >= det_count[img]) continue;
+    const int pt = cand_point[(long)img * cap + det_keep[i]];
+    int lvl = 0;
+    while (lvl + 1 < et.num_levels && pt >= et.start[lvl + 1]) ++lvl;
+    const float* e = et.ext[lvl] + ((long)img * et.hw[lvl] + (pt - et.start[lvl])) * 8;
+    const float dx = e[1], dy = e[2];
+    const float denom = fmaxf(sqrtf(dx * dx + dy * dy), 1e-12f);
+    dxdymags[i * 3 + 0] = e[0];
+    dxdymags[i * 3 + 1] = 0.1f * (dx / denom);
+    dxdymags[i * 3 + 2] = 0.1f * (dy / denom);
+    int best = 0;
+    float bs = sigmoidf_(e[3]);
+    for (int c = 1; c < 5; ++c) {
+      const float sc = sigmoidf_(e[3 + c]);
+      if (sc > bs) {
+        bs = sc;
+        best = c;
+      }
+    }
+    contacts[i] = best;
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -459,7 +502,8 @@ extern "C" int hn_fcos_preprocess_f32(const float* src, float* dst, int n, int h
 
 extern "C" int hn_fcos_candidates(const hn_fcos_levels* lv, int n, int num_classes, float score_thresh,
                                   float* cand_boxes, float* cand_scores, int32_t* cand_labels, int32_t* cand_sides,
-                                  int32_t* cand_level, int32_t* cand_count, int cap, void* stream) {
+                                  int32_t* cand_level, int32_t* cand_point, int32_t* cand_count, int cap,
+                                  void* stream) {
   HN_CHECK_ARG(lv && cand_boxes && cand_scores && cand_labels && cand_sides && cand_level && cand_count,
                "hn_fcos_candidates: null pointer");
   HN_CHECK_ARG(lv->num_levels > 0 && lv->num_levels <= HN_FCOS_MAX_LEVELS, "bad level count");
@@ -482,8 +526,33 @@ extern "C" int hn_fcos_candidates(const hn_fcos_levels* lv, int n, int num_class
     lt.start[l + 1] = lt.start[lv->num_levels];
   }
   hipLaunchKernelGGL(fcos_candidates_kernel, dim3(n), dim3(1024), 0, (hipStream_t)stream, lt, num_classes,
-                     score_thresh, cand_boxes, cand_scores, cand_labels, cand_sides, cand_level, cand_count, cap);
+                     score_thresh, cand_boxes, cand_scores, cand_labels, cand_sides, cand_level, cand_point, cand_count,
+                     cap);
   HN_CHECK_LAUNCH("fcos_candidates_kernel");
+  return HN_OK;
+}
+
+extern "C" int hn_fcos_ext_gather(const hn_fcos_levels* lv, const float* const* ext, const int32_t* det_keep,
+                                  const int32_t* cand_point, const int32_t* det_count, int n, int cap,
+                                  int32_t* det_contacts, float* det_dxdymags, void* stream) {
+  HN_CHECK_ARG(lv && ext && det_keep && cand_point && det_count && det_contacts && det_dxdymags,
+               "hn_fcos_ext_gather: null pointer");
+  HN_CHECK_ARG(lv->num_levels > 0 && lv->num_levels <= HN_FCOS_MAX_LEVELS, "bad level count");
+  HN_CHECK_ARG(n > 0 && cap > 0, "bad dims");
+  ExtTable et;
+  et.num_levels = lv->num_levels;
+  et.start[0] = 0;
+  for (int l = 0; l < HN_FCOS_MAX_LEVELS; ++l) {
+    const bool on = l < lv->num_levels;
+    if (on) HN_CHECK_ARG(lv->h[l] > 0 && lv->w[l] > 0 && ext[l], "bad level %d", l);
+    et.hw[l] = on ? lv->h[l] * lv->w[l] : 0;
+    et.ext[l] = on ? ext[l] : nullptr;
+    et.start[l + 1] = et.start[l] + et.hw[l];
+  }
+  const long total = (long)n * cap;
+  hipLaunchKernelGGL(fcos_ext_gather_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, et,
+                     det_keep, cand_point, det_count, n, cap, det_contacts, det_dxdymags);
+  HN_CHECK_LAUNCH("fcos_ext_gather_kernel");
   return HN_OK;
 }
 

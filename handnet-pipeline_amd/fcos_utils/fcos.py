@@ -4,7 +4,8 @@ Same constructor arguments, state_dict layout and eval-mode call contract as the
 reference class (fcos_utils/fcos.py:398-767): `model(images: list of [3,H,W] in 0..1)`
 returns one dict per image with `boxes [k,4]` (original-image pixels, unclipped),
 `scores [k]`, `labels [k] int64`, `sides [k] int64`, `feature_idx [k] float32`, sorted by
-descending score.  As in the reference, `score_thresh / nms_thresh / topk_candidates /
+descending score; with `ext=True` (the class default, used by trainval_net_fcos.py --test-only) the dicts hold
+`dxdymags [k,3]`, `contacts [k] int64` and `sides` instead of `feature_idx` (fcos.py:637-647).  As in the reference, `score_thresh / nms_thresh / topk_candidates /
 detections_per_img` are accepted and IGNORED: post-processing hard-codes score > 0.7 and
 NMS IoU 0.3 (fcos.py:600,635).  Training (targets / losses) is out of scope.
 """
@@ -26,10 +27,6 @@ class FCOS(EngineOwner):
                  score_thresh: float = 0.2, nms_thresh: float = 0.6, detections_per_img: int = 100,
                  topk_candidates: int = 1000):
         super().__init__()
-        if ext:
-            raise NotImplementedError(
-                "ext=True (contact-state / dxdy heads) is not on the HandNet hot path "
-                "(handnet_pipeline.py:16 builds FCOS(ext=False)); construct with ext=False")
         if anchor_generator is not None or head is not None:
             raise NotImplementedError("custom anchor_generator / head modules are not supported")
         if image_mean not in (None, [0.485, 0.456, 0.406]) or image_std not in (None, [0.229, 0.224, 0.225]):
@@ -41,7 +38,7 @@ class FCOS(EngineOwner):
         self.center_sampling_radius = center_sampling_radius
         self.score_thresh, self.nms_thresh = score_thresh, nms_thresh
         self.detections_per_img, self.topk_candidates = detections_per_img, topk_candidates
-        tree = build_state_tree(synth.make_fcos_state_dict(seed=0, num_classes=num_classes, ext=False))
+        tree = build_state_tree(synth.make_fcos_state_dict(seed=0, num_classes=num_classes, ext=ext))
         for name, child in tree.named_children():
             self.add_module(name, child)
 
@@ -50,7 +47,7 @@ class FCOS(EngineOwner):
         if self._engine is None:
             sd = {k: v.detach().cpu() for k, v in self.state_dict().items()}
             self._engine = FCOSEngine(sd, self.num_classes, device=dev, min_size=self.min_size,
-                                      max_size=self.max_size)
+                                      max_size=self.max_size, ext=self.ext)
         return self._engine
 
     def forward(self, images: List[torch.Tensor], targets=None) -> List[Dict[str, torch.Tensor]]:
@@ -59,10 +56,23 @@ class FCOS(EngineOwner):
         if len({tuple(i.shape) for i in images}) != 1:
             raise NotImplementedError("all images of a batch must share one size (the demo feeds 480x640 frames)")
         batch = torch.stack([i.float() for i in images])
-        det, _ = self.engine().detect(batch)
+        if self.ext:
+            det, _, contacts, dxdymags = self.engine().detect_ext(batch)
+        else:
+            det, _ = self.engine().detect(batch)
         counts = det.count.cpu().tolist()  # the list-of-dicts contract needs lengths on the host
         out = []
         for i, k in enumerate(counts):
+            if self.ext:  # fcos.py:637-647
+                out.append({
+                    "boxes": det.boxes[i, :k].clone(),
+                    "scores": det.scores[i, :k].clone(),
+                    "labels": det.labels[i, :k].to(torch.int64),
+                    "dxdymags": dxdymags[i, :k].clone(),
+                    "contacts": contacts[i, :k].to(torch.int64),
+                    "sides": det.sides[i, :k].to(torch.int64),
+                })
+                continue
             out.append({
                 "boxes": det.boxes[i, :k].clone(),
                 "scores": det.scores[i, :k].clone(),

@@ -11,7 +11,7 @@ from pathlib import Path
 
 from . import build as _build
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, TILE_256x128, TILE_64x128 = range(7)
 HN_FCOS_MAX_LEVELS = 5
@@ -60,7 +60,8 @@ SIGNATURES = {
     "hn_groupnorm_affine_f32": (C.c_int, [VP, VP, VP] + [C.c_int] * 4 + [C.c_float, VP, VP, VP, VP]),
     "hn_fcos_preprocess_f32": (C.c_int, [VP, VP] + [C.c_int] * 7 + [c_f32p, c_f32p, VP]),
     "hn_fcos_candidates": (C.c_int, [C.POINTER(FcosLevels), C.c_int, C.c_int, C.c_float,
-                                     VP, VP, VP, VP, VP, VP, C.c_int, VP]),
+                                     VP, VP, VP, VP, VP, VP, VP, C.c_int, VP]),
+    "hn_fcos_ext_gather": (C.c_int, [C.POINTER(FcosLevels), C.POINTER(VP), VP, VP, VP, C.c_int, C.c_int, VP, VP, VP]),
     "hn_fcos_nms_scratch_bytes": (C.c_int64, [C.c_int, C.c_int]),
     "hn_fcos_nms": (C.c_int, [VP] * 6 + [C.c_int, C.c_int, C.c_double, C.c_float, C.c_float] + [VP] * 9),
     "hn_nms": (C.c_int, [VP, VP, C.c_int, C.c_double, VP, VP, VP, VP]),

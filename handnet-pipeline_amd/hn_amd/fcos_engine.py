@@ -38,7 +38,7 @@ def resized_size(h: int, w: int, min_size: int = 800, max_size: int = 1333):
 
 class FCOSEngine:
     def __init__(self, state_dict, num_classes: int, device="cuda", min_size=800, max_size=1333,
-                 precision="f16x3"):
+                 precision="f16x3", ext=False):
         """precision: "f16x3" (split-fp16 operands, fp32-grade; default) or "f32" (exact f32 MFMA)."""
         if precision not in ("f32", "f16x3"):
             raise ValueError("precision must be 'f32' or 'f16x3'")
@@ -93,6 +93,12 @@ class FCOSEngine:
             pack_conv(sd[r + ".bbox_ctrness.weight"], sd[r + ".bbox_ctrness.bias"], pad=1)]).to(dev)
         if self.cls_out.cout != num_classes + 2:
             raise ValueError("checkpoint does not match num_classes")
+        # ext=True heads (fcos.py:255-264): dxdy-magnitude (3, ReLU) and contact state (5) from the cls tower
+        self.ext = ext
+        self.ext_out = concat_cout([
+            pack_conv(sd[c + ".hand_dydx_layer.weight"], sd[c + ".hand_dydx_layer.bias"], pad=1),
+            pack_conv(sd[c + ".hand_contact_state_layer.weight"], sd[c + ".hand_contact_state_layer.bias"], pad=1),
+        ]).to(dev) if ext else None
         self._gn_scratch = None
 
     # -----------------------------------------------------------------------------------
@@ -134,7 +140,7 @@ class FCOSEngine:
         return ops.groupnorm_affine(x, gamma, beta, groups=groups, scratch=self._gn_scratch)
 
     def head_level(self, feat):
-        """One FPN level -> (cls_lr [N,h,w,C+2], reg_ctr [N,h,w,5]) raw fp32 conv outputs.
+        """One FPN level -> (cls_lr [N,h,w,C+2], reg_ctr [N,h,w,5], ext [N,h,w,8] or None) raw fp32 conv outputs.
 
         conv -> GroupNorm -> ReLU -> conv: each tower conv writes its raw fp32 output, the
         statistics pass turns GroupNorm into a per-(image, channel) affine, and
@@ -147,10 +153,16 @@ class FCOSEngine:
         xc, sc_c, sh_c = t0[..., :256], sc[:, :256], sh[:, :256]
         xr, sc_r, sh_r = t0[..., 256:], sc[:, 256:], sh[:, 256:]
 
-        def nxt(x, cw, scale, shift, **kw):
+        def act(x, scale, shift):  # GroupNorm affine + ReLU, materialised (S32) or deferred to the conv load
+            return ops.to_split(x, scale, shift, relu=True) if s16 else (x, scale, shift)
+
+        def conv(a, cw, **kw):
             if s16:
-                return self._conv(ops.to_split(x, scale, shift, relu=True), cw, out_f32=True, **kw)
-            return self._conv(x, cw, in_scale=scale, in_shift=shift, **kw)
+                return self._conv(a, cw, out_f32=True, **kw)
+            return self._conv(a[0], cw, in_scale=a[1], in_shift=a[2], **kw)
+
+        def nxt(x, cw, scale, shift, **kw):
+            return conv(act(x, scale, shift), cw, **kw)
 
         for cw, (g, b) in zip(self.cls_tower, self.cls_gn):
             xc = nxt(xc, cw, sc_c, sh_c)
@@ -158,9 +170,11 @@ class FCOSEngine:
         for cw, (g, b) in zip(self.reg_tower, self.reg_gn):
             xr = nxt(xr, cw, sc_r, sh_r)
             sc_r, sh_r = self._gn(xr, g, b, 32)
-        cls_lr = nxt(xc, self.cls_out, sc_c, sh_c)
+        ac = act(xc, sc_c, sh_c)
+        cls_lr = conv(ac, self.cls_out)
+        ext = conv(ac, self.ext_out, relu_cols=3) if self.ext else None
         reg_ctr = nxt(xr, self.reg_out, sc_r, sh_r, relu_cols=4)
-        return cls_lr, reg_ctr
+        return cls_lr, reg_ctr, ext
 
     def forward_heads(self, images):
         """images [N,3,H,W] fp32 0..1 on the GPU -> per-level head tensors + geometry."""
@@ -172,6 +186,7 @@ class FCOSEngine:
         feats = self.backbone(x)
         outs = [self.head_level(f) for f in feats]
         strides = [ph // f.shape[1] for f in feats]
+        self._ext_levels = [o[2] for o in outs] if self.ext else None
         return [o[0] for o in outs], [o[1] for o in outs], strides, (oh, ow, ph, pw)
 
     def detect(self, images, cand=None, det=None, nms_scratch=None):
@@ -184,6 +199,14 @@ class FCOSEngine:
         ratio_w = (torch.tensor(float(w)) / torch.tensor(float(ow))).item()
         det = ops.fcos_nms(cand, NMS_THRESH, ratio_h, ratio_w, scratch=nms_scratch, out=det)
         return det, cand
+
+    def detect_ext(self, images):
+        """ext=True detector: (Detections, Candidates, contacts [N,cap] int32, dxdymags [N,cap,3])."""
+        if not self.ext:
+            raise RuntimeError("engine was built without the ext heads")
+        det, cand = self.detect(images)
+        contacts, dxdymags = ops.fcos_ext_gather(self._ext_levels, det, cand)
+        return det, cand, contacts, dxdymags
 
     # -----------------------------------------------------------------------------------
     def macs_per_frame(self, h=480, w=640) -> int:
@@ -208,4 +231,5 @@ class FCOSEngine:
             pts += a * b
         per_pt = self.tower0.macs_per_pixel() + sum(c.macs_per_pixel() for c in self.cls_tower + self.reg_tower)
         per_pt += self.cls_out.macs_per_pixel() + self.reg_out.macs_per_pixel()
+        per_pt += self.ext_out.macs_per_pixel() if self.ext else 0
         return total + pts * per_pt

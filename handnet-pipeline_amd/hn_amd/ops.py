@@ -277,6 +277,7 @@ class Candidates:
     sides: torch.Tensor
     level: torch.Tensor
     count: torch.Tensor
+    point: torch.Tensor = None  # anchor-point index of each candidate (row of the [P, ...] head tensors)
 
 
 @dataclass
@@ -294,7 +295,7 @@ def alloc_candidates(n, cap, device) -> Candidates:
     i32 = dict(device=device, dtype=torch.int32)
     return Candidates(torch.zeros((n, cap, 4), device=device), torch.zeros((n, cap), device=device),
                       torch.zeros((n, cap), **i32), torch.zeros((n, cap), **i32), torch.zeros((n, cap), **i32),
-                      torch.zeros((n,), **i32))
+                      torch.zeros((n,), **i32), torch.zeros((n, cap), **i32))
 
 
 def alloc_detections(n, cap, device) -> Detections:
@@ -322,9 +323,35 @@ def fcos_candidates(cls_lr, reg_ctr, strides, num_classes, score_thresh=0.7, out
         out = alloc_candidates(n, cap, cls_lr[0].device)
     cap = out.scores.shape[1]
     check(lib.hn_fcos_candidates(C.byref(lv), n, num_classes, score_thresh, ptr(out.boxes), ptr(out.scores),
-                                 ptr(out.labels), ptr(out.sides), ptr(out.level), ptr(out.count), cap, _stream()),
+                                 ptr(out.labels), ptr(out.sides), ptr(out.level),
+                                 ptr(out.point) if out.point is not None else None, ptr(out.count), cap, _stream()),
           "hn_fcos_candidates")
     return out
+
+
+def fcos_ext_gather(ext, det: "Detections", cand: Candidates):
+    """ext[l] [N,h,w,8] raw (relu(dxdy)[3], contact[5]) per level -> (contacts [N,cap] int32,
+    dxdymags [N,cap,3] fp32) for the kept detections (fcos.py:299-320,605-607,631-647)."""
+    lib = _lib.load()
+    if cand.point is None:
+        raise ValueError("candidates were produced without anchor-point indices")
+    lv = FcosLevels()
+    lv.num_levels = len(ext)
+    arr = (C.c_void_p * len(ext))()
+    for i, e in enumerate(ext):
+        _req(e, name="ext")
+        if e.shape[3] != 8:
+            raise ValueError("ext tensors must be [N,h,w,8]")
+        lv.h[i], lv.w[i], lv.stride[i] = e.shape[1], e.shape[2], 1
+        arr[i] = e.data_ptr()
+    n, cap = det.scores.shape
+    if sum(e.shape[1] * e.shape[2] for e in ext) != cand.scores.shape[1] or cand.scores.shape[1] != cap:
+        raise ValueError("ext levels do not match the candidate capacity")
+    contacts = torch.zeros((n, cap), device=det.scores.device, dtype=torch.int32)
+    dxdymags = torch.zeros((n, cap, 3), device=det.scores.device, dtype=torch.float32)
+    check(lib.hn_fcos_ext_gather(C.byref(lv), arr, ptr(det.keep), ptr(cand.point), ptr(det.count), n, cap,
+                                 ptr(contacts), ptr(dxdymags), _stream()), "hn_fcos_ext_gather")
+    return contacts, dxdymags
 
 
 def fcos_nms(cand: Candidates, iou_thresh, ratio_h, ratio_w, scratch=None, out: Detections | None = None):

@@ -33,7 +33,7 @@ extern "C" {
 #define HN_ERR_HIP 2
 
 /* ABI version; bumped whenever a struct below changes. */
-#define HN_ABI_VERSION 10
+#define HN_ABI_VERSION 11
 int hn_abi_version(void);
 const char* hn_last_error(void);
 
@@ -175,7 +175,18 @@ typedef struct hn_fcos_levels {
 int hn_fcos_candidates(const hn_fcos_levels* lv, int n, int num_classes, float score_thresh,
                        float* cand_boxes /* [n][cap][4] */, float* cand_scores /* [n][cap] */,
                        int32_t* cand_labels, int32_t* cand_sides, int32_t* cand_level /* [n][cap] */,
+                       int32_t* cand_point /* [n][cap] anchor-point index, may be NULL */,
                        int32_t* cand_count /* [n] */, int cap, void* stream);
+
+/* ext=True detector outputs (fcos_utils/fcos.py:255-264 layers, :299-320 head maths, :605-607 argmax,
+ * :631-647 gather) for the detections hn_fcos_nms kept.  ext[l] is the raw NHWC conv output
+ * [n][h_l][w_l][8] = relu(hand_dydx_layer)[3] then hand_contact_state_layer[5] (host array of
+ * lv->num_levels device pointers; lv supplies h/w only).  Row d of image i (d < det_count[i]):
+ *   det_dxdymags[i][d] = (mag, 0.1*dx/max(|(dx,dy)|,1e-12), 0.1*dy/...), det_contacts[i][d] = argmax. */
+int hn_fcos_ext_gather(const hn_fcos_levels* lv, const float* const* ext, const int32_t* det_keep,
+                       const int32_t* cand_point, const int32_t* det_count, int n, int cap,
+                       int32_t* det_contacts /* [n][cap] */, float* det_dxdymags /* [n][cap][3] */,
+                       void* stream);
 
 int64_t hn_fcos_nms_scratch_bytes(int n, int cap);
 int hn_fcos_nms(const float* cand_boxes, const float* cand_scores, const int32_t* cand_labels,

@@ -124,7 +124,7 @@ def backbone(x, sd):
 
 
 # ---------------------------------------------------------------------------------------
-# heads (fcos_utils/fcos.py:267-329, 373-395), ext=False
+# heads (fcos_utils/fcos.py:267-329, 373-395); ext=True adds the contact-state / dxdy outputs (:299-320)
 # ---------------------------------------------------------------------------------------
 def _tower(x, sd, name):
     for i in range(4):
@@ -138,19 +138,29 @@ def _flatten(t, k):
     return t.view(n, -1, k, h, w).permute(0, 3, 4, 1, 2).reshape(n, -1, k)
 
 
-def head(features, sd, num_classes):
-    cls_all, lr_all, reg_all, ctr_all = [], [], [], []
+def head(features, sd, num_classes, ext=False):
+    cls_all, lr_all, reg_all, ctr_all, contact_all, dxdy_all = [], [], [], [], [], []
     c = "head.classification_head"
     r = "head.regression_head"
     for feat in features:
         ct = _tower(feat, sd, c)
         cls_all.append(_flatten(F.conv2d(ct, sd[c + ".cls_logits.weight"], sd[c + ".cls_logits.bias"], padding=1), num_classes))
         lr_all.append(_flatten(F.conv2d(ct, sd[c + ".hand_lr_layer.weight"], sd[c + ".hand_lr_layer.bias"], padding=1), 2))
+        if ext:
+            d = F.relu(F.conv2d(ct, sd[c + ".hand_dydx_layer.weight"], sd[c + ".hand_dydx_layer.bias"], padding=1))
+            d = torch.cat([d[:, 0].unsqueeze(1), 0.1 * F.normalize(d[:, 1:], p=2, dim=1)], dim=1)  # fcos.py:301-303
+            dxdy_all.append(_flatten(d, 3))
+            contact_all.append(_flatten(F.conv2d(ct, sd[c + ".hand_contact_state_layer.weight"],
+                                                 sd[c + ".hand_contact_state_layer.bias"], padding=1), 5))
         rt = _tower(feat, sd, r)
         reg_all.append(_flatten(F.relu(F.conv2d(rt, sd[r + ".bbox_reg.weight"], sd[r + ".bbox_reg.bias"], padding=1)), 4))
         ctr_all.append(_flatten(F.conv2d(rt, sd[r + ".bbox_ctrness.weight"], sd[r + ".bbox_ctrness.bias"], padding=1), 1))
-    return {"cls_logits": torch.cat(cls_all, 1), "hand_lr": torch.cat(lr_all, 1),
-            "bbox_regression": torch.cat(reg_all, 1), "bbox_ctrness": torch.cat(ctr_all, 1)}
+    out = {"cls_logits": torch.cat(cls_all, 1), "hand_lr": torch.cat(lr_all, 1),
+           "bbox_regression": torch.cat(reg_all, 1), "bbox_ctrness": torch.cat(ctr_all, 1)}
+    if ext:
+        out["hand_contact_state"] = torch.cat(contact_all, 1)
+        out["hand_dxdy"] = torch.cat(dxdy_all, 1)
+    return out
 
 
 # ---------------------------------------------------------------------------------------
@@ -254,6 +264,10 @@ def candidates(head_out, anchors, num_anchors_per_level):
         m = masks[n]
         out.append({"boxes": decode_single(reg[n], anchors)[m], "scores": smax[n][m], "labels": lmax[n][m],
                     "sides": sides[n][m], "feature_idx": level[m], "index": torch.where(m)[0]})
+        if "hand_contact_state" in head_out:  # fcos.py:605-607,631-633
+            _, contact = torch.max(torch.sigmoid(head_out["hand_contact_state"][n]), dim=-1)
+            out[-1]["contacts"] = contact[m]
+            out[-1]["dxdymags"] = head_out["hand_dxdy"][n][m]
     return out
 
 
@@ -265,16 +279,19 @@ def postprocess(cands, image_sizes, original_sizes):
         dets.append({"boxes": resize_boxes(c["boxes"][keep], im_s, o_s), "scores": c["scores"][keep],
                      "labels": c["labels"][keep], "sides": c["sides"][keep].reshape(-1),
                      "feature_idx": c["feature_idx"][keep].reshape(-1), "keep": keep})
+        if "contacts" in c:  # ext=True dict (fcos.py:637-647)
+            dets[-1]["contacts"] = c["contacts"][keep].reshape(-1)
+            dets[-1]["dxdymags"] = c["dxdymags"][keep]
     return dets
 
 
-def fcos_forward(images, sd, num_classes=3, return_intermediates=False):
+def fcos_forward(images, sd, num_classes=3, return_intermediates=False, ext=False):
     """fcos_utils/fcos.py:675-767 (eval): list of [3,H,W] -> list of detection dicts."""
     with torch.no_grad():
         original_sizes = [tuple(img.shape[-2:]) for img in images]
         x, image_sizes = transform(images)
         feats = list(backbone(x, sd).values())[:-1]
-        ho = head(feats, sd, num_classes)
+        ho = head(feats, sd, num_classes, ext)
         grid = [tuple(f.shape[-2:]) for f in feats]
         anchors = anchors_for(tuple(x.shape[-2:]), grid)
         cands = candidates(ho, anchors, [g[0] * g[1] for g in grid])

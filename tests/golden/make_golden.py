@@ -5,7 +5,7 @@ Runs only in the build container (needs /root/reference; never on the GPU box, n
 test time).  The reference is imported under a stub shim for its NON-arithmetic
 dependencies; the arithmetic that runs is the reference's own.
 
-    python -B tests/golden/make_golden.py [a2j] [a2j_rgbd] [anchor] [fcos] [handnet] [handnet_rgbd]
+    python -B tests/golden/make_golden.py [a2j] [a2j_rgbd] [anchor] [fcos] [fcos_ext] [handnet] [handnet_rgbd]
 
 Outputs are small .npz files holding seeded inputs (or their seeds) and the reference's
 outputs.  Weights are NOT stored: they are regenerated from hn_amd.synth (seeded).
@@ -124,15 +124,17 @@ def gen_anchor():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["a2j", "a2j_rgbd", "anchor", "fcos", "handnet", "handnet_rgbd"]
+    what = sys.argv[1:] or ["a2j", "a2j_rgbd", "anchor", "fcos", "fcos_ext", "handnet", "handnet_rgbd"]
     if "a2j" in what:
         gen_a2j()
     if "a2j_rgbd" in what:
         gen_a2j_rgbd()
     if "anchor" in what:
         gen_anchor()
-    if "fcos" in what or "handnet" in what or "handnet_rgbd" in what:
-        from make_golden_fcos import gen_fcos, gen_handnet, gen_handnet_rgbd  # noqa: E402
+    if {"fcos", "fcos_ext", "handnet", "handnet_rgbd"} & set(what):
+        from make_golden_fcos import gen_fcos, gen_fcos_ext, gen_handnet, gen_handnet_rgbd  # noqa: E402
+        if "fcos_ext" in what:
+            gen_fcos_ext()
         if "handnet_rgbd" in what:
             gen_handnet_rgbd()
         if "fcos" in what:

@@ -123,6 +123,27 @@ def gen_fcos():
     )
 
 
+def gen_fcos_ext():
+    """ext=True detector (the class default; trainval_net_fcos.py --test-only): contact-state / dxdy outputs."""
+    install_fcos_shim()
+    from fcos_utils.fcos import FCOS
+    sd = synth.make_fcos_state_dict(seed=0, num_classes=3, ext=True)
+    _FCOS_SD["sd"] = sd
+    det = FCOS(num_classes=3, ext=True, nms_thresh=0.5).eval()
+    missing, unexpected = det.load_state_dict(sd, strict=False)
+    assert not missing, missing
+    rgb = synth.make_rgb(1, seed=1000)
+    with torch.inference_mode():
+        d = det([rgb[0]], None)[0]
+    assert set(d) == {"boxes", "scores", "labels", "dxdymags", "contacts", "sides"}, set(d)
+    print("fcos ext golden: detections", d["boxes"].shape[0], "contacts", np.bincount(d["contacts"].numpy(), minlength=5))
+    np.savez_compressed(
+        HERE / "fcos_ext_forward.npz", rgb_seed=np.int64(1000), weight_seed=np.int64(0),
+        boxes=d["boxes"].numpy(), scores=d["scores"].numpy(), labels=d["labels"].numpy(),
+        sides=d["sides"].numpy(), contacts=d["contacts"].numpy(), dxdymags=d["dxdymags"].numpy(),
+    )
+
+
 def gen_handnet():
     install_fcos_shim()
     from handnet_pipeline.handnet_pipeline import HandNet

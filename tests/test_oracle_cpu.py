@@ -81,6 +81,20 @@ def test_fcos_oracle_reproduces_reference_golden(golden_dir, fcos_sd):
     assert (np.diff(d["scores"].numpy()) <= 0).all()  # score-descending
 
 
+def test_fcos_ext_oracle_reproduces_reference_golden(golden_dir):
+    """SURVEY 8f #2: ext=True heads (fcos.py:255-264,299-320) and dict (fcos.py:637-647)."""
+    g = np.load(golden_dir / "fcos_ext_forward.npz")
+    sd = synth.make_fcos_state_dict(seed=0, num_classes=3, ext=True)
+    rgb = synth.make_rgb(1, seed=int(g["rgb_seed"]))
+    d = fcos_ref.fcos_forward([rgb[0]], sd, 3, ext=True)[0]
+    assert np.array_equal(d["labels"].numpy(), g["labels"])
+    assert np.array_equal(d["sides"].numpy(), g["sides"])
+    assert np.array_equal(d["contacts"].numpy(), g["contacts"])
+    assert np.abs(d["dxdymags"].numpy() - g["dxdymags"]).max() <= 1e-5
+    assert np.abs(d["boxes"].numpy() - g["boxes"]).max() <= 1e-3
+    assert np.abs(d["scores"].numpy() - g["scores"]).max() <= 1e-6
+
+
 def test_handnet_oracle_reproduces_reference_golden(golden_dir, fcos_sd, a2j_sd):
     g = np.load(golden_dir / "handnet_forward.npz")
     rgb = synth.make_rgb(2, seed=int(g["rgb_seed"]))
