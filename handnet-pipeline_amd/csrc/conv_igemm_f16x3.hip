@@ -15,9 +15,9 @@
 //   weights      fp16 [Cout][(Cin/32)*R*S][2][32] -- the same run structure along k; k tiles are
 //                ordered channel block OUTER, tap (r,s) INNER (weights.split_f16x3).
 //
-// Kernel (v3).  rocprof ablations of v2 (fp32 activations split in the loader; kept for
+// Kernel (v5).  rocprof ablations of v2 (fp32 activations split in the loader; kept for
 // reference in conv_igemm_f16x3_v2.hip.txt) showed the loader's conversion VALU (+27 %) and
-// its ds_write_b128 traffic (+15 %) to be the largest costs, so v3 has neither:
+// its ds_write_b128 traffic (+15 %) to be the largest costs, so since v3 there is neither:
 //   * both operands are staged global -> LDS by LDS-DMA (global_load_lds_dwordx4): no VGPR
 //     staging, no VALU, no ds_write.  One wave instruction moves 8 rows x 128 B; the gather
 //     (im2col row, zero page for padding taps) is expressed in the per-lane SOURCE address,
@@ -25,16 +25,25 @@
 //     lands at position cc ^ ((r >> 1) & 7), which makes every ds_read_b128 conflict-free;
 //   * NBUF LDS stages (2 for the 128x128 tile, 3-4 for the small tiles whose steps are shorter
 //     than the memory latency), DMA issued NBUF-1 steps ahead and retired with COUNTED vmcnt
-//     waits, ONE barrier per 32-deep k tile placed
-//     MID-step so that MFMAs sit on both sides of it; operand fragments are read 24 MFMAs
-//     before use;  s_waitcnt / s_barrier are raw (a __syncthreads() would drain the DMA);
+//     waits, ONE barrier per 32-deep k tile placed MID-step so that MFMAs sit on both sides;
 //   * MFMA shape 16x16x32 (v4): a register-only probe (tools/probes/mfma_peak*.hip) sustains
-//     1.65-1.9 PFLOP/s with it on this chip against 1.2-1.45 PFLOP/s for 32x32x16 (the chip
-//     holds a higher clock); one ds_read_b128 then covers a 16-row tile's whole 32-deep k run,
-//     so LDS traffic per MFMA FLOP is unchanged.  A step is split by output-column halves.
+//     1.65-1.9 PFLOP/s with it on this chip against 1.2-1.45 PFLOP/s for 32x32x16; one
+//     ds_read_b128 covers a 16-row tile's whole 32-deep k run.  A step is split by column halves;
+//   * v5: the k loop is ONE basic block whose MFMAs and LDS reads are volatile asm in a fixed,
+//     hand-interleaved order (HalfSched) with hand-counted lgkmcnt waits, a single set of A
+//     fragments refilled in place, and a saturating prefetch instead of tail branches.  The
+//     compiler-scheduled v4 loop serialised DMA issue -> fragment reads -> lgkmcnt(0) in front of
+//     the second MFMA half and copied 32 fragment registers per step; v5 is 8-10 % faster in
+//     steady state (tools/probes/exp/ab.sh: 422 vs 388 TFLOP/s on the 100x136x256->256 layer).
+// What bounds it now is the socket power cap, not issue slots: while this kernel loops rocm-smi
+// shows 1400 W (the cap) and sclk 1.84 GHz instead of 2.4 (tools/probes/exp/clocks.sh), so the
+// clock-adjusted dense-f16 peak is ~1.9 PFLOP/s; ablations (no DMA: +22 %, no LDS reads: +23 %)
+// show data movement energy, not MFMA issue, is what is left.
 // Epilogue: bias, residual (fp32 or S32), ReLU on a column prefix, output fp32 or S32.
 // Requires Cin % 32 == 0 (the 4-channel stems stay on the f32 kernel).
 #include "hn_common.h"
+
+#include <type_traits>
 
 namespace {
 
@@ -67,6 +76,55 @@ constexpr int BK = 32;    // k values per tile
 constexpr int ROWH = 64;  // halfs per LDS row (hi 32 | lo 32) = 128 bytes
 
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+
+// Issue plan of the second half of a k step.  MFMA k (term-major: term = k / (TM*TH), row tile i, column
+// tile jj) is preceded by the memory instructions whose slot is k.  Instruction list q: the DPT LDS-DMA pieces of
+// tile t+NBUF, the 2*TH half-0 W fragment reads of tile t+1, then the A fragments of tile t+1 -- lo[i] may
+// be overwritten once term 0 (the only user of lo) is through row tile i, hi[i] once term 2 is.
+// One MFMA whose place in the instruction stream is fixed: accumulator tied in an AGPR quad, and (volatile +
+// memory clobber) neither other pinned MFMAs nor LDS reads / LDS-DMA move across it.  The builtin form let
+// the scheduler hoist fragment reads over the loop back-edge or sink MFMAs past the barrier, and the
+// allocator then rotated accumulators through copies (v_accvgpr_mov) in the hot loop.
+__device__ __forceinline__ void mfma_pinned(f32x4& c, const f16x8& a, const f16x8& b) {
+  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b) : "memory");
+}
+
+// LDS read with a fixed place in the instruction stream; the compiler neither sees that it is asynchronous
+// nor inserts waits for it -- the consumer waits with lgkm_wait<N>() (LDS reads return in issue order).
+template <int OFF>
+__device__ __forceinline__ void lds_read_pinned(f16x8& dst, unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field is 16 bits");
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait() {
+  static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit counter");
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const _Float16* p) { return (unsigned)(size_t)(lds_void*)p; }
+
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
+template <int TM, int TH, int DPT>
+struct HalfSched {
+  static constexpr int NM = 3 * TM * TH;
+  static constexpr int NMEM = DPT + 2 * TH + 2 * TM;
+  static constexpr int earliest(int q) {
+    return q < DPT + 2 * TH ? 0
+           : q < DPT + 2 * TH + TM ? (q - DPT - 2 * TH + 1) * TH
+                                   : 2 * TM * TH + (q - DPT - 2 * TH - TM + 1) * TH;
+  }
+  static constexpr int slot(int q) {
+    const int spread = (q * NM) / NMEM;
+    return earliest(q) > spread ? earliest(q) : spread;
+  }
+};
 
 template <int BM, int BN, int WM, int WN, int NBUF>
 __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const ConvParams16 p) {
@@ -130,30 +188,41 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
   // (SALU); per lane only the two bounds checks and one 64-bit add remain.
   int cur_r = 0, cur_s = 0, cur_cb = 0, load_t = 0;
 
+  // one DMA instruction (8 rows x 128 B per wave): A piece `it` gathers im2col rows, B piece `it` weight rows
+  auto dma_a_piece = [&](int it, _Float16* Ad, int dr, int ds, long uoff) {
+    const bool ok = (unsigned)(a_ih0[it] + dr) < (unsigned)p.H && (unsigned)(a_iw0[it] + ds) < (unsigned)p.W;
+    const _Float16* src = ok ? a_row[it] + uoff : g_zero_page16 + a_cc[it];  // padding taps read zeros
+    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(Ad + (it * ROWS_PASS + grp_row) * ROWH), 16, 0, 0);
+  };
+  auto dma_b_piece = [&](int it, _Float16* Bd, long boff) {
+    __builtin_amdgcn_global_load_lds((gbl_void*)(b_ptr[it] + boff), (lds_void*)(Bd + (it * ROWS_PASS + grp_row) * ROWH),
+                                     16, 0, 0);
+  };
+  // branch-free advance of (tap, channel block) to the next k tile: keeps the hot loop one basic block
+  // saturates at the last tile: the pipeline keeps issuing (redundant, never read) loads of it past the end
+  // instead of branching around the DMA
+  auto advance_tile = [&]() {
+    const int adv = load_t + 1 < p.ktiles ? 1 : 0;
+    load_t += adv;
+    const int s1 = cur_s + adv;
+    const int ws = s1 == p.S ? 1 : 0;
+    cur_s = ws ? 0 : s1;
+    const int r1 = cur_r + ws;
+    const int wr = r1 == p.R ? 1 : 0;
+    cur_r = wr ? 0 : r1;
+    cur_cb += wr;
+  };
   auto dma_tile = [&](int buf) {
     const int dr = cur_r * p.dil, ds = cur_s * p.dil;
     const long uoff = ((long)dr * p.W + ds) * p.xs + (long)cur_cb * (2 * BK);  // wave-uniform
     _Float16* Ad = As + buf * A_BUF;
     _Float16* Bd = Bs + buf * B_BUF;
 #pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-      const bool ok = (unsigned)(a_ih0[it] + dr) < (unsigned)p.H && (unsigned)(a_iw0[it] + ds) < (unsigned)p.W;
-      const _Float16* src = ok ? a_row[it] + uoff : g_zero_page16 + a_cc[it];  // padding taps read zeros
-      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(Ad + (it * ROWS_PASS + grp_row) * ROWH), 16, 0, 0);
-    }
+    for (int it = 0; it < A_IT; ++it) dma_a_piece(it, Ad, dr, ds, uoff);
     const long boff = (long)load_t * (2 * BK);
 #pragma unroll
-    for (int it = 0; it < B_IT; ++it)
-      __builtin_amdgcn_global_load_lds((gbl_void*)(b_ptr[it] + boff),
-                                       (lds_void*)(Bd + (it * ROWS_PASS + grp_row) * ROWH), 16, 0, 0);
-    ++load_t;
-    if (++cur_s == p.S) {
-      cur_s = 0;
-      if (++cur_r == p.R) {
-        cur_r = 0;
-        ++cur_cb;
-      }
-    }
+    for (int it = 0; it < B_IT; ++it) dma_b_piece(it, Bd, boff);
+    advance_tile();
   };
 
   f32x4 acc[TM][TN];
@@ -189,88 +258,112 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
   struct BFrag {
     f16x8 h[TH], l[TH];
   };
-  auto read_a = [&](AFrag& f, int buf) {
-    const _Float16* Ab = As + buf * A_BUF;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      f.h[i] = *reinterpret_cast<const f16x8*>(&Ab[a_rd[i][0]]);
-      f.l[i] = *reinterpret_cast<const f16x8*>(&Ab[a_rd[i][1]]);
-    }
-  };
-  auto read_b = [&](BFrag& f, int buf, int half) {
-    const _Float16* Bb = Bs + buf * B_BUF;
-#pragma unroll
-    for (int jj = 0; jj < TH; ++jj) {
-      f.h[jj] = *reinterpret_cast<const f16x8*>(&Bb[b_rd[half * TH + jj][0]]);
-      f.l[jj] = *reinterpret_cast<const f16x8*>(&Bb[b_rd[half * TH + jj][1]]);
-    }
-  };
-  // TM*TH*3 MFMAs: all row tiles x one half of the column tiles, full 32-deep k
-  // (small cross terms first, dominant hi*hi last)
-  auto mma_half = [&](const AFrag& a, const BFrag& b, int half) {
-    // term-major order: the three MFMAs that chain through one accumulator are TM*TH issues
-    // apart, so no MFMA waits on the result of its predecessor (16x16x32 has a 4-pass latency)
-#pragma unroll
-    for (int term = 0; term < 3; ++term)
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int jj = 0; jj < TH; ++jj) {
-          const int j = half * TH + jj;
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(term == 0 ? a.l[i] : a.h[i], term == 1 ? b.l[jj] : b.h[jj],
-                                                             acc[i][j], 0, 0, 0);
-        }
-  };
+  // LDS byte addresses of this lane's fragment chunks in stage 0; row tile i / column tile j adds
+  // i * TILE_OFF (the swizzle depends on row bits 1..3 only), a stage adds A_BUF / B_BUF halfs
+  constexpr int TILE_OFF = 16 * ROWH * 2;
+  const unsigned a_rd_hi = lds_addr(As + a_rd[0][0]), a_rd_lo = lds_addr(As + a_rd[0][1]);
+  const unsigned b_rd_hi = lds_addr(Bs + b_rd[0][0]), b_rd_lo = lds_addr(Bs + b_rd[0][1]);
+  BFrag b0, b1;
+  AFrag af;  // ONE set of A fragments: the next tile's are read into each register after its last use
+  constexpr int DPT = A_IT + B_IT;  // DMA instructions each wave issues per k tile
+  using S2 = HalfSched<TM, TH, DPT>;
   // all of this wave's DMA has landed and all of its LDS reads have returned; then rendezvous
   auto drain_and_barrier = [&]() {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
-
   const int T = p.ktiles;
-  BFrag b0, b1;
-  constexpr int DPT = A_IT + B_IT;  // DMA instructions each wave issues per k tile
-  // one step = tile t in LDS stage `cs`; its A fragments are in `ac`, its column-half-0 W
-  // fragments in b0; tiles t+1 .. t+NBUF-1 are in flight or landed (stage `ns` holds t+1):
-  //   first half : MFMAs of column half 0 || W fragments of half 1 are read
-  //   wait       : counted vmcnt -- only tile t+1 has to be complete, the NBUF-2 younger tiles
-  //                stay in flight across the barrier (small tiles have ~200-cycle steps, far
-  //                shorter than the L2/HBM latency, so they prefetch 2-3 steps ahead)
+  // One step = tile t in LDS stage `cs`; its A fragments are in `af`, its column-half-0 W fragments in
+  // b0; tiles t+1 .. t+NBUF-1 are in flight or landed (stage `ns` holds t+1):
+  //   first half : W fragments of half 1 are read (b1) || MFMAs of column half 0
+  //   wait       : counted vmcnt -- only tile t+1 has to be complete, the NBUF-2 younger tiles stay in
+  //                flight across the barrier -- and all LDS reads of stage `cs` have returned
   //   barrier    : tile t+1 is complete for every wave and nobody reads stage `cs` any more
-  //   second half: MFMAs of column half 1 || DMA of tile t+NBUF into stage `cs` || A and
-  //                half-0 W fragments of tile t+1 are read (into the other A set)
-  auto step = [&](const AFrag& ac, AFrag& an, int t, int cs, int ns) {
-    read_b(b1, cs, 1);
-    mma_half(ac, b0, 0);
-    if (t + 1 < T) {
-      if (t + NBUF - 1 <= T - 1)
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NBUF - 2) * DPT) : "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // tail: fewer tiles in flight
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if (t + NBUF < T) dma_tile(cs);  // tile t+NBUF overwrites tile t
-      read_a(an, ns);
-      read_b(b0, ns, 0);
-    }
-    mma_half(ac, b1, 1);
+  //   second half: MFMAs of column half 1, one memory instruction issued in front of each (HalfSched):
+  //                the DMA pieces of tile t+NBUF into stage `cs`, then the fragments of tile t+1
+  // The body is ONE basic block with a fixed instruction order: MFMAs and LDS reads are volatile asm
+  // (the builtin forms let the compiler put lgkmcnt(0) in front of MFMAs that needed no read, hoist
+  // reads over the back-edge and rotate accumulators through copies), the LDS waits are counted by
+  // hand (reads return in issue order), and past the end of k the DMA re-loads the last tile into a
+  // stage nobody reads instead of branching.
+  auto step_main = [&](int cs, int ns) {
+    const unsigned bcur_hi = b_rd_hi + cs * (B_BUF * 2), bcur_lo = b_rd_lo + cs * (B_BUF * 2);
+    static_for<0, TH>([&](auto JJ) {
+      constexpr int jj = decltype(JJ)::value;
+      lds_read_pinned<(TH + jj) * TILE_OFF>(b1.h[jj], bcur_hi);
+      lds_read_pinned<(TH + jj) * TILE_OFF>(b1.l[jj], bcur_lo);
+    });
+    // outstanding reads, oldest first: b0 (2*TH), af.l (TM), af.h (TM) of this tile, then b1 (2*TH)
+    static_for<0, S2::NM>([&](auto K) {
+      constexpr int k = decltype(K)::value;
+      constexpr int term = k / (TM * TH), i = (k / TH) % TM, jj = k % TH;
+      if constexpr (k == 0) lgkm_wait<TM + 2 * TH>();                             // all of af.l (and b0)
+      if constexpr (term == 1 && jj == 0) lgkm_wait<2 * TH + (TM - 1 - i)>();     // af.h[i]
+      mfma_pinned(acc[i][jj], term == 0 ? af.l[i] : af.h[i], term == 1 ? b0.l[jj] : b0.h[jj]);
+    });
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NBUF - 2) * DPT) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const int dr = cur_r * p.dil, ds = cur_s * p.dil;
+    const long uoff = ((long)dr * p.W + ds) * p.xs + (long)cur_cb * (2 * BK);
+    const long boff = (long)load_t * (2 * BK);
+    _Float16* Ad = As + cs * A_BUF;
+    _Float16* Bd = Bs + cs * B_BUF;
+    const unsigned anx_hi = a_rd_hi + ns * (A_BUF * 2), anx_lo = a_rd_lo + ns * (A_BUF * 2);
+    const unsigned bnx_hi = b_rd_hi + ns * (B_BUF * 2), bnx_lo = b_rd_lo + ns * (B_BUF * 2);
+    static_for<0, S2::NM + 1>([&](auto K) {
+      constexpr int k = decltype(K)::value;
+      static_for<0, S2::NMEM>([&](auto Q) {
+        constexpr int q = decltype(Q)::value;
+        if constexpr (S2::slot(q) == k) {
+          if constexpr (q < A_IT) {
+            dma_a_piece(q, Ad, dr, ds, uoff);
+          } else if constexpr (q < DPT) {
+            dma_b_piece(q - A_IT, Bd, boff);
+          } else if constexpr (q < DPT + 2 * TH) {
+            constexpr int jj = (q - DPT) >> 1;
+            if constexpr ((q - DPT) & 1)
+              lds_read_pinned<jj * TILE_OFF>(b0.l[jj], bnx_lo);
+            else
+              lds_read_pinned<jj * TILE_OFF>(b0.h[jj], bnx_hi);
+          } else if constexpr (q < DPT + 2 * TH + TM) {
+            constexpr int i = q - DPT - 2 * TH;
+            lds_read_pinned<i * TILE_OFF>(af.l[i], anx_lo);
+          } else {
+            constexpr int i = q - DPT - 2 * TH - TM;
+            lds_read_pinned<i * TILE_OFF>(af.h[i], anx_hi);
+          }
+        }
+      });
+      if constexpr (k < S2::NM) {
+        constexpr int term = k / (TM * TH), i = (k / TH) % TM, jj = k % TH;
+        mfma_pinned(acc[i][TH + jj], term == 0 ? af.l[i] : af.h[i], term == 1 ? b1.l[jj] : b1.h[jj]);
+      }
+    });
+    advance_tile();
   };
   // prologue: tile 0 -> stage 0 (waited for); tiles 1..NBUF-1 are put in flight behind it
   dma_tile(0);
   drain_and_barrier();
-  for (int i = 1; i < NBUF; ++i)
-    if (i < T) dma_tile(i);
-  AFrag a0, a1;
-  read_a(a0, 0);
-  read_b(b0, 0, 0);
+  for (int i = 1; i < NBUF; ++i) dma_tile(i);
+  static_for<0, TH>([&](auto JJ) {  // same issue order as inside a step: b0, af.l, af.h
+    constexpr int jj = decltype(JJ)::value;
+    lds_read_pinned<jj * TILE_OFF>(b0.h[jj], b_rd_hi);
+    lds_read_pinned<jj * TILE_OFF>(b0.l[jj], b_rd_lo);
+  });
+  static_for<0, TM>([&](auto I) { lds_read_pinned<decltype(I)::value * TILE_OFF>(af.l[decltype(I)::value], a_rd_lo); });
+  static_for<0, TM>([&](auto I) { lds_read_pinned<decltype(I)::value * TILE_OFF>(af.h[decltype(I)::value], a_rd_hi); });
   int cs = 0, ns = 1;
   for (int t = 0; t < T; ++t) {
-    step(a0, a1, t, cs, ns);
-    a0 = a1;  // register copies (2*TM*4 v_mov per step) keep the loop body single and the accumulators pinned
+    step_main(cs, ns);
     cs = ns;
     ns = ns + 1 == NBUF ? 0 : ns + 1;
   }
+  // the pinned MFMAs / reads are opaque to the compiler's hazard and counter tracking: retire everything
+  // before the epilogue touches the accumulators
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant tail loads must land before LDS is reused / freed
 
   // ---- epilogue: bias, residual, ReLU, NHWC store ----
   const float* res32 = reinterpret_cast<const float*>(p.res);
@@ -495,7 +588,7 @@ extern "C" int hn_conv2d_nhwc_f16x3(const hn_conv_desc* d, const void* x16, cons
     case HN_TILE_64x64: return launch16<64, 64, 2, 2, 3>(p, st);
     case HN_TILE_128x32: return launch16<128, 32, 4, 1, 3>(p, st);
     case HN_TILE_64x128: return launch16<64, 128, 2, 2, 3>(p, st);
-    case HN_TILE_256x128: return launch16<256, 128, 4, 2, 2>(p, st);
+    case HN_TILE_256x128: return launch16<256, 128, 2, 2, 2>(p, st);
     case HN_TILE_32x64: return launch16<32, 64, 1, 2, 4>(p, st);
     default: return hn::fail(HN_ERR_ARG, "unknown tile id %d", d->tile);
   }

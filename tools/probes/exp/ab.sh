@@ -1,0 +1,12 @@
+#!/bin/bash
+# A/B: library built from the previous commit's conv kernel vs the working tree, long runs (power-capped chip)
+cd $GRAFT_REPO_ROOT
+L=handnet-pipeline_amd/csrc/libhandnet_hip.so
+cp $L /tmp/lib_new.so
+shapes=("1 32 100 136 256 256 3 1 1 600 0 0" "1 32 50 68 256 256 3 1 1 2000 0 0" "2 32 200 272 64 64 3 1 1 1500 0 1" "1 32 100 136 128 128 3 1 1 1500 0 1" "3 32 11 11 256 256 3 1 1 5000 0 1" "1 32 25 34 512 512 3 1 1 3000 0 1")
+for v in old new old new; do
+  cp tools/probes/exp/lib_$v.so $L 2>/dev/null || cp /tmp/lib_new.so $L
+  echo "== $v"
+  for s in "${shapes[@]}"; do python tools/perf_conv.py f16x3 $s 2>&1 | grep -v amdgpu.ids; done
+done
+cp /tmp/lib_new.so $L
