@@ -65,6 +65,8 @@ struct ConvParams16 {
   int M, Ktot, ktiles;
   int relu_cols, res_mode, res_h, res_w;
   int xs;             // input pixel stride in halfs
+  int pitch;          // input row pitch in pixels (W for dense tensors; the bordered stem image is wider)
+  long lo_off;        // halfs from a row's 64-byte hi run to its lo run (32 in S32; plane distance for the stem image)
   int ys;             // output pixel stride (floats for fp32 output, halfs for S32)
   int rs;             // residual pixel stride (same convention)
   int out_split, res_split;
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
 
   // ---- DMA geometry: lane -> (row = tid >> 3 within a pass, LDS position pos = tid & 7) ----
   const int drow = tid >> 3, dpos = tid & 7;
-  int a_ih0[A_IT], a_iw0[A_IT], a_cc[A_IT];
+  int a_ih0[A_IT], a_iw0[A_IT], a_cc[A_IT];  // a_cc: chunk offset inside the zero page
   const _Float16* a_row[A_IT];  // address of (img, ih0, iw0, channel 0) + swizzled chunk; may lie outside the image
 #pragma unroll
   for (int it = 0; it < A_IT; ++it) {
@@ -167,8 +169,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
     const int oh = rem / p.OW, ow = rem - oh * p.OW;
     a_ih0[it] = oh * p.stride - p.pad;
     a_iw0[it] = ow * p.stride - p.pad;
-    a_cc[it] = (dpos ^ swz(row)) * 8;  // source chunk (halfs) that belongs at this LDS position
-    a_row[it] = p.x + ((long)img * p.H * p.W + (long)a_ih0[it] * p.W + a_iw0[it]) * p.xs + a_cc[it];
+    const int chunk = dpos ^ swz(row);  // source chunk that belongs at this LDS position: 0-3 hi run, 4-7 lo run
+    a_cc[it] = chunk * 8;
+    a_row[it] = p.x + (((long)img * p.H + a_ih0[it]) * p.pitch + a_iw0[it]) * p.xs + (chunk & 3) * 8 +
+                (chunk >> 2) * p.lo_off;
   }
   const _Float16* b_ptr[B_IT];
 #pragma unroll
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
   };
   auto dma_tile = [&](int buf) {
     const int dr = cur_r * p.dil, ds = cur_s * p.dil;
-    const long uoff = ((long)dr * p.W + ds) * p.xs + (long)cur_cb * (2 * BK);  // wave-uniform
+    const long uoff = ((long)dr * p.pitch + ds) * p.xs + (long)cur_cb * (2 * BK);  // wave-uniform
     _Float16* Ad = As + buf * A_BUF;
     _Float16* Bd = Bs + buf * B_BUF;
 #pragma unroll
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     const int dr = cur_r * p.dil, ds = cur_s * p.dil;
-    const long uoff = ((long)dr * p.W + ds) * p.xs + (long)cur_cb * (2 * BK);
+    const long uoff = ((long)dr * p.pitch + ds) * p.xs + (long)cur_cb * (2 * BK);
     const long boff = (long)load_t * (2 * BK);
     _Float16* Ad = As + cs * A_BUF;
     _Float16* Bd = Bs + cs * B_BUF;
@@ -572,6 +576,8 @@ extern "C" int hn_conv2d_nhwc_f16x3(const hn_conv_desc* d, const void* x16, cons
   p.relu_cols = d->relu_cols; p.res_mode = d->res_mode; p.res_h = d->res_h; p.res_w = d->res_w;
   p.out_split = d->out_split; p.res_split = d->res_split;
   p.xs = d->in_pix_stride ? d->in_pix_stride : 2 * d->cin;
+  p.pitch = d->w;
+  p.lo_off = 32;
   p.ys = d->out_pix_stride ? d->out_pix_stride : (d->out_split ? 2 : 1) * d->cout;
   p.rs = d->res_pix_stride ? d->res_pix_stride : (d->res_split ? 2 : 1) * d->cout;
   p.vec_epi = (d->cout % 8 == 0) && (p.out_split || p.ys % 4 == 0) &&
@@ -593,3 +599,41 @@ extern "C" int hn_conv2d_nhwc_f16x3(const hn_conv_desc* d, const void* x16, cons
     default: return hn::fail(HN_ERR_ARG, "unknown tile id %d", d->tile);
   }
 }
+
+// Stem convolution (R x R, 4-channel pixels, R <= 8) on the f16x3 kernel.  The image is stored as two fp16
+// planes (hi, lo) of [n][ph + 2*pad][pw + 2*pad][4] with a physically zero border, so the R*4 <= 32
+// values one filter ROW touches are 64 contiguous bytes per plane: filter row ky is one 32-deep k tile
+// (k = kx*4 + c, zero weights for k >= R*4), the im2col row of output pixel (oy, ox) starts at bordered
+// pixel (oy*stride + ky, ox*stride), and no tap is ever out of bounds.  Same kernel, same DMA path.
+extern "C" int hn_conv_stem_f16x3(const void* x16, int n, int ph, int pw, int pad, int r, int stride, int cout,
+                                  const void* w16, const float* bias, int relu, void* y, int out_split, void* stream) {
+  HN_CHECK_ARG(x16 && w16 && y, "hn_conv_stem_f16x3: null pointer");
+  HN_CHECK_ARG(n > 0 && ph > 0 && pw > 0 && cout > 0 && stride > 0, "bad dims");
+  HN_CHECK_ARG(r >= 1 && r <= 8 && pad == r / 2, "stem filter must be R x R with R <= 8 and pad = R/2");
+  HN_CHECK_ARG(!out_split || cout % 32 == 0, "S32 output needs cout %% 32 == 0 (got %d)", cout);
+  const int hb = ph + 2 * pad, wb = pw + 2 * pad;
+  const int oh = (hb - r) / stride + 1, ow = (wb - r) / stride + 1;
+  HN_CHECK_ARG((ow - 1) * stride + 8 <= wb, "the 8-pixel k run of the last output column leaves the bordered row");
+  HN_CHECK_ARG((int64_t)n * oh * ow < (int64_t)1 << 31, "too many output pixels");
+  HN_CHECK_ARG((uintptr_t)x16 % 16 == 0 && (stride * 4 * 2) % 16 == 0 && (wb * 4 * 2) % 16 == 0,
+               "LDS-DMA needs 16-byte aligned rows (stride and bordered width must be even)");
+  ConvParams16 p;
+  p.x = (const _Float16*)x16; p.w = (const _Float16*)w16; p.bias = bias; p.res = nullptr; p.y = y;
+  p.N = n; p.H = hb; p.W = wb; p.Cin = 32; p.Cout = cout; p.R = r; p.S = 1;
+  p.stride = stride; p.pad = 0; p.dil = 1; p.OH = oh; p.OW = ow;
+  p.M = n * oh * ow;
+  p.Ktot = r * 32;
+  p.ktiles = r;
+  p.relu_cols = relu ? cout : 0; p.res_mode = 0; p.res_h = p.res_w = 0;
+  p.out_split = out_split; p.res_split = 0;
+  p.xs = 4; p.pitch = wb; p.lo_off = (long)n * hb * wb * 4;
+  p.ys = (out_split ? 2 : 1) * cout;
+  p.rs = 0;
+  p.vec_epi = (cout % 8 == 0) && ((uintptr_t)y % 16 == 0) && (bias == nullptr || (uintptr_t)bias % 16 == 0);
+  p.tiles_m = p.tiles_n = p.nblocks = 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (cout <= 32) return launch16<128, 32, 4, 1, 3>(p, st);
+  if (cout <= 64) return launch16<128, 64, 2, 2, 2>(p, st);
+  return launch16<128, 128, 2, 2, 2>(p, st);
+}
+

@@ -64,6 +64,50 @@ __global__ __launch_bounds__(256) void fcos_preprocess_kernel(const float* __res
   }
 }
 
+// Same arithmetic, but the result is written as the stem's split image: two fp16 planes (hi, lo) of
+// [n][ph + 2b][pw + 2b][4] with a zero border of b pixels (hn_conv_stem_f16x3).
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void fcos_preprocess_split_kernel(const float* __restrict__ src,
+                                                                    _Float16* __restrict__ dst, int n, int h, int w,
+                                                                    int oh, int ow, int ph, int pw, int b,
+                                                                    float scale_h, float scale_w, Norm3 nm) {
+  const int hb = ph + 2 * b, wb = pw + 2 * b;
+  const long total = (long)n * hb * wb;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % wb) - b;
+    const long t = i / wb;
+    const int oy = (int)(t % hb) - b;
+    const int img = (int)(t / hb);
+    float o[3] = {0.f, 0.f, 0.f};
+    if ((unsigned)oy < (unsigned)oh && (unsigned)ox < (unsigned)ow) {
+      int y0, y1, x0, x1;
+      float wy0, wy1, wx0, wx1;
+      src_index(scale_h, oy, h, y0, y1, wy0, wy1);
+      src_index(scale_w, ox, w, x0, x1, wx0, wx1);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float* pl = src + ((long)img * 3 + c) * h * w;
+        const float m = nm.mean[c], s = nm.stdv[c];
+        const float v00 = (pl[(long)y0 * w + x0] - m) / s, v01 = (pl[(long)y0 * w + x1] - m) / s;
+        const float v10 = (pl[(long)y1 * w + x0] - m) / s, v11 = (pl[(long)y1 * w + x1] - m) / s;
+        const float r0 = v00 * wx0 + v01 * wx1;
+        const float r1 = v10 * wx0 + v11 * wx1;
+        o[c] = r0 * wy0 + r1 * wy1;
+      }
+    }
+    f16x4 hi, lo;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      hi[c] = (_Float16)o[c];
+      lo[c] = (_Float16)(o[c] - (float)hi[c]);
+    }
+    hi[3] = lo[3] = (_Float16)0.f;
+    *reinterpret_cast<f16x4*>(dst + i * 4) = hi;
+    *reinterpret_cast<f16x4*>(dst + (total + i) * 4) = lo;
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // candidates: score / argmax / threshold / decode / ordered compaction
 // ---------------------------------------------------------------------------------------
@@ -497,6 +541,23 @@ extern "C" int hn_fcos_preprocess_f32(const float* src, float* dst, int n, int h
   hipLaunchKernelGGL(fcos_preprocess_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, src, dst,
                      n, h, w, oh, ow, ph, pw, scale_h, scale_w, nm);
   HN_CHECK_LAUNCH("fcos_preprocess_kernel");
+  return HN_OK;
+}
+
+extern "C" int hn_fcos_preprocess_split(const float* src, void* dst16, int n, int h, int w, int oh, int ow, int ph,
+                                        int pw, int border, const float mean[3], const float stdv[3], void* stream) {
+  HN_CHECK_ARG(src && dst16 && mean && stdv, "hn_fcos_preprocess_split: null pointer");
+  HN_CHECK_ARG(n > 0 && h > 0 && w > 0 && oh > 0 && ow > 0 && ph >= oh && pw >= ow && border >= 0, "bad dims");
+  Norm3 nm;
+  for (int c = 0; c < 3; ++c) {
+    nm.mean[c] = mean[c];
+    nm.stdv[c] = stdv[c];
+  }
+  const float scale_h = (float)h / (float)oh, scale_w = (float)w / (float)ow;
+  const long total = (long)n * (ph + 2 * border) * (pw + 2 * border);
+  hipLaunchKernelGGL(fcos_preprocess_split_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     (_Float16*)dst16, n, h, w, oh, ow, ph, pw, border, scale_h, scale_w, nm);
+  HN_CHECK_LAUNCH("fcos_preprocess_split_kernel");
   return HN_OK;
 }
 

@@ -18,7 +18,7 @@ import math
 import torch
 
 from . import ops
-from .weights import ConvW, bn_scale_shift, concat_cout, pack_conv
+from .weights import ConvW, bn_scale_shift, concat_cout, pack_conv, pack_stem_split
 
 IMAGE_MEAN = (0.485, 0.456, 0.406)
 IMAGE_STD = (0.229, 0.224, 0.225)
@@ -54,6 +54,9 @@ class FCOSEngine:
             return pack_conv(sd[conv + ".weight"], None, bn_scale_shift(sd, bn), **kw).to(dev)
 
         self.stem = cbn(p + "conv1", p + "bn1", stride=2, pad=3)  # Cin 3 -> padded to 4
+        # f16x3 mode: the stem runs on the split kernel too, one filter row (7 taps x 4 channels) per k tile
+        self.stem16 = pack_stem_split(sd[p + "conv1.weight"], bn_scale_shift(sd, p + "bn1")).to(dev) \
+            if precision == "f16x3" else None
         self.blocks = []
         for li, (planes, blocks, stride) in enumerate(_R34, start=1):
             for b in range(blocks):
@@ -116,8 +119,12 @@ class FCOSEngine:
         return oh, ow, ph, pw
 
     def backbone(self, x):
-        """x [N,PH,PW,4] fp32 -> [P3, P4, P5] (256 channels, strides 8/16/32; S32 in f16x3 mode)."""
-        x = self._conv(x, self.stem, relu=True, algo_cin=3)
+        """x: preprocessed canvas -- fp32 [N,PH,PW,4], or the fp16 stem image [2,N,PH+6,PW+6,4] of
+        ops.fcos_preprocess_split (f16x3 mode) -> [P3, P4, P5] (256 channels, strides 8/16/32; S32 in f16x3 mode)."""
+        if x.dtype == torch.float16:
+            x = ops.conv_stem_split(x, self.stem16.w16, self.stem16.bias, 64, r=7, stride=2, relu=True)
+        else:
+            x = self._conv(x, self.stem, relu=True, algo_cin=3)
         x = ops.maxpool3x3s2_nhwc(x)
         feats = []
         for blk in self.blocks:
@@ -182,7 +189,8 @@ class FCOSEngine:
             raise ValueError("expected [N,3,H,W]")
         n, _, h, w = images.shape
         oh, ow, ph, pw = self.geometry(h, w)
-        x = ops.fcos_preprocess(images.float().contiguous(), oh, ow, ph, pw, IMAGE_MEAN, IMAGE_STD)
+        pre = ops.fcos_preprocess_split if self.precision == "f16x3" else ops.fcos_preprocess
+        x = pre(images.float().contiguous(), oh, ow, ph, pw, IMAGE_MEAN, IMAGE_STD)
         feats = self.backbone(x)
         outs = [self.head_level(f) for f in feats]
         strides = [ph // f.shape[1] for f in feats]

@@ -269,6 +269,53 @@ def fcos_preprocess(images, oh, ow, ph, pw, mean, std, out=None):
     return out
 
 
+def fcos_preprocess_split(images, oh, ow, ph, pw, mean, std, border=3, out=None):
+    """images [N,3,H,W] fp32 (0..1) -> stem image: fp16 [2 (hi, lo), N, ph+2b, pw+2b, 4], zero border b."""
+    lib = _lib.load()
+    _req(images, name="images")
+    n, c, h, w = images.shape
+    if c != 3:
+        raise ValueError("images must be [N,3,H,W]")
+    if out is None:
+        out = torch.empty((2, n, ph + 2 * border, pw + 2 * border, 4), device=images.device, dtype=torch.float16)
+    m = (C.c_float * 3)(*[float(v) for v in mean])
+    s = (C.c_float * 3)(*[float(v) for v in std])
+    check(lib.hn_fcos_preprocess_split(ptr(images), ptr(out), n, h, w, oh, ow, ph, pw, border, m, s, _stream()),
+          "hn_fcos_preprocess_split")
+    return out
+
+
+def conv_stem_split(x16, w16, bias, cout, r=7, stride=2, relu=True, out_split=True, algo_cin=3, out=None):
+    """Stem conv on the f16x3 kernel.  x16: stem image from fcos_preprocess_split (border = r // 2);
+    w16: weights.pack_stem_split(...).w16.  -> [N, oh, ow, cout] fp32 or S32."""
+    lib = _lib.load()
+    pad = r // 2
+    if x16.dim() != 5 or x16.shape[0] != 2 or x16.shape[4] != 4 or x16.dtype != torch.float16 or not x16.is_cuda \
+            or not x16.is_contiguous():
+        raise ValueError("x16 must be the contiguous fp16 GPU stem image [2, N, H+2p, W+2p, 4]")
+    n, hb, wb = x16.shape[1:4]
+    ph, pw = hb - 2 * pad, wb - 2 * pad
+    oh, ow = (hb - r) // stride + 1, (wb - r) // stride + 1
+    if tuple(w16.shape) != (cout, r, 2, 32) or w16.dtype != torch.float16 or not w16.is_cuda or not w16.is_contiguous():
+        raise ValueError("w16 must be the fp16 GPU tensor [cout, r, 2, 32] from weights.pack_stem_split")
+    if out is None:
+        if out_split:
+            out = torch.empty((n, oh, ow, cout // 32, 2, 32), device=x16.device, dtype=torch.float16)
+        else:
+            out = torch.empty((n, oh, ow, cout), device=x16.device, dtype=torch.float32)
+    prof = CONV_PROFILE
+    if prof is not None:
+        timer = HipTimer()
+        timer.start()
+    check(lib.hn_conv_stem_f16x3(ptr(x16), n, ph, pw, pad, r, stride, cout, ptr(w16), ptr(bias), 1 if relu else 0,
+                                 ptr(out), 1 if is_split(out) else 0, _stream()), "hn_conv_stem_f16x3")
+    if prof is not None:
+        timer.stop()
+        tile = 4 if cout <= 32 else (2 if cout <= 64 else 1)  # HN_TILE_128x32 / 128x64 / 128x128
+        prof.append((("f16x3", tile), n * oh * ow * cout * r * r * algo_cin, timer, (n, ph, pw, 4, cout, r, stride, 1)))
+    return out
+
+
 @dataclass
 class Candidates:
     boxes: torch.Tensor

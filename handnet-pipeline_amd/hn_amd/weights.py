@@ -23,7 +23,10 @@ class ConvW:
     w16: torch.Tensor | None = None  # split-fp16 filter bank for hn_conv2d_nhwc_f16x3 (Cin % 32 == 0 only)
 
     def to(self, device):
-        w16 = split_f16x3(self.w).to(device) if self.w.shape[3] % 32 == 0 else None
+        if self.w16 is not None:  # packed by hand (stem): keep
+            w16 = self.w16.to(device)
+        else:
+            w16 = split_f16x3(self.w).to(device) if self.w.shape[3] % 32 == 0 else None
         return ConvW(self.w.to(device).contiguous(), None if self.bias is None else self.bias.to(device).contiguous(),
                      self.stride, self.pad, self.dil, w16)
 
@@ -51,6 +54,25 @@ def split_f16x3(w: torch.Tensor) -> torch.Tensor:
     hi = tiles.half()
     lo = (tiles - hi.float()).half()
     return torch.stack([hi, lo], dim=2).contiguous()
+
+
+def pack_stem_split(weight, bn=None, stride=2) -> "ConvW":
+    """R x R stem conv ([Cout, Cin<=4, R, R], optional BN fold) for hn_conv_stem_f16x3: each filter ROW becomes
+    one 32-deep k tile with k = kx*4 + c (zeros for k >= 4R), stored as fp16 [Cout][R][2][32] (hi run, lo run)."""
+    w = weight.double()
+    cout, cin, r, s = w.shape
+    if r != s or r > 8 or cin > 4:
+        raise ValueError("stem filter must be R x R with R <= 8 and Cin <= 4")
+    bias = None
+    if bn is not None:
+        scale, shift = bn
+        w = w * scale.view(-1, 1, 1, 1)
+        bias = shift.float()
+    rows = torch.zeros((cout, r, 1, 32), dtype=torch.float64)
+    rows[:, :, 0, :4 * r].view(cout, r, r, 4)[..., :cin] = w.permute(0, 2, 3, 1)  # [o, ky, kx, c]
+    nhwc = torch.zeros((cout, r, r, 4), dtype=torch.float32)
+    nhwc[..., :cin] = w.permute(0, 2, 3, 1).float()
+    return ConvW(nhwc.contiguous(), bias, stride, r // 2, 1, split_f16x3(rows.float()))
 
 
 def _pad_to(c: int, m: int) -> int:

@@ -33,7 +33,7 @@ extern "C" {
 #define HN_ERR_HIP 2
 
 /* ABI version; bumped whenever a struct below changes. */
-#define HN_ABI_VERSION 11
+#define HN_ABI_VERSION 12
 int hn_abi_version(void);
 const char* hn_last_error(void);
 
@@ -147,6 +147,19 @@ int hn_groupnorm_affine_f32(const float* x /* [n][hw][c] */, const float* gamma,
 int hn_fcos_preprocess_f32(const float* src, float* dst, int n, int h, int w,
                            int oh, int ow, int ph, int pw,
                            const float mean[3], const float stdv[3], void* stream);
+
+/* Split-precision stem path.  hn_fcos_preprocess_split is hn_fcos_preprocess_f32 with the output stored as
+ * the stem image of hn_conv_stem_f16x3: two fp16 planes (hi then lo, hi + lo = the fp32 value to 2^-22) of
+ * [n][ph + 2*border][pw + 2*border][4], zero outside the resized image (border, padding, channel 3).
+ * hn_conv_stem_f16x3 runs the R x R / stride convolution (pad = border = R/2, R <= 8; torchvision resnet
+ * conv1 at fcos_utils/fcos.py:737) on the f16x3 kernel: w16 is fp16 [cout][R][2][32] with k = kx*4 + c inside
+ * a filter row (hn_amd.weights.pack_stem_split); y is [n][oh][ow][cout] fp32 or S32 (out_split). */
+int hn_fcos_preprocess_split(const float* src, void* dst16, int n, int h, int w, int oh, int ow,
+                             int ph, int pw, int border, const float mean[3], const float stdv[3],
+                             void* stream);
+int hn_conv_stem_f16x3(const void* x16, int n, int ph, int pw, int pad, int r, int stride, int cout,
+                       const void* w16, const float* bias, int relu, void* y, int out_split,
+                       void* stream);
 
 /* ------------------------------------------------------------------------------------
  * FCOS post-processing.  Replaces fcos_utils/fcos.py:572-659 (postprocess_detections),

@@ -40,11 +40,37 @@ def test_preprocess_matches_transform(oracle_run, engine):
     assert (y[..., :3] - ref).abs().max().item() <= 1e-5
 
 
+def test_split_stem_matches_f32_path(oracle_run, engine, fcos_sd):
+    """The f16x3 stem (split image with a zero border, one filter row per k tile) vs the same arithmetic in
+    fp64 on the host: preprocess planes recombine to the fp32 canvas to 2^-21 relative, conv1+bn1+ReLU to 2e-5."""
+    import torch.nn.functional as F
+    from hn_amd import ops
+    from hn_amd.fcos_engine import IMAGE_MEAN, IMAGE_STD
+    from hn_amd.weights import bn_scale_shift
+    rgb, _, inter = oracle_run
+    x32 = ops.fcos_preprocess(rgb.cuda(), 800, 1066, 800, 1088, IMAGE_MEAN, IMAGE_STD)
+    x16 = ops.fcos_preprocess_split(rgb.cuda(), 800, 1066, 800, 1088, IMAGE_MEAN, IMAGE_STD)
+    assert tuple(x16.shape) == (2, rgb.shape[0], 806, 1094, 4)
+    rec = x16[0].float() + x16[1].float()
+    inner = rec[:, 3:-3, 3:-3]
+    assert (inner - x32).abs().max().item() <= 2.0 ** -21 * x32.abs().max().item() + 3e-8
+    border = rec.clone()
+    border[:, 3:-3, 3:-3] = 0
+    assert float(border.abs().max()) == 0.0
+    y = ops.from_split(ops.conv_stem_split(x16, engine.stem16.w16, engine.stem16.bias, 64))
+    scale, shift = bn_scale_shift(fcos_sd, "backbone.body.bn1")
+    ref = F.conv2d(x32.cpu().double().permute(0, 3, 1, 2)[:, :3], fcos_sd["backbone.body.conv1.weight"].double(),
+                   stride=2, padding=3)
+    ref = torch.relu(ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).permute(0, 2, 3, 1)
+    assert tuple(y.shape) == tuple(ref.shape) == (rgb.shape[0], 400, 544, 64)
+    assert (y.cpu().double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
 def test_backbone_and_heads_match_oracle(oracle_run, engine):
     rgb, _, inter = oracle_run
     from hn_amd import ops
     from hn_amd.fcos_engine import IMAGE_MEAN, IMAGE_STD
-    x = ops.fcos_preprocess(rgb.cuda(), 800, 1066, 800, 1088, IMAGE_MEAN, IMAGE_STD)
+    x = ops.fcos_preprocess_split(rgb.cuda(), 800, 1066, 800, 1088, IMAGE_MEAN, IMAGE_STD)
     feats = engine.backbone(x)
     for f, rf in zip(feats, inter["features"]):
         f32 = ops.from_split(f) if ops.is_split(f) else f
