@@ -544,6 +544,8 @@ extern "C" int hn_conv2d_f16x3_pick_tile(const hn_conv_desc* d) {
   // workgroup per CU; below that the small-M A2J layers prefer more, smaller workgroups
   const int64_t want = 256;
   if (d->cout > 64 && nblocks16(d, 128, 128) >= want) return HN_TILE_128x128;
+  // Cout <= 64 with many rows: four waves stacked along M keep the 64x64 wave tile of the big kernel (+3 %)
+  if (d->cout <= 64 && nblocks16(d, 256, 64) >= 2 * want) return HN_TILE_256x64;
   if (nblocks16(d, 128, 64) >= want) return HN_TILE_128x64;
   return HN_TILE_64x64;
 }
@@ -596,6 +598,7 @@ extern "C" int hn_conv2d_nhwc_f16x3(const hn_conv_desc* d, const void* x16, cons
     case HN_TILE_64x128: return launch16<64, 128, 2, 2, 3>(p, st);
     case HN_TILE_256x128: return launch16<256, 128, 2, 2, 2>(p, st);
     case HN_TILE_32x64: return launch16<32, 64, 1, 2, 4>(p, st);
+    case HN_TILE_256x64: return launch16<256, 64, 4, 1, 2>(p, st);
     default: return hn::fail(HN_ERR_ARG, "unknown tile id %d", d->tile);
   }
 }
