@@ -71,6 +71,7 @@ struct ConvParams16 {
   int rs;             // residual pixel stride (same convention)
   int out_split, res_split;
   int vec_epi;        // 1: 16-byte epilogue through LDS (Cout % 8 == 0 and aligned strides)
+  float* gn_partial;  // optional GroupNorm partial sums [ceil(M/32)][Cout/8][4] (see hn_conv2d_nhwc_f16x3_gn)
   int tiles_m, tiles_n, nblocks;
 };
 
@@ -395,6 +396,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
           for (int j = 0; j < TN; ++j) patch[prow * PWP + j * 16 + (lane & 15)] = acc[i + ii][j][r];
         }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // GroupNorm statistics of this 32-row group, per 8-channel unit, split at the image boundary
+      // (a group touches at most two images when OH*OW >= 32): [sum, sumsq] of image A, then of image A+1
+      float gsum[4] = {0.f, 0.f, 0.f, 0.f};
+      const int m_grp = m0 + wm * (BM / WM) + i * 16;
+      const int m_split = (m_grp / ohow + 1) * ohow;  // first row of the next image
 #pragma unroll
       for (int k = 0; k < (32 * GROUPS) / 64; ++k) {
         const int q = lane + 64 * k;
@@ -417,6 +423,19 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
             v[e] += b0[e];
             v[4 + e] += b1[e];
           }
+        }
+        if (p.gn_partial) {
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            s1 += v[e];
+            s2 += v[e] * v[e];
+          }
+          const bool second = m >= m_split;
+          gsum[0] += second ? 0.f : s1;
+          gsum[1] += second ? 0.f : s2;
+          gsum[2] += second ? s1 : 0.f;
+          gsum[3] += second ? s2 : 0.f;
         }
         if (p.res_mode) {
           long rpix = m;
@@ -466,6 +485,18 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
           }
           *reinterpret_cast<f32x4*>(q32) = o0;
           *reinterpret_cast<f32x4*>(q32 + 4) = o1;
+        }
+      }
+      if (p.gn_partial) {
+        // lanes with equal (lane % GROUPS) hold the same channel unit: fixed-order butterfly over the rows
+#pragma unroll
+        for (int o = GROUPS; o < 64; o <<= 1)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) gsum[e] += __shfl_xor(gsum[e], o);
+        const int n = n0 + wn * (BN / WN) + lane * 8;
+        if (lane < GROUPS && n < p.Cout && m_grp < p.M) {
+          f32x4 o4 = {gsum[0], gsum[1], gsum[2], gsum[3]};
+          *reinterpret_cast<f32x4*>(p.gn_partial + ((long)(m_grp >> 5) * (p.Cout >> 3) + (n >> 3)) * 4) = o4;
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // patch reads done before the next pass rewrites it
@@ -550,8 +581,28 @@ extern "C" int hn_conv2d_f16x3_pick_tile(const hn_conv_desc* d) {
   return HN_TILE_64x64;
 }
 
+static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, const float* bias, const void* residual,
+                      void* y, float* gn_partial, void* stream);
+
 extern "C" int hn_conv2d_nhwc_f16x3(const hn_conv_desc* d, const void* x16, const void* w16, const float* bias,
                                     const void* residual, void* y, void* stream) {
+  return conv16_run(d, x16, w16, bias, residual, y, nullptr, stream);
+}
+
+// The same convolution, additionally emitting the GroupNorm partial sums of its fp32 output from the
+// epilogue (fcos.py:232-239: conv -> GroupNorm): gn_partial [ceil(M/32)][Cout/8][4] = per 32-row group and
+// 8-channel unit {sum, sumsq of the rows of the group's first image, sum, sumsq of the rows of the next
+// image}; hn_groupnorm_finalize_rows32 turns them into the scale / shift tables.  Saves re-reading the
+// output (hn_groupnorm_affine_f32's first pass).
+extern "C" int hn_conv2d_nhwc_f16x3_gn(const hn_conv_desc* d, const void* x16, const void* w16, const float* bias,
+                                       void* y, float* gn_partial, void* stream) {
+  HN_CHECK_ARG(gn_partial, "hn_conv2d_nhwc_f16x3_gn: null gn_partial");
+  HN_CHECK_ARG(d && d->cout % 8 == 0, "GroupNorm statistics need cout %% 8 == 0");
+  return conv16_run(d, x16, w16, bias, nullptr, y, gn_partial, stream);
+}
+
+static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, const float* bias, const void* residual,
+                      void* y, float* gn_partial, void* stream) {
   HN_CHECK_ARG(d && x16 && w16 && y, "hn_conv2d_nhwc_f16x3: null pointer");
   HN_CHECK_ARG(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, "bad tensor dims");
   HN_CHECK_ARG(d->cin % 32 == 0, "f16x3 conv needs cin %% 32 == 0 (got %d); use hn_conv2d_nhwc_f32", d->cin);
@@ -587,6 +638,12 @@ extern "C" int hn_conv2d_nhwc_f16x3(const hn_conv_desc* d, const void* x16, cons
               ((uintptr_t)y % 16 == 0) && (bias == nullptr || (uintptr_t)bias % 16 == 0) &&
               (residual == nullptr || (uintptr_t)residual % 16 == 0);
   p.tiles_m = p.tiles_n = p.nblocks = 0;
+  p.gn_partial = gn_partial;
+  if (gn_partial) {
+    HN_CHECK_ARG(p.vec_epi && !d->out_split && d->res_mode == 0 && d->relu_cols == 0,
+                 "GroupNorm statistics need the vector epilogue, fp32 output, no residual and no ReLU");
+    HN_CHECK_ARG(d->oh * d->ow >= 32, "GroupNorm statistics in the epilogue need OH*OW >= 32");
+  }
   hipStream_t st = (hipStream_t)stream;
   switch (hn_conv2d_f16x3_pick_tile(d)) {
     case HN_TILE_128x128: return launch16<128, 128, 2, 2, 2>(p, st);
@@ -630,6 +687,7 @@ extern "C" int hn_conv_stem_f16x3(const void* x16, int n, int ph, int pw, int pa
   p.relu_cols = relu ? cout : 0; p.res_mode = 0; p.res_h = p.res_w = 0;
   p.out_split = out_split; p.res_split = 0;
   p.xs = 4; p.pitch = wb; p.lo_off = (long)n * hb * wb * 4;
+  p.gn_partial = nullptr;
   p.ys = (out_split ? 2 : 1) * cout;
   p.rs = 0;
   p.vec_epi = (cout % 8 == 0) && ((uintptr_t)y % 16 == 0) && (bias == nullptr || (uintptr_t)bias % 16 == 0);

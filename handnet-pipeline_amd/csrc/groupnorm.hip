@@ -89,7 +89,64 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
   }
 }
 
+// Finalize from the partial sums a conv epilogue wrote (hn_conv2d_nhwc_f16x3_gn): record (rg, unit) holds
+// {sum, sumsq} of the rows of 32-row group rg that belong to image (32*rg)/hw, then those of the next image.
+// One wave per (image, group); fixed lane assignment + fp64 butterfly -> bitwise reproducible.
+__global__ __launch_bounds__(256) void gn_finalize_rows32_kernel(const float* __restrict__ partial,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, int hw, int c,
+                                                                 int groups, float eps, float* __restrict__ scale,
+                                                                 float* __restrict__ shift) {
+  const int img = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (g >= groups) return;
+  const int cpg = c / groups, upg = cpg >> 3, units = c >> 3;
+  const long row0 = (long)img * hw, row1 = row0 + hw - 1;
+  const int rg0 = (int)(row0 >> 5), rg1 = (int)(row1 >> 5);
+  const int items = (rg1 - rg0 + 1) * upg;
+  double s = 0.0, ss = 0.0;
+  for (int k = lane; k < items; k += 64) {
+    const int rg = rg0 + k / upg, u = g * upg + k % upg;
+    const int img_a = (int)(((long)rg << 5) / hw);
+    const float* pp = partial + ((long)rg * units + u) * 4 + (img_a == img ? 0 : 2);
+    s += (double)pp[0];
+    ss += (double)pp[1];
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o);
+    ss += __shfl_xor(ss, o);
+  }
+  const double cnt = (double)hw * cpg;
+  const double mean = s / cnt;
+  double var = ss / cnt - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  for (int e = lane; e < cpg; e += 64) {
+    const int ch = g * cpg + e;
+    const float sc = gamma[ch] * rstd;
+    scale[(long)img * c + ch] = sc;
+    shift[(long)img * c + ch] = beta[ch] - (float)mean * sc;
+  }
+}
+
 }  // namespace
+
+extern "C" int64_t hn_groupnorm_rows32_scratch_floats(int64_t rows, int c) {
+  if (rows <= 0 || c <= 0) return 0;
+  return ((rows + 31) / 32) * (c / 8) * 4;
+}
+
+extern "C" int hn_groupnorm_finalize_rows32(const float* partial, const float* gamma, const float* beta, int n, int hw,
+                                            int c, int groups, float eps, float* scale, float* shift, void* stream) {
+  HN_CHECK_ARG(partial && gamma && beta && scale && shift, "hn_groupnorm_finalize_rows32: null pointer");
+  HN_CHECK_ARG(n > 0 && hw >= 32 && c > 0 && groups > 0 && c % groups == 0, "bad dims (hw must be >= 32)");
+  HN_CHECK_ARG((c / groups) % 8 == 0, "channels per group (%d) must be a multiple of 8", c / groups);
+  hipLaunchKernelGGL(gn_finalize_rows32_kernel, dim3((groups + 3) / 4, n), dim3(256), 0, (hipStream_t)stream, partial,
+                     gamma, beta, hw, c, groups, eps, scale, shift);
+  HN_CHECK_LAUNCH("gn_finalize_rows32_kernel");
+  return HN_OK;
+}
 
 extern "C" int64_t hn_groupnorm_scratch_floats(int n, int hw, int c, int groups) {
   (void)c;

@@ -149,16 +149,29 @@ class FCOSEngine:
     def head_level(self, feat):
         """One FPN level -> (cls_lr [N,h,w,C+2], reg_ctr [N,h,w,5], ext [N,h,w,8] or None) raw fp32 conv outputs.
 
-        conv -> GroupNorm -> ReLU -> conv: each tower conv writes its raw fp32 output, the
-        statistics pass turns GroupNorm into a per-(image, channel) affine, and
-          f16x3: one hn_affine_split_f32 pass applies affine + ReLU and emits the S32 input of
-                 the next conv (whose hot loop is then pure DMA + MFMA);
-          f32  : the next conv applies the affine + ReLU while staging its input (in_affine)."""
+        conv -> GroupNorm -> ReLU -> conv: each tower conv writes its raw fp32 output, GroupNorm becomes a
+        per-(image, channel) affine, and
+          f16x3: the conv epilogue also emits the GroupNorm partial sums (no second read of its output), a
+                 tiny finalize kernel builds the tables, and one hn_affine_split_f32 pass applies affine + ReLU
+                 and emits the S32 input of the next conv (whose hot loop is then pure DMA + MFMA);
+          f32  : a statistics pass reads the output back; the next conv applies the affine + ReLU while
+                 staging its input (in_affine)."""
         s16 = self.precision == "f16x3"
-        t0 = self._conv(feat, self.tower0, out_f32=True)          # [N,h,w,512] raw
-        sc, sh = self._gn(t0, self.gn0_gamma, self.gn0_beta, 64)  # 2 x GroupNorm(32,256)
-        xc, sc_c, sh_c = t0[..., :256], sc[:, :256], sh[:, :256]
-        xr, sc_r, sh_r = t0[..., 256:], sc[:, 256:], sh[:, 256:]
+        n, fh, fw = feat.shape[:3]
+        hw = fh * fw
+        fused_gn = s16 and hw >= 32
+        if fused_gn:
+            need = ops.gn_rows32_scratch_floats(n * hw, 512)
+            if self._gn_scratch is None or self._gn_scratch.numel() < need:
+                self._gn_scratch = torch.empty((need,), device=feat.device, dtype=torch.float32)
+
+        def conv_gn(a, cw, gamma, beta, groups):
+            """tower conv + the GroupNorm tables of its output -> (raw output, scale, shift)"""
+            if fused_gn:
+                y = self._conv(a, cw, out_f32=True, gn_partial=self._gn_scratch)
+                return (y, *ops.groupnorm_finalize_rows32(self._gn_scratch, gamma, beta, n, hw, groups))
+            y = self._conv(a, cw, out_f32=True) if s16 else self._conv(a[0], cw, in_scale=a[1], in_shift=a[2])
+            return (y, *self._gn(y, gamma, beta, groups))
 
         def act(x, scale, shift):  # GroupNorm affine + ReLU, materialised (S32) or deferred to the conv load
             return ops.to_split(x, scale, shift, relu=True) if s16 else (x, scale, shift)
@@ -168,19 +181,21 @@ class FCOSEngine:
                 return self._conv(a, cw, out_f32=True, **kw)
             return self._conv(a[0], cw, in_scale=a[1], in_shift=a[2], **kw)
 
-        def nxt(x, cw, scale, shift, **kw):
-            return conv(act(x, scale, shift), cw, **kw)
-
+        if s16:
+            t0, sc, sh = conv_gn(feat, self.tower0, self.gn0_gamma, self.gn0_beta, 64)  # 2 x GroupNorm(32,256)
+        else:
+            t0 = self._conv(feat, self.tower0, out_f32=True)          # [N,h,w,512] raw
+            sc, sh = self._gn(t0, self.gn0_gamma, self.gn0_beta, 64)
+        xc, sc_c, sh_c = t0[..., :256], sc[:, :256], sh[:, :256]
+        xr, sc_r, sh_r = t0[..., 256:], sc[:, 256:], sh[:, 256:]
         for cw, (g, b) in zip(self.cls_tower, self.cls_gn):
-            xc = nxt(xc, cw, sc_c, sh_c)
-            sc_c, sh_c = self._gn(xc, g, b, 32)
+            xc, sc_c, sh_c = conv_gn(act(xc, sc_c, sh_c), cw, g, b, 32)
         for cw, (g, b) in zip(self.reg_tower, self.reg_gn):
-            xr = nxt(xr, cw, sc_r, sh_r)
-            sc_r, sh_r = self._gn(xr, g, b, 32)
+            xr, sc_r, sh_r = conv_gn(act(xr, sc_r, sh_r), cw, g, b, 32)
         ac = act(xc, sc_c, sh_c)
         cls_lr = conv(ac, self.cls_out)
         ext = conv(ac, self.ext_out, relu_cols=3) if self.ext else None
-        reg_ctr = nxt(xr, self.reg_out, sc_r, sh_r, relu_cols=4)
+        reg_ctr = conv(act(xr, sc_r, sh_r), self.reg_out, relu_cols=4)
         return cls_lr, reg_ctr, ext
 
     def forward_heads(self, images):

@@ -118,7 +118,7 @@ TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x64", 4: "128x32", 5: "256x128", 
 
 def conv2d_nhwc(x, w, bias=None, *, stride=1, pad=0, dil=1, relu=False, relu_cols=None,
                 residual=None, res_upsample=False, in_scale=None, in_shift=None, out=None, tile=0,
-                algo_cin=None, w16=None, out_split=False):
+                algo_cin=None, w16=None, out_split=False, gn_partial=None):
     """Convolution with fused epilogue.  x: fp32 [N,H,W,Cin] or S32 split; w [Cout,R,S,Cin] fp32.
 
     w16 given  -> f16x3 kernel (split-fp16 operands on the f16 MFMA, fp32-grade results); an fp32
@@ -128,7 +128,9 @@ def conv2d_nhwc(x, w, bias=None, *, stride=1, pad=0, dil=1, relu=False, relu_col
     residual   -> fp32 or S32 tensor added before the ReLU; res_upsample = nearest-neighbour
                   read of a coarser map (FPN top-down path).
     algo_cin   -> input channels the reference's conv really has when Cin is zero-padded
-                  (FLOP accounting only)."""
+                  (FLOP accounting only).
+    gn_partial -> (f16x3, fp32 output, no residual / ReLU) fp32 scratch of gn_rows32_scratch_floats(rows, Cout)
+                  floats: the epilogue also writes GroupNorm partial sums for groupnorm_finalize_rows32()."""
     lib = _lib.load()
     _req(w, name="w")
     cout, r, s, cin = w.shape
@@ -200,9 +202,20 @@ def conv2d_nhwc(x, w, bias=None, *, stride=1, pad=0, dil=1, relu=False, relu_col
         if (not w16.is_cuda or w16.dtype != torch.float16 or not w16.is_contiguous()
                 or w16.numel() != 2 * w.numel()):
             raise ValueError("w16 must be the contiguous fp16 GPU tensor produced by weights.split_f16x3(w)")
-        check(lib.hn_conv2d_nhwc_f16x3(C.byref(d), ptr(x), ptr(w16), ptr(bias), ptr(residual), ptr(out), _stream()),
-              "hn_conv2d_nhwc_f16x3")
+        if gn_partial is not None:
+            if residual is not None or rc or d.out_split:
+                raise ValueError("gn_partial needs an fp32 output without residual / ReLU")
+            need = lib.hn_groupnorm_rows32_scratch_floats(n * d.oh * d.ow, cout)
+            if not gn_partial.is_cuda or gn_partial.dtype != torch.float32 or gn_partial.numel() < need:
+                raise ValueError(f"gn_partial must be an fp32 GPU buffer of >= {need} floats")
+            check(lib.hn_conv2d_nhwc_f16x3_gn(C.byref(d), ptr(x), ptr(w16), ptr(bias), ptr(out), ptr(gn_partial),
+                                              _stream()), "hn_conv2d_nhwc_f16x3_gn")
+        else:
+            check(lib.hn_conv2d_nhwc_f16x3(C.byref(d), ptr(x), ptr(w16), ptr(bias), ptr(residual), ptr(out),
+                                           _stream()), "hn_conv2d_nhwc_f16x3")
     else:
+        if gn_partial is not None:
+            raise ValueError("gn_partial is an f16x3-kernel feature")
         check(lib.hn_conv2d_nhwc_f32(C.byref(d), ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(in_scale),
                                      ptr(in_shift), ptr(out), _stream()), "hn_conv2d_nhwc_f32")
     if prof is not None:
@@ -250,6 +263,26 @@ def groupnorm_affine(x, gamma, beta, groups=32, eps=1e-5, scratch=None, scale=No
         shift = torch.empty((n, c), device=x.device, dtype=torch.float32)
     check(lib.hn_groupnorm_affine_f32(ptr(x), ptr(gamma), ptr(beta), n, h * w, c, groups, eps, ptr(scratch),
                                       ptr(scale), ptr(shift), _stream()), "hn_groupnorm_affine_f32")
+    return scale, shift
+
+
+def gn_rows32_scratch_floats(rows, c):
+    return _lib.load().hn_groupnorm_rows32_scratch_floats(int(rows), int(c))
+
+
+def groupnorm_finalize_rows32(partial, gamma, beta, n, hw, groups=32, eps=1e-5, scale=None, shift=None):
+    """Partial sums written by conv2d_nhwc(..., gn_partial=partial) -> (scale [N,C], shift [N,C])."""
+    lib = _lib.load()
+    _req(partial, name="partial"); _req(gamma, name="gamma"); _req(beta, name="beta")
+    c = gamma.numel()
+    if partial.numel() < lib.hn_groupnorm_rows32_scratch_floats(n * hw, c):
+        raise ValueError("partial buffer too small")
+    if scale is None:
+        scale = torch.empty((n, c), device=partial.device, dtype=torch.float32)
+    if shift is None:
+        shift = torch.empty((n, c), device=partial.device, dtype=torch.float32)
+    check(lib.hn_groupnorm_finalize_rows32(ptr(partial), ptr(gamma), ptr(beta), n, hw, c, groups, eps, ptr(scale),
+                                           ptr(shift), _stream()), "hn_groupnorm_finalize_rows32")
     return scale, shift
 
 

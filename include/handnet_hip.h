@@ -33,7 +33,7 @@ extern "C" {
 #define HN_ERR_HIP 2
 
 /* ABI version; bumped whenever a struct below changes. */
-#define HN_ABI_VERSION 12
+#define HN_ABI_VERSION 13
 int hn_abi_version(void);
 const char* hn_last_error(void);
 
@@ -138,6 +138,18 @@ int64_t hn_groupnorm_scratch_floats(int n, int hw, int c, int groups);
 int hn_groupnorm_affine_f32(const float* x /* [n][hw][c] */, const float* gamma,
                             const float* beta, int n, int hw, int c, int groups, float eps,
                             float* partial, float* scale, float* shift, void* stream);
+
+/* Fused variant for the f16x3 path: hn_conv2d_nhwc_f16x3_gn is hn_conv2d_nhwc_f16x3 (fp32 output, no
+ * residual / ReLU, cout % 8 == 0, oh*ow >= 32) whose epilogue also writes GroupNorm partial sums
+ * gn_partial [ceil(n*oh*ow / 32)][cout/8][4] (hn_groupnorm_rows32_scratch_floats floats);
+ * hn_groupnorm_finalize_rows32 reduces them to the same scale / shift tables as hn_groupnorm_affine_f32
+ * without re-reading the conv output. */
+int hn_conv2d_nhwc_f16x3_gn(const hn_conv_desc* desc, const void* x16, const void* w16,
+                            const float* bias, void* y, float* gn_partial, void* stream);
+int64_t hn_groupnorm_rows32_scratch_floats(int64_t rows, int c);
+int hn_groupnorm_finalize_rows32(const float* partial, const float* gamma, const float* beta,
+                                 int n, int hw, int c, int groups, float eps,
+                                 float* scale, float* shift, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * FCOS pre-processing: normalize + bilinear resize (align_corners=False, scale =

@@ -138,7 +138,7 @@ F16X3_CASES = [
 
 
 @pytest.mark.parametrize("case", F16X3_CASES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 def test_conv_f16x3_matches_fp64_reference(case, tile):
     """Error budget: operands carry 22 bits (hi+lo), products exact, fp32 accumulate =>
     same 1e-4*scale bar as the exact-f32 kernel, checked against an fp64 convolution."""
@@ -255,3 +255,36 @@ def test_conv_f16x3_split_in_out_residual():
     ref2 = ops_ref.conv2d_nhwc(ops.from_split(xs).cpu()[..., 128:].contiguous(), wt, b, residual=res)
     _check(wide_out[..., 512:].contiguous(), ref2, "fp32 residual / sliced fp32 out")
     assert float(wide_out[..., :512].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,groups,tile", [
+    (3, 10, 13, 64, 256, 32, 0),     # hw = 130: row groups straddle image boundaries, M not a multiple of 32
+    (2, 25, 34, 256, 512, 64, 1),    # tower0 shape of the P5 level (two stacked GroupNorm(32,256))
+    (2, 9, 7, 32, 64, 8, 2),         # 128x64 tile, hw = 63
+    (5, 6, 6, 32, 64, 4, 3),         # hw = 36: a 32-row group can end in the next image; 16 channels per group
+    (2, 20, 20, 64, 64, 8, 8),       # 256x64 tile
+])
+def test_conv_f16x3_groupnorm_partials_in_epilogue(n, h, w, cin, cout, groups, tile):
+    """GroupNorm statistics emitted by the conv epilogue + rows32 finalize == the stand-alone statistics pass
+    over the same output (both fp32 partials combined in fp64), and the conv output itself is unchanged."""
+    from hn_amd import ops
+    from hn_amd.weights import split_f16x3
+    g = torch.Generator().manual_seed(n * 1000 + cout)
+    x = torch.randn((n, h, w, cin), generator=g)
+    wt = torch.randn((cout, 3, 3, cin), generator=g) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn((cout,), generator=g)
+    gamma = torch.rand((cout,), generator=g) + 0.5
+    beta = torch.randn((cout,), generator=g) * 0.1
+    x16 = ops.to_split(x.cuda())
+    w16 = split_f16x3(wt).cuda()
+    part = torch.full((ops.gn_rows32_scratch_floats(n * h * w, cout),), float("nan"), device="cuda")
+    y = ops.conv2d_nhwc(x16, wt.cuda(), b.cuda(), pad=1, w16=w16, tile=tile, gn_partial=part)
+    y_plain = ops.conv2d_nhwc(x16, wt.cuda(), b.cuda(), pad=1, w16=w16, tile=tile)
+    assert torch.equal(y, y_plain)
+    assert not torch.isnan(part).any()          # every (row group, channel unit) record is written exactly once
+    sc, sh = ops.groupnorm_finalize_rows32(part, gamma.cuda(), beta.cuda(), n, h * w, groups)
+    sc_ref, sh_ref = ops.groupnorm_affine(y, gamma.cuda(), beta.cuda(), groups=groups)
+    assert (sc - sc_ref).abs().max().item() <= 2e-6 * sc_ref.abs().max().item()
+    assert (sh - sh_ref).abs().max().item() <= 2e-6 * max(1.0, sh_ref.abs().max().item())
+    with pytest.raises(ValueError):
+        ops.conv2d_nhwc(x16, wt.cuda(), b.cuda(), pad=1, w16=w16, relu=True, gn_partial=part)
