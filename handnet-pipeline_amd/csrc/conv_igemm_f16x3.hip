@@ -656,6 +656,7 @@ static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, c
     case HN_TILE_256x128: return launch16<256, 128, 2, 2, 2>(p, st);
     case HN_TILE_32x64: return launch16<32, 64, 1, 2, 4>(p, st);
     case HN_TILE_256x64: return launch16<256, 64, 4, 1, 2>(p, st);
+    case HN_TILE_256x128_W8: return launch16<256, 128, 4, 2, 2>(p, st);
     default: return hn::fail(HN_ERR_ARG, "unknown tile id %d", d->tile);
   }
 }

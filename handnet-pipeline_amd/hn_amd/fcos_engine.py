@@ -14,6 +14,7 @@ Everything stays on the device; nothing here synchronises with the host.
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 
@@ -38,7 +39,7 @@ def resized_size(h: int, w: int, min_size: int = 800, max_size: int = 1333):
 
 class FCOSEngine:
     def __init__(self, state_dict, num_classes: int, device="cuda", min_size=800, max_size=1333,
-                 precision="f16x3", ext=False):
+                 precision="f16x3", ext=False, head_streams=None):
         """precision: "f16x3" (split-fp16 operands, fp32-grade; default) or "f32" (exact f32 MFMA)."""
         if precision not in ("f32", "f16x3"):
             raise ValueError("precision must be 'f32' or 'f16x3'")
@@ -102,7 +103,9 @@ class FCOSEngine:
             pack_conv(sd[c + ".hand_dydx_layer.weight"], sd[c + ".hand_dydx_layer.bias"], pad=1),
             pack_conv(sd[c + ".hand_contact_state_layer.weight"], sd[c + ".hand_contact_state_layer.bias"], pad=1),
         ]).to(dev) if ext else None
-        self._gn_scratch = None
+        self._gn_scratch = {}
+        self._side = None
+        self.head_streams = int(os.environ.get("HN_HEAD_STREAMS", "1")) if head_streams is None else head_streams
 
     # -----------------------------------------------------------------------------------
     def _conv(self, x, cw: ConvW, relu=False, out_f32=False, **kw):
@@ -139,64 +142,110 @@ class FCOSEngine:
         lat3 = self._conv(c3, self.inner[0], residual=lat4, res_upsample=True)
         return [self._conv(lat3, self.layer[0]), self._conv(lat4, self.layer[1]), self._conv(lat5, self.layer[2])]
 
-    def _gn(self, x, gamma, beta, groups):
+    def _scratch(self, key, need, device):
+        """Per-chain GroupNorm scratch (chains may run on different streams)."""
+        buf = self._gn_scratch.get(key)
+        if buf is None or buf.numel() < need:
+            buf = self._gn_scratch[key] = torch.empty((need,), device=device, dtype=torch.float32)
+        return buf
+
+    def _gn(self, x, gamma, beta, groups, key=0):
         n, h, w, c = x.shape
         need = ops._lib.load().hn_groupnorm_scratch_floats(n, h * w, c, groups)
-        if self._gn_scratch is None or self._gn_scratch.numel() < need:
-            self._gn_scratch = torch.empty((need,), device=x.device, dtype=torch.float32)
-        return ops.groupnorm_affine(x, gamma, beta, groups=groups, scratch=self._gn_scratch)
+        return ops.groupnorm_affine(x, gamma, beta, groups=groups, scratch=self._scratch(key, need, x.device))
 
-    def head_level(self, feat):
-        """One FPN level -> (cls_lr [N,h,w,C+2], reg_ctr [N,h,w,5], ext [N,h,w,8] or None) raw fp32 conv outputs.
-
-        conv -> GroupNorm -> ReLU -> conv: each tower conv writes its raw fp32 output, GroupNorm becomes a
-        per-(image, channel) affine, and
-          f16x3: the conv epilogue also emits the GroupNorm partial sums (no second read of its output), a
-                 tiny finalize kernel builds the tables, and one hn_affine_split_f32 pass applies affine + ReLU
-                 and emits the S32 input of the next conv (whose hot loop is then pure DMA + MFMA);
-          f32  : a statistics pass reads the output back; the next conv applies the affine + ReLU while
-                 staging its input (in_affine)."""
+    # -----------------------------------------------------------------------------------
+    # head: conv -> GroupNorm -> ReLU -> conv.  Each tower conv writes its raw fp32 output, GroupNorm becomes
+    # a per-(image, channel) affine, and
+    #   f16x3: the conv epilogue also emits the GroupNorm partial sums (no second read of its output), a
+    #          tiny finalize kernel builds the tables, and one hn_affine_split_f32 pass applies affine + ReLU
+    #          and emits the S32 input of the next conv (whose hot loop is then pure DMA + MFMA);
+    #   f32  : a statistics pass reads the output back; the next conv applies the affine + ReLU while
+    #          staging its input (in_affine).
+    # -----------------------------------------------------------------------------------
+    def _conv_gn(self, a, cw, gamma, beta, groups, n, hw, key):
+        """tower conv + the GroupNorm tables of its output -> (raw output, scale, shift)"""
         s16 = self.precision == "f16x3"
+        if s16 and hw >= 32:
+            part = self._scratch(key, ops.gn_rows32_scratch_floats(n * hw, cw.cout), cw.w.device)
+            y = self._conv(a, cw, out_f32=True, gn_partial=part)
+            return (y, *ops.groupnorm_finalize_rows32(part, gamma, beta, n, hw, groups))
+        y = self._conv(a, cw, out_f32=True) if s16 else self._conv(a[0], cw, in_scale=a[1], in_shift=a[2])
+        return (y, *self._gn(y, gamma, beta, groups, key))
+
+    def _act(self, x, scale, shift):
+        """GroupNorm affine + ReLU, materialised (S32) or deferred to the next conv's load (f32 mode)."""
+        return ops.to_split(x, scale, shift, relu=True) if self.precision == "f16x3" else (x, scale, shift)
+
+    def _out_conv(self, a, cw, **kw):
+        if self.precision == "f16x3":
+            return self._conv(a, cw, out_f32=True, **kw)
+        return self._conv(a[0], cw, in_scale=a[1], in_shift=a[2], **kw)
+
+    def _tower0(self, feat, key):
+        """Layer 0 of BOTH towers on one FPN level: one 256->512 conv, one GroupNorm with 64 groups."""
         n, fh, fw = feat.shape[:3]
-        hw = fh * fw
-        fused_gn = s16 and hw >= 32
-        if fused_gn:
-            need = ops.gn_rows32_scratch_floats(n * hw, 512)
-            if self._gn_scratch is None or self._gn_scratch.numel() < need:
-                self._gn_scratch = torch.empty((need,), device=feat.device, dtype=torch.float32)
+        if self.precision == "f16x3":
+            return self._conv_gn(feat, self.tower0, self.gn0_gamma, self.gn0_beta, 64, n, fh * fw, key)
+        t0 = self._conv(feat, self.tower0, out_f32=True)
+        return (t0, *self._gn(t0, self.gn0_gamma, self.gn0_beta, 64, key))
 
-        def conv_gn(a, cw, gamma, beta, groups):
-            """tower conv + the GroupNorm tables of its output -> (raw output, scale, shift)"""
-            if fused_gn:
-                y = self._conv(a, cw, out_f32=True, gn_partial=self._gn_scratch)
-                return (y, *ops.groupnorm_finalize_rows32(self._gn_scratch, gamma, beta, n, hw, groups))
-            y = self._conv(a, cw, out_f32=True) if s16 else self._conv(a[0], cw, in_scale=a[1], in_shift=a[2])
-            return (y, *self._gn(y, gamma, beta, groups))
-
-        def act(x, scale, shift):  # GroupNorm affine + ReLU, materialised (S32) or deferred to the conv load
-            return ops.to_split(x, scale, shift, relu=True) if s16 else (x, scale, shift)
-
-        def conv(a, cw, **kw):
-            if s16:
-                return self._conv(a, cw, out_f32=True, **kw)
-            return self._conv(a[0], cw, in_scale=a[1], in_shift=a[2], **kw)
-
-        if s16:
-            t0, sc, sh = conv_gn(feat, self.tower0, self.gn0_gamma, self.gn0_beta, 64)  # 2 x GroupNorm(32,256)
-        else:
-            t0 = self._conv(feat, self.tower0, out_f32=True)          # [N,h,w,512] raw
-            sc, sh = self._gn(t0, self.gn0_gamma, self.gn0_beta, 64)
-        xc, sc_c, sh_c = t0[..., :256], sc[:, :256], sh[:, :256]
-        xr, sc_r, sh_r = t0[..., 256:], sc[:, 256:], sh[:, 256:]
+    def _cls_chain(self, t0, sc, sh, key):
+        n, fh, fw = t0.shape[:3]
+        x, sc, sh = t0[..., :256], sc[:, :256], sh[:, :256]
         for cw, (g, b) in zip(self.cls_tower, self.cls_gn):
-            xc, sc_c, sh_c = conv_gn(act(xc, sc_c, sh_c), cw, g, b, 32)
+            x, sc, sh = self._conv_gn(self._act(x, sc, sh), cw, g, b, 32, n, fh * fw, key)
+        a = self._act(x, sc, sh)
+        cls_lr = self._out_conv(a, self.cls_out)
+        ext = self._out_conv(a, self.ext_out, relu_cols=3) if self.ext else None
+        return cls_lr, ext
+
+    def _reg_chain(self, t0, sc, sh, key):
+        n, fh, fw = t0.shape[:3]
+        x, sc, sh = t0[..., 256:], sc[:, 256:], sh[:, 256:]
         for cw, (g, b) in zip(self.reg_tower, self.reg_gn):
-            xr, sc_r, sh_r = conv_gn(act(xr, sc_r, sh_r), cw, g, b, 32)
-        ac = act(xc, sc_c, sh_c)
-        cls_lr = conv(ac, self.cls_out)
-        ext = conv(ac, self.ext_out, relu_cols=3) if self.ext else None
-        reg_ctr = conv(act(xr, sc_r, sh_r), self.reg_out, relu_cols=4)
-        return cls_lr, reg_ctr, ext
+            x, sc, sh = self._conv_gn(self._act(x, sc, sh), cw, g, b, 32, n, fh * fw, key)
+        return self._out_conv(self._act(x, sc, sh), self.reg_out, relu_cols=4)
+
+    def head_level(self, feat, key=0):
+        """One FPN level -> (cls_lr [N,h,w,C+2], reg_ctr [N,h,w,5], ext [N,h,w,8] or None) raw fp32 conv outputs."""
+        t0, sc, sh = self._tower0(feat, key)
+        cls_lr, ext = self._cls_chain(t0, sc, sh, key)
+        return cls_lr, self._reg_chain(t0, sc, sh, key), ext
+
+    def heads(self, feats):
+        """All levels.  With head_streams > 1 the 2 x levels independent tower chains are spread over side
+        streams so that the tail of one convolution's grid (e.g. 1700 workgroups on 512 slots at the
+        stride-16 level) is filled by another chain's workgroups."""
+        if self.head_streams <= 1:
+            return [self.head_level(f, key=i) for i, f in enumerate(feats)]
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = [torch.cuda.Stream(device=self.device) for _ in range(self.head_streams)]
+        lv = [self._tower0(f, ("t0", i)) for i, f in enumerate(feats)]
+        fork = torch.cuda.Event()
+        fork.record(main)
+        chains = [(i, kind) for i in range(len(feats)) for kind in ("cls", "reg")]
+        results = {}
+        for ci, (i, kind) in enumerate(chains):
+            st = self._side[ci % len(self._side)]
+            st.wait_event(fork)
+            with torch.cuda.stream(st):
+                if kind == "cls":
+                    results[(i, "cls")] = self._cls_chain(*lv[i], key=("cls", i))
+                else:
+                    results[(i, "reg")] = self._reg_chain(*lv[i], key=("reg", i))
+        for st in self._side:
+            main.wait_stream(st)
+        outs = []
+        for i in range(len(feats)):
+            cls_lr, ext = results[(i, "cls")]
+            reg_ctr = results[(i, "reg")]
+            for t in (cls_lr, ext, reg_ctr):
+                if t is not None:
+                    t.record_stream(main)  # allocated on a side stream, consumed on the main one
+            outs.append((cls_lr, reg_ctr, ext))
+        return outs
 
     def forward_heads(self, images):
         """images [N,3,H,W] fp32 0..1 on the GPU -> per-level head tensors + geometry."""
@@ -207,7 +256,7 @@ class FCOSEngine:
         pre = ops.fcos_preprocess_split if self.precision == "f16x3" else ops.fcos_preprocess
         x = pre(images.float().contiguous(), oh, ow, ph, pw, IMAGE_MEAN, IMAGE_STD)
         feats = self.backbone(x)
-        outs = [self.head_level(f) for f in feats]
+        outs = self.heads(feats)
         strides = [ph // f.shape[1] for f in feats]
         self._ext_levels = [o[2] for o in outs] if self.ext else None
         return [o[0] for o in outs], [o[1] for o in outs], strides, (oh, ow, ph, pw)

@@ -113,7 +113,7 @@ def from_split(xs16, out=None):
 # bench.py's roofline leg: when set to a list, every conv launch is bracketed by HIP events
 # on the launch stream and ((precision, tile id), algorithmic MACs, timer, shape) is appended.
 CONV_PROFILE = None
-TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x64", 4: "128x32", 5: "256x128", 6: "64x128", 7: "32x64", 8: "256x64"}
+TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x64", 4: "128x32", 5: "256x128", 6: "64x128", 7: "32x64", 8: "256x64", 9: "256x128w8"}
 
 
 def conv2d_nhwc(x, w, bias=None, *, stride=1, pad=0, dil=1, relu=False, relu_cols=None,

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Run on the GPU box (gpurun): collects everything the numbers in DESIGN.md / bench.py's roofline object are
+# checked against into gpurun_out/<tag>/; tools/save_profiles.py then condenses it into profiles/.
+#   usage: bash tools/collect_profiles.sh <tag>
+# Separate rocprofv3 passes: kernel trace + stats, then one --pmc pass per HBM counter (never combined with traces).
+set -u
+tag=${1:-r01c}
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/$tag
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+B="python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline"
+python3 $R/bench.py > $O/bench_default.log 2>&1; tail -1 $O/bench_default.log > $O/bench_pipeline_b32.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B > $O/bench_under_rocprof.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $B --no-roofline > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- $B --no-roofline > /dev/null 2>&1
+python3 $R/tools/layer_table.py f16x3 32 2>&1 | grep -v amdgpu.ids > $O/layer_table_b32.txt
+python3 $R/bench.py --workload a2j --no-cpu-baseline --steps 50 --warmup 10 2>&1 | tail -1 > $O/bench_a2j_b64.json
+python3 $R/bench.py --workload fcos --no-cpu-baseline --steps 20 --warmup 5 2>&1 | tail -1 > $O/bench_fcos_b16.json
+python3 $R/bench.py --precision f32 --no-cpu-baseline --steps 5 --warmup 2 2>&1 | tail -1 > $O/bench_pipeline_b32_f32.json
+python3 $R/bench.py --batch 64 --no-cpu-baseline --no-roofline --steps 10 --warmup 3 2>&1 | tail -1 > $O/bench_pipeline_b64.json
+bash $R/tools/probes/exp/clocks.sh > $O/clocks_power.txt 2>&1
+echo collected into $O
