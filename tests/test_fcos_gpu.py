@@ -254,3 +254,25 @@ def test_head_side_streams_give_identical_results(fcos_sd, oracle_run):
     torch.cuda.synchronize()
     assert torch.equal(da.count, db.count) and int(da.count.min()) > 0
     assert torch.equal(da.boxes, db.boxes) and torch.equal(da.scores, db.scores) and torch.equal(da.labels, db.labels)
+
+
+def test_other_frame_size_wide(fcos_sd, engine):
+    """A 360x640 frame (16:9): the max_size branch of the resize rule (749x1333 -> canvas 768x1344, levels
+    96x168 / 48x84 / 24x42) through the same kernels, vs the oracle; agreement as in the 480x640 end-to-end test."""
+    from hn_amd import synth
+    from oracle import fcos_ref
+    rgb = synth.make_rgb(1, h=360, w=640, seed=77)
+    dets, inter = fcos_ref.fcos_forward([rgb[0]], fcos_sd, 3, return_intermediates=True)
+    oh, ow, ph, pw = engine.geometry(360, 640)
+    assert (oh, ow) == tuple(inter["image_sizes"][0]) and (ph, pw) == tuple(inter["x"].shape[-2:]) == (768, 1344)
+    det, cand = engine.detect(rgb.cuda())
+    ref = dets[0]
+    k = int(det.count[0])
+    assert abs(int(cand.count[0]) - len(inter["candidates"][0]["scores"])) <= 3
+    boxes, labels = det.boxes[0, :k].cpu(), det.labels[0, :k].cpu().long()
+    matched = 0
+    for b, l in zip(ref["boxes"], ref["labels"]):
+        d = (boxes - b).abs().max(dim=1)[0]
+        j = int(d.argmin())
+        matched += int(d[j] < 1e-2 and labels[j] == l)
+    assert len(ref["labels"]) > 20 and matched >= 0.98 * len(ref["labels"]) and k <= 1.02 * len(ref["labels"]) + 1
