@@ -1,5 +1,9 @@
 #!/bin/bash
-# A/B: library built from the previous commit's conv kernel vs the working tree, long runs (power-capped chip)
+# A/B: library built from the previous commit's conv kernel vs the working tree, long runs (power-capped chip).
+# Build the comparison library first (not tracked):
+#   git show <rev>:handnet-pipeline_amd/csrc/conv_igemm_f16x3.hip > /tmp/conv_igemm_f16x3_old.hip
+#   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Iinclude -Ihandnet-pipeline_amd/csrc -c /tmp/conv_igemm_f16x3_old.hip -o /tmp/conv_old.o
+#   hipcc --offload-arch=gfx950 -shared -fPIC -o tools/probes/exp/lib_old.so /tmp/conv_old.o handnet-pipeline_amd/csrc/build/{conv_igemm_f32,hn_common,split_ops,a2j_ops,groupnorm,fcos_post}.o
 cd $GRAFT_REPO_ROOT
 L=handnet-pipeline_amd/csrc/libhandnet_hip.so
 cp $L /tmp/lib_new.so
