@@ -72,6 +72,11 @@ struct ConvParams16 {
   int out_split, res_split;
   int vec_epi;        // 1: 16-byte epilogue through LDS (Cout % 8 == 0 and aligned strides)
   float* gn_partial;  // optional GroupNorm partial sums [ceil(M/32)][Cout/8][4] (see hn_conv2d_nhwc_f16x3_gn)
+  // split-K (small-M layers): gridDim.y workgroups share an output tile, each sums kt_per k tiles into
+  // split_ws[z][M][Cout] (fp32, no epilogue); splitk_reduce_kernel adds them in z order and finishes
+  int splits, kt_per;
+  float* split_ws;
+  int64_t split_ws_bytes;
   int tiles_m, tiles_n, nblocks;
 };
 
@@ -111,6 +116,90 @@ __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (B < E) {
     f(std::integral_constant<int, B>{});
     static_for<B + 1, E>(f);
+  }
+}
+
+// residual add, ReLU on a column prefix and the 16-byte store of 8 consecutive channels n..n+7 of output
+// pixel m (fp32 or S32); shared by the conv epilogue and the split-K reduction
+__device__ __forceinline__ void epi_finish8(const ConvParams16& p, int m, int n, float (&v)[8], int ohow) {
+  if (p.res_mode) {
+    long rpix = m;
+    if (p.res_mode == 2) {
+      const int img = m / ohow;
+      const int rem = m - img * ohow;
+      const int oh = rem / p.OW, ow = rem - oh * p.OW;
+      const int sh_ = (int)(((long)oh * p.res_h) / p.OH), sw_ = (int)(((long)ow * p.res_w) / p.OW);
+      rpix = ((long)img * p.res_h + sh_) * p.res_w + sw_;
+    }
+    if (p.res_split) {
+      const _Float16* q16 = reinterpret_cast<const _Float16*>(p.res) + rpix * p.rs + (n >> 5) * 64 + (n & 31);
+      const f16x8 rh = *reinterpret_cast<const f16x8*>(q16), rl = *reinterpret_cast<const f16x8*>(q16 + 32);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += (float)rh[e] + (float)rl[e];
+    } else {
+      const float* q32 = reinterpret_cast<const float*>(p.res) + rpix * p.rs + n;
+      const f32x4 r0 = *reinterpret_cast<const f32x4*>(q32), r1 = *reinterpret_cast<const f32x4*>(q32 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] += r0[e];
+        v[4 + e] += r1[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    if (n + e < p.relu_cols) v[e] = fmaxf(v[e], 0.f);
+  if (p.out_split) {
+    f16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const _Float16 h = (_Float16)v[e];
+      hi[e] = h;
+      lo[e] = (_Float16)(v[e] - (float)h);
+    }
+    _Float16* q16 = reinterpret_cast<_Float16*>(p.y) + (long)m * p.ys + (n >> 5) * 64 + (n & 31);
+    *reinterpret_cast<f16x8*>(q16) = hi;
+    *reinterpret_cast<f16x8*>(q16 + 32) = lo;
+  } else {
+    float* q32 = reinterpret_cast<float*>(p.y) + (long)m * p.ys + n;
+    f32x4 o0, o1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o0[e] = v[e];
+      o1[e] = v[4 + e];
+    }
+    *reinterpret_cast<f32x4*>(q32) = o0;
+    *reinterpret_cast<f32x4*>(q32 + 4) = o1;
+  }
+}
+
+// z-ordered sum of the split-K partial tiles + bias + the common epilogue tail; one thread = 8 channels of a pixel
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams16 p) {
+  const int units = p.Cout >> 3;
+  const long total = (long)p.M * units;
+  const int ohow = p.OH * p.OW;
+  const long plane = (long)p.M * p.Cout;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(i / units), n = (int)(i - (long)m * units) * 8;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float* src = p.split_ws + (long)m * p.Cout + n;
+    for (int z = 0; z < p.splits; ++z) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(src + z * plane), b = *reinterpret_cast<const f32x4*>(src + z * plane + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] += a[e];
+        v[4 + e] += b[e];
+      }
+    }
+    if (p.bias) {
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] += b0[e];
+        v[4 + e] += b1[e];
+      }
+    }
+    epi_finish8(p, m, n, v, ohow);
   }
 }
 
@@ -191,7 +280,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
   // XCD is ~1 MB instead of ~8 MB and the 4 MB L2 serves it (tap-outer order re-fetched the
   // input 3-7x over the fabric: FETCH_SIZE, profiles/).  Per step the tap offset is wave-uniform
   // (SALU); per lane only the two bounds checks and one 64-bit add remain.
-  int cur_r = 0, cur_s = 0, cur_cb = 0, load_t = 0;
+  // this workgroup's k tiles: [t_begin, t_end) (everything unless split-K)
+  const int t_begin = p.splits > 1 ? (int)blockIdx.y * p.kt_per : 0;
+  const int t_end = p.splits > 1 ? min(t_begin + p.kt_per, p.ktiles) : p.ktiles;
+  int load_t = t_begin, cur_cb = t_begin / (p.R * p.S);
+  int cur_r = (t_begin - cur_cb * p.R * p.S) / p.S, cur_s = t_begin - cur_cb * p.R * p.S - cur_r * p.S;
 
   // one DMA instruction (8 rows x 128 B per wave): A piece `it` gathers im2col rows, B piece `it` weight rows
   auto dma_a_piece = [&](int it, _Float16* Ad, int dr, int ds, long uoff) {
@@ -207,7 +300,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
   // saturates at the last tile: the pipeline keeps issuing (redundant, never read) loads of it past the end
   // instead of branching around the DMA
   auto advance_tile = [&]() {
-    const int adv = load_t + 1 < p.ktiles ? 1 : 0;
+    const int adv = load_t + 1 < t_end ? 1 : 0;
     load_t += adv;
     const int s1 = cur_s + adv;
     const int ws = s1 == p.S ? 1 : 0;
@@ -278,7 +371,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
-  const int T = p.ktiles;
+  const int T = t_end - t_begin;
   // One step = tile t in LDS stage `cs`; its A fragments are in `af`, its column-half-0 W fragments in
   // b0; tiles t+1 .. t+NBUF-1 are in flight or landed (stage `ns` holds t+1):
   //   first half : W fragments of half 1 are read (b1) || MFMAs of column half 0
@@ -371,10 +464,22 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant tail loads must land before LDS is reused / freed
 
   // ---- epilogue: bias, residual, ReLU, NHWC store ----
-  const float* res32 = reinterpret_cast<const float*>(p.res);
-  const _Float16* res16 = reinterpret_cast<const _Float16*>(p.res);
-  float* y32 = reinterpret_cast<float*>(p.y);
-  _Float16* y16 = reinterpret_cast<_Float16*>(p.y);
+  // A split-K workgroup stores its raw fp32 partial tile into plane blockIdx.y of the workspace instead
+  // (dense [M][Cout], no bias / residual / ReLU): the reduction kernel finishes the job.
+  ConvParams16 q = p;
+  if (p.splits > 1) {
+    q.y = p.split_ws + (long)blockIdx.y * p.M * p.Cout;
+    q.ys = p.Cout;
+    q.bias = nullptr;
+    q.res_mode = 0;
+    q.relu_cols = 0;
+    q.out_split = 0;
+    q.gn_partial = nullptr;
+  }
+  const float* res32 = reinterpret_cast<const float*>(q.res);
+  const _Float16* res16 = reinterpret_cast<const _Float16*>(q.res);
+  float* y32 = reinterpret_cast<float*>(q.y);
+  _Float16* y16 = reinterpret_cast<_Float16*>(q.y);
   if (p.vec_epi) {
     // Vector path (Cout % 8 == 0): every wave transposes its accumulators through a private
     // LDS patch (32 rows x TN*16 columns per pass) so that each lane then owns 8 consecutive
@@ -403,8 +508,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
       const int m_split = (m_grp / ohow + 1) * ohow;  // first row of the next image
 #pragma unroll
       for (int k = 0; k < (32 * GROUPS) / 64; ++k) {
-        const int q = lane + 64 * k;
-        const int prow = q / GROUPS, g = q - prow * GROUPS;
+        const int qq = lane + 64 * k;
+        const int prow = qq / GROUPS, g = qq - prow * GROUPS;
         const int m = m0 + wm * (BM / WM) + i * 16 + prow;
         const int n = n0 + wn * (BN / WN) + g * 8;
         const f32x4 c0 = *reinterpret_cast<const f32x4*>(&patch[prow * PWP + g * 8]);
@@ -416,15 +521,15 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
           v[e] = c0[e];
           v[4 + e] = c1[e];
         }
-        if (p.bias) {
-          const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+        if (q.bias) {
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(q.bias + n), b1 = *reinterpret_cast<const f32x4*>(q.bias + n + 4);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             v[e] += b0[e];
             v[4 + e] += b1[e];
           }
         }
-        if (p.gn_partial) {
+        if (q.gn_partial) {
           float s1 = 0.f, s2 = 0.f;
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
@@ -437,57 +542,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
           gsum[2] += second ? s1 : 0.f;
           gsum[3] += second ? s2 : 0.f;
         }
-        if (p.res_mode) {
-          long rpix = m;
-          if (p.res_mode == 2) {
-            const int img = m / ohow;
-            const int rem = m - img * ohow;
-            const int oh = rem / p.OW, ow = rem - oh * p.OW;
-            const int sh_ = (int)(((long)oh * p.res_h) / p.OH), sw_ = (int)(((long)ow * p.res_w) / p.OW);
-            rpix = ((long)img * p.res_h + sh_) * p.res_w + sw_;
-          }
-          if (p.res_split) {
-            const _Float16* q16 = res16 + rpix * p.rs + (n >> 5) * 64 + (n & 31);
-            const f16x8 rh = *reinterpret_cast<const f16x8*>(q16), rl = *reinterpret_cast<const f16x8*>(q16 + 32);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += (float)rh[e] + (float)rl[e];
-          } else {
-            const float* q32 = res32 + rpix * p.rs + n;
-            const f32x4 r0 = *reinterpret_cast<const f32x4*>(q32), r1 = *reinterpret_cast<const f32x4*>(q32 + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              v[e] += r0[e];
-              v[4 + e] += r1[e];
-            }
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (n + e < p.relu_cols) v[e] = fmaxf(v[e], 0.f);
-        if (p.out_split) {
-          f16x8 hi, lo;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const _Float16 h = (_Float16)v[e];
-            hi[e] = h;
-            lo[e] = (_Float16)(v[e] - (float)h);
-          }
-          _Float16* q16 = y16 + (long)m * p.ys + (n >> 5) * 64 + (n & 31);
-          *reinterpret_cast<f16x8*>(q16) = hi;
-          *reinterpret_cast<f16x8*>(q16 + 32) = lo;
-        } else {
-          float* q32 = y32 + (long)m * p.ys + n;
-          f32x4 o0, o1;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            o0[e] = v[e];
-            o1[e] = v[4 + e];
-          }
-          *reinterpret_cast<f32x4*>(q32) = o0;
-          *reinterpret_cast<f32x4*>(q32 + 4) = o1;
-        }
+        epi_finish8(q, m, n, v, ohow);
       }
-      if (p.gn_partial) {
+      if (q.gn_partial) {
         // lanes with equal (lane % GROUPS) hold the same channel unit: fixed-order butterfly over the rows
 #pragma unroll
         for (int o = GROUPS; o < 64; o <<= 1)
@@ -496,7 +553,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
         const int n = n0 + wn * (BN / WN) + lane * 8;
         if (lane < GROUPS && n < p.Cout && m_grp < p.M) {
           f32x4 o4 = {gsum[0], gsum[1], gsum[2], gsum[3]};
-          *reinterpret_cast<f32x4*>(p.gn_partial + ((long)(m_grp >> 5) * (p.Cout >> 3) + (n >> 3)) * 4) = o4;
+          *reinterpret_cast<f32x4*>(q.gn_partial + ((long)(m_grp >> 5) * (p.Cout >> 3) + (n >> 3)) * 4) = o4;
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // patch reads done before the next pass rewrites it
@@ -555,8 +612,32 @@ int launch16(const ConvParams16& p0, hipStream_t st) {
   p.tiles_m = hn::cdiv(p.M, BM);
   p.tiles_n = hn::cdiv(p.Cout, BN);
   p.nblocks = p.tiles_m * p.tiles_n;
-  hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, NBUF>), dim3(p.nblocks), dim3(WM * WN * 64), 0, st, p);
+  // Split-K for grids that leave most of the chip idle AND have a long serial k loop (~0.33 us per 32-deep
+  // tile): e.g. the 2048->512 3x3 A2J layer at batch 1 is 8 workgroups x 576 tiles = 190 us.  Up to 16
+  // workgroups then share an output tile, each keeping >= 16 tiles.  Shorter loops stay single-pass: the
+  // second launch costs more than it saves (measured in-pipeline, tools/probes/exp/splitk.sh).
+  p.splits = 1;
+  p.kt_per = p.ktiles;
+  if (p.split_ws && p.vec_epi && !p.gn_partial && p.nblocks < 256 && p.ktiles >= 128) {
+    int want = hn::cdiv(512, p.nblocks);
+    want = want < p.ktiles / 16 ? want : p.ktiles / 16;
+    want = want < 16 ? want : 16;
+    const int64_t plane_bytes = (int64_t)p.M * p.Cout * 4;
+    if ((int64_t)want * plane_bytes > p.split_ws_bytes) want = (int)(p.split_ws_bytes / plane_bytes);
+    if (want > 1) {
+      p.kt_per = hn::cdiv(p.ktiles, want);
+      p.splits = hn::cdiv(p.ktiles, p.kt_per);  // every split has at least one tile
+    }
+  }
+  hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, NBUF>), dim3(p.nblocks, p.splits), dim3(WM * WN * 64), 0,
+                     st, p);
   HN_CHECK_LAUNCH("conv_igemm_f16x3_kernel");
+  if (p.splits > 1) {
+    const long total = (long)p.M * (p.Cout >> 3);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, p);
+    HN_CHECK_LAUNCH("splitk_reduce_kernel");
+  }
   return HN_OK;
 }
 
@@ -582,11 +663,21 @@ extern "C" int hn_conv2d_f16x3_pick_tile(const hn_conv_desc* d) {
 }
 
 static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, const float* bias, const void* residual,
-                      void* y, float* gn_partial, void* stream);
+                      void* y, float* gn_partial, void* workspace, int64_t workspace_bytes, void* stream);
 
 extern "C" int hn_conv2d_nhwc_f16x3(const hn_conv_desc* d, const void* x16, const void* w16, const float* bias,
                                     const void* residual, void* y, void* stream) {
-  return conv16_run(d, x16, w16, bias, residual, y, nullptr, stream);
+  return conv16_run(d, x16, w16, bias, residual, y, nullptr, nullptr, 0, stream);
+}
+
+// The same convolution with a caller-provided fp32 workspace, which lets small grids use split-K
+// (deterministic: partial tiles are summed in a fixed order by a second kernel).  The workspace is only
+// touched between this call's two launches, so one buffer per stream serves every convolution.
+extern "C" int hn_conv2d_nhwc_f16x3_ws(const hn_conv_desc* d, const void* x16, const void* w16, const float* bias,
+                                       const void* residual, void* y, void* workspace, int64_t workspace_bytes,
+                                       void* stream) {
+  HN_CHECK_ARG(workspace == nullptr || ((uintptr_t)workspace % 16 == 0 && workspace_bytes >= 0), "bad workspace");
+  return conv16_run(d, x16, w16, bias, residual, y, nullptr, workspace, workspace_bytes, stream);
 }
 
 // The same convolution, additionally emitting the GroupNorm partial sums of its fp32 output from the
@@ -598,11 +689,11 @@ extern "C" int hn_conv2d_nhwc_f16x3_gn(const hn_conv_desc* d, const void* x16, c
                                        void* y, float* gn_partial, void* stream) {
   HN_CHECK_ARG(gn_partial, "hn_conv2d_nhwc_f16x3_gn: null gn_partial");
   HN_CHECK_ARG(d && d->cout % 8 == 0, "GroupNorm statistics need cout %% 8 == 0");
-  return conv16_run(d, x16, w16, bias, nullptr, y, gn_partial, stream);
+  return conv16_run(d, x16, w16, bias, nullptr, y, gn_partial, nullptr, 0, stream);
 }
 
 static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, const float* bias, const void* residual,
-                      void* y, float* gn_partial, void* stream) {
+                      void* y, float* gn_partial, void* workspace, int64_t workspace_bytes, void* stream) {
   HN_CHECK_ARG(d && x16 && w16 && y, "hn_conv2d_nhwc_f16x3: null pointer");
   HN_CHECK_ARG(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, "bad tensor dims");
   HN_CHECK_ARG(d->cin % 32 == 0, "f16x3 conv needs cin %% 32 == 0 (got %d); use hn_conv2d_nhwc_f32", d->cin);
@@ -639,6 +730,10 @@ static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, c
               (residual == nullptr || (uintptr_t)residual % 16 == 0);
   p.tiles_m = p.tiles_n = p.nblocks = 0;
   p.gn_partial = gn_partial;
+  p.split_ws = (float*)workspace;
+  p.split_ws_bytes = workspace ? workspace_bytes : 0;
+  p.splits = 1;
+  p.kt_per = p.ktiles;
   if (gn_partial) {
     HN_CHECK_ARG(p.vec_epi && !d->out_split && d->res_mode == 0 && d->relu_cols == 0,
                  "GroupNorm statistics need the vector epilogue, fp32 output, no residual and no ReLU");
@@ -689,6 +784,7 @@ extern "C" int hn_conv_stem_f16x3(const void* x16, int n, int ph, int pw, int pa
   p.out_split = out_split; p.res_split = 0;
   p.xs = 4; p.pitch = wb; p.lo_off = (long)n * hb * wb * 4;
   p.gn_partial = nullptr;
+  p.split_ws = nullptr; p.split_ws_bytes = 0; p.splits = 1; p.kt_per = p.ktiles;
   p.ys = (out_split ? 2 : 1) * cout;
   p.rs = 0;
   p.vec_epi = (cout % 8 == 0) && ((uintptr_t)y % 16 == 0) && (bias == nullptr || (uintptr_t)bias % 16 == 0);

@@ -11,7 +11,7 @@ from pathlib import Path
 
 from . import build as _build
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, TILE_256x128, TILE_64x128 = range(7)
 HN_FCOS_MAX_LEVELS = 5
@@ -59,6 +59,7 @@ SIGNATURES = {
     "hn_groupnorm_scratch_floats": (C.c_int64, [C.c_int] * 4),
     "hn_groupnorm_affine_f32": (C.c_int, [VP, VP, VP] + [C.c_int] * 4 + [C.c_float, VP, VP, VP, VP]),
     "hn_fcos_preprocess_f32": (C.c_int, [VP, VP] + [C.c_int] * 7 + [c_f32p, c_f32p, VP]),
+    "hn_conv2d_nhwc_f16x3_ws": (C.c_int, [C.POINTER(ConvDesc)] + [VP] * 6 + [C.c_int64, VP]),
     "hn_conv2d_nhwc_f16x3_gn": (C.c_int, [C.POINTER(ConvDesc)] + [VP] * 6),
     "hn_groupnorm_rows32_scratch_floats": (C.c_int64, [C.c_int64, C.c_int]),
     "hn_groupnorm_finalize_rows32": (C.c_int, [VP, VP, VP] + [C.c_int] * 4 + [C.c_float, VP, VP, VP]),

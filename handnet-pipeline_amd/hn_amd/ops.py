@@ -7,6 +7,7 @@ there is deliberately no CPU or eager fallback.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -116,9 +117,24 @@ CONV_PROFILE = None
 TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x64", 4: "128x32", 5: "256x128", 6: "64x128", 7: "32x64", 8: "256x64", 9: "256x128w8"}
 
 
+# split-K workspace: one fp32 buffer per (device, stream) -- a convolution only uses it between its own two
+# launches, and launches on one stream are ordered
+CONV_WORKSPACE_BYTES = 32 << 20
+SPLITK = os.environ.get("HN_SPLITK", "1") != "0"  # development switch (tools/probes/exp/splitk.sh)
+_WORKSPACES = {}
+
+
+def _conv_workspace(device):
+    key = (device.index, _stream())
+    ws = _WORKSPACES.get(key)
+    if ws is None:
+        ws = _WORKSPACES[key] = torch.empty((CONV_WORKSPACE_BYTES // 4,), device=device, dtype=torch.float32)
+    return ws
+
+
 def conv2d_nhwc(x, w, bias=None, *, stride=1, pad=0, dil=1, relu=False, relu_cols=None,
                 residual=None, res_upsample=False, in_scale=None, in_shift=None, out=None, tile=0,
-                algo_cin=None, w16=None, out_split=False, gn_partial=None):
+                algo_cin=None, w16=None, out_split=False, gn_partial=None, splitk=True):
     """Convolution with fused epilogue.  x: fp32 [N,H,W,Cin] or S32 split; w [Cout,R,S,Cin] fp32.
 
     w16 given  -> f16x3 kernel (split-fp16 operands on the f16 MFMA, fp32-grade results); an fp32
@@ -129,6 +145,7 @@ def conv2d_nhwc(x, w, bias=None, *, stride=1, pad=0, dil=1, relu=False, relu_col
                   read of a coarser map (FPN top-down path).
     algo_cin   -> input channels the reference's conv really has when Cin is zero-padded
                   (FLOP accounting only).
+    splitk     -> (f16x3) allow split-K for small grids (deterministic two-launch scheme, needs the workspace).
     gn_partial -> (f16x3, fp32 output, no residual / ReLU) fp32 scratch of gn_rows32_scratch_floats(rows, Cout)
                   floats: the epilogue also writes GroupNorm partial sums for groupnorm_finalize_rows32()."""
     lib = _lib.load()
@@ -211,8 +228,11 @@ def conv2d_nhwc(x, w, bias=None, *, stride=1, pad=0, dil=1, relu=False, relu_col
             check(lib.hn_conv2d_nhwc_f16x3_gn(C.byref(d), ptr(x), ptr(w16), ptr(bias), ptr(out), ptr(gn_partial),
                                               _stream()), "hn_conv2d_nhwc_f16x3_gn")
         else:
-            check(lib.hn_conv2d_nhwc_f16x3(C.byref(d), ptr(x), ptr(w16), ptr(bias), ptr(residual), ptr(out),
-                                           _stream()), "hn_conv2d_nhwc_f16x3")
+            splitk = splitk and SPLITK
+            ws = _conv_workspace(x.device) if splitk else None
+            check(lib.hn_conv2d_nhwc_f16x3_ws(C.byref(d), ptr(x), ptr(w16), ptr(bias), ptr(residual), ptr(out),
+                                              ptr(ws), ws.numel() * 4 if splitk else 0, _stream()),
+                  "hn_conv2d_nhwc_f16x3_ws")
     else:
         if gn_partial is not None:
             raise ValueError("gn_partial is an f16x3-kernel feature")

@@ -33,7 +33,7 @@ extern "C" {
 #define HN_ERR_HIP 2
 
 /* ABI version; bumped whenever a struct below changes. */
-#define HN_ABI_VERSION 13
+#define HN_ABI_VERSION 14
 int hn_abi_version(void);
 const char* hn_last_error(void);
 
@@ -139,6 +139,14 @@ int64_t hn_groupnorm_scratch_floats(int n, int hw, int c, int groups);
 int hn_groupnorm_affine_f32(const float* x /* [n][hw][c] */, const float* gamma,
                             const float* beta, int n, int hw, int c, int groups, float eps,
                             float* partial, float* scale, float* shift, void* stream);
+
+/* hn_conv2d_nhwc_f16x3 with a caller-provided workspace (fp32 scratch, 16-byte aligned, any size; only used
+ * between this call's own launches, so one buffer per stream serves all convolutions).  With it, layers
+ * whose output grid would leave most CUs idle (n*oh*ow small: the 11x11 A2J maps, everything at batch 1)
+ * run split-K: up to 16 workgroups share an output tile, partial tiles are summed in a fixed order. */
+int hn_conv2d_nhwc_f16x3_ws(const hn_conv_desc* desc, const void* x16, const void* w16,
+                            const float* bias, const void* residual, void* y,
+                            void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Fused variant for the f16x3 path: hn_conv2d_nhwc_f16x3_gn is hn_conv2d_nhwc_f16x3 (fp32 output, no
  * residual / ReLU, cout % 8 == 0, oh*ow >= 32) whose epilogue also writes GroupNorm partial sums

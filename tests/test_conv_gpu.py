@@ -279,7 +279,7 @@ def test_conv_f16x3_groupnorm_partials_in_epilogue(n, h, w, cin, cout, groups, t
     w16 = split_f16x3(wt).cuda()
     part = torch.full((ops.gn_rows32_scratch_floats(n * h * w, cout),), float("nan"), device="cuda")
     y = ops.conv2d_nhwc(x16, wt.cuda(), b.cuda(), pad=1, w16=w16, tile=tile, gn_partial=part)
-    y_plain = ops.conv2d_nhwc(x16, wt.cuda(), b.cuda(), pad=1, w16=w16, tile=tile)
+    y_plain = ops.conv2d_nhwc(x16, wt.cuda(), b.cuda(), pad=1, w16=w16, tile=tile, splitk=False)
     assert torch.equal(y, y_plain)
     assert not torch.isnan(part).any()          # every (row group, channel unit) record is written exactly once
     sc, sh = ops.groupnorm_finalize_rows32(part, gamma.cuda(), beta.cuda(), n, h * w, groups)
@@ -288,3 +288,48 @@ def test_conv_f16x3_groupnorm_partials_in_epilogue(n, h, w, cin, cout, groups, t
     assert (sh - sh_ref).abs().max().item() <= 2e-6 * max(1.0, sh_ref.abs().max().item())
     with pytest.raises(ValueError):
         ops.conv2d_nhwc(x16, wt.cuda(), b.cuda(), pad=1, w16=w16, relu=True, gn_partial=part)
+
+
+@pytest.mark.parametrize("case", [
+    # n, h, w, cin, cout, r, stride, dil, residual ("s32" / "up" / None), out_split
+    (1, 11, 11, 1024, 256, 3, 1, 1, None, True),      # 8 workgroups x 288 k tiles -> 16 splits
+    (2, 11, 11, 2048, 512, 3, 1, 1, "s32", True),     # A2J layer4-style bottleneck conv with a split residual
+    (1, 25, 34, 4096, 256, 1, 1, 1, "up", False),     # 1x1 + nearest-2x top-down add (FPN style), fp32 out
+    (3, 11, 11, 512, 512, 3, 1, 2, None, True),       # dilated, 144 k tiles
+    (1, 7, 5, 512, 336, 3, 1, 1, None, False),        # ragged M (35 rows), Cout not a multiple of the tile
+])
+def test_conv_f16x3_splitk_matches_plain_and_reference(case):
+    """Small grids run split-K (partial tiles in a workspace, summed in fixed order by a second launch): same
+    fp32-grade error bar as the single-pass kernel, bitwise repeatable, and every epilogue mode still applies."""
+    from hn_amd import ops
+    from hn_amd.weights import split_f16x3
+    from oracle import ops_ref
+    n, h, w, cin, cout, r, stride, dil, res, osplit = case
+    pad = dil * (r // 2)
+    x = _rand((n, h, w, cin), 41)
+    wt = _rand((cout, r, r, cin), 42, scale=(2.0 / (cin * r * r)) ** 0.5)
+    b = _rand((cout,), 43, 0.1)
+    oh, ow = ops.conv_out_size(h, w, r, r, stride, pad, dil)
+    kw = dict(stride=stride, pad=pad, dil=dil, relu=True, w16=split_f16x3(wt).cuda(), out_split=osplit)
+    ref = ops_ref.conv2d_nhwc(x.double(), wt.double(), b.double(), stride, pad, dil, relu_cols=0)
+    if res == "s32":
+        rt = _rand((n, oh, ow, cout), 44)
+        kw["residual"] = ops.to_split(rt.cuda())
+        ref = ref + rt.double()
+    elif res == "up":
+        rt = _rand((n, (oh + 1) // 2, (ow + 1) // 2, cout), 44)
+        kw["residual"], kw["res_upsample"] = rt.cuda(), True
+        iy = (torch.arange(oh) * rt.shape[1]) // oh
+        ix = (torch.arange(ow) * rt.shape[2]) // ow
+        ref = ref + rt.double()[:, iy][:, :, ix]
+    ref = torch.relu(ref).float()
+    x16 = ops.to_split(x.cuda())
+    y_split = ops.conv2d_nhwc(x16, wt.cuda(), b.cuda(), **kw)
+    y_again = ops.conv2d_nhwc(x16, wt.cuda(), b.cuda(), **kw)
+    y_plain = ops.conv2d_nhwc(x16, wt.cuda(), b.cuda(), splitk=False, **kw)
+    assert torch.equal(y_split, y_again)
+    f = (lambda t: ops.from_split(t)) if osplit else (lambda t: t)
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((f(y_split).cpu() - ref).abs().max()) <= 2e-5 * scale
+    assert float((f(y_plain).cpu() - ref).abs().max()) <= 2e-5 * scale
+    assert not torch.equal(y_split, y_plain)   # the split path really ran (different summation order)

@@ -32,7 +32,10 @@ if prec == "f16x3":
     sc = sh = None
     if osplit:
         y = torch.empty((n, oh, ow, cout // 32, 2, 32), device="cuda", dtype=torch.float16)
+import os
 kw = dict(stride=stride, pad=pad, dil=dil, relu=True, tile=tile, w16=w16, out=y, in_scale=sc, in_shift=sh)
+if prec == "f16x3":
+    kw["splitk"] = os.environ.get("HN_SPLITK", "1") != "0"
 for _ in range(3):
     ops.conv2d_nhwc(x, wt, b, **kw)
 torch.cuda.synchronize()
