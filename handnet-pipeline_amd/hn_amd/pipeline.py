@@ -54,16 +54,24 @@ class HandNetEngine:
         static tensors and call run() to replay the captured step."""
         key = (tuple(images.shape), tuple(depth.shape))
         if key not in self._graphs:
-            s_img, s_dep = images.clone(), depth.clone()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(2):  # warm-up (allocator, lazy module load) outside capture
-                    self.forward_device(s_img, s_dep)
-            torch.cuda.current_stream().wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                out = self.forward_device(s_img, s_dep)
-            self._graphs[key] = (g, s_img, s_dep, out)
+            with torch.inference_mode(False), torch.no_grad():
+                return self._capture(key, images, depth)
         g, s_img, s_dep, out = self._graphs[key]
+        return g.replay, s_img, s_dep, out
+
+    def _capture(self, key, images, depth):
+        # static buffers are ordinary (non-inference) tensors so that later copy_() works in any mode
+        s_img, s_dep = torch.empty_like(images), torch.empty_like(depth)
+        s_img.copy_(images)
+        s_dep.copy_(depth)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):  # warm-up (allocator, lazy module load) outside capture
+                self.forward_device(s_img, s_dep)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = self.forward_device(s_img, s_dep)
+        self._graphs[key] = (g, s_img, s_dep, out)
         return g.replay, s_img, s_dep, out

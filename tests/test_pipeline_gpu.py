@@ -175,6 +175,26 @@ def test_handnet_rgbd_matches_reference_golden(fcos_sd, a2j_rgbd_sd, golden_dir,
         net([rgb[0], rgb[1]], depth_images=depth)      # an RGBD model needs the 4-channel tensor
 
 
+def test_handnet_graph_mode_equals_eager(handnet):
+    """HandNet.enable_graph(): captured replay returns what the eager call returns, also for new inputs of the
+    same shape (inputs are copied into the captured buffers)."""
+    from hn_amd import synth
+    depth = synth.make_depth(2, seed=31).cuda()
+    outs = {}
+    for mode in (False, True):
+        handnet.enable_graph(mode)
+        for seed in (41, 42):
+            rgb = synth.make_rgb(2, seed=seed).cuda()
+            with torch.inference_mode():
+                kp, db, cr = handnet([rgb[0], rgb[1]], depth_images=depth)
+            outs[(mode, seed)] = (kp.clone(), db.clone(), cr.clone())
+    handnet.enable_graph(False)
+    for seed in (41, 42):
+        for a, b in zip(outs[(False, seed)], outs[(True, seed)]):
+            assert a.shape == b.shape and (a.float() - b.float()).abs().max().item() < 1e-5
+    assert not torch.equal(outs[(True, 41)][0], outs[(True, 42)][0])
+
+
 def test_convert_joints_matches_reference_formula():
     """crop-uvd -> image-uvd -> camera xyz (mm) on the device vs the oracle's restatement of
     a2j/a2j.py:17-34 + datasets3d/a2jdataset.py:31-38.  Tolerance 1e-2 mm on O(100-1000) mm values."""
