@@ -144,6 +144,52 @@ def make_fcos_state_dict(seed: int = 0, num_classes: int = 3, ext: bool = False)
 
 
 # ---------------------------------------------------------------------------------------
+# Pose2Mesh lifter (pose2mesh/lib/models/{pose2mesh_net,posenet,meshnet}.py), 'mano' configuration
+# ---------------------------------------------------------------------------------------
+P2M_CL_F = [(5, 32, 64, 64), (64, 128, 256), (256, 256, 256), (256, 256, 256), (256, 256, 256), (256, 128, 128),
+            (128, 64, 3)]                                                       # meshnet.py:22-27
+P2M_CL_K = 3                                                                    # Chebyshev order (meshnet.py:21)
+
+
+def _linear(sd, seed, name, fout, fin, std, bias_std=0.02):
+    sd[name + ".weight"] = _normal(seed, name + ".weight", (fout, fin), std=std)
+    sd[name + ".bias"] = _normal(seed, name + ".bias", (fout,), std=bias_std)
+
+
+def make_pose2mesh_state_dict(seed: int = 0, graph_sizes=(1152, 576, 288, 144, 72, 36, 21), num_joint: int = 21,
+                              hid: int = 4096) -> "OrderedDict[str, torch.Tensor]":
+    """FlatPose2Mesh checkpoint layout (keys as listed by the reference's state_dict()).  graph_sizes are the
+    vertex counts of build_coarse_graphs' hierarchy, finest first, joint graph last; the model drops the
+    second-to-last level (meshnet.py:37)."""
+    sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    p = "pose_lifter."
+    _linear(sd, seed, p + "w1", hid, num_joint * 2, std=math.sqrt(1.0 / (num_joint * 2)))
+    _bn(sd, seed, p + "batch_norm1", hid)              # present in the checkpoint, unused by forward (posenet.py:78-88)
+    for st in range(2):
+        q = f"{p}linear_stages.{st}."
+        _linear(sd, seed, q + "w1", hid, hid, std=math.sqrt(2.0 / hid))
+        _bn(sd, seed, q + "batch_norm1", hid)
+        _linear(sd, seed, q + "w2", hid, hid, std=math.sqrt(1.0 / hid))
+        _bn(sd, seed, q + "batch_norm2", hid)
+    _linear(sd, seed, p + "w2", num_joint * 3, hid, std=100.0 * math.sqrt(1.0 / hid))   # millimetre-scale joints
+    m = "pose2mesh."
+    levels = list(graph_sizes)
+    del levels[-2]
+    _linear(sd, seed, m + "fc", levels[-2] * P2M_CL_F[1][0], levels[-1] * P2M_CL_F[0][-1],
+            std=math.sqrt(1.0 / (levels[-1] * P2M_CL_F[0][-1])))
+    idx = 0
+    for bi, chain in enumerate(P2M_CL_F):
+        for li in range(len(chain) - 1):
+            fin, fout = P2M_CL_K * chain[li], chain[li + 1]
+            last = bi == len(P2M_CL_F) - 1 and li == len(chain) - 2
+            _linear(sd, seed, f"{m}cl.{idx}", fout, fin, std=math.sqrt((1.0 if last else 2.0) / fin))
+            if not last:
+                _bn(sd, seed, f"{m}bn.{idx}", fout)
+            idx += 1
+    return sd
+
+
+# ---------------------------------------------------------------------------------------
 # synthetic inputs (SURVEY 8d)
 # ---------------------------------------------------------------------------------------
 def make_rgb(n: int, h: int = 480, w: int = 640, seed: int = 1000) -> torch.Tensor:

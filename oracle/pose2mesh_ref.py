@@ -1,0 +1,110 @@
+"""Oracle for the Pose2Mesh lifter: CPU restatement of
+pose2mesh/lib/models/pose2mesh_net.py:9-24 (FlatPose2Mesh), posenet.py:12-88 (LinearModel, eval),
+meshnet.py:79-117 (Pose2Mesh.forward, 'mano' configuration) and backbones/cheby_graph_conv.py:5-42.
+Test infrastructure only.  Pinned by tests/golden/pose2mesh_forward.npz (reference modules imported in the
+build container on a synthetic mesh hierarchy; see tests/golden/make_golden_p2m.py).
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+import torch.nn.functional as F
+
+CL_F = [(5, 32, 64, 64), (64, 128, 256), (256, 256, 256), (256, 256, 256), (256, 256, 256), (256, 128, 128),
+        (128, 64, 3)]   # meshnet.py:22-27 ('mano')
+CL_K = 3               # meshnet.py:21
+BN_EPS = 1e-5
+
+
+def load_graphs(npz):
+    """Laplacians of the fixture (finest first, joint graph last) as scipy CSR matrices."""
+    out = []
+    for i in range(int(npz["num_levels"])):
+        shape = tuple(int(v) for v in npz[f"L{i}_shape"])
+        out.append(sp.csr_matrix((npz[f"L{i}_data"], npz[f"L{i}_indices"], npz[f"L{i}_indptr"]), shape=shape))
+    return out
+
+
+def _bn_eval(x, sd, name):
+    return F.batch_norm(x, sd[name + ".running_mean"], sd[name + ".running_var"], sd[name + ".weight"],
+                        sd[name + ".bias"], False, 0.0, BN_EPS)
+
+
+def posenet(x, sd, p="pose_lifter."):
+    """LinearModel.forward, eval (posenet.py:78-88; Linear.forward :27-41; dropout is the identity)."""
+    y = F.linear(x, sd[p + "w1.weight"], sd[p + "w1.bias"])
+    for st in range(2):
+        q = f"{p}linear_stages.{st}."
+        z = F.relu(_bn_eval(y, sd, q + "batch_norm1"))
+        z = F.linear(z, sd[q + "w1.weight"], sd[q + "w1.bias"])
+        z = F.relu(_bn_eval(z, sd, q + "batch_norm2"))
+        z = F.linear(z, sd[q + "w2.weight"], sd[q + "w2.bias"])
+        y = y + z
+    return F.linear(y, sd[p + "w2.weight"], sd[p + "w2.bias"])
+
+
+def _to_torch_sparse(L):
+    c = L.tocoo()
+    idx = torch.from_numpy(np.vstack((c.row, c.col)).astype(np.int64))
+    return torch.sparse_coo_tensor(idx, torch.from_numpy(c.data.astype(np.float32)), c.shape).coalesce()
+
+
+def graph_conv_cheby(x, weight, bias, bn, L, K):
+    """cheby_graph_conv.py:5-42.  x [B,V,Fin]; features are ordered (fin, k) in the Linear's input."""
+    B, V, Fin = x.shape
+    x0 = x.permute(1, 2, 0).contiguous().view(V, Fin * B)
+    xs = [x0]
+    if K > 1:
+        x1 = torch.sparse.mm(L, x0)
+        xs.append(x1)
+    for _ in range(2, K):
+        x2 = 2 * torch.sparse.mm(L, x1) - x0
+        xs.append(x2)
+        x0, x1 = x1, x2
+    t = torch.stack(xs, 0).view(K, V, Fin, B).permute(3, 1, 2, 0).contiguous().view(B * V, Fin * K)
+    t = F.linear(t, weight, bias)
+    if bn is not None:
+        t = F.batch_norm(t, bn[0], bn[1], bn[2], bn[3], False, 0.0, BN_EPS)
+    return t.view(B, V, -1)
+
+
+def meshnet(x, sd, graphs, p="pose2mesh."):
+    """Pose2Mesh.forward (meshnet.py:79-117).  graphs: full hierarchy; level [-2] is dropped (meshnet.py:37)."""
+    Ls = [_to_torch_sparse(g) for g in graphs]
+    del Ls[-2]
+    B = x.shape[0]
+    x = x.view(-1, Ls[-1].shape[0], CL_F[0][0])
+    cl_i = 0
+    nblk = len(CL_F)
+    for i in range(nblk):
+        input_x = x
+        for li in range(len(CL_F[i]) - 1):
+            ldx = -(i + 1) + (1 if i == nblk - 1 else 0)
+            last = i == nblk - 1 and li == len(CL_F[i]) - 2
+            bn = None if last else tuple(sd[f"{p}bn.{cl_i}.{k}"] for k in ("running_mean", "running_var", "weight", "bias"))
+            x = graph_conv_cheby(x, sd[f"{p}cl.{cl_i}.weight"], sd[f"{p}cl.{cl_i}.bias"], bn, Ls[ldx], CL_K)
+            if not last:
+                x = F.relu(x)
+            cl_i += 1
+        if i == 0:      # joints -> coarsest mesh level through one dense layer (meshnet.py:101-103)
+            x = F.linear(x.reshape(B, -1), sd[p + "fc.weight"], sd[p + "fc.bias"]).view(B, Ls[-2].shape[0], CL_F[1][0])
+        elif i < nblk - 2:
+            input_x = F.interpolate(input_x, size=x.shape[2], mode="linear")   # along the FEATURE axis (meshnet.py:106)
+            x = input_x + x
+            x = x.permute(0, 2, 1).contiguous()
+            x = F.interpolate(x, scale_factor=2)                                # nn.Upsample(scale_factor=2), nearest
+            x = x.permute(0, 2, 1).contiguous()
+        elif i == nblk - 2:
+            input_x = F.interpolate(input_x, size=x.shape[2], mode="linear")
+            x = input_x + x
+    return x
+
+
+def pose2mesh_forward(pose2d, sd, graphs):
+    """FlatPose2Mesh.forward (pose2mesh_net.py:17-24): pose2d [B,J,2] -> (cam_mesh [B,V,3], pose3d [B,J,3])."""
+    with torch.no_grad():
+        B, J = pose2d.shape[:2]
+        pose3d = posenet(pose2d.reshape(B, -1), sd).reshape(-1, J, 3)
+        comb = torch.cat((pose2d, pose3d / 1000), dim=2)
+        return meshnet(comb, sd, graphs), pose3d

@@ -151,3 +151,16 @@ def test_nms_oracle_semantics():
     # classes 0 / 1 and both survive); 1 (class 1) is suppressed by 3 (class 1)
     k = fcos_ref.batched_nms(boxes, scores, torch.tensor([0, 1, 0, 1]), 0.3)
     assert k.tolist() == [0, 3, 2]
+
+
+def test_pose2mesh_oracle_reproduces_reference_golden(golden_dir):
+    """SURVEY 8f #4: FlatPose2Mesh (PoseNet MLP + Chebyshev graph-conv mesh net) restated vs the imported reference."""
+    from oracle import pose2mesh_ref
+    g = np.load(golden_dir / "pose2mesh_forward.npz")
+    graphs = pose2mesh_ref.load_graphs(g)
+    sd = synth.make_pose2mesh_state_dict(seed=int(g["weight_seed"]), graph_sizes=[m.shape[0] for m in graphs])
+    pose2d = torch.randn((3, 21, 2), generator=torch.Generator().manual_seed(int(g["input_seed"])))
+    mesh, pose3d = pose2mesh_ref.pose2mesh_forward(pose2d, sd, graphs)
+    assert mesh.shape == (3, graphs[0].shape[0], 3) and pose3d.shape == (3, 21, 3)
+    assert np.abs(pose3d.numpy() - g["pose3d"]).max() <= 1e-3          # values ~1e2 (millimetres)
+    assert np.abs(mesh.numpy() - g["mesh"]).max() <= 1e-4
