@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None, help="frames (or crops) per GPU; default 32 (a2j: 64)")
-    ap.add_argument("--workload", choices=["pipeline", "a2j", "fcos"], default="pipeline")
+    ap.add_argument("--workload", choices=["pipeline", "a2j", "fcos", "pose2mesh"], default="pipeline")
     ap.add_argument("--precision", choices=["f16x3", "f32"], default="f16x3",
                     help="f16x3: split-fp16 operands on the f16 MFMA (fp32-grade results); f32: exact f32 MFMA")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
@@ -65,7 +65,31 @@ def build_workload(args, dev, rank):
     from hn_amd.pipeline import HandNetEngine
 
     wl = args.workload
-    batch = args.batch or (64 if wl == "a2j" else 32 if wl == "pipeline" else 16)
+    batch = args.batch or (64 if wl == "a2j" else 32 if wl in ("pipeline", "pose2mesh") else 16)
+    if wl == "pose2mesh":   # the lifter that follows the path in the live demo
+        import numpy as np
+        import scipy.sparse as sp
+        from hn_amd.pose2mesh_engine import Pose2MeshEngine
+        g = np.load(REPO / "tests" / "golden" / "pose2mesh_forward.npz")   # graph hierarchy (data fixture)
+        graphs = [sp.csr_matrix((g[f"L{i}_data"], g[f"L{i}_indices"], g[f"L{i}_indptr"]),
+                                shape=tuple(int(v) for v in g[f"L{i}_shape"])) for i in range(int(g["num_levels"]))]
+        sd = synth.make_pose2mesh_state_dict(0, graph_sizes=[m.shape[0] for m in graphs])
+        eng = Pose2MeshEngine(sd, graphs, device=dev)
+        x = torch.randn((batch, 21, 2), generator=torch.Generator().manual_seed(5000 + rank)).to(dev)
+        macs = sum(int(v.numel()) for k, v in sd.items() if k.startswith("pose_lifter") and k.endswith("weight") and v.dim() == 2)
+        macs += int(sd["pose2mesh.fc.weight"].numel())
+        lv = [m.shape[0] for m in graphs]
+        del lv[-2]
+        from hn_amd.pose2mesh_engine import CL_F
+        idx = 0
+        for bi, chain in enumerate(CL_F):
+            v = lv[-(bi + 1) + (1 if bi == len(CL_F) - 1 else 0)]
+            for li in range(len(chain) - 1):
+                macs += v * int(sd[f"pose2mesh.cl.{idx}.weight"].numel())
+                idx += 1
+        info = {"batch_per_gpu": batch, "unit": "meshes/s", "gflop_per_unit": 2 * macs / 1e9,
+                "name": "Pose2Mesh lifter (PoseNet MLP + Chebyshev graph-conv mesh net), 21 joints -> 1152-vertex hierarchy"}
+        return (lambda: eng.forward(x)), info, None
     a2j_sd = synth.make_a2j_state_dict(0)
     fcos_sd = synth.make_fcos_state_dict(0, 3)
     info = {"batch_per_gpu": batch}
@@ -257,7 +281,7 @@ def main():
             "data": "synthetic (seeded uniform RGB in [0,1), depth 0.3-1.5 m; random-init weights of the "
                     "reference architectures, hn_amd.synth seed 0)",
             "config": {"workload": info["name"], "batch_per_gpu": batch, "global_batch": batch * world,
-                       "frame": "640x480 RGB-D" if args.workload != "a2j" else "176x176 depth crop",
+                       "frame": {"a2j": "176x176 depth crop", "pose2mesh": "21 x 2-D joints"}.get(args.workload, "640x480 RGB-D"),
                        "parallelism": f"frames sharded over {world} GPU(s), all-gather of per-frame results",
                        "gflop_per_unit": round(info["gflop_per_unit"], 3), "hipgraph": bool(args.graph)},
             "algorithmic_tflops": round(value * info["gflop_per_unit"] / 1e3, 2),

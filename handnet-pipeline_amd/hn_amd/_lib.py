@@ -11,7 +11,7 @@ from pathlib import Path
 
 from . import build as _build
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, TILE_256x128, TILE_64x128 = range(7)
 HN_FCOS_MAX_LEVELS = 5
@@ -63,6 +63,9 @@ SIGNATURES = {
     "hn_conv2d_nhwc_f16x3_gn": (C.c_int, [C.POINTER(ConvDesc)] + [VP] * 6),
     "hn_groupnorm_rows32_scratch_floats": (C.c_int64, [C.c_int64, C.c_int]),
     "hn_groupnorm_finalize_rows32": (C.c_int, [VP, VP, VP] + [C.c_int] * 4 + [C.c_float, VP, VP, VP]),
+    "hn_spmm_csr_f32": (C.c_int, [VP, VP, VP, C.c_int, VP, VP, C.c_int, C.c_int, VP]),
+    "hn_cheby3_basis_split": (C.c_int, [VP, VP, VP, C.c_int, VP, VP, VP, C.c_int, C.c_int, C.c_int, VP]),
+    "hn_feat_interp_add_f32": (C.c_int, [VP, VP, VP, C.c_int64, C.c_int, C.c_int, C.c_int, VP]),
     "hn_fcos_preprocess_split": (C.c_int, [VP, VP] + [C.c_int] * 8 + [c_f32p, c_f32p, VP]),
     "hn_conv_stem_f16x3": (C.c_int, [VP] + [C.c_int] * 7 + [VP, VP, C.c_int, VP, C.c_int, VP]),
     "hn_fcos_candidates": (C.c_int, [C.POINTER(FcosLevels), C.c_int, C.c_int, C.c_float,

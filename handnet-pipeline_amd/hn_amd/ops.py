@@ -584,3 +584,64 @@ class HipTimer:
             lib.hn_event_destroy(self._b)
         except Exception:
             pass
+
+
+# ---------------------------------------------------------------------------------------
+# Pose2Mesh lifter: Chebyshev graph convolution helpers (csrc/graph_ops.hip)
+# ---------------------------------------------------------------------------------------
+@dataclass
+class CsrGraph:
+    indptr: torch.Tensor   # int32 [V+1]
+    indices: torch.Tensor  # int32 [nnz], ascending per row
+    values: torch.Tensor   # fp32 [nnz]
+    v: int
+
+
+def csr_graph(L, device) -> CsrGraph:
+    """scipy sparse matrix (or anything with .tocsr()) / torch sparse tensor -> device CSR."""
+    if torch.is_tensor(L):
+        c = L.coalesce() if L.layout == torch.sparse_coo else L.to_sparse_coo().coalesce()
+        import scipy.sparse as sp
+        idx = c.indices().cpu().numpy()
+        L = sp.csr_matrix((c.values().cpu().numpy(), (idx[0], idx[1])), shape=tuple(c.shape))
+    m = L.tocsr().astype(np.float32)
+    m.sort_indices()
+    if m.shape[0] != m.shape[1]:
+        raise ValueError("graph Laplacian must be square")
+    return CsrGraph(torch.from_numpy(m.indptr.astype(np.int32)).to(device), torch.from_numpy(m.indices.astype(np.int32)).to(device),
+                    torch.from_numpy(m.data.astype(np.float32)).to(device), m.shape[0])
+
+
+def spmm_csr(g: CsrGraph, x):
+    """x fp32 [B,V,F] -> L x."""
+    _req(x, name="x")
+    b, v, f = x.shape
+    if v != g.v:
+        raise ValueError("vertex count mismatch")
+    y = torch.empty_like(x)
+    check(_lib.load().hn_spmm_csr_f32(ptr(g.indptr), ptr(g.indices), ptr(g.values), v, ptr(x), ptr(y), b, f, _stream()),
+          "hn_spmm_csr_f32")
+    return y
+
+
+def cheby3_basis_split(g: CsrGraph, x0, x1):
+    """x0, x1 = L x0 (fp32 [B,V,F]) -> S32 operand [B,V,1,Cpad/32,2,32] holding [x0 | x1 | 2 L x1 - x0 | 0]."""
+    _req(x0, name="x0"); _req(x1, name="x1")
+    b, v, f = x0.shape
+    cpad = (3 * f + 31) // 32 * 32
+    out = torch.empty((b, v, 1, cpad // 32, 2, 32), device=x0.device, dtype=torch.float16)
+    check(_lib.load().hn_cheby3_basis_split(ptr(g.indptr), ptr(g.indices), ptr(g.values), v, ptr(x0), ptr(x1), ptr(out),
+                                            b, f, cpad, _stream()), "hn_cheby3_basis_split")
+    return out
+
+
+def feat_interp_add(xin, y, up=1):
+    """y [B,V,Fo] + linear interpolation of xin [B,V,Fi] along the feature axis, rows repeated `up` times."""
+    _req(xin, name="xin"); _req(y, name="y")
+    b, v, fo = y.shape
+    if tuple(xin.shape[:2]) != (b, v):
+        raise ValueError("shape mismatch")
+    out = torch.empty((b, v * up, fo), device=y.device, dtype=torch.float32)
+    check(_lib.load().hn_feat_interp_add_f32(ptr(xin), ptr(y), ptr(out), b * v, xin.shape[2], fo, up, _stream()),
+          "hn_feat_interp_add_f32")
+    return out

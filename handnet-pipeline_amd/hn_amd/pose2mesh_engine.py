@@ -1,0 +1,147 @@
+"""Pose2Mesh lifter on MI355X: 2-D hand joints -> 3-D joints (MLP) -> mesh vertices (Chebyshev graph convs).
+
+Arithmetic follows pose2mesh/lib/models/pose2mesh_net.py:17-24, posenet.py:27-41,78-88 (eval) and
+meshnet.py:79-117 ('mano' configuration, K = 3) of the reference:
+  Linear / Linear+BatchNorm1d(+ReLU)      -> hn_conv2d_nhwc_f16x3_ws as a 1x1 convolution over [batch][vertex]
+                                             rows (split-fp16 operands, fp32-grade; BatchNorm folded in fp64;
+                                             long-k layers such as the 4096x4096 MLP run split-K)
+  pre-activation BatchNorm+ReLU (posenet) -> hn_affine_split_f32 (the same pass that feeds GroupNorm'd towers)
+  Chebyshev recursion x1 = L x0, x2 = 2 L x1 - x0 and the (fin, k) concat -> hn_spmm_csr_f32 +
+                                             hn_cheby3_basis_split, which writes the conv's S32 operand directly
+                                             (k-major channel order; the Linear's columns are permuted to match)
+  block residual (feature-axis linear interpolation + add) and nearest x2 vertex up-sampling
+                                          -> hn_feat_interp_add_f32
+Everything stays on the device.  Graph Laplacians are host-side preprocessing (graph_utils.build_coarse_graphs),
+passed in as scipy / torch sparse matrices, finest level first, joint graph last.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .weights import ConvW, split_f16x3
+
+CL_F = [(5, 32, 64, 64), (64, 128, 256), (256, 256, 256), (256, 256, 256), (256, 256, 256), (256, 128, 128),
+        (128, 64, 3)]   # meshnet.py:22-27
+CL_K = 3
+BN_EPS = 1e-5
+
+
+def _pad32(c):
+    return (c + 31) // 32 * 32
+
+
+def _dense(weight, bias, device, cin_pad=None) -> ConvW:
+    """[Fout, Fin] fp64 -> 1x1 conv weights with Cin padded to a multiple of 32."""
+    fout, fin = weight.shape
+    cpad = _pad32(fin) if cin_pad is None else cin_pad
+    w = torch.zeros((fout, 1, 1, cpad), dtype=torch.float32)
+    w[:, 0, 0, :fin] = weight.float()
+    return ConvW(w.contiguous(), None if bias is None else bias.float().contiguous(), 1, 0, 1, split_f16x3(w)).to(device)
+
+
+class Pose2MeshEngine:
+    def __init__(self, state_dict, graph_L, num_joint: int = 21, device="cuda"):
+        sd = {k: v.detach().double().cpu() for k, v in state_dict.items() if v.dtype.is_floating_point}
+        dev = torch.device(device)
+        self.device, self.num_joint = dev, num_joint
+        levels = [ops.csr_graph(L, dev) for L in graph_L]
+        del levels[-2]                                   # meshnet.py:37
+        self.graphs = levels
+        if levels[-1].v != num_joint:
+            raise ValueError("the last graph must be the joint graph")
+        p = "pose_lifter."
+        self.p_w1 = _dense(sd[p + "w1.weight"], sd[p + "w1.bias"], dev)
+        self.p_stages = []
+        for st in range(2):
+            q = f"{p}linear_stages.{st}."
+            self.p_stages.append({
+                "bn1": self._bn_table(sd, q + "batch_norm1", dev), "w1": _dense(sd[q + "w1.weight"], sd[q + "w1.bias"], dev),
+                "bn2": self._bn_table(sd, q + "batch_norm2", dev), "w2": _dense(sd[q + "w2.weight"], sd[q + "w2.bias"], dev)})
+        self.p_w2 = _dense(sd[p + "w2.weight"], sd[p + "w2.bias"], dev)
+        m = "pose2mesh."
+        self.fc = _dense(sd[m + "fc.weight"], sd[m + "fc.bias"], dev)
+        self.cl = []
+        idx = 0
+        for bi, chain in enumerate(CL_F):
+            for li in range(len(chain) - 1):
+                fin, fout = chain[li], chain[li + 1]
+                fin_pad = (fin + 3) // 4 * 4 if fin % 4 else fin
+                fin_pad = max(fin_pad, 8) if fin % 4 else fin_pad
+                w = sd[f"{m}cl.{idx}.weight"].view(fout, fin, CL_K)          # reference column order (fin, k)
+                b = sd[f"{m}cl.{idx}.bias"]
+                last = bi == len(CL_F) - 1 and li == len(chain) - 2
+                if not last:                                                  # fold BatchNorm1d (eval)
+                    s = sd[f"{m}bn.{idx}.weight"] / torch.sqrt(sd[f"{m}bn.{idx}.running_var"] + BN_EPS)
+                    w = w * s.view(-1, 1, 1)
+                    b = (b - sd[f"{m}bn.{idx}.running_mean"]) * s + sd[f"{m}bn.{idx}.bias"]
+                wk = torch.zeros((fout, CL_K, fin_pad), dtype=torch.float64)  # k-major, features zero-padded
+                wk[:, :, :fin] = w.permute(0, 2, 1)
+                self.cl.append((_dense(wk.reshape(fout, CL_K * fin_pad), b, dev), fin_pad, not last))
+                idx += 1
+
+    @staticmethod
+    def _bn_table(sd, name, dev):
+        s = sd[name + ".weight"] / torch.sqrt(sd[name + ".running_var"] + BN_EPS)
+        t = sd[name + ".bias"] - sd[name + ".running_mean"] * s
+        return s.float().to(dev), t.float().to(dev)
+
+    # -----------------------------------------------------------------------------------
+    def _linear(self, x, cw: ConvW, relu=False, residual=None):
+        """x: S32 [B,1,1,...] or fp32 [B,1,1,C] -> fp32 [B,1,1,Fout]"""
+        return ops.conv2d_nhwc(x, cw.w, cw.bias, relu=relu, residual=residual, w16=cw.w16)
+
+    def posenet(self, x2d):
+        """[B, 2J] fp32 -> [B, 3J] (LinearModel.forward, eval)"""
+        b = x2d.shape[0]
+        xin = torch.zeros((b, 1, 1, self.p_w1.cin), device=self.device, dtype=torch.float32)
+        xin[:, 0, 0, : x2d.shape[1]] = x2d
+        y = self._linear(xin, self.p_w1)
+        for st in self.p_stages:
+            s1, t1 = (t.expand(b, -1).contiguous() for t in st["bn1"])
+            z = self._linear(ops.to_split(y, s1, t1, relu=True), st["w1"])
+            s2, t2 = (t.expand(b, -1).contiguous() for t in st["bn2"])
+            y = self._linear(ops.to_split(z, s2, t2, relu=True), st["w2"], residual=y)
+        return self._linear(y, self.p_w2).reshape(b, -1)
+
+    def _graph_conv(self, x, layer, g):
+        cw, fin_pad, relu = layer
+        b, v, f = x.shape
+        if f != fin_pad:
+            xp = torch.zeros((b, v, fin_pad), device=self.device, dtype=torch.float32)
+            xp[..., :f] = x
+            x = xp
+        x = x.contiguous()
+        basis = ops.cheby3_basis_split(g, x, ops.spmm_csr(g, x))
+        return ops.conv2d_nhwc(basis, cw.w, cw.bias, relu=relu, w16=cw.w16).view(b, v, -1)
+
+    def meshnet(self, x):
+        """[B, J, 5] -> [B, V0, 3] (Pose2Mesh.forward)"""
+        b = x.shape[0]
+        nblk = len(CL_F)
+        li = 0
+        for i in range(nblk):
+            xin = x
+            g = self.graphs[-(i + 1) + (1 if i == nblk - 1 else 0)]
+            for _ in range(len(CL_F[i]) - 1):
+                x = self._graph_conv(x, self.cl[li], g)
+                li += 1
+            if i == 0:
+                x = self._linear(x.reshape(b, 1, 1, -1), self.fc).view(b, self.graphs[-2].v, CL_F[1][0])
+            elif i < nblk - 2:
+                x = ops.feat_interp_add(xin.contiguous(), x.contiguous(), up=2)
+            elif i == nblk - 2:
+                x = ops.feat_interp_add(xin.contiguous(), x.contiguous(), up=1)
+        return x
+
+    def forward(self, pose2d):
+        """pose2d [B,J,2] fp32 on the GPU -> (cam_mesh [B,V0,3], pose3d [B,J,3]), both on the GPU."""
+        if pose2d.dim() != 3 or pose2d.shape[1:] != (self.num_joint, 2):
+            raise ValueError(f"expected [B,{self.num_joint},2]")
+        if not pose2d.is_cuda:
+            raise RuntimeError("Pose2MeshEngine needs GPU tensors (no CPU fallback)")
+        pose2d = pose2d.float().contiguous()
+        b = pose2d.shape[0]
+        pose3d = self.posenet(pose2d.reshape(b, -1)).reshape(b, self.num_joint, 3)
+        comb = torch.cat((pose2d, pose3d / 1000), dim=2)          # pose2mesh_net.py:20 (glue, 105 floats per sample)
+        return self.meshnet(comb), pose3d

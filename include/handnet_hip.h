@@ -33,7 +33,7 @@ extern "C" {
 #define HN_ERR_HIP 2
 
 /* ABI version; bumped whenever a struct below changes. */
-#define HN_ABI_VERSION 14
+#define HN_ABI_VERSION 15
 int hn_abi_version(void);
 const char* hn_last_error(void);
 
@@ -275,6 +275,28 @@ int hn_a2j_aggregate_f32(const float* cls, const float* reg, const float* dep,
 int hn_convert_joints_f32(const float* kp, const int64_t* crop_box, const int32_t* valid,
                           int n, int joints, float crop_w, float crop_h,
                           const float* paras /* host, 4 floats, or NULL */, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Pose2Mesh lifter: Chebyshev graph convolution helpers.  Replaces
+ * pose2mesh/lib/models/backbones/cheby_graph_conv.py:5-42 (torch.sparse.mm recursion + concat / permute)
+ * and the block residual of meshnet.py:105-113; the Linear + BatchNorm1d + ReLU of a graph conv run on
+ * hn_conv2d_nhwc_f16x3_ws as a 1x1 convolution over [batch][vertex] rows (BatchNorm folded into the weights).
+ * L is a CSR matrix (int32 indptr [v+1], indices, fp32 values; indices ascending per row); activations are
+ * fp32 [batch][v][f], f % 4 == 0.
+ *   hn_spmm_csr_f32        y = L x
+ *   hn_cheby3_basis_split  x2 = 2 L x1 - x0; out16 = S32 rows [x0 | x1 | x2 | 0-pad] of cpad channels
+ *                          (order k-major: channel k*f + i; the reference's (i, k) order is absorbed by
+ *                          permuting the Linear's columns at load time, hn_amd/pose2mesh_engine.py)
+ *   hn_feat_interp_add_f32 out[r*up + u][:] = y[r][:] + interp_linear(xin[r][:], fi -> fo), u < up
+ *                          (F.interpolate(mode='linear') along the feature axis + nn.Upsample(2) on vertices)
+ * ------------------------------------------------------------------------------------ */
+int hn_spmm_csr_f32(const int32_t* indptr, const int32_t* indices, const float* values, int v,
+                    const float* x, float* y, int batch, int f, void* stream);
+int hn_cheby3_basis_split(const int32_t* indptr, const int32_t* indices, const float* values, int v,
+                          const float* x0, const float* x1, void* out16, int batch, int f, int cpad,
+                          void* stream);
+int hn_feat_interp_add_f32(const float* xin, const float* y, float* out, int64_t rows, int fi, int fo,
+                           int up, void* stream);
 
 #ifdef __cplusplus
 }
