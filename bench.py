@@ -89,6 +89,13 @@ def build_workload(args, dev, rank):
                 idx += 1
         info = {"batch_per_gpu": batch, "unit": "meshes/s", "gflop_per_unit": 2 * macs / 1e9,
                 "name": "Pose2Mesh lifter (PoseNet MLP + Chebyshev graph-conv mesh net), 21 joints -> 1152-vertex hierarchy"}
+        if args.graph:
+            run, _, out = eng.graphed(x)
+
+            def step():
+                run()
+                return out
+            return step, info, None
         return (lambda: eng.forward(x)), info, None
     a2j_sd = synth.make_a2j_state_dict(0)
     fcos_sd = synth.make_fcos_state_dict(0, 3)

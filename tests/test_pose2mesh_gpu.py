@@ -73,3 +73,11 @@ def test_pose2mesh_dropin_matches_reference_golden(p2m):
     assert mesh[:, rev, :].shape == (3, 778, 3)
     with pytest.raises(RuntimeError):
         model.engine().forward(pose2d)          # CPU tensor: no fallback
+    # hipGraph replay of the launch-bound forward reproduces the eager result, also for new inputs
+    run, s_in, (g_mesh, g_pose) = model.engine().graphed(pose2d.cuda())
+    other = torch.randn((3, 21, 2), generator=torch.Generator().manual_seed(9)).cuda()
+    s_in.copy_(other)
+    run()
+    e_mesh, e_pose = model.engine().forward(other)
+    torch.cuda.synchronize()
+    assert torch.equal(g_mesh, e_mesh) and torch.equal(g_pose, e_pose)
