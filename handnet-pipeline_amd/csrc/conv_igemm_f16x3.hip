@@ -74,7 +74,7 @@ struct ConvParams16 {
   float* gn_partial;  // optional GroupNorm partial sums [ceil(M/32)][Cout/8][4] (see hn_conv2d_nhwc_f16x3_gn)
   // split-K (small-M layers): gridDim.y workgroups share an output tile, each sums kt_per k tiles into
   // split_ws[z][M][Cout] (fp32, no epilogue); splitk_reduce_kernel adds them in z order and finishes
-  int splits, kt_per;
+  int splits, kt_per, splitk_mode;
   float* split_ws;
   int64_t split_ws_bytes;
   int tiles_m, tiles_n, nblocks;
@@ -614,13 +614,16 @@ int launch16(const ConvParams16& p0, hipStream_t st) {
   p.nblocks = p.tiles_m * p.tiles_n;
   // Split-K for grids that leave most of the chip idle AND have a long serial k loop (~0.33 us per 32-deep
   // tile): e.g. the 2048->512 3x3 A2J layer at batch 1 is 8 workgroups x 576 tiles = 190 us.  Up to 16
-  // workgroups then share an output tile, each keeping >= 16 tiles.  Shorter loops stay single-pass: the
-  // second launch costs more than it saves (measured in-pipeline, tools/probes/exp/splitk.sh).
+  // workgroups then share an output tile, each keeping >= 16 tiles.  Shorter loops stay single-pass unless
+  // the caller says launches are free (desc.splitk = 1, graph replay): in eager mode the second launch
+  // costs more than it saves (measured in-pipeline, tools/probes/exp/splitk.sh).
   p.splits = 1;
   p.kt_per = p.ktiles;
-  if (p.split_ws && p.vec_epi && !p.gn_partial && p.nblocks < 256 && p.ktiles >= 128) {
+  const int min_tiles = p.splitk_mode > 0 ? 8 : 128;  // hn_conv_desc.splitk
+  const int min_per = p.splitk_mode > 0 ? 4 : 16;
+  if (p.split_ws && p.splitk_mode >= 0 && p.vec_epi && !p.gn_partial && p.nblocks < 256 && p.ktiles >= min_tiles) {
     int want = hn::cdiv(512, p.nblocks);
-    want = want < p.ktiles / 16 ? want : p.ktiles / 16;
+    want = want < p.ktiles / min_per ? want : p.ktiles / min_per;
     want = want < 16 ? want : 16;
     const int64_t plane_bytes = (int64_t)p.M * p.Cout * 4;
     if ((int64_t)want * plane_bytes > p.split_ws_bytes) want = (int)(p.split_ws_bytes / plane_bytes);
@@ -732,6 +735,7 @@ static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, c
   p.gn_partial = gn_partial;
   p.split_ws = (float*)workspace;
   p.split_ws_bytes = workspace ? workspace_bytes : 0;
+  p.splitk_mode = d->splitk;
   p.splits = 1;
   p.kt_per = p.ktiles;
   if (gn_partial) {
@@ -784,7 +788,7 @@ extern "C" int hn_conv_stem_f16x3(const void* x16, int n, int ph, int pw, int pa
   p.out_split = out_split; p.res_split = 0;
   p.xs = 4; p.pitch = wb; p.lo_off = (long)n * hb * wb * 4;
   p.gn_partial = nullptr;
-  p.split_ws = nullptr; p.split_ws_bytes = 0; p.splits = 1; p.kt_per = p.ktiles;
+  p.split_ws = nullptr; p.split_ws_bytes = 0; p.splits = 1; p.kt_per = p.ktiles; p.splitk_mode = -1;
   p.ys = (out_split ? 2 : 1) * cout;
   p.rs = 0;
   p.vec_epi = (cout % 8 == 0) && ((uintptr_t)y % 16 == 0) && (bias == nullptr || (uintptr_t)bias % 16 == 0);

@@ -11,7 +11,7 @@ from pathlib import Path
 
 from . import build as _build
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, TILE_256x128, TILE_64x128 = range(7)
 HN_FCOS_MAX_LEVELS = 5
@@ -25,7 +25,7 @@ class ConvDesc(C.Structure):
     _fields_ = [(k, C.c_int32) for k in (
         "n", "h", "w", "cin", "cout", "r", "s", "stride", "pad", "dil", "oh", "ow",
         "relu_cols", "res_mode", "res_h", "res_w", "in_affine", "tile", "out_split", "res_split",
-        "res_pix_stride", "in_pix_stride", "out_pix_stride", "in_affine_stride")]
+        "res_pix_stride", "in_pix_stride", "out_pix_stride", "in_affine_stride", "splitk")]
 
 
 class FcosLevels(C.Structure):

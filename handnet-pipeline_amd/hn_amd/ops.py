@@ -69,7 +69,7 @@ def make_conv_desc(n, h, w, cin, cout, r, s, stride=1, pad=0, dil=1, relu_cols=0
     return ConvDesc(n=n, h=h, w=w, cin=cin, cout=cout, r=r, s=s, stride=stride, pad=pad, dil=dil,
                     oh=oh, ow=ow, relu_cols=relu_cols, res_mode=res_mode, res_h=res_h, res_w=res_w,
                     in_affine=in_affine, tile=tile, out_split=0, res_split=0, res_pix_stride=0,
-                    in_pix_stride=in_pix_stride, out_pix_stride=out_pix_stride, in_affine_stride=0)
+                    in_pix_stride=in_pix_stride, out_pix_stride=out_pix_stride, in_affine_stride=0, splitk=0)
 
 
 def to_split(x, scale=None, shift=None, relu=False, out=None):
@@ -121,6 +121,20 @@ TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x64", 4: "128x32", 5: "256x128", 
 # launches, and launches on one stream are ordered
 CONV_WORKSPACE_BYTES = 32 << 20
 SPLITK = os.environ.get("HN_SPLITK", "1") != "0"  # development switch (tools/probes/exp/splitk.sh)
+SPLITK_EAGER = False  # set by launch_cost_hidden(): split short k loops too (pays when launches are free)
+
+
+class launch_cost_hidden:
+    """Context for code whose launches will be replayed from a hipGraph: small grids then use split-K even for
+    short k loops (batch 1: 270 -> 298 frames/s under replay; in eager mode the extra launches cost more)."""
+
+    def __enter__(self):
+        global SPLITK_EAGER
+        self._old, SPLITK_EAGER = SPLITK_EAGER, True
+
+    def __exit__(self, *a):
+        global SPLITK_EAGER
+        SPLITK_EAGER = self._old
 _WORKSPACES = {}
 
 
@@ -229,6 +243,7 @@ def conv2d_nhwc(x, w, bias=None, *, stride=1, pad=0, dil=1, relu=False, relu_col
                                               _stream()), "hn_conv2d_nhwc_f16x3_gn")
         else:
             splitk = splitk and SPLITK
+            d.splitk = (1 if SPLITK_EAGER else 0) if splitk else -1
             ws = _conv_workspace(x.device) if splitk else None
             check(lib.hn_conv2d_nhwc_f16x3_ws(C.byref(d), ptr(x), ptr(w16), ptr(bias), ptr(residual), ptr(out),
                                               ptr(ws), ws.numel() * 4 if splitk else 0, _stream()),

@@ -66,12 +66,13 @@ class HandNetEngine:
         s_dep.copy_(depth)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):  # warm-up (allocator, lazy module load) outside capture
-                self.forward_device(s_img, s_dep)
-        torch.cuda.current_stream().wait_stream(side)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            out = self.forward_device(s_img, s_dep)
+        with ops.launch_cost_hidden():
+            with torch.cuda.stream(side):
+                for _ in range(2):  # warm-up (allocator, lazy module load) outside capture
+                    self.forward_device(s_img, s_dep)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self.forward_device(s_img, s_dep)
         self._graphs[key] = (g, s_img, s_dep, out)
         return g.replay, s_img, s_dep, out

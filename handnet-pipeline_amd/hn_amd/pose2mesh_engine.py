@@ -140,7 +140,7 @@ class Pose2MeshEngine:
         returns (run, static_input, (mesh, pose3d)); copy new joints into static_input and call run()."""
         key = tuple(pose2d.shape)
         if key not in self._graphs:
-            with torch.inference_mode(False), torch.no_grad():
+            with torch.inference_mode(False), torch.no_grad(), ops.launch_cost_hidden():
                 s_in = torch.empty_like(pose2d, dtype=torch.float32)
                 s_in.copy_(pose2d)
                 side = torch.cuda.Stream()

@@ -33,7 +33,7 @@ extern "C" {
 #define HN_ERR_HIP 2
 
 /* ABI version; bumped whenever a struct below changes. */
-#define HN_ABI_VERSION 15
+#define HN_ABI_VERSION 16
 int hn_abi_version(void);
 const char* hn_last_error(void);
 
@@ -76,6 +76,9 @@ typedef struct hn_conv_desc {
                                  (2 x parent channels)                                     */
   int32_t out_pix_stride;    /* elements between consecutive output pixels; 0 = dense    */
   int32_t in_affine_stride;  /* floats between rows of in_scale / in_shift; 0 = cin     */
+  int32_t splitk;            /* f16x3 + workspace: 0 = split-K only for long k loops (an extra launch
+                              * per conv costs eager callers more than it saves), 1 = also for short
+                              * ones (launch cost hidden, e.g. under hipGraph replay), -1 = never */
 } hn_conv_desc;
 
 #define HN_TILE_AUTO 0

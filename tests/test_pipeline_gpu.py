@@ -129,7 +129,8 @@ def test_pipeline_batch_consistency_and_graph(handnet):
     run()
     torch.cuda.synchronize()
     assert torch.equal(out.crop_box, full.crop_box)
-    assert (out.keypoints - full.keypoints).abs().max().item() < 1e-5
+    # graph capture also splits short k loops (launches are free there): same values to fp32 rounding, not bitwise
+    assert (out.keypoints - full.keypoints).abs().max().item() < 3e-4   # ~1e-6 relative on pixel coordinates ~1e2
 
 
 def test_rgbd_crop_reorders_channels():
@@ -191,7 +192,7 @@ def test_handnet_graph_mode_equals_eager(handnet):
     handnet.enable_graph(False)
     for seed in (41, 42):
         for a, b in zip(outs[(False, seed)], outs[(True, seed)]):
-            assert a.shape == b.shape and (a.float() - b.float()).abs().max().item() < 1e-5
+            assert a.shape == b.shape and (a.float() - b.float()).abs().max().item() < 3e-4
     assert not torch.equal(outs[(True, 41)][0], outs[(True, 42)][0])
 
 
