@@ -654,14 +654,19 @@ int64_t nblocks16(const hn_conv_desc* d, int bm, int bn) {
 extern "C" int hn_conv2d_f16x3_pick_tile(const hn_conv_desc* d) {
   if (!d) return HN_TILE_64x64;
   if (d->tile != HN_TILE_AUTO) return d->tile;
-  if (d->cout <= 32) return HN_TILE_128x32;
-  // measured (tools/perf_conv.py tile sweep): the largest tile wins as soon as it yields one
-  // workgroup per CU; below that the small-M A2J layers prefer more, smaller workgroups
+  // From tools/tile_sweep.py (every distinct conv shape of the pipeline, batch 1 and 32, clocks kept hot):
+  // within 0.3 % (batch 32) / 2 % (batch 1) of the best tile per shape.
+  if (d->cout <= 32) return nblocks16(d, 128, 32) < 64 ? HN_TILE_32x64 : HN_TILE_128x32;
   const int64_t want = 256;
+  // the largest tile wins as soon as it yields one workgroup per CU
   if (d->cout > 64 && nblocks16(d, 128, 128) >= want) return HN_TILE_128x128;
   // Cout <= 64 with many rows: four waves stacked along M keep the 64x64 wave tile of the big kernel (+3 %)
   if (d->cout <= 64 && nblocks16(d, 256, 64) >= 2 * want) return HN_TILE_256x64;
+  // mid-size grids: 128 columns per workgroup when there are that many (fewer weight re-reads), else 128 rows
+  if (d->cout >= 128 && nblocks16(d, 64, 128) >= 192) return HN_TILE_64x128;
   if (nblocks16(d, 128, 64) >= want) return HN_TILE_128x64;
+  // tiny grids (11x11 maps, batch 1): 2-wave workgroups double the number of CUs that have work
+  if (nblocks16(d, 64, 64) < 128) return HN_TILE_32x64;
   return HN_TILE_64x64;
 }
 

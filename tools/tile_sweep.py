@@ -32,6 +32,18 @@ for kind, macs, timer, shape in recs:
 del eng, fcos, a2j
 torch.cuda.empty_cache()
 TILES = [1, 2, 3, 4, 6, 7, 8]
+# small kernels in isolation leave the GPU in a low DPM state and time 2-3x slow: keep the clocks up with a
+# heavy convolution right before every timed loop
+_hx = ops.to_split(torch.randn((8, 100, 136, 256), generator=torch.Generator().manual_seed(1)).cuda())
+_hw = torch.randn((256, 3, 3, 256), generator=torch.Generator().manual_seed(2)) * 0.02
+_hw16 = split_f16x3(_hw).cuda()
+_hw = _hw.cuda()
+
+
+def heat():
+    for _ in range(12):
+        ops.conv2d_nhwc(_hx, _hw, None, pad=1, w16=_hw16, out_split=True)
+
 print(f"# batch {batch}: {len(shapes)} distinct shapes; us per launch by tile {[ops.TILE_NAMES[t] for t in TILES]}")
 tot_now = tot_best = 0.0
 for shape, (picked, calls) in sorted(shapes.items(), key=lambda kv: kv[0]):
@@ -53,8 +65,9 @@ for shape, (picked, calls) in sorted(shapes.items(), key=lambda kv: kv[0]):
         kw = dict(stride=stride, pad=pad, dil=dil, relu=True, tile=t, w16=w16, out_split=osplit)
         y = ops.conv2d_nhwc(x, wt, b, **kw)
         kw["out"] = y
-        for _ in range(5):
+        for _ in range(3):
             ops.conv2d_nhwc(x, wt, b, **kw)
+        heat()
         tm = ops.HipTimer()
         tm.start()
         for _ in range(iters):
