@@ -333,3 +333,33 @@ def test_conv_f16x3_splitk_matches_plain_and_reference(case):
     assert float((f(y_split).cpu() - ref).abs().max()) <= 2e-5 * scale
     assert float((f(y_plain).cpu() - ref).abs().max()) <= 2e-5 * scale
     assert not torch.equal(y_split, y_plain)   # the split path really ran (different summation order)
+
+
+def test_conv_f16x3_random_shapes_auto_tile():
+    """Seeded sweep over ragged shapes through the AUTO tile / split-K heuristics (whatever they pick must be right):
+    odd spatial sizes, Cout not a multiple of any tile, strides, dilation, 1x1 and 3x3, S32 and fp32 outputs."""
+    import random
+    from hn_amd import ops
+    from hn_amd.weights import split_f16x3
+    from oracle import ops_ref
+    rnd = random.Random(1234)
+    for case in range(24):
+        n, h, w = rnd.randint(1, 3), rnd.randint(1, 40), rnd.randint(1, 40)
+        cin = rnd.choice([32, 64, 96, 160, 512])
+        cout = rnd.choice([8, 24, 40, 64, 72, 136, 256, 5, 3])
+        r = rnd.choice([1, 3])
+        stride, dil = rnd.choice([1, 1, 2]), rnd.choice([1, 1, 2])
+        pad = dil * (r // 2)
+        if (h + 2 * pad - dil * (r - 1) - 1) < 0 or (w + 2 * pad - dil * (r - 1) - 1) < 0:
+            continue
+        x = _rand((n, h, w, cin), 100 + case)
+        wt = _rand((cout, r, r, cin), 200 + case, scale=(2.0 / (cin * r * r)) ** 0.5)
+        b = _rand((cout,), 300 + case, 0.1)
+        osplit = cout % 32 == 0 and rnd.random() < 0.5
+        ref = ops_ref.conv2d_nhwc(x.double(), wt.double(), b.double(), stride, pad, dil, relu_cols=cout).float()
+        y = ops.conv2d_nhwc(ops.to_split(x.cuda()), wt.cuda(), b.cuda(), stride=stride, pad=pad, dil=dil, relu=True,
+                            w16=split_f16x3(wt).cuda(), out_split=osplit)
+        y = ops.from_split(y) if osplit else y
+        scale = max(1.0, float(ref.abs().max()))
+        err = float((y.cpu() - ref).abs().max())
+        assert y.shape == ref.shape and err <= 2e-5 * scale, (case, (n, h, w, cin, cout, r, stride, dil), err)
