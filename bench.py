@@ -27,6 +27,9 @@ import sys
 import time
 from pathlib import Path
 
+# the host driver only supports dmabuf IPC: without this RCCL fails with hipIpcGetMemHandle: invalid argument
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO / "handnet-pipeline_amd"))
 sys.path.insert(0, str(REPO))
