@@ -86,7 +86,7 @@ typedef struct hn_conv_desc {
 #define HN_TILE_128x64 2
 #define HN_TILE_64x64 3
 #define HN_TILE_128x32 4
-#define HN_TILE_256x128 5   /* f16x3: 4 waves with 128x64 wave tiles (f32 kernel: 8 waves); slower than 2 x 128x128 per CU, kept for sweeps */
+#define HN_TILE_256x128 5   /* f16x3 only: 4 waves with 128x64 wave tiles; slower than two 128x128 workgroups per CU, kept for sweeps */
 #define HN_TILE_64x128 6
 #define HN_TILE_32x64 7   /* f16x3 only: 2-wave workgroups for small-M layers */
 #define HN_TILE_256x64 8  /* f16x3 only: Cout <= 64 layers with 64x64 wave tiles (4 waves stacked along M) */
