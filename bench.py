@@ -121,7 +121,7 @@ def build_workload(args, dev, rank):
     depth = synth.make_depth(batch, seed=2000 + rank).to(dev)
     eng = HandNetEngine(fcos, a2j, 3)
     info.update(unit="frames/s", gflop_per_unit=2 * (fcos.macs_per_frame() + a2j.macs_per_crop()) / 1e9,
-                name="Full HandNet pipeline (FCOS -> crop -> A2J), 640x480 RGB-D (BASELINE config 4)")
+                name="Full HandNet pipeline (FCOS -> crop -> A2J), 640x480 RGB-D (BASELINE config 4)", engine=eng)
     if args.graph:
         run, _, _, out = eng.graphed(rgb, depth)
 
@@ -193,8 +193,9 @@ def measured_traffic(prec, tile):
     return None
 
 
-def cpu_baseline(args, sds):
-    """Oracle (CPU restatement of the reference path) on a bounded sample, all host cores."""
+def cpu_baseline(args, sds, engine=None, dev=None):
+    """Oracle (CPU restatement of the reference path) on a bounded sample, all host cores.  For the pipeline the
+    same frames also go through the HIP engine, and the difference is reported next to the timing ("parity")."""
     from hn_amd import synth
     from oracle import a2j_ref, handnet_ref
     # one GPU's share of the host is 16 cores on the benchmark boxes; more threads than that
@@ -221,10 +222,25 @@ def cpu_baseline(args, sds):
     t0 = time.time()
     reps = 2
     for _ in range(reps):
-        handnet_ref.handnet_forward(imgs, depth, fcos_sd, a2j_sd, 3)
+        kp_ref, _, crops_ref = handnet_ref.handnet_forward(imgs, depth, fcos_sd, a2j_sd, 3)
     dt = time.time() - t0
-    return {"value": round(n * reps / dt, 3), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"{reps} x batch-{n} full-pipeline oracle forward (torch CPU fp32, FCOS+crop+A2J)"}
+    res = {"value": round(n * reps / dt, 3), "unit": "frames/s", "cores": threads, "kind": "port",
+           "sample": f"{reps} x batch-{n} full-pipeline oracle forward (torch CPU fp32, FCOS+crop+A2J)"}
+    if engine is not None:
+        from hn_amd import ops
+        out = engine.forward_device(rgb.to(dev), depth.to(dev))
+        has = out.has_hand.bool().cpu()
+        kp = out.keypoints.cpu()
+        same_box = bool(has.all()) and crops_ref.shape[0] == n and torch.equal(out.crop_box.cpu(), crops_ref)
+        paras = (617.343, 617.343, 312.42, 241.42)   # SURVEY 8d intrinsics for the millimetre figure
+        par = {"frames": n, "crop_boxes_identical": same_box,
+               "max_abs_keypoint_diff": float((kp - kp_ref).abs().max()), "tolerance": 1e-3}
+        if same_box:
+            xyz = ops.convert_joints(out.keypoints, out.crop_box, out.has_hand, paras).cpu()
+            xyz_ref = ops.convert_joints(kp_ref.to(dev), crops_ref.to(dev), out.has_hand, paras).cpu()
+            par["mm_epe"] = float((xyz - xyz_ref).norm(dim=-1).mean())
+        res["parity"] = par
+    return res
 
 
 def main():
@@ -276,7 +292,7 @@ def main():
         roof = roofline_leg(step, max(1, min(args.steps, 3)))
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args, sds)
+        cpu = cpu_baseline(args, sds, info.get("engine"), dev)
 
     if rank == 0:
         units = world * batch * args.steps
