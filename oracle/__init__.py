@@ -18,5 +18,8 @@ Pinning status
     /root/reference and from this image, the reference holds no tests or fixtures for
     them => PARITY UNPINNED for those functions; they are restated from the published
     torchvision-0.11.3 algorithm and anchored on the reference call sites
-    (fcos_utils/fcos.py:476,505,635,709,737).
+    (fcos_utils/fcos.py:476,505,635,709,737).  Partial pin: stem + layer1-3 of the trunk reproduce the
+    reference's in-tree a2j/resnet.py ResNet(BasicBlock) (tests/golden/resnet34_intree.npz).
+  * Pose2Mesh lifter (pose2mesh_ref.py): arithmetic pinned (tests/golden/pose2mesh_forward.npz, reference
+    modules imported) on a synthetic mesh hierarchy -- the MANO files the real graphs derive from are absent.
 """

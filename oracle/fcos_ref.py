@@ -94,17 +94,23 @@ def _basic_block(x, sd, p, stride):
 _R34 = [(64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)]
 
 
-def backbone(x, sd):
-    """[N,3,PH,PW] -> OrderedDict('0','1','2','pool') of 256-channel maps (strides 8,16,32,64)."""
-    p = "backbone.body."
+def body(x, sd, p="backbone.body."):
+    """ResNet-34 trunk -> [C2, C3, C4, C5] (strides 4, 8, 16, 32).  Stem and layer1-3 are cross-checked against the
+    reference's in-tree a2j/resnet.py ResNet(BasicBlock) (tests/golden/resnet34_intree.npz); layer4's stride-2
+    first block is torchvision's (the in-tree class uses stride 1 + dilation there)."""
     x = F.relu(_frozen_bn(F.conv2d(x, sd[p + "conv1.weight"], stride=2, padding=3), sd, p + "bn1"))
     x = F.max_pool2d(x, 3, 2, 1)
     cs = []
     for li, (planes, blocks, stride) in enumerate(_R34, start=1):
         for b in range(blocks):
             x = _basic_block(x, sd, f"{p}layer{li}.{b}.", stride if b == 0 else 1)
-        if li >= 2:
-            cs.append(x)
+        cs.append(x)
+    return cs
+
+
+def backbone(x, sd):
+    """[N,3,PH,PW] -> OrderedDict('0','1','2','pool') of 256-channel maps (strides 8,16,32,64)."""
+    cs = body(x, sd)[1:]
     f = "backbone.fpn."
 
     def inner(i, t):

@@ -107,6 +107,29 @@ def gen_a2j_rgbd():
     print("a2j_rgbd_forward.npz: keypoints[0,:3] =", out[0, :3].tolist())
 
 
+def gen_resnet34_intree():
+    """Partial pin of the (otherwise torchvision-defined, unpinned) ResNet-34 trunk: the reference's in-tree
+    a2j/resnet.py ResNet(BasicBlock, [3,4,6,3]) has the same stem and layer1-3 wiring (its layer4 differs: stride 1 +
+    dilation, resnet.py:112), so its C2/C3/C4 on the synthetic FCOS trunk weights are a golden for oracle.fcos_ref.body."""
+    install_a2j_shim()
+    import a2j.resnet as R
+    net = R.ResNet(R.BasicBlock, [3, 4, 6, 3]).eval()
+    fsd = synth.make_fcos_state_dict(seed=0, num_classes=3)
+    sd = {k[len("backbone.body."):]: v for k, v in fsd.items() if k.startswith("backbone.body.")}
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(k.startswith("fc.") or k.endswith("num_batches_tracked") for k in missing), missing
+    x = torch.randn((1, 3, 96, 128), generator=torch.Generator().manual_seed(6000))
+    with torch.inference_mode():
+        t = net.maxpool(net.relu(net.bn1(net.conv1(x))))
+        c2 = net.layer1(t)
+        c3 = net.layer2(c2)
+        c4 = net.layer3(c3)
+    np.savez_compressed(HERE / "resnet34_intree.npz", input_seed=np.int64(6000), c2=c2[:, ::8].numpy(),
+                        c3=c3[:, ::16].numpy(), c4=c4[:, ::32].numpy())
+    print("resnet34_intree.npz:", tuple(c2.shape), tuple(c3.shape), tuple(c4.shape))
+
+
 def gen_anchor():
     """Stand-alone post_process golden (a2j/anchor.py:57-82) incl. a spiked (peaked-softmax) case."""
     install_a2j_shim()
@@ -124,11 +147,13 @@ def gen_anchor():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["a2j", "a2j_rgbd", "anchor", "fcos", "fcos_ext", "handnet", "handnet_rgbd"]
+    what = sys.argv[1:] or ["a2j", "a2j_rgbd", "resnet34", "anchor", "fcos", "fcos_ext", "handnet", "handnet_rgbd"]
     if "a2j" in what:
         gen_a2j()
     if "a2j_rgbd" in what:
         gen_a2j_rgbd()
+    if "resnet34" in what:
+        gen_resnet34_intree()
     if "anchor" in what:
         gen_anchor()
     if {"fcos", "fcos_ext", "handnet", "handnet_rgbd"} & set(what):

@@ -95,6 +95,16 @@ def test_fcos_ext_oracle_reproduces_reference_golden(golden_dir):
     assert np.abs(d["scores"].numpy() - g["scores"]).max() <= 1e-6
 
 
+def test_resnet34_trunk_matches_intree_basicblock_resnet(golden_dir, fcos_sd):
+    """Stem + layer1-3 of the restated torchvision ResNet-34 trunk vs the reference's in-tree ResNet(BasicBlock)."""
+    g = np.load(golden_dir / "resnet34_intree.npz")
+    x = torch.randn((1, 3, 96, 128), generator=torch.Generator().manual_seed(int(g["input_seed"])))
+    c2, c3, c4, _ = fcos_ref.body(x, fcos_sd)
+    assert np.abs(c2[:, ::8].numpy() - g["c2"]).max() <= 1e-5
+    assert np.abs(c3[:, ::16].numpy() - g["c3"]).max() <= 1e-5
+    assert np.abs(c4[:, ::32].numpy() - g["c4"]).max() <= 1e-5
+
+
 def test_handnet_oracle_reproduces_reference_golden(golden_dir, fcos_sd, a2j_sd):
     g = np.load(golden_dir / "handnet_forward.npz")
     rgb = synth.make_rgb(2, seed=int(g["rgb_seed"]))
