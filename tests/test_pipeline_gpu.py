@@ -216,3 +216,20 @@ def test_convert_joints_matches_reference_formula():
             assert np.abs(xyz[i].numpy() - ref_xyz).max() < 1e-2
         else:
             assert float(xyz[i].abs().max()) == 0.0
+
+
+def test_pipeline_batch32_permutation_invariance(handnet):
+    """BASELINE config 4 size: frames are independent, so permuting the 32 frames of a batch permutes the results
+    (what the contiguous multi-GPU sharding relies on) -- integer boxes exactly, keypoints to fp32 rounding."""
+    from hn_amd import synth
+    rgb = synth.make_rgb(32, seed=1234).cuda()
+    depth = synth.make_depth(32, seed=4321).cuda()
+    perm = torch.randperm(32, generator=torch.Generator().manual_seed(5)).cuda()
+    eng = handnet.engine()
+    a = eng.forward_device(rgb, depth)
+    b = eng.forward_device(rgb[perm].contiguous(), depth[perm].contiguous())
+    torch.cuda.synchronize()
+    assert int(a.has_hand.sum()) >= 24
+    assert torch.equal(a.has_hand[perm], b.has_hand) and torch.equal(a.crop_box[perm], b.crop_box)
+    assert torch.equal(a.detections.count[perm], b.detections.count)
+    assert (a.keypoints[perm] - b.keypoints).abs().max().item() < 1e-4
