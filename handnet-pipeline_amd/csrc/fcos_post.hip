@@ -304,6 +304,7 @@ __device__ __forceinline__ bool iou_gt(float ax1, float ay1, float ax2, float ay
 
 __global__ __launch_bounds__(1024) void nms_kernel(const NmsArgs a) {
   __shared__ unsigned long long keys_lds[kSortLds];
+  __shared__ float kept_lds[kSortLds * kKeptRec];
   __shared__ float red[16];
   __shared__ float maxc_s;
   const int img = blockIdx.x;
@@ -318,13 +319,20 @@ __global__ __launch_bounds__(1024) void nms_kernel(const NmsArgs a) {
   }
   char* scr = a.scratch + (long)img * a.scratch_stride;
   unsigned long long* keys_g = reinterpret_cast<unsigned long long*>(scr);
-  float* kept = reinterpret_cast<float*>(scr + (long)a.pad_cap * 8);
   const int npad = pow2_at_least(K);
   unsigned long long* keys = npad <= kSortLds ? keys_lds : keys_g;
+  // The greedy pass re-reads the kept list once per 64-candidate tile, one record per iteration with a
+  // data-dependent exit: from global memory that is one L2 round trip per kept box (~170 us for 250
+  // candidates); the usual case (K <= 2048) keeps it in LDS.
+  float* kept = npad <= kSortLds ? kept_lds : reinterpret_cast<float*>(scr + (long)a.pad_cap * 8);
 
+  // only as many waves as the padded sort needs stay: every __syncthreads() below then rendezvous 4 waves
+  // instead of 16 for the usual ~250 candidates (terminated waves do not take part in s_barrier)
+  const int nthreads = npad < 64 ? 64 : (npad < (int)blockDim.x ? npad : (int)blockDim.x);
+  if (tid >= nthreads) return;
   // keys + max coordinate (torchvision's coordinate trick needs boxes.max())
   float mx = -3.402823466e38f;
-  for (int i = tid; i < npad; i += blockDim.x) {
+  for (int i = tid; i < npad; i += nthreads) {
     keys[i] = i < K ? make_key(scores[i], i) : ~0ull;
     if (i < K) {
       const f32x4 b = *reinterpret_cast<const f32x4*>(boxes + (long)i * 4);
@@ -336,14 +344,14 @@ __global__ __launch_bounds__(1024) void nms_kernel(const NmsArgs a) {
   __syncthreads();
   if (tid == 0) {
     float m = red[0];
-    for (int k = 1; k < (int)(blockDim.x >> 6); ++k) m = fmaxf(m, red[k]);
+    for (int k = 1; k < (nthreads >> 6); ++k) m = fmaxf(m, red[k]);
     maxc_s = m;
   }
   // bitonic sort (ascending keys = descending score, ties by ascending index)
   for (int k = 2; k <= npad; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
       __syncthreads();
-      for (int i = tid; i < npad; i += blockDim.x) {
+      for (int i = tid; i < npad; i += nthreads) {
         const int ixj = i ^ j;
         if (ixj > i) {
           const unsigned long long x = keys[i], y = keys[ixj];
