@@ -77,7 +77,7 @@ class HandNet(EngineOwner):
 
     def enable_graph(self, on: bool = True):
         """Opt in to hipGraph replay: the first call with a given input shape captures the whole step, later
-        calls copy the inputs into the captured buffers and replay (batch 1: 258 -> 300 frames/s; the launch
+        calls copy the inputs into the captured buffers and replay (no per-launch host cost; the launch
         sequence is static by construction).  Results of forward_device() then alias the captured output
         buffers and are overwritten by the next call; forward() returns fresh tensors either way."""
         self.use_graph = bool(on)

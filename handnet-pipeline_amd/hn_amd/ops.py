@@ -140,12 +140,14 @@ TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x64", 4: "128x32", 5: "256x128", 
 # launches, and launches on one stream are ordered
 CONV_WORKSPACE_BYTES = 32 << 20
 SPLITK = os.environ.get("HN_SPLITK", "1") != "0"  # development switch (tools/probes/exp/splitk.sh)
-SPLITK_EAGER = False  # set by launch_cost_hidden(): split short k loops too (pays when launches are free)
+# split short k loops too (desc.splitk = 1).  It used to pay only under graph replay; since the host path got
+# cheaper (raw stream handle, cached descriptors) it also wins in eager mode (batch 1: 294 -> 301 frames/s)
+SPLITK_EAGER = os.environ.get("HN_SPLITK_EAGER", "1") == "1"
 
 
 class launch_cost_hidden:
-    """Context for code whose launches will be replayed from a hipGraph: small grids then use split-K even for
-    short k loops (batch 1: 270 -> 298 frames/s under replay; in eager mode the extra launches cost more)."""
+    """Context for code whose launches will be replayed from a hipGraph: forces the aggressive split-K setting
+    (the default since the host path became cheap; HN_SPLITK_EAGER=0 restores the conservative eager rule)."""
 
     def __enter__(self):
         global SPLITK_EAGER
