@@ -49,26 +49,28 @@ __global__ __launch_bounds__(256) void pack_depth_kernel(const float* __restrict
   }
 }
 
-// One workgroup per crop; thread c = a*J + j owns one (anchor-in-cell, joint) channel
-// and walks the fh*fw cells, so every cell read is one contiguous A*J-float run.
+// One workgroup per crop.  Thread (g, c): c = a*J + j owns one (anchor-in-cell, joint) channel, so every cell
+// read is one contiguous A*J-float run; the G = blockDim/(A*J) thread groups take the cells p = g, g+G, ...
+// (a single group walked all fh*fw cells with two dependent loads each: 60 us of pure latency per launch).
 // Pass 1: per-joint max of the logits (exact, order independent).
-// Pass 2: e = exp(x - max); running sums of e, e*(anchor+offset), e*depth.
-// The 16 per-anchor partials of a joint are then combined in fixed order through LDS.
+// Pass 2: e = exp(x - max); partial sums of e, e*(anchor+offset), e*depth per (group, anchor, joint), then
+// combined through LDS in a fixed order (group-major, then anchor): bitwise reproducible.
 constexpr int kAnchorsPerCell = 16;
+constexpr int kMaxGroups = 3;
 
 __global__ __launch_bounds__(1024) void a2j_aggregate_kernel(const float* __restrict__ cls,
                                                              const float* __restrict__ reg,
                                                              const float* __restrict__ dep,
                                                              const int* __restrict__ valid, int fh, int fw,
-                                                             int J, int stride, float* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // [4][A*J]
+                                                             int J, int stride, int G, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [G][4][A*J]
   const int k = blockIdx.x;
   const int AJ = kAnchorsPerCell * J;
-  const int c = threadIdx.x;
-  const bool active = c < AJ;
-  const int a = active ? c / J : 0, j = active ? c - a * J : 0;
+  const int g = threadIdx.x / AJ, c = threadIdx.x - g * AJ;
+  const bool active = g < G;
+  const int a = c / J, j = c - a * J;
   if (valid && valid[k] == 0) {  // uniform per workgroup
-    if (c < J * 3) out[(long)k * J * 3 + c] = 0.f;
+    if ((int)threadIdx.x < J * 3) out[(long)k * J * 3 + threadIdx.x] = 0.f;
     return;
   }
   const int cells = fh * fw;
@@ -78,45 +80,48 @@ __global__ __launch_bounds__(1024) void a2j_aggregate_kernel(const float* __rest
 
   float mx = -FLT_MAX;
   if (active)
-    for (int p = 0; p < cells; ++p) mx = fmaxf(mx, clsk[(long)p * AJ + c]);
-  if (active) lds[c] = mx;
+    for (int p = g; p < cells; p += G) mx = fmaxf(mx, clsk[(long)p * AJ + c]);
+  if (active) lds[g * AJ + c] = mx;
   __syncthreads();
   float mj = -FLT_MAX;
   if (active)
-    for (int aa = 0; aa < kAnchorsPerCell; ++aa) mj = fmaxf(mj, lds[aa * J + j]);
+    for (int gg = 0; gg < G; ++gg)
+      for (int aa = 0; aa < kAnchorsPerCell; ++aa) mj = fmaxf(mj, lds[gg * AJ + aa * J + j]);
   __syncthreads();
 
-  float s = 0.f, s0 = 0.f, s1 = 0.f, sd = 0.f;
   if (active) {
+    float s = 0.f, s0 = 0.f, s1 = 0.f, sd = 0.f;
     const float p0 = 2.f + 4.f * (float)(a >> 2), p1 = 2.f + 4.f * (float)(a & 3);
-    for (int hh = 0; hh < fh; ++hh) {
-      const float a0 = (float)(hh * stride) + p0;
-      for (int ww = 0; ww < fw; ++ww) {
-        const long p = (long)hh * fw + ww;
-        const float e = expf(clsk[p * AJ + c] - mj);
-        const float2 r = *reinterpret_cast<const float2*>(regk + (p * AJ + c) * 2);
-        const float a1 = (float)(ww * stride) + p1;
-        s += e;
-        s0 += e * (a0 + r.x);
-        s1 += e * (a1 + r.y);
-        sd += e * depk[p * AJ + c];
-      }
+    for (int p = g; p < cells; p += G) {
+      const int hh = p / fw, ww = p - hh * fw;
+      const float e = expf(clsk[(long)p * AJ + c] - mj);
+      const float2 r = *reinterpret_cast<const float2*>(regk + ((long)p * AJ + c) * 2);
+      const float a0 = (float)(hh * stride) + p0, a1 = (float)(ww * stride) + p1;
+      s += e;
+      s0 += e * (a0 + r.x);
+      s1 += e * (a1 + r.y);
+      sd += e * depk[(long)p * AJ + c];
     }
-    lds[c] = s;
-    lds[AJ + c] = s0;
-    lds[2 * AJ + c] = s1;
-    lds[3 * AJ + c] = sd;
+    float* o = lds + (long)g * 4 * AJ;
+    o[c] = s;
+    o[AJ + c] = s0;
+    o[2 * AJ + c] = s1;
+    o[3 * AJ + c] = sd;
   }
   __syncthreads();
-  if (c < J) {
+  if ((int)threadIdx.x < J) {
+    const int jj = threadIdx.x;
     float t = 0.f, t0 = 0.f, t1 = 0.f, td = 0.f;
-    for (int aa = 0; aa < kAnchorsPerCell; ++aa) {
-      t += lds[aa * J + c];
-      t0 += lds[AJ + aa * J + c];
-      t1 += lds[2 * AJ + aa * J + c];
-      td += lds[3 * AJ + aa * J + c];
+    for (int gg = 0; gg < G; ++gg) {
+      const float* o = lds + (long)gg * 4 * AJ;
+      for (int aa = 0; aa < kAnchorsPerCell; ++aa) {
+        t += o[aa * J + jj];
+        t0 += o[AJ + aa * J + jj];
+        t1 += o[2 * AJ + aa * J + jj];
+        td += o[3 * AJ + aa * J + jj];
+      }
     }
-    float* o = out + ((long)k * J + c) * 3;
+    float* o = out + ((long)k * J + jj) * 3;
     o[0] = t0 / t;
     o[1] = t1 / t;
     o[2] = td / t;
@@ -199,9 +204,11 @@ extern "C" int hn_a2j_aggregate_f32(const float* cls, const float* reg, const fl
   HN_CHECK_ARG(joints > 0 && joints * kAnchorsPerCell <= 1024, "joints must be in [1, 64]");
   if (k == 0) return HN_OK;
   const int aj = kAnchorsPerCell * joints;
-  const int threads = ((aj + 63) / 64) * 64;
-  hipLaunchKernelGGL(a2j_aggregate_kernel, dim3(k), dim3(threads), 4 * aj * sizeof(float), (hipStream_t)stream,
-                     cls, reg, dep, valid, fh, fw, joints, stride, out);
+  int groups = 1024 / aj;
+  groups = groups > kMaxGroups ? kMaxGroups : groups;
+  const int threads = ((groups * aj + 63) / 64) * 64;
+  hipLaunchKernelGGL(a2j_aggregate_kernel, dim3(k), dim3(threads), groups * 4 * aj * sizeof(float),
+                     (hipStream_t)stream, cls, reg, dep, valid, fh, fw, joints, stride, groups, out);
   HN_CHECK_LAUNCH("a2j_aggregate_kernel");
   return HN_OK;
 }
