@@ -365,7 +365,15 @@ __global__ __launch_bounds__(1024) void nms_kernel(const NmsArgs a) {
     }
   }
   __syncthreads();
-  if (wave != 0) return;  // the greedy pass is one wavefront; it uses no workgroup barrier below
+  // Greedy pass, 64 candidates (one tile) at a time in score order.  Up to four waves share the two
+  // IoU-heavy parts of a tile -- the check against the boxes kept so far (wave w takes kept entries w, w+W, ..)
+  // and the in-tile suppression masks (wave w takes 64/W of the tile's columns) -- and wave 0 then resolves the
+  // tile sequentially.  Same comparisons as a single wave, only distributed: results are bit-identical.
+  const int W = (nthreads >> 6) < 4 ? (nthreads >> 6) : 4;
+  if (wave >= W) return;
+  __shared__ unsigned long long alive_w[4];
+  __shared__ unsigned long long mask_w[4][64];
+  __shared__ int nk_s;
 
   // batched_nms: coordinate trick iff boxes.numel() <= 4000, else per-class on raw boxes
   const bool classwise = labels != nullptr;
@@ -393,17 +401,18 @@ __global__ __launch_bounds__(1024) void nms_kernel(const NmsArgs a) {
     }
     const float area = (x2 - x1) * (y2 - y1);
     bool alive = has;
-    // against the boxes kept so far (wave-uniform reads of the kept list)
-    for (int q = 0; q < nk; ++q) {
+    // against the boxes kept so far (wave-uniform reads of the kept list), this wave's share
+    for (int q = wave; q < nk; q += W) {
       const float* kr = kept + (long)q * kKeptRec;
       const float kx1 = kr[0], ky1 = kr[1], kx2 = kr[2], ky2 = kr[3], ka = kr[4];
       const int kl = __float_as_int(kr[5]);
       if (alive && (trick || !classwise || kl == lab) && iou_gt(kx1, ky1, kx2, ky2, ka, x1, y1, x2, y2, area, thr))
         alive = false;
     }
-    // inside the tile: mask of later lanes this lane would suppress
+    // inside the tile: mask of later lanes this lane would suppress, this wave's share of the columns
     unsigned long long mask = 0ull;
-    for (int j = 0; j < 64; ++j) {
+    const int jn = 64 / W;
+    for (int j = wave * jn; j < (wave + 1) * jn; ++j) {
       const float jx1 = __shfl(x1, j), jy1 = __shfl(y1, j), jx2 = __shfl(x2, j), jy2 = __shfl(y2, j);
       const float ja = __shfl(area, j);
       const int jl = __shfl(lab, j);
@@ -412,35 +421,54 @@ __global__ __launch_bounds__(1024) void nms_kernel(const NmsArgs a) {
           iou_gt(x1, y1, x2, y2, area, jx1, jy1, jx2, jy2, ja, thr))
         mask |= 1ull << j;
     }
-    unsigned long long alive_bits = __ballot(alive);
-    for (int i = 0; i < 64; ++i) {
-      const unsigned long long mi = __shfl(mask, i);
-      if ((alive_bits >> i) & 1ull) alive_bits &= ~mi;
+    const unsigned long long my_alive = __ballot(alive);
+    if (W > 1) {
+      if (lane == 0) alive_w[wave] = my_alive;
+      mask_w[wave][lane] = mask;
+      __syncthreads();
     }
-    const bool keep = (alive_bits >> lane) & 1ull;
-    if (keep) {
-      const int pos = nk + __popcll(alive_bits & ((1ull << lane) - 1ull));
-      float* kr = kept + (long)pos * kKeptRec;
-      kr[0] = x1; kr[1] = y1; kr[2] = x2; kr[3] = y2; kr[4] = area; kr[5] = __int_as_float(lab);
-      const long o = (long)img * a.cap + pos;
-      if (a.det_boxes) {
-        float ox1 = raw[0], oy1 = raw[1], ox2 = raw[2], oy2 = raw[3];
-        if (a.rescale) {
-          ox1 = ox1 * a.ratio_w; ox2 = ox2 * a.ratio_w;
-          oy1 = oy1 * a.ratio_h; oy2 = oy2 * a.ratio_h;
-        }
-        a.det_boxes[o * 4 + 0] = ox1; a.det_boxes[o * 4 + 1] = oy1;
-        a.det_boxes[o * 4 + 2] = ox2; a.det_boxes[o * 4 + 3] = oy2;
+    if (wave == 0) {
+      unsigned long long alive_bits = my_alive;
+      for (int w = 1; w < W; ++w) {
+        alive_bits &= alive_w[w];
+        mask |= mask_w[w][lane];
       }
-      if (a.det_scores) a.det_scores[o] = scores[idx];
-      if (a.det_labels) a.det_labels[o] = lab;
-      if (a.det_sides) a.det_sides[o] = a.sides[(long)img * a.cap + idx];
-      if (a.det_level) a.det_level[o] = a.level[(long)img * a.cap + idx];
-      if (a.det_keep) a.det_keep[o] = idx;
+      for (int i = 0; i < 64; ++i) {
+        const unsigned long long mi = __shfl(mask, i);
+        if ((alive_bits >> i) & 1ull) alive_bits &= ~mi;
+      }
+      const bool keep = (alive_bits >> lane) & 1ull;
+      if (keep) {
+        const int pos = nk + __popcll(alive_bits & ((1ull << lane) - 1ull));
+        float* kr = kept + (long)pos * kKeptRec;
+        kr[0] = x1; kr[1] = y1; kr[2] = x2; kr[3] = y2; kr[4] = area; kr[5] = __int_as_float(lab);
+        const long o = (long)img * a.cap + pos;
+        if (a.det_boxes) {
+          float ox1 = raw[0], oy1 = raw[1], ox2 = raw[2], oy2 = raw[3];
+          if (a.rescale) {
+            ox1 = ox1 * a.ratio_w; ox2 = ox2 * a.ratio_w;
+            oy1 = oy1 * a.ratio_h; oy2 = oy2 * a.ratio_h;
+          }
+          a.det_boxes[o * 4 + 0] = ox1; a.det_boxes[o * 4 + 1] = oy1;
+          a.det_boxes[o * 4 + 2] = ox2; a.det_boxes[o * 4 + 3] = oy2;
+        }
+        if (a.det_scores) a.det_scores[o] = scores[idx];
+        if (a.det_labels) a.det_labels[o] = lab;
+        if (a.det_sides) a.det_sides[o] = a.sides[(long)img * a.cap + idx];
+        if (a.det_level) a.det_level[o] = a.level[(long)img * a.cap + idx];
+        if (a.det_keep) a.det_keep[o] = idx;
+      }
+      nk += __popcll(alive_bits);
+      if (lane == 0) nk_s = nk;
+      __threadfence_block();  // kept[] written above is read by every lane in the next tile
     }
-    nk += __popcll(alive_bits);
-    __threadfence_block();  // kept[] written above is read by every lane in the next tile
+    if (W > 1) {
+      __threadfence();   // kept[] may live in global scratch (K > 2048): make it visible to the other waves
+      __syncthreads();
+      nk = nk_s;
+    }
   }
+  if (wave != 0) return;
   if (lane == 0 && a.det_count) a.det_count[img] = nk;
 }
 
