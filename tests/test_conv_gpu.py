@@ -304,6 +304,8 @@ def test_conv_f16x3_splitk_matches_plain_and_reference(case):
     from hn_amd import ops
     from hn_amd.weights import split_f16x3
     from oracle import ops_ref
+    if not ops.SPLITK:
+        pytest.skip("split-K disabled by HN_SPLITK=0")
     n, h, w, cin, cout, r, stride, dil, res, osplit = case
     pad = dil * (r // 2)
     x = _rand((n, h, w, cin), 41)
