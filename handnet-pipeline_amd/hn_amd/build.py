@@ -70,6 +70,20 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     return LIB_PATH
 
 
+def build_abi_example(force: bool = False) -> Path:
+    """examples/abi_smoke.cpp: a C++ host bound to include/handnet_hip.h only (no Python, no torch)."""
+    src = REPO_ROOT / "examples" / "abi_smoke.cpp"
+    exe = CSRC / "build" / "abi_smoke"
+    if force or _newer([src, REPO_ROOT / "include" / "handnet_hip.h", LIB_PATH], exe):
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O2", "-std=c++17", f"-I{REPO_ROOT / 'include'}", str(src),
+               f"-L{CSRC}", "-lhandnet_hip", "-Wl,-rpath,$ORIGIN/..", "-o", str(exe)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on abi_smoke.cpp:\n{r.stdout}\n{r.stderr}")
+    return exe
+
+
 if __name__ == "__main__":
     p = build_library(force="--force" in sys.argv, verbose=True)
     print(p)
+    print(build_abi_example(force="--force" in sys.argv))
