@@ -74,6 +74,13 @@ struct ConvParams16 {
   float* gn_partial;  // optional GroupNorm partial sums [ceil(M/32)][Cout/8][4] (see hn_conv2d_nhwc_f16x3_gn)
   // split-K (small-M layers): gridDim.y workgroups share an output tile, each sums kt_per k tiles into
   // split_ws[z][M][Cout] (fp32, no epilogue); splitk_reduce_kernel adds them in z order and finishes
+  // grouped launch (hn_conv2d_nhwc_f16x3_grouped): gridDim.z same-shape problems with their own tensors
+  int groups;
+  const _Float16* gx[HN_CONV_MAX_GROUP];
+  const _Float16* gw[HN_CONV_MAX_GROUP];
+  const float* gbias[HN_CONV_MAX_GROUP];
+  void* gy[HN_CONV_MAX_GROUP];
+  float* ggn[HN_CONV_MAX_GROUP];
   int splits, kt_per, splitk_mode;
   float* split_ws;
   int64_t split_ws_bytes;
@@ -245,6 +252,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
   const int wm = wave / WN, wn = wave - wm * WN;
   const int ohow = p.OH * p.OW;
 
+  // grouped launch: workgroup z works on problem z (same shapes, its own tensors)
+  // (constant indices + selects: a dynamic index into the kernel-argument arrays would send the whole
+  // parameter block through scratch memory -- measured: -40 % on every convolution)
+  const int gz = p.groups > 1 ? (int)blockIdx.z : 0;
+#define HN_GROUP_SEL(arr) (gz == 0 ? p.arr[0] : gz == 1 ? p.arr[1] : gz == 2 ? p.arr[2] : p.arr[3])
+  const _Float16* x_base = p.groups > 1 ? HN_GROUP_SEL(gx) : p.x;
+  const _Float16* w_base = p.groups > 1 ? HN_GROUP_SEL(gw) : p.w;
+
   // ---- DMA geometry: lane -> (row = tid >> 3 within a pass, LDS position pos = tid & 7) ----
   const int drow = tid >> 3, dpos = tid & 7;
   int a_ih0[A_IT], a_iw0[A_IT], a_cc[A_IT];  // a_cc: chunk offset inside the zero page
@@ -261,7 +276,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
     a_iw0[it] = ow * p.stride - p.pad;
     const int chunk = dpos ^ swz(row);  // source chunk that belongs at this LDS position: 0-3 hi run, 4-7 lo run
     a_cc[it] = chunk * 8;
-    a_row[it] = p.x + (((long)img * p.H + a_ih0[it]) * p.pitch + a_iw0[it]) * p.xs + (chunk & 3) * 8 +
+    a_row[it] = x_base + (((long)img * p.H + a_ih0[it]) * p.pitch + a_iw0[it]) * p.xs + (chunk & 3) * 8 +
                 (chunk >> 2) * p.lo_off;
   }
   const _Float16* b_ptr[B_IT];
@@ -270,7 +285,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
     const int row = drow + it * ROWS_PASS;
     int n = n0 + row;
     n = n < p.Cout ? n : p.Cout - 1;  // columns >= Cout are never stored
-    b_ptr[it] = p.w + (long)n * p.Ktot * 2 + (dpos ^ swz(row)) * 8;
+    b_ptr[it] = w_base + (long)n * p.Ktot * 2 + (dpos ^ swz(row)) * 8;
   }
   // wave-uniform LDS row base of this wave's 8-row group inside a pass
   const int grp_row = __builtin_amdgcn_readfirstlane(wave) * 8;
@@ -467,6 +482,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
   // A split-K workgroup stores its raw fp32 partial tile into plane blockIdx.y of the workspace instead
   // (dense [M][Cout], no bias / residual / ReLU): the reduction kernel finishes the job.
   ConvParams16 q = p;
+  if (p.groups > 1) {
+    q.bias = HN_GROUP_SEL(gbias);
+    q.y = HN_GROUP_SEL(gy);
+    q.gn_partial = HN_GROUP_SEL(ggn);
+  }
+#undef HN_GROUP_SEL
   if (p.splits > 1) {
     q.y = p.split_ws + (long)blockIdx.y * p.M * p.Cout;
     q.ys = p.Cout;
@@ -583,7 +604,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
         const int n = n0 + wn * (BN / WN) + j * 16 + (lane & 15);
         if (n >= p.Cout) continue;
         float v = acc[i][j][r];
-        if (p.bias) v += p.bias[n];
+        if (q.bias) v += q.bias[n];
         if (p.res_mode) {
           if (p.res_split) {
             const _Float16* q = res16 + rpix * p.rs + (n >> 5) * 64 + (n & 31);
@@ -632,8 +653,12 @@ int launch16(const ConvParams16& p0, hipStream_t st) {
       p.splits = hn::cdiv(p.ktiles, p.kt_per);  // every split has at least one tile
     }
   }
-  hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, NBUF>), dim3(p.nblocks, p.splits), dim3(WM * WN * 64), 0,
-                     st, p);
+  if (p.groups > 1) {  // grouped problems never split (the grid is already groups x larger)
+    p.splits = 1;
+    p.kt_per = p.ktiles;
+  }
+  hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, NBUF>), dim3(p.nblocks, p.splits, p.groups > 1 ? p.groups : 1),
+                     dim3(WM * WN * 64), 0, st, p);
   HN_CHECK_LAUNCH("conv_igemm_f16x3_kernel");
   if (p.splits > 1) {
     const long total = (long)p.M * (p.Cout >> 3);
@@ -671,7 +696,8 @@ extern "C" int hn_conv2d_f16x3_pick_tile(const hn_conv_desc* d) {
 }
 
 static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, const float* bias, const void* residual,
-                      void* y, float* gn_partial, void* workspace, int64_t workspace_bytes, void* stream);
+                      void* y, float* gn_partial, void* workspace, int64_t workspace_bytes, void* stream,
+                      const hn_conv_group* group = nullptr);
 
 extern "C" int hn_conv2d_nhwc_f16x3(const hn_conv_desc* d, const void* x16, const void* w16, const float* bias,
                                     const void* residual, void* y, void* stream) {
@@ -700,8 +726,27 @@ extern "C" int hn_conv2d_nhwc_f16x3_gn(const hn_conv_desc* d, const void* x16, c
   return conv16_run(d, x16, w16, bias, nullptr, y, gn_partial, nullptr, 0, stream);
 }
 
+// Same-shape convolutions as ONE launch (gridDim.z = count): the cls / reg tower layers of one FPN level, or the
+// three A2J head layers, are independent and identical in shape; on their own each leaves CUs idle at small
+// batch and costs a launch.  (Side streams do not help on this platform: tools/probes/exp/streams.sh.)
+extern "C" int hn_conv2d_nhwc_f16x3_grouped(const hn_conv_desc* d, const hn_conv_group* group, void* stream) {
+  HN_CHECK_ARG(d && group, "hn_conv2d_nhwc_f16x3_grouped: null pointer");
+  HN_CHECK_ARG(group->count >= 1 && group->count <= HN_CONV_MAX_GROUP, "group count must be 1..%d", HN_CONV_MAX_GROUP);
+  HN_CHECK_ARG(d->res_mode == 0, "grouped convolutions take no residual");
+  bool any_gn = false, all_gn = true;
+  for (int g = 0; g < group->count; ++g) {
+    HN_CHECK_ARG(group->x16[g] && group->w16[g] && group->y[g], "group member %d has a null tensor", g);
+    any_gn = any_gn || group->gn_partial[g];
+    all_gn = all_gn && group->gn_partial[g];
+  }
+  HN_CHECK_ARG(any_gn == all_gn, "gn_partial must be given for every group member or for none");
+  return conv16_run(d, group->x16[0], group->w16[0], group->bias[0], nullptr, group->y[0], nullptr, nullptr, 0, stream,
+                    group);
+}
+
 static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, const float* bias, const void* residual,
-                      void* y, float* gn_partial, void* workspace, int64_t workspace_bytes, void* stream) {
+                      void* y, float* gn_partial, void* workspace, int64_t workspace_bytes, void* stream,
+                      const hn_conv_group* group) {
   HN_CHECK_ARG(d && x16 && w16 && y, "hn_conv2d_nhwc_f16x3: null pointer");
   HN_CHECK_ARG(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, "bad tensor dims");
   HN_CHECK_ARG(d->cin % 32 == 0, "f16x3 conv needs cin %% 32 == 0 (got %d); use hn_conv2d_nhwc_f32", d->cin);
@@ -741,6 +786,18 @@ static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, c
   p.split_ws = (float*)workspace;
   p.split_ws_bytes = workspace ? workspace_bytes : 0;
   p.splitk_mode = d->splitk;
+  p.groups = 1;
+  if (group) {
+    p.groups = group->count;
+    for (int g = 0; g < group->count; ++g) {
+      p.gx[g] = (const _Float16*)group->x16[g]; p.gw[g] = (const _Float16*)group->w16[g];
+      p.gbias[g] = group->bias[g]; p.gy[g] = group->y[g]; p.ggn[g] = group->gn_partial[g];
+      p.vec_epi = p.vec_epi && ((uintptr_t)group->y[g] % 16 == 0) &&
+                  (group->bias[g] == nullptr || (uintptr_t)group->bias[g] % 16 == 0);
+    }
+    p.gn_partial = group->gn_partial[0];   // the checks below apply to every member (same descriptor)
+    p.split_ws = nullptr;
+  }
   p.splits = 1;
   p.kt_per = p.ktiles;
   if (gn_partial) {
@@ -793,7 +850,7 @@ extern "C" int hn_conv_stem_f16x3(const void* x16, int n, int ph, int pw, int pa
   p.out_split = out_split; p.res_split = 0;
   p.xs = 4; p.pitch = wb; p.lo_off = (long)n * hb * wb * 4;
   p.gn_partial = nullptr;
-  p.split_ws = nullptr; p.split_ws_bytes = 0; p.splits = 1; p.kt_per = p.ktiles; p.splitk_mode = -1;
+  p.split_ws = nullptr; p.split_ws_bytes = 0; p.splits = 1; p.kt_per = p.ktiles; p.splitk_mode = -1; p.groups = 1;
   p.ys = (out_split ? 2 : 1) * cout;
   p.rs = 0;
   p.vec_epi = (cout % 8 == 0) && ((uintptr_t)y % 16 == 0) && (bias == nullptr || (uintptr_t)bias % 16 == 0);

@@ -11,7 +11,7 @@ from pathlib import Path
 
 from . import build as _build
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, TILE_256x128, TILE_64x128 = range(7)
 HN_FCOS_MAX_LEVELS = 5
@@ -26,6 +26,15 @@ class ConvDesc(C.Structure):
         "n", "h", "w", "cin", "cout", "r", "s", "stride", "pad", "dil", "oh", "ow",
         "relu_cols", "res_mode", "res_h", "res_w", "in_affine", "tile", "out_split", "res_split",
         "res_pix_stride", "in_pix_stride", "out_pix_stride", "in_affine_stride", "splitk")]
+
+
+CONV_MAX_GROUP = 4
+
+
+class ConvGroup(C.Structure):  # == struct hn_conv_group
+    _fields_ = [("count", C.c_int32), ("x16", C.c_void_p * CONV_MAX_GROUP), ("w16", C.c_void_p * CONV_MAX_GROUP),
+                ("bias", C.c_void_p * CONV_MAX_GROUP), ("y", C.c_void_p * CONV_MAX_GROUP),
+                ("gn_partial", C.c_void_p * CONV_MAX_GROUP)]
 
 
 class FcosLevels(C.Structure):
@@ -60,6 +69,7 @@ SIGNATURES = {
     "hn_groupnorm_affine_f32": (C.c_int, [VP, VP, VP] + [C.c_int] * 4 + [C.c_float, VP, VP, VP, VP]),
     "hn_fcos_preprocess_f32": (C.c_int, [VP, VP] + [C.c_int] * 7 + [c_f32p, c_f32p, VP]),
     "hn_conv2d_nhwc_f16x3_ws": (C.c_int, [C.POINTER(ConvDesc)] + [VP] * 6 + [C.c_int64, VP]),
+    "hn_conv2d_nhwc_f16x3_grouped": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvGroup), VP]),
     "hn_conv2d_nhwc_f16x3_gn": (C.c_int, [C.POINTER(ConvDesc)] + [VP] * 6),
     "hn_groupnorm_rows32_scratch_floats": (C.c_int64, [C.c_int64, C.c_int]),
     "hn_groupnorm_finalize_rows32": (C.c_int, [VP, VP, VP] + [C.c_int] * 4 + [C.c_float, VP, VP, VP]),

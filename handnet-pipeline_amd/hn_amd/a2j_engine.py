@@ -7,6 +7,8 @@ first layers run as ONE 2048 -> 512 conv (wider N tile, x4 gathered once).
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
@@ -28,6 +30,7 @@ class A2JEngine:
         self.device = torch.device(device)
         self.joints = num_joints
         self.rgbd = rgbd
+        self.group_heads = os.environ.get("HN_GROUP_CONVS", "1") != "0"
         p = "Backbone.model."
         dev = self.device
 
@@ -98,10 +101,7 @@ class A2JEngine:
         return x3, x
 
     def heads(self, x3, x4):
-        c = x3
-        for cw in self.cls_convs:
-            c = self._conv(c, cw)
-        cls = self._conv(c, self.cls_out, relu=False, out_f32=True)
+        c = self._conv(x3, self.cls_convs[0])
         rd = self._conv(x4, self.regdep_conv1)
         # the fused tensor has 512 channels: 0..255 regression tower, 256..511 depth tower
         # (read in place as channel-slice views: no copy)
@@ -109,6 +109,19 @@ class A2JEngine:
             r, d = rd[:, :, :, :8], rd[:, :, :, 8:]
         else:
             r, d = rd[..., :256], rd[..., 256:]
+        if self.precision == "f16x3" and self.group_heads:
+            # layers 2-4 of the three heads are independent 256->256 3x3 convs on 11x11 maps: ONE launch per
+            # layer (layer 2 splits 1 + 2 because r / d are still slices of the fused tensor), outputs 2 + 1
+            c = self._conv(c, self.cls_convs[1])
+            r, d = ops.conv2d_nhwc_grouped([r, d], [self.reg_convs[0], self.dep_convs[0]], pad=1, relu=True, out_split=True)
+            for i in (1, 2):
+                c, r, d = ops.conv2d_nhwc_grouped([c, r, d], [self.cls_convs[i + 1], self.reg_convs[i], self.dep_convs[i]],
+                                                  pad=1, relu=True, out_split=True)
+            cls, dep = ops.conv2d_nhwc_grouped([c, d], [self.cls_out, self.dep_out], pad=1)
+            return cls, self._conv(r, self.reg_out, relu=False, out_f32=True), dep
+        for cw in self.cls_convs[1:]:
+            c = self._conv(c, cw)
+        cls = self._conv(c, self.cls_out, relu=False, out_f32=True)
         for cw in self.reg_convs:
             r = self._conv(r, cw)
         for cw in self.dep_convs:

@@ -106,6 +106,7 @@ class FCOSEngine:
         self._gn_scratch = {}
         self._side = None
         self.head_streams = int(os.environ.get("HN_HEAD_STREAMS", "1")) if head_streams is None else head_streams
+        self.group_towers = os.environ.get("HN_GROUP_CONVS", "1") != "0"
 
     # -----------------------------------------------------------------------------------
     def _conv(self, x, cw: ConvW, relu=False, out_f32=False, **kw):
@@ -210,8 +211,28 @@ class FCOSEngine:
     def head_level(self, feat, key=0):
         """One FPN level -> (cls_lr [N,h,w,C+2], reg_ctr [N,h,w,5], ext [N,h,w,8] or None) raw fp32 conv outputs."""
         t0, sc, sh = self._tower0(feat, key)
-        cls_lr, ext = self._cls_chain(t0, sc, sh, key)
-        return cls_lr, self._reg_chain(t0, sc, sh, key), ext
+        n, fh, fw = t0.shape[:3]
+        hw = fh * fw
+        if self.precision != "f16x3" or hw < 32 or not self.group_towers:
+            cls_lr, ext = self._cls_chain(t0, sc, sh, key)
+            return cls_lr, self._reg_chain(t0, sc, sh, key), ext
+        # f16x3: layer k of the cls tower and of the reg tower are independent and identical in shape -> ONE
+        # launch each (gridDim.z = 2).  Fewer launches and fuller grids at small batch, neutral at batch 32.
+        xc, sc_c, sh_c = t0[..., :256], sc[:, :256], sh[:, :256]
+        xr, sc_r, sh_r = t0[..., 256:], sc[:, 256:], sh[:, 256:]
+        need = ops.gn_rows32_scratch_floats(n * hw, 256)
+        pc = self._scratch((key, "gc"), need, t0.device)
+        pr = self._scratch((key, "gr"), need, t0.device)
+        for cwc, (gc, bc), cwr, (gr, br) in zip(self.cls_tower, self.cls_gn, self.reg_tower, self.reg_gn):
+            xc, xr = ops.conv2d_nhwc_grouped([self._act(xc, sc_c, sh_c), self._act(xr, sc_r, sh_r)], [cwc, cwr], pad=1,
+                                             gn_partials=[pc, pr])
+            sc_c, sh_c = ops.groupnorm_finalize_rows32(pc, gc, bc, n, hw, 32)
+            sc_r, sh_r = ops.groupnorm_finalize_rows32(pr, gr, br, n, hw, 32)
+        ac = self._act(xc, sc_c, sh_c)
+        cls_lr = self._out_conv(ac, self.cls_out)
+        ext = self._out_conv(ac, self.ext_out, relu_cols=3) if self.ext else None
+        reg_ctr = self._out_conv(self._act(xr, sc_r, sh_r), self.reg_out, relu_cols=4)
+        return cls_lr, reg_ctr, ext
 
     def heads(self, feats):
         """All levels.  With head_streams > 1 the 2 x levels independent tower chains are spread over side

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, FcosLevels, check, ptr
+from ._lib import ConvDesc, ConvGroup, FcosLevels, check, ptr
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -283,6 +283,62 @@ def conv2d_nhwc(x, w, bias=None, *, stride=1, pad=0, dil=1, relu=False, relu_col
             kind = ("f32", lib.hn_conv2d_pick_tile(C.byref(d)))
         prof.append((kind, macs, timer, (n, h, wd, cin, cout, r, stride, dil)))
     return out
+
+
+def conv2d_nhwc_grouped(xs, ws, *, pad=0, relu=False, relu_cols=None, out_split=False, gn_partials=None, tile=0):
+    """Same-shape stride-1 f16x3 convolutions as ONE launch.  xs: S32 inputs; ws: ConvW-like objects with
+    .w [Cout,R,S,Cin] / .bias / .w16 (all of one shape); gn_partials: None or one GroupNorm-sum buffer per member.
+    Returns the list of outputs.  A single member falls through to conv2d_nhwc."""
+    k = len(xs)
+    if k != len(ws) or k == 0 or k > _lib.CONV_MAX_GROUP:
+        raise ValueError(f"need 1..{_lib.CONV_MAX_GROUP} inputs and as many weight sets")
+    if k == 1:
+        return [conv2d_nhwc(xs[0], ws[0].w, ws[0].bias, pad=pad, relu=relu, relu_cols=relu_cols, w16=ws[0].w16,
+                            out_split=out_split, tile=tile, gn_partial=None if gn_partials is None else gn_partials[0])]
+    lib = _lib.load()
+    cout, r, s, cin = ws[0].w.shape
+    x0 = xs[0]
+    xstride = _pixel_stride(x0, "x")
+    n, h, wd = x0.shape[:3]
+    for x, cw in zip(xs, ws):
+        if not is_split(x) or tuple(x.shape) != tuple(x0.shape) or _pixel_stride(x, "x") != xstride:
+            raise ValueError("grouped inputs must be S32 tensors of one shape and pixel stride")
+        if tuple(cw.w.shape) != (cout, r, s, cin) or cw.w16 is None or (cw.bias is None) != (ws[0].bias is None):
+            raise ValueError("grouped weights must share one shape (and all or none have a bias)")
+    if channels(x0) != cin:
+        raise ValueError(f"weight Cin {cin} != input channels {channels(x0)}")
+    rc = (cout if relu else 0) if relu_cols is None else relu_cols
+    d = make_conv_desc(n, h, wd, cin, cout, r, s, 1, pad, 1, rc, 0, 0, 0, 0, tile,
+                       in_pix_stride=0 if xstride == 2 * cin else xstride)
+    d.out_split = 1 if out_split else 0
+    d.splitk = -1
+    if gn_partials is not None:
+        if out_split or rc:
+            raise ValueError("gn_partials need fp32 outputs without ReLU")
+        need = lib.hn_groupnorm_rows32_scratch_floats(n * d.oh * d.ow, cout)
+        if len(gn_partials) != k or any(g.numel() < need or g.dtype != torch.float32 or not g.is_cuda for g in gn_partials):
+            raise ValueError(f"need {k} fp32 GPU gn_partial buffers of >= {need} floats")
+    outs = []
+    grp = ConvGroup()
+    grp.count = k
+    for i, (x, cw) in enumerate(zip(xs, ws)):
+        if out_split:
+            y = torch.empty((n, d.oh, d.ow, cout // 32, 2, 32), device=x.device, dtype=torch.float16)
+        else:
+            y = torch.empty((n, d.oh, d.ow, cout), device=x.device, dtype=torch.float32)
+        outs.append(y)
+        grp.x16[i], grp.w16[i], grp.bias[i], grp.y[i] = ptr(x), ptr(cw.w16), ptr(cw.bias), ptr(y)
+        grp.gn_partial[i] = None if gn_partials is None else ptr(gn_partials[i])
+    prof = CONV_PROFILE
+    if prof is not None:
+        timer = HipTimer()
+        timer.start()
+    check(lib.hn_conv2d_nhwc_f16x3_grouped(C.byref(d), C.byref(grp), _stream()), "hn_conv2d_nhwc_f16x3_grouped")
+    if prof is not None:
+        timer.stop()
+        prof.append((("f16x3", lib.hn_conv2d_f16x3_pick_tile(C.byref(d))), k * n * d.oh * d.ow * cout * r * s * cin, timer,
+                     (k * n, h, wd, cin, cout, r, 1, 1)))
+    return outs
 
 
 def maxpool3x3s2_nhwc(x, out=None):

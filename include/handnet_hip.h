@@ -33,7 +33,7 @@ extern "C" {
 #define HN_ERR_HIP 2
 
 /* ABI version; bumped whenever a struct below changes. */
-#define HN_ABI_VERSION 16
+#define HN_ABI_VERSION 17
 int hn_abi_version(void);
 const char* hn_last_error(void);
 
@@ -150,6 +150,22 @@ int hn_groupnorm_affine_f32(const float* x /* [n][hw][c] */, const float* gamma,
 int hn_conv2d_nhwc_f16x3_ws(const hn_conv_desc* desc, const void* x16, const void* w16,
                             const float* bias, const void* residual, void* y,
                             void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Up to HN_CONV_MAX_GROUP convolutions that share ONE descriptor (identical shapes, strides and epilogue flags; no
+ * residual, no split-K) as a single launch: member g reads x16[g] / w16[g] / bias[g] (bias may be NULL) and writes
+ * y[g]; gn_partial[g] is either given for every member (semantics of hn_conv2d_nhwc_f16x3_gn) or NULL for all.
+ * Used for the cls / reg tower layers of an FPN level (fcos.py:276,377) and the three A2J head layers
+ * (a2j/a2j.py:70-181), which are independent and identical in shape. */
+#define HN_CONV_MAX_GROUP 4
+typedef struct hn_conv_group {
+  int32_t count;
+  const void* x16[HN_CONV_MAX_GROUP];
+  const void* w16[HN_CONV_MAX_GROUP];
+  const float* bias[HN_CONV_MAX_GROUP];
+  void* y[HN_CONV_MAX_GROUP];
+  float* gn_partial[HN_CONV_MAX_GROUP];
+} hn_conv_group;
+int hn_conv2d_nhwc_f16x3_grouped(const hn_conv_desc* desc, const hn_conv_group* group, void* stream);
 
 /* Fused variant for the f16x3 path: hn_conv2d_nhwc_f16x3_gn is hn_conv2d_nhwc_f16x3 (fp32 output, no
  * residual / ReLU, cout % 8 == 0, oh*ow >= 32) whose epilogue also writes GroupNorm partial sums

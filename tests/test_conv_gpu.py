@@ -365,3 +365,32 @@ def test_conv_f16x3_random_shapes_auto_tile():
         scale = max(1.0, float(ref.abs().max()))
         err = float((y.cpu() - ref).abs().max())
         assert y.shape == ref.shape and err <= 2e-5 * scale, (case, (n, h, w, cin, cout, r, stride, dil), err)
+
+
+def test_conv_f16x3_grouped_equals_separate_launches():
+    """hn_conv2d_nhwc_f16x3_grouped: three same-shape convolutions in one launch (gridDim.z) give bit-identical
+    results to three launches -- S32 outputs with ReLU, fp32 outputs with GroupNorm partial sums, slice inputs."""
+    from types import SimpleNamespace as NS
+    from hn_amd import ops
+    from hn_amd.weights import split_f16x3
+    g = torch.Generator().manual_seed(77)
+    n, h, w, cin, cout = 2, 11, 11, 256, 256
+    wide = ops.to_split(torch.randn((n, h, w, 3 * cin), generator=g).cuda())
+    xs = [wide[:, :, :, 8 * i:8 * (i + 1)] for i in range(3)]          # channel-slice views, equal pixel stride
+    ws = []
+    for i in range(3):
+        wt = torch.randn((cout, 3, 3, cin), generator=g) * (2.0 / (9 * cin)) ** 0.5
+        ws.append(NS(w=wt.cuda(), bias=torch.randn((cout,), generator=g).cuda(), w16=split_f16x3(wt).cuda()))
+    ys = ops.conv2d_nhwc_grouped(xs, ws, pad=1, relu=True, out_split=True)
+    for x, cw, y in zip(xs, ws, ys):
+        ref = ops.conv2d_nhwc(x, cw.w, cw.bias, pad=1, relu=True, w16=cw.w16, out_split=True, splitk=False)
+        assert torch.equal(y, ref)
+    need = ops.gn_rows32_scratch_floats(n * h * w, cout)
+    parts = [torch.full((need,), float("nan"), device="cuda") for _ in range(2)]
+    ys = ops.conv2d_nhwc_grouped(xs[:2], ws[:2], pad=1, gn_partials=parts)
+    for x, cw, y, part in zip(xs, ws, ys, parts):
+        ref_part = torch.empty_like(part)
+        ref = ops.conv2d_nhwc(x, cw.w, cw.bias, pad=1, w16=cw.w16, gn_partial=ref_part)
+        assert torch.equal(y, ref) and torch.equal(part, ref_part)
+    with pytest.raises(ValueError):
+        ops.conv2d_nhwc_grouped([xs[0], wide[:, :, :, :16]], ws[:2], pad=1)     # different shapes
