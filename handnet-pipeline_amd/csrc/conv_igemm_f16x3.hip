@@ -81,6 +81,7 @@ struct ConvParams16 {
   const float* gbias[HN_CONV_MAX_GROUP];
   void* gy[HN_CONV_MAX_GROUP];
   float* ggn[HN_CONV_MAX_GROUP];
+  int gn_units;       // 8-channel units per row group in the GroupNorm slab (Cout/8 unless members share a slab)
   int splits, kt_per, splitk_mode;
   float* split_ws;
   int64_t split_ws_bytes;
@@ -574,7 +575,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
         const int n = n0 + wn * (BN / WN) + lane * 8;
         if (lane < GROUPS && n < p.Cout && m_grp < p.M) {
           f32x4 o4 = {gsum[0], gsum[1], gsum[2], gsum[3]};
-          *reinterpret_cast<f32x4*>(q.gn_partial + ((long)(m_grp >> 5) * (p.Cout >> 3) + (n >> 3)) * 4) = o4;
+          *reinterpret_cast<f32x4*>(q.gn_partial + ((long)(m_grp >> 5) * p.gn_units + (n >> 3)) * 4) = o4;
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // patch reads done before the next pass rewrites it
@@ -740,6 +741,7 @@ extern "C" int hn_conv2d_nhwc_f16x3_grouped(const hn_conv_desc* d, const hn_conv
     all_gn = all_gn && group->gn_partial[g];
   }
   HN_CHECK_ARG(any_gn == all_gn, "gn_partial must be given for every group member or for none");
+  HN_CHECK_ARG(group->gn_units == 0 || group->gn_units >= d->cout / 8, "gn_units smaller than cout/8");
   return conv16_run(d, group->x16[0], group->w16[0], group->bias[0], nullptr, group->y[0], nullptr, nullptr, 0, stream,
                     group);
 }
@@ -787,8 +789,10 @@ static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, c
   p.split_ws_bytes = workspace ? workspace_bytes : 0;
   p.splitk_mode = d->splitk;
   p.groups = 1;
+  p.gn_units = d->cout >> 3;
   if (group) {
     p.groups = group->count;
+    if (group->gn_units > 0) p.gn_units = group->gn_units;
     for (int g = 0; g < group->count; ++g) {
       p.gx[g] = (const _Float16*)group->x16[g]; p.gw[g] = (const _Float16*)group->w16[g];
       p.gbias[g] = group->bias[g]; p.gy[g] = group->y[g]; p.ggn[g] = group->gn_partial[g];
@@ -850,7 +854,7 @@ extern "C" int hn_conv_stem_f16x3(const void* x16, int n, int ph, int pw, int pa
   p.out_split = out_split; p.res_split = 0;
   p.xs = 4; p.pitch = wb; p.lo_off = (long)n * hb * wb * 4;
   p.gn_partial = nullptr;
-  p.split_ws = nullptr; p.split_ws_bytes = 0; p.splits = 1; p.kt_per = p.ktiles; p.splitk_mode = -1; p.groups = 1;
+  p.split_ws = nullptr; p.split_ws_bytes = 0; p.splits = 1; p.kt_per = p.ktiles; p.splitk_mode = -1; p.groups = 1; p.gn_units = cout >> 3;
   p.ys = (out_split ? 2 : 1) * cout;
   p.rs = 0;
   p.vec_epi = (cout % 8 == 0) && ((uintptr_t)y % 16 == 0) && (bias == nullptr || (uintptr_t)bias % 16 == 0);

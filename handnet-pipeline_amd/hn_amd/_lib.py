@@ -11,7 +11,7 @@ from pathlib import Path
 
 from . import build as _build
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, TILE_256x128, TILE_64x128 = range(7)
 HN_FCOS_MAX_LEVELS = 5
@@ -34,7 +34,7 @@ CONV_MAX_GROUP = 4
 class ConvGroup(C.Structure):  # == struct hn_conv_group
     _fields_ = [("count", C.c_int32), ("x16", C.c_void_p * CONV_MAX_GROUP), ("w16", C.c_void_p * CONV_MAX_GROUP),
                 ("bias", C.c_void_p * CONV_MAX_GROUP), ("y", C.c_void_p * CONV_MAX_GROUP),
-                ("gn_partial", C.c_void_p * CONV_MAX_GROUP)]
+                ("gn_partial", C.c_void_p * CONV_MAX_GROUP), ("gn_units", C.c_int32)]
 
 
 class FcosLevels(C.Structure):

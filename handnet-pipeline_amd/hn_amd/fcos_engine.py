@@ -89,6 +89,7 @@ class FCOSEngine:
         self.gn0_beta = torch.cat([gn(c, 0, "bias"), gn(r, 0, "bias")]).to(dev)
         self.cls_gn = [(gn(c, i, "weight").to(dev), gn(c, i, "bias").to(dev)) for i in range(1, 4)]
         self.reg_gn = [(gn(r, i, "weight").to(dev), gn(r, i, "bias").to(dev)) for i in range(1, 4)]
+        self.both_gn = [(torch.cat([gc, gr]), torch.cat([bc, br])) for (gc, bc), (gr, br) in zip(self.cls_gn, self.reg_gn)]
         self.cls_out = concat_cout([
             pack_conv(sd[c + ".cls_logits.weight"], sd[c + ".cls_logits.bias"], pad=1),
             pack_conv(sd[c + ".hand_lr_layer.weight"], sd[c + ".hand_lr_layer.bias"], pad=1)]).to(dev)
@@ -217,21 +218,18 @@ class FCOSEngine:
             cls_lr, ext = self._cls_chain(t0, sc, sh, key)
             return cls_lr, self._reg_chain(t0, sc, sh, key), ext
         # f16x3: layer k of the cls tower and of the reg tower are independent and identical in shape -> ONE
-        # launch each (gridDim.z = 2).  Fewer launches and fuller grids at small batch, neutral at batch 32.
-        xc, sc_c, sh_c = t0[..., :256], sc[:, :256], sh[:, :256]
-        xr, sc_r, sh_r = t0[..., 256:], sc[:, 256:], sh[:, 256:]
-        need = ops.gn_rows32_scratch_floats(n * hw, 256)
-        pc = self._scratch((key, "gc"), need, t0.device)
-        pr = self._scratch((key, "gr"), need, t0.device)
-        for cwc, (gc, bc), cwr, (gr, br) in zip(self.cls_tower, self.cls_gn, self.reg_tower, self.reg_gn):
-            xc, xr = ops.conv2d_nhwc_grouped([self._act(xc, sc_c, sh_c), self._act(xr, sc_r, sh_r)], [cwc, cwr], pad=1,
-                                             gn_partials=[pc, pr])
-            sc_c, sh_c = ops.groupnorm_finalize_rows32(pc, gc, bc, n, hw, 32)
-            sc_r, sh_r = ops.groupnorm_finalize_rows32(pr, gr, br, n, hw, 32)
-        ac = self._act(xc, sc_c, sh_c)
+        # launch each (gridDim.z = 2) whose two outputs stay stacked as [N,h,w,512] like tower0's, so that
+        # ONE GroupNorm finalize (64 groups) and ONE affine+split pass serve both towers of a layer.
+        part = self._scratch((key, "g2"), ops.gn_rows32_scratch_floats(n * hw, 512), t0.device)
+        for cwc, cwr, (g2, b2) in zip(self.cls_tower, self.reg_tower, self.both_gn):
+            a = self._act(t0, sc, sh)                                   # S32 [N,h,w,16,2,32]
+            t0 = ops.conv2d_nhwc_grouped([a[:, :, :, :8], a[:, :, :, 8:]], [cwc, cwr], pad=1, stacked_gn=part)
+            sc, sh = ops.groupnorm_finalize_rows32(part, g2, b2, n, hw, 64)
+        a = self._act(t0, sc, sh)
+        ac, ar = a[:, :, :, :8], a[:, :, :, 8:]
         cls_lr = self._out_conv(ac, self.cls_out)
         ext = self._out_conv(ac, self.ext_out, relu_cols=3) if self.ext else None
-        reg_ctr = self._out_conv(self._act(xr, sc_r, sh_r), self.reg_out, relu_cols=4)
+        reg_ctr = self._out_conv(ar, self.reg_out, relu_cols=4)
         return cls_lr, reg_ctr, ext
 
     def heads(self, feats):

@@ -285,11 +285,16 @@ def conv2d_nhwc(x, w, bias=None, *, stride=1, pad=0, dil=1, relu=False, relu_col
     return out
 
 
-def conv2d_nhwc_grouped(xs, ws, *, pad=0, relu=False, relu_cols=None, out_split=False, gn_partials=None, tile=0):
+def conv2d_nhwc_grouped(xs, ws, *, pad=0, relu=False, relu_cols=None, out_split=False, gn_partials=None, tile=0,
+                        stacked_gn=None):
     """Same-shape stride-1 f16x3 convolutions as ONE launch.  xs: S32 inputs; ws: ConvW-like objects with
     .w [Cout,R,S,Cin] / .bias / .w16 (all of one shape); gn_partials: None or one GroupNorm-sum buffer per member.
-    Returns the list of outputs.  A single member falls through to conv2d_nhwc."""
+    Returns the list of outputs.  A single member falls through to conv2d_nhwc.
+    stacked_gn: an fp32 buffer -> the members write channel slices of ONE fp32 tensor [N,oh,ow,k*Cout] and ONE
+    GroupNorm slab (k*Cout/8 units per row group); returns that stacked tensor instead of a list."""
     k = len(xs)
+    if stacked_gn is not None and (k < 2 or gn_partials is not None or out_split):
+        raise ValueError("stacked_gn needs >= 2 members, fp32 outputs and no separate gn_partials")
     if k != len(ws) or k == 0 or k > _lib.CONV_MAX_GROUP:
         raise ValueError(f"need 1..{_lib.CONV_MAX_GROUP} inputs and as many weight sets")
     if k == 1:
@@ -321,7 +326,23 @@ def conv2d_nhwc_grouped(xs, ws, *, pad=0, relu=False, relu_cols=None, out_split=
     outs = []
     grp = ConvGroup()
     grp.count = k
+    grp.gn_units = 0
+    if stacked_gn is not None:
+        if rc:
+            raise ValueError("stacked_gn needs outputs without ReLU")
+        need = lib.hn_groupnorm_rows32_scratch_floats(n * d.oh * d.ow, k * cout)
+        if stacked_gn.numel() < need or stacked_gn.dtype != torch.float32 or not stacked_gn.is_cuda:
+            raise ValueError(f"stacked_gn must be an fp32 GPU buffer of >= {need} floats")
+        stacked = torch.empty((n, d.oh, d.ow, k * cout), device=x0.device, dtype=torch.float32)
+        d.out_pix_stride = k * cout
+        grp.gn_units = k * cout // 8
+        for i, (x, cw) in enumerate(zip(xs, ws)):
+            grp.x16[i], grp.w16[i], grp.bias[i] = ptr(x), ptr(cw.w16), ptr(cw.bias)
+            grp.y[i] = stacked.data_ptr() + 4 * i * cout
+            grp.gn_partial[i] = stacked_gn.data_ptr() + 4 * 4 * i * (cout // 8)
     for i, (x, cw) in enumerate(zip(xs, ws)):
+        if stacked_gn is not None:
+            break
         if out_split:
             y = torch.empty((n, d.oh, d.ow, cout // 32, 2, 32), device=x.device, dtype=torch.float16)
         else:
@@ -338,7 +359,7 @@ def conv2d_nhwc_grouped(xs, ws, *, pad=0, relu=False, relu_cols=None, out_split=
         timer.stop()
         prof.append((("f16x3", lib.hn_conv2d_f16x3_pick_tile(C.byref(d))), k * n * d.oh * d.ow * cout * r * s * cin, timer,
                      (k * n, h, wd, cin, cout, r, 1, 1)))
-    return outs
+    return stacked if stacked_gn is not None else outs
 
 
 def maxpool3x3s2_nhwc(x, out=None):

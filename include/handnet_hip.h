@@ -33,7 +33,7 @@ extern "C" {
 #define HN_ERR_HIP 2
 
 /* ABI version; bumped whenever a struct below changes. */
-#define HN_ABI_VERSION 17
+#define HN_ABI_VERSION 18
 int hn_abi_version(void);
 const char* hn_last_error(void);
 
@@ -164,6 +164,10 @@ typedef struct hn_conv_group {
   const float* bias[HN_CONV_MAX_GROUP];
   void* y[HN_CONV_MAX_GROUP];
   float* gn_partial[HN_CONV_MAX_GROUP];
+  int32_t gn_units;  /* 8-channel units per 32-row group in the GroupNorm slab; 0 = cout/8.  With y[g] / gn_partial[g]
+                      * pointing at channel offset g*cout of ONE [rows][count*cout] tensor / slab (desc.out_pix_stride =
+                      * count*cout, gn_units = count*cout/8) the members' outputs stay stacked, so one
+                      * hn_groupnorm_finalize_rows32 and one hn_affine_split_f32 serve all of them. */
 } hn_conv_group;
 int hn_conv2d_nhwc_f16x3_grouped(const hn_conv_desc* desc, const hn_conv_group* group, void* stream);
 

@@ -394,3 +394,31 @@ def test_conv_f16x3_grouped_equals_separate_launches():
         assert torch.equal(y, ref) and torch.equal(part, ref_part)
     with pytest.raises(ValueError):
         ops.conv2d_nhwc_grouped([xs[0], wide[:, :, :, :16]], ws[:2], pad=1)     # different shapes
+
+
+def test_conv_f16x3_grouped_stacked_outputs_and_shared_gn_slab():
+    """Two grouped members writing channel halves of ONE fp32 tensor and ONE GroupNorm slab (the FCOS towers):
+    equals the two separate convolutions, and the 64-group finalize of the shared slab equals the statistics pass."""
+    from types import SimpleNamespace as NS
+    from hn_amd import ops
+    from hn_amd.weights import split_f16x3
+    g = torch.Generator().manual_seed(78)
+    n, h, w, c = 3, 10, 13, 256
+    a = ops.to_split(torch.randn((n, h, w, 2 * c), generator=g).cuda())
+    xs = [a[:, :, :, :8], a[:, :, :, 8:]]
+    ws = []
+    for i in range(2):
+        wt = torch.randn((c, 3, 3, c), generator=g) * (2.0 / (9 * c)) ** 0.5
+        ws.append(NS(w=wt.cuda(), bias=torch.randn((c,), generator=g).cuda(), w16=split_f16x3(wt).cuda()))
+    part = torch.full((ops.gn_rows32_scratch_floats(n * h * w, 2 * c),), float("nan"), device="cuda")
+    y = ops.conv2d_nhwc_grouped(xs, ws, pad=1, stacked_gn=part)
+    assert tuple(y.shape) == (n, h, w, 2 * c) and not torch.isnan(part).any()
+    for i in range(2):
+        ref = ops.conv2d_nhwc(xs[i], ws[i].w, ws[i].bias, pad=1, w16=ws[i].w16, splitk=False)
+        assert torch.equal(y[..., i * c:(i + 1) * c], ref)
+    gamma = (torch.rand((2 * c,), generator=g) + 0.5).cuda()
+    beta = (torch.randn((2 * c,), generator=g) * 0.1).cuda()
+    sc, sh = ops.groupnorm_finalize_rows32(part, gamma, beta, n, h * w, 64)
+    sc_ref, sh_ref = ops.groupnorm_affine(y, gamma, beta, groups=64)
+    assert (sc - sc_ref).abs().max().item() <= 2e-6 * sc_ref.abs().max().item()
+    assert (sh - sh_ref).abs().max().item() <= 2e-6 * max(1.0, sh_ref.abs().max().item())
