@@ -81,6 +81,8 @@ struct ConvParams16 {
   const float* gbias[HN_CONV_MAX_GROUP];
   void* gy[HN_CONV_MAX_GROUP];
   float* ggn[HN_CONV_MAX_GROUP];
+  int gH[HN_CONV_MAX_GROUP], gW[HN_CONV_MAX_GROUP], gOH[HN_CONV_MAX_GROUP], gOW[HN_CONV_MAX_GROUP];
+  int gM[HN_CONV_MAX_GROUP], gnblocks[HN_CONV_MAX_GROUP];   // members may differ in spatial size (FPN levels)
   int gn_units;       // 8-channel units per row group in the GroupNorm slab (Cout/8 unless members share a slab)
   int splits, kt_per, splitk_mode;
   float* split_ws;
@@ -229,6 +231,38 @@ struct HalfSched {
 template <int BM, int BN, int WM, int WN, int NBUF>
 __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const ConvParams16 p) {
   static_assert(NBUF >= 2 && NBUF <= 6, "2..6 LDS stages");
+  // Grouped launch: workgroup z works on member z -- its own tensors and, for FPN levels, its own spatial size.
+  // Only these fields differ per member; they live in a small local struct `o` (picked with constant-index
+  // selects: a dynamic index into the kernel-argument arrays would send the whole parameter block through
+  // scratch memory, -40 % on every convolution; copying the whole block and patching it spills 480 SGPRs).
+  // Workgroups beyond a smaller member's tile count leave at once.
+  struct {
+    const _Float16 *x, *w;
+    const float* bias;
+    void* y;
+    float* gn_partial;
+    int H, W, pitch, OH, OW, M, nblocks;
+  } o = {p.x, p.w, p.bias, p.y, p.gn_partial, p.H, p.W, p.pitch, p.OH, p.OW, p.M, p.nblocks};
+  if (p.groups > 1) {
+    const int gz = (int)blockIdx.z;
+#define HN_GROUP_SEL(arr) \
+  (gz == 0 ? p.arr[0] : gz == 1 ? p.arr[1] : gz == 2 ? p.arr[2] : gz == 3 ? p.arr[3] : gz == 4 ? p.arr[4] : p.arr[5])
+    static_assert(HN_CONV_MAX_GROUP == 6, "select chain covers six members");
+    o.nblocks = HN_GROUP_SEL(gnblocks);
+    if ((int)blockIdx.x >= o.nblocks) return;
+    o.x = HN_GROUP_SEL(gx);
+    o.w = HN_GROUP_SEL(gw);
+    o.bias = HN_GROUP_SEL(gbias);
+    o.y = HN_GROUP_SEL(gy);
+    o.gn_partial = HN_GROUP_SEL(ggn);
+    o.H = HN_GROUP_SEL(gH);
+    o.W = HN_GROUP_SEL(gW);
+    o.pitch = o.W;
+    o.OH = HN_GROUP_SEL(gOH);
+    o.OW = HN_GROUP_SEL(gOW);
+    o.M = HN_GROUP_SEL(gM);
+#undef HN_GROUP_SEL
+  }
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;  // 16x16 MFMA tiles per wave
   static_assert(TM >= 2 && TM % 2 == 0 && TN >= 2 && TN % 2 == 0, "wave tile must be a multiple of 32x32");
@@ -243,7 +277,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
 
   int lid;
   {
-    const int bid = blockIdx.x, nb = p.nblocks;
+    const int bid = blockIdx.x, nb = o.nblocks;
     const int q = nb >> 3, rr = nb & 7, xcd = bid & 7, loc = bid >> 3;
     lid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
   }
@@ -251,15 +285,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave - wm * WN;
-  const int ohow = p.OH * p.OW;
+  const int ohow = o.OH * o.OW;
 
-  // grouped launch: workgroup z works on problem z (same shapes, its own tensors)
-  // (constant indices + selects: a dynamic index into the kernel-argument arrays would send the whole
-  // parameter block through scratch memory -- measured: -40 % on every convolution)
-  const int gz = p.groups > 1 ? (int)blockIdx.z : 0;
-#define HN_GROUP_SEL(arr) (gz == 0 ? p.arr[0] : gz == 1 ? p.arr[1] : gz == 2 ? p.arr[2] : p.arr[3])
-  const _Float16* x_base = p.groups > 1 ? HN_GROUP_SEL(gx) : p.x;
-  const _Float16* w_base = p.groups > 1 ? HN_GROUP_SEL(gw) : p.w;
 
   // ---- DMA geometry: lane -> (row = tid >> 3 within a pass, LDS position pos = tid & 7) ----
   const int drow = tid >> 3, dpos = tid & 7;
@@ -269,15 +296,15 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
   for (int it = 0; it < A_IT; ++it) {
     const int row = drow + it * ROWS_PASS;
     int m = m0 + row;
-    m = m < p.M ? m : p.M - 1;  // rows >= M are never stored
+    m = m < o.M ? m : o.M - 1;  // rows >= M are never stored
     const int img = m / ohow;
     const int rem = m - img * ohow;
-    const int oh = rem / p.OW, ow = rem - oh * p.OW;
+    const int oh = rem / o.OW, ow = rem - oh * o.OW;
     a_ih0[it] = oh * p.stride - p.pad;
     a_iw0[it] = ow * p.stride - p.pad;
     const int chunk = dpos ^ swz(row);  // source chunk that belongs at this LDS position: 0-3 hi run, 4-7 lo run
     a_cc[it] = chunk * 8;
-    a_row[it] = x_base + (((long)img * p.H + a_ih0[it]) * p.pitch + a_iw0[it]) * p.xs + (chunk & 3) * 8 +
+    a_row[it] = o.x + (((long)img * o.H + a_ih0[it]) * o.pitch + a_iw0[it]) * p.xs + (chunk & 3) * 8 +
                 (chunk >> 2) * p.lo_off;
   }
   const _Float16* b_ptr[B_IT];
@@ -286,7 +313,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
     const int row = drow + it * ROWS_PASS;
     int n = n0 + row;
     n = n < p.Cout ? n : p.Cout - 1;  // columns >= Cout are never stored
-    b_ptr[it] = w_base + (long)n * p.Ktot * 2 + (dpos ^ swz(row)) * 8;
+    b_ptr[it] = o.w + (long)n * p.Ktot * 2 + (dpos ^ swz(row)) * 8;
   }
   // wave-uniform LDS row base of this wave's 8-row group inside a pass
   const int grp_row = __builtin_amdgcn_readfirstlane(wave) * 8;
@@ -304,7 +331,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
 
   // one DMA instruction (8 rows x 128 B per wave): A piece `it` gathers im2col rows, B piece `it` weight rows
   auto dma_a_piece = [&](int it, _Float16* Ad, int dr, int ds, long uoff) {
-    const bool ok = (unsigned)(a_ih0[it] + dr) < (unsigned)p.H && (unsigned)(a_iw0[it] + ds) < (unsigned)p.W;
+    const bool ok = (unsigned)(a_ih0[it] + dr) < (unsigned)o.H && (unsigned)(a_iw0[it] + ds) < (unsigned)o.W;
     const _Float16* src = ok ? a_row[it] + uoff : g_zero_page16 + a_cc[it];  // padding taps read zeros
     __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(Ad + (it * ROWS_PASS + grp_row) * ROWH), 16, 0, 0);
   };
@@ -328,7 +355,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
   };
   auto dma_tile = [&](int buf) {
     const int dr = cur_r * p.dil, ds = cur_s * p.dil;
-    const long uoff = ((long)dr * p.pitch + ds) * p.xs + (long)cur_cb * (2 * BK);  // wave-uniform
+    const long uoff = ((long)dr * o.pitch + ds) * p.xs + (long)cur_cb * (2 * BK);  // wave-uniform
     _Float16* Ad = As + buf * A_BUF;
     _Float16* Bd = Bs + buf * B_BUF;
 #pragma unroll
@@ -420,7 +447,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     const int dr = cur_r * p.dil, ds = cur_s * p.dil;
-    const long uoff = ((long)dr * p.pitch + ds) * p.xs + (long)cur_cb * (2 * BK);
+    const long uoff = ((long)dr * o.pitch + ds) * p.xs + (long)cur_cb * (2 * BK);
     const long boff = (long)load_t * (2 * BK);
     _Float16* Ad = As + cs * A_BUF;
     _Float16* Bd = Bs + cs * B_BUF;
@@ -483,14 +510,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
   // A split-K workgroup stores its raw fp32 partial tile into plane blockIdx.y of the workspace instead
   // (dense [M][Cout], no bias / residual / ReLU): the reduction kernel finishes the job.
   ConvParams16 q = p;
-  if (p.groups > 1) {
-    q.bias = HN_GROUP_SEL(gbias);
-    q.y = HN_GROUP_SEL(gy);
-    q.gn_partial = HN_GROUP_SEL(ggn);
-  }
-#undef HN_GROUP_SEL
+  q.x = o.x; q.w = o.w; q.bias = o.bias; q.y = o.y; q.gn_partial = o.gn_partial;
+  q.H = o.H; q.W = o.W; q.pitch = o.pitch; q.OH = o.OH; q.OW = o.OW; q.M = o.M;
   if (p.splits > 1) {
-    q.y = p.split_ws + (long)blockIdx.y * p.M * p.Cout;
+    q.y = p.split_ws + (long)blockIdx.y * o.M * p.Cout;
     q.ys = p.Cout;
     q.bias = nullptr;
     q.res_mode = 0;
@@ -536,7 +559,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
         const int n = n0 + wn * (BN / WN) + g * 8;
         const f32x4 c0 = *reinterpret_cast<const f32x4*>(&patch[prow * PWP + g * 8]);
         const f32x4 c1 = *reinterpret_cast<const f32x4*>(&patch[prow * PWP + g * 8 + 4]);
-        if (m >= p.M || n >= p.Cout) continue;
+        if (m >= o.M || n >= p.Cout) continue;
         float v[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -573,7 +596,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
 #pragma unroll
           for (int e = 0; e < 4; ++e) gsum[e] += __shfl_xor(gsum[e], o);
         const int n = n0 + wn * (BN / WN) + lane * 8;
-        if (lane < GROUPS && n < p.Cout && m_grp < p.M) {
+        if (lane < GROUPS && n < p.Cout && m_grp < o.M) {
           f32x4 o4 = {gsum[0], gsum[1], gsum[2], gsum[3]};
           *reinterpret_cast<f32x4*>(q.gn_partial + ((long)(m_grp >> 5) * p.gn_units + (n >> 3)) * 4) = o4;
         }
@@ -589,15 +612,15 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
     for (int r = 0; r < 4; ++r) {
       const int row = wm * (BM / WM) + i * 16 + lg * 4 + r;
       const int m = m0 + row;
-      if (m >= p.M) continue;
+      if (m >= o.M) continue;
       long rpix = 0;
       if (p.res_mode == 1) {
         rpix = (long)m;
       } else if (p.res_mode == 2) {
         const int img = m / ohow;
         const int rem = m - img * ohow;
-        const int oh = rem / p.OW, ow = rem - oh * p.OW;
-        const int sh_ = (int)(((long)oh * p.res_h) / p.OH), sw_ = (int)(((long)ow * p.res_w) / p.OW);
+        const int oh = rem / o.OW, ow = rem - oh * o.OW;
+        const int sh_ = (int)(((long)oh * p.res_h) / o.OH), sw_ = (int)(((long)ow * p.res_w) / o.OW);
         rpix = ((long)img * p.res_h + sh_) * p.res_w + sw_;
       }
 #pragma unroll
@@ -654,11 +677,17 @@ int launch16(const ConvParams16& p0, hipStream_t st) {
       p.splits = hn::cdiv(p.ktiles, p.kt_per);  // every split has at least one tile
     }
   }
+  int grid_x = p.nblocks;
   if (p.groups > 1) {  // grouped problems never split (the grid is already groups x larger)
     p.splits = 1;
     p.kt_per = p.ktiles;
+    grid_x = 0;
+    for (int g = 0; g < p.groups; ++g) {
+      p.gnblocks[g] = hn::cdiv(p.gM[g], BM) * p.tiles_n;
+      grid_x = grid_x > p.gnblocks[g] ? grid_x : p.gnblocks[g];
+    }
   }
-  hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, NBUF>), dim3(p.nblocks, p.splits, p.groups > 1 ? p.groups : 1),
+  hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, NBUF>), dim3(grid_x, p.splits, p.groups > 1 ? p.groups : 1),
                      dim3(WM * WN * 64), 0, st, p);
   HN_CHECK_LAUNCH("conv_igemm_f16x3_kernel");
   if (p.splits > 1) {
@@ -746,6 +775,8 @@ extern "C" int hn_conv2d_nhwc_f16x3_grouped(const hn_conv_desc* d, const hn_conv
                     group);
 }
 
+static inline bool gn_of_group_needs_32(const hn_conv_group* group, int g) { return group->gn_partial[g] != nullptr; }
+
 static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, const float* bias, const void* residual,
                       void* y, float* gn_partial, void* workspace, int64_t workspace_bytes, void* stream,
                       const hn_conv_group* group) {
@@ -790,17 +821,34 @@ static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, c
   p.splitk_mode = d->splitk;
   p.groups = 1;
   p.gn_units = d->cout >> 3;
+  hn_conv_desc tile_desc = *d;  // what the tile heuristic sees: for a group, all members' rows together
   if (group) {
     p.groups = group->count;
     if (group->gn_units > 0) p.gn_units = group->gn_units;
+    int64_t total_m = 0;
     for (int g = 0; g < group->count; ++g) {
+      const int gh = group->h[g] > 0 ? group->h[g] : d->h, gw = group->w[g] > 0 ? group->w[g] : d->w;
+      p.gH[g] = gh; p.gW[g] = gw;
+      p.gOH[g] = (gh + 2 * d->pad - d->dil * (d->r - 1) - 1) / d->stride + 1;
+      p.gOW[g] = (gw + 2 * d->pad - d->dil * (d->s - 1) - 1) / d->stride + 1;
+      HN_CHECK_ARG(p.gOH[g] > 0 && p.gOW[g] > 0, "group member %d has an empty output", g);
+      HN_CHECK_ARG((int64_t)d->n * p.gOH[g] * p.gOW[g] < (int64_t)1 << 31, "too many output pixels");
+      p.gM[g] = d->n * p.gOH[g] * p.gOW[g];
+      total_m += p.gM[g];
+      if (gn_of_group_needs_32(group, g)) HN_CHECK_ARG(p.gOH[g] * p.gOW[g] >= 32, "GroupNorm statistics need OH*OW >= 32");
       p.gx[g] = (const _Float16*)group->x16[g]; p.gw[g] = (const _Float16*)group->w16[g];
       p.gbias[g] = group->bias[g]; p.gy[g] = group->y[g]; p.ggn[g] = group->gn_partial[g];
       p.vec_epi = p.vec_epi && ((uintptr_t)group->y[g] % 16 == 0) &&
                   (group->bias[g] == nullptr || (uintptr_t)group->bias[g] % 16 == 0);
     }
-    p.gn_partial = group->gn_partial[0];   // the checks below apply to every member (same descriptor)
+    p.gn_partial = group->gn_partial[0];
     p.split_ws = nullptr;
+    if (group->gn_partial[0])
+      HN_CHECK_ARG(p.vec_epi && !d->out_split && d->relu_cols == 0,
+                   "GroupNorm statistics need the vector epilogue, fp32 output and no ReLU");
+    tile_desc.n = 1;
+    tile_desc.oh = (int)(total_m < ((int64_t)1 << 30) ? total_m : ((int64_t)1 << 30));
+    tile_desc.ow = 1;
   }
   p.splits = 1;
   p.kt_per = p.ktiles;
@@ -810,7 +858,7 @@ static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, c
     HN_CHECK_ARG(d->oh * d->ow >= 32, "GroupNorm statistics in the epilogue need OH*OW >= 32");
   }
   hipStream_t st = (hipStream_t)stream;
-  switch (hn_conv2d_f16x3_pick_tile(d)) {
+  switch (hn_conv2d_f16x3_pick_tile(&tile_desc)) {
     case HN_TILE_128x128: return launch16<128, 128, 2, 2, 2>(p, st);
     // LDS stage counts from an in-pipeline sweep (tools/stage_sweep.py): extra stages only pay
     // where they do not cost occupancy

@@ -11,7 +11,7 @@ from pathlib import Path
 
 from . import build as _build
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, TILE_256x128, TILE_64x128 = range(7)
 HN_FCOS_MAX_LEVELS = 5
@@ -28,13 +28,14 @@ class ConvDesc(C.Structure):
         "res_pix_stride", "in_pix_stride", "out_pix_stride", "in_affine_stride", "splitk")]
 
 
-CONV_MAX_GROUP = 4
+CONV_MAX_GROUP = 6
 
 
 class ConvGroup(C.Structure):  # == struct hn_conv_group
     _fields_ = [("count", C.c_int32), ("x16", C.c_void_p * CONV_MAX_GROUP), ("w16", C.c_void_p * CONV_MAX_GROUP),
                 ("bias", C.c_void_p * CONV_MAX_GROUP), ("y", C.c_void_p * CONV_MAX_GROUP),
-                ("gn_partial", C.c_void_p * CONV_MAX_GROUP), ("gn_units", C.c_int32)]
+                ("gn_partial", C.c_void_p * CONV_MAX_GROUP), ("h", C.c_int32 * CONV_MAX_GROUP),
+                ("w", C.c_int32 * CONV_MAX_GROUP), ("gn_units", C.c_int32)]
 
 
 class FcosLevels(C.Structure):

@@ -223,7 +223,9 @@ class FCOSEngine:
         part = self._scratch((key, "g2"), ops.gn_rows32_scratch_floats(n * hw, 512), t0.device)
         for cwc, cwr, (g2, b2) in zip(self.cls_tower, self.reg_tower, self.both_gn):
             a = self._act(t0, sc, sh)                                   # S32 [N,h,w,16,2,32]
-            t0 = ops.conv2d_nhwc_grouped([a[:, :, :, :8], a[:, :, :, 8:]], [cwc, cwr], pad=1, stacked_gn=part)
+            t0 = torch.empty((n, fh, fw, 512), device=t0.device, dtype=torch.float32)
+            ops.conv2d_nhwc_grouped([a[:, :, :, :8], a[:, :, :, 8:]], [cwc, cwr], pad=1, outs=[t0, t0],
+                                    out_channel_offsets=[0, 256], gn=[(part, 0), (part, 32)], gn_units=64)
             sc, sh = ops.groupnorm_finalize_rows32(part, g2, b2, n, hw, 64)
         a = self._act(t0, sc, sh)
         ac, ar = a[:, :, :, :8], a[:, :, :, 8:]
@@ -232,10 +234,42 @@ class FCOSEngine:
         reg_ctr = self._out_conv(ar, self.reg_out, relu_cols=4)
         return cls_lr, reg_ctr, ext
 
+    def heads_grouped(self, feats):
+        """All FPN levels in lockstep (f16x3): the tower weights are shared across levels and the cls / reg towers are
+        independent, so layer k of both towers on all levels is ONE grouped launch (gridDim.z = 2 x levels, members of
+        different map sizes); tower0 and each output conv are one launch over the levels.  6 conv launches per frame
+        batch instead of 18 -- and grids that fill the chip at batch 1."""
+        L = len(feats)
+        n = feats[0].shape[0]
+        dev = feats[0].device
+        dims = [tuple(f.shape[1:3]) for f in feats]
+        hw = [h * w for h, w in dims]
+        parts = [self._scratch(("lv", l), ops.gn_rows32_scratch_floats(n * hw[l], 512), dev) for l in range(L)]
+        new_t = lambda: [torch.empty((n, h, w, 512), device=dev, dtype=torch.float32) for h, w in dims]  # noqa: E731
+        t = new_t()
+        ops.conv2d_nhwc_grouped(feats, [self.tower0] * L, pad=1, outs=t, gn=[(parts[l], 0) for l in range(L)], gn_units=64)
+        aff = [ops.groupnorm_finalize_rows32(parts[l], self.gn0_gamma, self.gn0_beta, n, hw[l], 64) for l in range(L)]
+        for cwc, cwr, (g2, b2) in zip(self.cls_tower, self.reg_tower, self.both_gn):
+            a = [self._act(t[l], *aff[l]) for l in range(L)]            # S32 [N,h,w,16,2,32]: cls blocks 0-7, reg 8-15
+            t = new_t()
+            ops.conv2d_nhwc_grouped([x[:, :, :, :8] for x in a] + [x[:, :, :, 8:] for x in a], [cwc] * L + [cwr] * L,
+                                    pad=1, outs=t + t, out_channel_offsets=[0] * L + [256] * L,
+                                    gn=[(parts[l], 0) for l in range(L)] + [(parts[l], 32) for l in range(L)], gn_units=64)
+            aff = [ops.groupnorm_finalize_rows32(parts[l], g2, b2, n, hw[l], 64) for l in range(L)]
+        a = [self._act(t[l], *aff[l]) for l in range(L)]
+        ac, ar = [x[:, :, :, :8] for x in a], [x[:, :, :, 8:] for x in a]
+        cls_lr = ops.conv2d_nhwc_grouped(ac, [self.cls_out] * L, pad=1)
+        ext = ops.conv2d_nhwc_grouped(ac, [self.ext_out] * L, pad=1, relu_cols=3) if self.ext else [None] * L
+        reg_ctr = ops.conv2d_nhwc_grouped(ar, [self.reg_out] * L, pad=1, relu_cols=4)
+        return list(zip(cls_lr, reg_ctr, ext))
+
     def heads(self, feats):
         """All levels.  With head_streams > 1 the 2 x levels independent tower chains are spread over side
         streams so that the tail of one convolution's grid (e.g. 1700 workgroups on 512 slots at the
         stride-16 level) is filled by another chain's workgroups."""
+        if (self.head_streams <= 1 and self.group_towers and self.precision == "f16x3" and 2 * len(feats) <= 6
+                and all(f.shape[1] * f.shape[2] >= 32 for f in feats)):
+            return self.heads_grouped(feats)
         if self.head_streams <= 1:
             return [self.head_level(f, key=i) for i, f in enumerate(feats)]
         main = torch.cuda.current_stream()

@@ -72,6 +72,7 @@ def _pixel_stride(t: torch.Tensor, name: str) -> int:
 
 
 _DESC_TEMPLATES = {}
+_CONV_PLANS = {}
 
 
 def make_conv_desc(n, h, w, cin, cout, r, s, stride=1, pad=0, dil=1, relu_cols=0, res_mode=0,
@@ -184,6 +185,24 @@ def conv2d_nhwc(x, w, bias=None, *, stride=1, pad=0, dil=1, relu=False, relu_col
     gn_partial -> (f16x3, fp32 output, no residual / ReLU) fp32 scratch of gn_rows32_scratch_floats(rows, Cout)
                   floats: the epilogue also writes GroupNorm partial sums for groupnorm_finalize_rows32()."""
     lib = _lib.load()
+    # Plan cache: a call whose tensors have the shapes / strides / flags of an earlier call reuses that call's
+    # validated descriptor (the checks below cost more host time than the launch at batch 1).
+    plan_key = None
+    if (out is None and in_scale is None and w16 is not None and gn_partial is None and CONV_PROFILE is None
+            and x.dtype == torch.float16 and x.is_cuda):
+        plan_key = (x.device.index, x.shape, x.stride(), w.data_ptr(), w16.data_ptr(), None if bias is None else bias.data_ptr(),
+                    stride, pad, dil, relu, relu_cols, tile, out_split, res_upsample, splitk, SPLITK, SPLITK_EAGER,
+                    None if residual is None else (residual.shape, residual.stride(), residual.dtype))
+        plan = _CONV_PLANS.get(plan_key)
+        if plan is not None:
+            tpl, out_shape, out_dtype, use_ws = plan
+            d = ConvDesc.from_buffer_copy(tpl)
+            out = torch.empty(out_shape, device=x.device, dtype=out_dtype)
+            ws = _conv_workspace(x.device) if use_ws else None
+            check(lib.hn_conv2d_nhwc_f16x3_ws(C.byref(d), ptr(x), ptr(w16), ptr(bias), ptr(residual), ptr(out),
+                                              ptr(ws), ws.numel() * 4 if use_ws else 0, _stream()),
+                  "hn_conv2d_nhwc_f16x3_ws")
+            return out
     _req(w, name="w")
     cout, r, s, cin = w.shape
     use16 = w16 is not None
@@ -266,6 +285,11 @@ def conv2d_nhwc(x, w, bias=None, *, stride=1, pad=0, dil=1, relu=False, relu_col
             splitk = splitk and SPLITK
             d.splitk = (1 if SPLITK_EAGER else 0) if splitk else -1
             ws = _conv_workspace(x.device) if splitk else None
+            if plan_key is not None:
+                if bias is not None and not bias.is_contiguous():
+                    plan_key = None
+                else:
+                    _CONV_PLANS[plan_key] = (ConvDesc.from_buffer_copy(d), tuple(out.shape), out.dtype, bool(splitk))
             check(lib.hn_conv2d_nhwc_f16x3_ws(C.byref(d), ptr(x), ptr(w16), ptr(bias), ptr(residual), ptr(out),
                                               ptr(ws), ws.numel() * 4 if splitk else 0, _stream()),
                   "hn_conv2d_nhwc_f16x3_ws")
@@ -285,71 +309,74 @@ def conv2d_nhwc(x, w, bias=None, *, stride=1, pad=0, dil=1, relu=False, relu_col
     return out
 
 
-def conv2d_nhwc_grouped(xs, ws, *, pad=0, relu=False, relu_cols=None, out_split=False, gn_partials=None, tile=0,
-                        stacked_gn=None):
-    """Same-shape stride-1 f16x3 convolutions as ONE launch.  xs: S32 inputs; ws: ConvW-like objects with
-    .w [Cout,R,S,Cin] / .bias / .w16 (all of one shape); gn_partials: None or one GroupNorm-sum buffer per member.
-    Returns the list of outputs.  A single member falls through to conv2d_nhwc.
-    stacked_gn: an fp32 buffer -> the members write channel slices of ONE fp32 tensor [N,oh,ow,k*Cout] and ONE
-    GroupNorm slab (k*Cout/8 units per row group); returns that stacked tensor instead of a list."""
+def conv2d_nhwc_grouped(xs, ws, *, pad=0, relu=False, relu_cols=None, out_split=False, tile=0, gn_partials=None,
+                        outs=None, out_channel_offsets=None, gn=None, gn_units=0):
+    """Independent stride-1 f16x3 convolutions with identical channels / filter / batch as ONE launch
+    (gridDim.z = member); the members may differ in spatial size (the FPN levels of one layer).
+      xs            S32 inputs (same N, channels and pixel stride); ws: ConvW-like objects (.w [Cout,R,S,Cin], .bias,
+                    .w16), all of one shape
+      outs          optional preallocated outputs (one per member, or the same tensor several times); member i writes
+                    channels [out_channel_offsets[i], +Cout) of outs[i] -- stacking members in one wide tensor keeps
+                    e.g. the cls / reg towers of a level together.  Default: fresh dense outputs.
+      gn_partials   one GroupNorm-sum buffer per member (each Cout/8 units wide), or
+      gn, gn_units  [(buffer, unit offset)] per member into slabs that are gn_units units wide (stacked members).
+    Returns the list of outputs.  A single plain member falls through to conv2d_nhwc."""
     k = len(xs)
-    if stacked_gn is not None and (k < 2 or gn_partials is not None or out_split):
-        raise ValueError("stacked_gn needs >= 2 members, fp32 outputs and no separate gn_partials")
     if k != len(ws) or k == 0 or k > _lib.CONV_MAX_GROUP:
         raise ValueError(f"need 1..{_lib.CONV_MAX_GROUP} inputs and as many weight sets")
-    if k == 1:
+    if k == 1 and outs is None and gn is None:
         return [conv2d_nhwc(xs[0], ws[0].w, ws[0].bias, pad=pad, relu=relu, relu_cols=relu_cols, w16=ws[0].w16,
                             out_split=out_split, tile=tile, gn_partial=None if gn_partials is None else gn_partials[0])]
     lib = _lib.load()
     cout, r, s, cin = ws[0].w.shape
     x0 = xs[0]
     xstride = _pixel_stride(x0, "x")
-    n, h, wd = x0.shape[:3]
+    n = x0.shape[0]
     for x, cw in zip(xs, ws):
-        if not is_split(x) or tuple(x.shape) != tuple(x0.shape) or _pixel_stride(x, "x") != xstride:
-            raise ValueError("grouped inputs must be S32 tensors of one shape and pixel stride")
+        if not is_split(x) or x.shape[0] != n or channels(x) != cin or _pixel_stride(x, "x") != xstride:
+            raise ValueError("grouped inputs must be S32 tensors of one batch size, channel count and pixel stride")
         if tuple(cw.w.shape) != (cout, r, s, cin) or cw.w16 is None or (cw.bias is None) != (ws[0].bias is None):
             raise ValueError("grouped weights must share one shape (and all or none have a bias)")
-    if channels(x0) != cin:
-        raise ValueError(f"weight Cin {cin} != input channels {channels(x0)}")
     rc = (cout if relu else 0) if relu_cols is None else relu_cols
-    d = make_conv_desc(n, h, wd, cin, cout, r, s, 1, pad, 1, rc, 0, 0, 0, 0, tile,
+    h0, w0 = x0.shape[1:3]
+    d = make_conv_desc(n, h0, w0, cin, cout, r, s, 1, pad, 1, rc, 0, 0, 0, 0, tile,
                        in_pix_stride=0 if xstride == 2 * cin else xstride)
-    d.out_split = 1 if out_split else 0
     d.splitk = -1
     if gn_partials is not None:
-        if out_split or rc:
-            raise ValueError("gn_partials need fp32 outputs without ReLU")
-        need = lib.hn_groupnorm_rows32_scratch_floats(n * d.oh * d.ow, cout)
-        if len(gn_partials) != k or any(g.numel() < need or g.dtype != torch.float32 or not g.is_cuda for g in gn_partials):
-            raise ValueError(f"need {k} fp32 GPU gn_partial buffers of >= {need} floats")
-    outs = []
+        if gn is not None or len(gn_partials) != k:
+            raise ValueError("give gn_partials (one per member) or gn, not both")
+        gn, gn_units = [(g, 0) for g in gn_partials], 0
+    if gn is not None and (rc or out_split):
+        raise ValueError("GroupNorm sums need fp32 outputs without ReLU")
+    sizes = [conv_out_size(x.shape[1], x.shape[2], r, s, 1, pad, 1) for x in xs]
+    if outs is None:
+        if out_split:
+            outs = [torch.empty((n, oh, ow, cout // 32, 2, 32), device=x0.device, dtype=torch.float16) for oh, ow in sizes]
+        else:
+            outs = [torch.empty((n, oh, ow, cout), device=x0.device, dtype=torch.float32) for oh, ow in sizes]
+    offs = [0] * k if out_channel_offsets is None else list(out_channel_offsets)
+    ystride = _pixel_stride(outs[0], "out")
+    d.out_split = 1 if is_split(outs[0]) else 0
+    d.out_pix_stride = 0 if ystride == (2 * cout if d.out_split else cout) else ystride
     grp = ConvGroup()
     grp.count = k
-    grp.gn_units = 0
-    if stacked_gn is not None:
-        if rc:
-            raise ValueError("stacked_gn needs outputs without ReLU")
-        need = lib.hn_groupnorm_rows32_scratch_floats(n * d.oh * d.ow, k * cout)
-        if stacked_gn.numel() < need or stacked_gn.dtype != torch.float32 or not stacked_gn.is_cuda:
-            raise ValueError(f"stacked_gn must be an fp32 GPU buffer of >= {need} floats")
-        stacked = torch.empty((n, d.oh, d.ow, k * cout), device=x0.device, dtype=torch.float32)
-        d.out_pix_stride = k * cout
-        grp.gn_units = k * cout // 8
-        for i, (x, cw) in enumerate(zip(xs, ws)):
-            grp.x16[i], grp.w16[i], grp.bias[i] = ptr(x), ptr(cw.w16), ptr(cw.bias)
-            grp.y[i] = stacked.data_ptr() + 4 * i * cout
-            grp.gn_partial[i] = stacked_gn.data_ptr() + 4 * 4 * i * (cout // 8)
-    for i, (x, cw) in enumerate(zip(xs, ws)):
-        if stacked_gn is not None:
-            break
-        if out_split:
-            y = torch.empty((n, d.oh, d.ow, cout // 32, 2, 32), device=x.device, dtype=torch.float16)
-        else:
-            y = torch.empty((n, d.oh, d.ow, cout), device=x.device, dtype=torch.float32)
-        outs.append(y)
-        grp.x16[i], grp.w16[i], grp.bias[i], grp.y[i] = ptr(x), ptr(cw.w16), ptr(cw.bias), ptr(y)
-        grp.gn_partial[i] = None if gn_partials is None else ptr(gn_partials[i])
+    grp.gn_units = int(gn_units)
+    units = gn_units if gn_units else cout // 8
+    for i, (x, cw, y, (oh, ow)) in enumerate(zip(xs, ws, outs, sizes)):
+        if (tuple(y.shape[:3]) != (n, oh, ow) or is_split(y) != bool(d.out_split) or _pixel_stride(y, "out") != ystride
+                or offs[i] % 32 or offs[i] + cout > channels(y)):
+            raise ValueError("grouped outputs must match their member's size and share type / pixel stride")
+        elt = 2 if d.out_split else 4
+        grp.x16[i], grp.w16[i], grp.bias[i] = ptr(x), ptr(cw.w16), ptr(cw.bias)
+        grp.y[i] = y.data_ptr() + elt * (2 * offs[i] if d.out_split else offs[i])
+        grp.h[i], grp.w[i] = x.shape[1], x.shape[2]
+        grp.gn_partial[i] = None
+        if gn is not None:
+            buf, uoff = gn[i]
+            need = lib.hn_groupnorm_rows32_scratch_floats(n * oh * ow, units * 8)
+            if buf.numel() < need or buf.dtype != torch.float32 or not buf.is_cuda or uoff * 8 + cout > units * 8:
+                raise ValueError(f"member {i}: GroupNorm slab must be an fp32 GPU buffer of >= {need} floats")
+            grp.gn_partial[i] = buf.data_ptr() + 16 * uoff
     prof = CONV_PROFILE
     if prof is not None:
         timer = HipTimer()
@@ -357,9 +384,11 @@ def conv2d_nhwc_grouped(xs, ws, *, pad=0, relu=False, relu_cols=None, out_split=
     check(lib.hn_conv2d_nhwc_f16x3_grouped(C.byref(d), C.byref(grp), _stream()), "hn_conv2d_nhwc_f16x3_grouped")
     if prof is not None:
         timer.stop()
-        prof.append((("f16x3", lib.hn_conv2d_f16x3_pick_tile(C.byref(d))), k * n * d.oh * d.ow * cout * r * s * cin, timer,
-                     (k * n, h, wd, cin, cout, r, 1, 1)))
-    return stacked if stacked_gn is not None else outs
+        rows = sum(n * oh * ow for oh, ow in sizes)
+        tot = make_conv_desc(1, rows, 1, cin, cout, 1, 1)          # what the tile heuristic saw: all rows together
+        prof.append((("f16x3", lib.hn_conv2d_f16x3_pick_tile(C.byref(tot))), rows * cout * r * s * cin, timer,
+                     (1, rows, 1, cin, cout, r, 1, 1)))
+    return outs
 
 
 def maxpool3x3s2_nhwc(x, out=None):

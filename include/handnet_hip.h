@@ -33,7 +33,7 @@ extern "C" {
 #define HN_ERR_HIP 2
 
 /* ABI version; bumped whenever a struct below changes. */
-#define HN_ABI_VERSION 18
+#define HN_ABI_VERSION 19
 int hn_abi_version(void);
 const char* hn_last_error(void);
 
@@ -151,12 +151,12 @@ int hn_conv2d_nhwc_f16x3_ws(const hn_conv_desc* desc, const void* x16, const voi
                             const float* bias, const void* residual, void* y,
                             void* workspace, int64_t workspace_bytes, void* stream);
 
-/* Up to HN_CONV_MAX_GROUP convolutions that share ONE descriptor (identical shapes, strides and epilogue flags; no
- * residual, no split-K) as a single launch: member g reads x16[g] / w16[g] / bias[g] (bias may be NULL) and writes
+/* Up to HN_CONV_MAX_GROUP convolutions that share ONE descriptor (identical channels, filter, batch, strides and epilogue
+ * flags -- only the spatial size may differ per member; no residual, no split-K) as a single launch: member g reads x16[g] / w16[g] / bias[g] (bias may be NULL) and writes
  * y[g]; gn_partial[g] is either given for every member (semantics of hn_conv2d_nhwc_f16x3_gn) or NULL for all.
  * Used for the cls / reg tower layers of an FPN level (fcos.py:276,377) and the three A2J head layers
  * (a2j/a2j.py:70-181), which are independent and identical in shape. */
-#define HN_CONV_MAX_GROUP 4
+#define HN_CONV_MAX_GROUP 6
 typedef struct hn_conv_group {
   int32_t count;
   const void* x16[HN_CONV_MAX_GROUP];
@@ -164,6 +164,8 @@ typedef struct hn_conv_group {
   const float* bias[HN_CONV_MAX_GROUP];
   void* y[HN_CONV_MAX_GROUP];
   float* gn_partial[HN_CONV_MAX_GROUP];
+  int32_t h[HN_CONV_MAX_GROUP], w[HN_CONV_MAX_GROUP];  /* per-member input size; 0 = the descriptor's (members may be the
+                      * FPN levels of one layer: same channels / filter / batch, different maps) */
   int32_t gn_units;  /* 8-channel units per 32-row group in the GroupNorm slab; 0 = cout/8.  With y[g] / gn_partial[g]
                       * pointing at channel offset g*cout of ONE [rows][count*cout] tensor / slab (desc.out_pix_stride =
                       * count*cout, gn_units = count*cout/8) the members' outputs stay stacked, so one

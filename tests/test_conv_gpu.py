@@ -411,8 +411,10 @@ def test_conv_f16x3_grouped_stacked_outputs_and_shared_gn_slab():
         wt = torch.randn((c, 3, 3, c), generator=g) * (2.0 / (9 * c)) ** 0.5
         ws.append(NS(w=wt.cuda(), bias=torch.randn((c,), generator=g).cuda(), w16=split_f16x3(wt).cuda()))
     part = torch.full((ops.gn_rows32_scratch_floats(n * h * w, 2 * c),), float("nan"), device="cuda")
-    y = ops.conv2d_nhwc_grouped(xs, ws, pad=1, stacked_gn=part)
-    assert tuple(y.shape) == (n, h, w, 2 * c) and not torch.isnan(part).any()
+    y = torch.empty((n, h, w, 2 * c), device="cuda")
+    ops.conv2d_nhwc_grouped(xs, ws, pad=1, outs=[y, y], out_channel_offsets=[0, c], gn=[(part, 0), (part, c // 8)],
+                            gn_units=2 * c // 8)
+    assert not torch.isnan(part).any()
     for i in range(2):
         ref = ops.conv2d_nhwc(xs[i], ws[i].w, ws[i].bias, pad=1, w16=ws[i].w16, splitk=False)
         assert torch.equal(y[..., i * c:(i + 1) * c], ref)
@@ -422,3 +424,21 @@ def test_conv_f16x3_grouped_stacked_outputs_and_shared_gn_slab():
     sc_ref, sh_ref = ops.groupnorm_affine(y, gamma, beta, groups=64)
     assert (sc - sc_ref).abs().max().item() <= 2e-6 * sc_ref.abs().max().item()
     assert (sh - sh_ref).abs().max().item() <= 2e-6 * max(1.0, sh_ref.abs().max().item())
+
+
+def test_conv_f16x3_grouped_members_of_different_spatial_size():
+    """The FPN-level case: same weights / channels / batch, three map sizes, one launch; each member equals its own
+    single launch, including the 5-channel (scalar-epilogue) output convs with a partial ReLU."""
+    from types import SimpleNamespace as NS
+    from hn_amd import ops
+    from hn_amd.weights import split_f16x3
+    g = torch.Generator().manual_seed(79)
+    n, cin = 2, 64
+    xs = [ops.to_split(torch.randn((n, h, w, cin), generator=g).cuda()) for h, w in ((20, 28), (10, 14), (5, 7))]
+    for cout, rc in ((128, None), (5, 4)):
+        wt = torch.randn((cout, 3, 3, cin), generator=g) * (2.0 / (9 * cin)) ** 0.5
+        cw = NS(w=wt.cuda(), bias=torch.randn((cout,), generator=g).cuda(), w16=split_f16x3(wt).cuda())
+        ys = ops.conv2d_nhwc_grouped(xs, [cw] * 3, pad=1, relu_cols=rc)
+        for x, y in zip(xs, ys):
+            ref = ops.conv2d_nhwc(x, cw.w, cw.bias, pad=1, relu_cols=rc, w16=cw.w16, splitk=False)
+            assert y.shape == ref.shape and torch.equal(y, ref)

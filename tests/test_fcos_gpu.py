@@ -242,9 +242,10 @@ def test_fcos_ext_matches_reference_golden(golden_dir):
     assert matched >= 0.98 * len(g["labels"]) and len(boxes) <= 1.02 * len(g["labels"]) + 1
 
 
-def test_head_side_streams_give_identical_results(fcos_sd, oracle_run):
+def test_head_side_streams_agree_with_default_path(fcos_sd, oracle_run):
     """FCOSEngine(head_streams=6) runs the six independent tower chains on side streams (off by default: it
-    measured 1.5 % slower); same kernels, same order inside a chain => bit-identical detections."""
+    measured slower).  The default path groups the same convolutions into lock-step launches with other tile
+    shapes, whose GroupNorm partial sums are reduced in a different order: same detections to fp32 rounding."""
     from hn_amd.fcos_engine import FCOSEngine
     rgb, _, _ = oracle_run
     a = FCOSEngine(fcos_sd, 3, device="cuda", head_streams=1)
@@ -252,8 +253,12 @@ def test_head_side_streams_give_identical_results(fcos_sd, oracle_run):
     da, _ = a.detect(rgb.cuda())
     db, _ = b.detect(rgb.cuda())
     torch.cuda.synchronize()
-    assert torch.equal(da.count, db.count) and int(da.count.min()) > 0
-    assert torch.equal(da.boxes, db.boxes) and torch.equal(da.scores, db.scores) and torch.equal(da.labels, db.labels)
+    for i in range(rgb.shape[0]):
+        ka, kb = int(da.count[i]), int(db.count[i])
+        assert ka > 0 and abs(ka - kb) <= 1
+        k = min(ka, kb)
+        same = ((da.boxes[i, :k] - db.boxes[i, :k]).abs().max(dim=1)[0] < 1e-3) & (da.labels[i, :k] == db.labels[i, :k])
+        assert int(same.sum()) >= 0.98 * k
 
 
 def test_other_frame_size_wide(fcos_sd, engine):
