@@ -495,6 +495,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
   });
   static_for<0, TM>([&](auto I) { lds_read_pinned<decltype(I)::value * TILE_OFF>(af.l[decltype(I)::value], a_rd_lo); });
   static_for<0, TM>([&](auto I) { lds_read_pinned<decltype(I)::value * TILE_OFF>(af.h[decltype(I)::value], a_rd_hi); });
+  // A wait the compiler's counter model can see (the asm ones it cannot): every kernel-argument load it still has
+  // in flight retires HERE.  Otherwise the compiler may defer that wait to the first use inside the loop, where it
+  // becomes an s_waitcnt lgkmcnt(0) per iteration that also drains the pinned LDS reads (seen once while adding
+  // code to the epilogue: -13 % at batch 32).
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
   int cs = 0, ns = 1;
   for (int t = 0; t < T; ++t) {
     step_main(cs, ns);
