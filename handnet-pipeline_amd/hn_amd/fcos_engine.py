@@ -142,6 +142,9 @@ class FCOSEngine:
         lat5 = self._conv(c5, self.inner[2])
         lat4 = self._conv(c4, self.inner[1], residual=lat5, res_upsample=True)
         lat3 = self._conv(c3, self.inner[0], residual=lat4, res_upsample=True)
+        if self.precision == "f16x3" and self.group_towers:
+            # the three FPN output convs (own weights, own map size) are independent: one grouped launch
+            return ops.conv2d_nhwc_grouped([lat3, lat4, lat5], self.layer, pad=1, out_split=True)
         return [self._conv(lat3, self.layer[0]), self._conv(lat4, self.layer[1]), self._conv(lat5, self.layer[2])]
 
     def _scratch(self, key, need, device):
