@@ -4,6 +4,11 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Both forms run N ranks, one per GPU: started without a torchrun environment and with --gpus > 1, this
+file launches `python -m torch.distributed.run` on itself BEFORE anything touches the GPU (the parent
+never initialises HIP, relays the children's output and exits with their status).  A world size that
+differs from --gpus is an error, never a silent single-GPU run.
+
 One "step" = one pass of HandNet (FCOS detector, top-1 hand crop, A2J) over one batch of
 synthetic 640x480 RGB-D frames already resident in HBM, plus -- for N > 1 -- the all-gather
 of the per-frame results (RCCL).  Weak scaling: every rank processes its own `--batch`
@@ -11,18 +16,27 @@ frames (BASELINE.json config 4: 32 frames on one GPU; config 5: 8 x 32).  Rank 0
 JSON line; `value` is whole-job frames/s = N * batch * K / max-over-ranks(time).
 
 Extra objects in the line:
-  roofline      dominant kernel (an instantiation of conv_igemm_f32_kernel): algorithmic
-                FLOP per launch / average launch duration, both measured live with HIP events
-                on the launch stream over K instrumented steps, vs the 157.3 TFLOP/s
-                f32-MFMA peak (MI355X_MICROARCH.md).
+  roofline      dominant kernel (the conv_igemm_f16x3_kernel instantiation with the largest share of
+                the step; conv_igemm_f32_kernel with --precision f32): ALGORITHMIC FLOP per launch /
+                average launch duration, both measured live with HIP events on the launch stream
+                over instrumented steps, vs the dense f16 MFMA peak of 2.5 PFLOP/s (157.3 TFLOP/s
+                f32-MFMA peak in f32 mode; MI355X_MICROARCH.md).  f16x3 issues 3 MFMAs per
+                algorithmic MAC; the issued rate is reported beside it.  `clock_mhz` is the shader
+                clock sampled in-kernel (s_memtime / s_memrealtime) on a side stream WHILE the
+                instrumented steps run.  `traffic` is the HBM byte count per launch from the committed
+                rocprofv3 PMC passes (profiles/traffic_latest.json) and is null unless that
+                collection was made at the same launches/step and FLOP/launch (`traffic_source`).
   cpu_baseline  the oracle (CPU restatement, kind "port") timed on this box's host cores on a
-                bounded sample of the same workload (rank 0, N == 1 only).
+                bounded sample of the same workload (rank 0, N == 1 only); the same frames go
+                through the HIP engine and the agreement is reported as `parity`.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -53,7 +67,8 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=4, help="frames in the bounded CPU sample")
+    ap.add_argument("--cpu-frames", type=int, default=32,
+                    help="frames in the bounded CPU sample (also the frames of the HIP-vs-oracle parity figures)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo = rehearsal of the N > 1 plumbing on a box with fewer GPUs than ranks "
                          "(results are gathered through host memory; not a performance mode)")
@@ -133,17 +148,24 @@ def build_workload(args, dev, rank):
     return step, info, (fcos_sd, a2j_sd)
 
 
-def roofline_leg(step, steps):
-    """Bracket every conv launch with HIP events (on the launch stream) for `steps` steps."""
+def roofline_leg(step, steps, ms_per_step):
+    """Bracket every conv launch with HIP events (on the launch stream) for `steps` steps; a one-wave sampler on a
+    side stream reads the shader clock the chip holds meanwhile."""
     from hn_amd import ops
+    side = torch.cuda.Stream()
+    clock = torch.zeros((1,), device="cuda", dtype=torch.float32)
+    torch.cuda.synchronize()
     ops.CONV_PROFILE = []
     try:
+        step()                                    # chip under load before the sampling window opens
+        ops.clock_sample(max(1000, int(0.8 * 1e3 * ms_per_step * steps)), out=clock, stream=side)
         for _ in range(steps):
             step()
         torch.cuda.synchronize()
         recs = ops.CONV_PROFILE
     finally:
         ops.CONV_PROFILE = None
+    clock_mhz = float(clock.item())
     groups = {}
     for kind, macs, timer, shape in recs:
         g = groups.setdefault(kind, {"ms": 0.0, "flop": 0.0, "launches": 0, "bytes": 0.0})
@@ -158,19 +180,29 @@ def roofline_leg(step, steps):
     (prec, tile), g = max(groups.items(), key=lambda kv: kv[1]["ms"])
     tot_ms = sum(v["ms"] for v in groups.values())
     tot_flop = sum(v["flop"] for v in groups.values())
+    steps += 1                                    # the load-up step was instrumented too
     achieved = g["flop"] / (g["ms"] * 1e-3) / 1e12
     # f16x3 issues 3 f16 MFMAs per algorithmic MAC; `achieved` stays ALGORITHMIC FLOP/s and is
     # priced against the dense f16 MFMA peak (the issued-MFMA rate is reported next to it).
     peak = F16_MFMA_PEAK_TFLOPS if prec == "f16x3" else F32_MFMA_PEAK_TFLOPS
+    kernel = f"conv_igemm_{prec}_kernel<{ops.TILE_NAMES.get(tile, tile)}>"
+    gf_launch = round(g["flop"] / g["launches"] / 1e9, 3)
+    traffic, traffic_source = measured_traffic(kernel, gf_launch, g["launches"] // steps)
+    issued = achieved * (3 if prec == "f16x3" else 1)
     return {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-        "frac": round(achieved / peak, 4), "traffic": measured_traffic(prec, tile),
+        "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
         "algorithmic_bytes_per_launch": int(g["bytes"] / g["launches"]),
-        "kernel": f"conv_igemm_{prec}_kernel<{ops.TILE_NAMES.get(tile, tile)}>",
-        "mfma_issued_tflops": round(achieved * (3 if prec == "f16x3" else 1), 2),
-        "mfma_issued_frac": round(achieved * (3 if prec == "f16x3" else 1) / peak, 4),
+        "kernel": kernel,
+        # shader clock sampled in-kernel while the instrumented steps ran, and the same fraction against the MFMA
+        # peak AT that clock (the nominal peak assumes 2400 MHz; under this load the chip holds less)
+        "clock_mhz": round(clock_mhz, 1),
+        "frac_at_clock": round(achieved / (peak * clock_mhz / 2400.0), 4) if clock_mhz > 0 else None,
+        "mfma_issued_frac_at_clock": round(issued / (peak * clock_mhz / 2400.0), 4) if clock_mhz > 0 else None,
+        "mfma_issued_tflops": round(issued, 2),
+        "mfma_issued_frac": round(issued / peak, 4),
         "avg_launch_us": round(1e3 * g["ms"] / g["launches"], 2),
-        "gflop_per_launch": round(g["flop"] / g["launches"] / 1e9, 3),
+        "gflop_per_launch": gf_launch,
         "launches_per_step": g["launches"] // steps,
         "share_of_conv_time": round(g["ms"] / tot_ms, 3),
         "all_conv_achieved": round(tot_flop / (tot_ms * 1e-3) / 1e12, 2),
@@ -178,19 +210,33 @@ def roofline_leg(step, steps):
     }
 
 
-def measured_traffic(prec, tile):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
-    same command (profiles/traffic_latest.json, written by tools/save_profiles.py); None if absent."""
-    from hn_amd import ops
+def measured_traffic(kernel, gflop_per_launch, launches_per_step):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/traffic_latest.json, written by tools/save_profiles.py).  The collection is stamped with the
+    launches/step and GFLOP/launch of the dominant kernel it was made at; a figure collected for another
+    configuration (an older commit, another batch) is NOT paired with this run: (None, reason)."""
     f = REPO / "profiles" / "traffic_latest.json"
     if not f.exists():
-        return None
-    bm, bn = ops.TILE_NAMES.get(tile, "0x0").split("x")
-    want = f"conv_igemm_{prec}_kernel<{bm}, {bn},"
-    for name, rec in json.loads(f.read_text())["kernels"].items():
-        if want in name:
-            return rec["hbm_bytes_per_launch"]
-    return None
+        return None, "no profiles/traffic_latest.json"
+    rec = json.loads(f.read_text())
+    stamp = rec.get("bench")
+    if not stamp:
+        return None, f"{f.name} ({rec.get('tag')}) carries no bench stamp"
+    if stamp.get("kernel") != kernel:
+        return None, f"{rec.get('tag')}: collected for {stamp.get('kernel')}, this run's dominant kernel is {kernel}"
+    if (stamp.get("launches_per_step") != launches_per_step
+            or abs(stamp.get("gflop_per_launch", 0.0) - gflop_per_launch) > 5e-3 * gflop_per_launch):
+        return None, (f"{rec.get('tag')} (commit {rec.get('commit')}): collected at {stamp.get('launches_per_step')} "
+                      f"launches/step x {stamp.get('gflop_per_launch')} GFLOP, this run has {launches_per_step} x "
+                      f"{gflop_per_launch}")
+    want = stamp["kernel"].replace("conv_igemm_", "").split("_kernel<")
+    prec, tile = want[0], want[1].rstrip(">")
+    bm, bn = tile.split("x")
+    needle = f"conv_igemm_{prec}_kernel<{bm}, {bn},"
+    for name, k in rec["kernels"].items():
+        if needle in name:
+            return k["hbm_bytes_per_launch"], f"profiles/{rec.get('tag')}_traffic.json (commit {rec.get('commit')})"
+    return None, f"{rec.get('tag')}: no {needle} record"
 
 
 def cpu_baseline(args, sds, engine=None, dev=None):
@@ -217,40 +263,66 @@ def cpu_baseline(args, sds, engine=None, dev=None):
     fcos_sd, a2j_sd = sds
     rgb = synth.make_rgb(n, seed=1000)
     depth = synth.make_depth(n, seed=2000)
-    imgs = [rgb[i] for i in range(n)]
-    handnet_ref.handnet_forward(imgs[:1], depth[:1], fcos_sd, a2j_sd, 3)  # warm-up
-    t0 = time.time()
-    reps = 2
-    for _ in range(reps):
-        kp_ref, _, crops_ref = handnet_ref.handnet_forward(imgs, depth, fcos_sd, a2j_sd, 3)
-    dt = time.time() - t0
-    res = {"value": round(n * reps / dt, 3), "unit": "frames/s", "cores": threads, "kind": "port",
-           "sample": f"{reps} x batch-{n} full-pipeline oracle forward (torch CPU fp32, FCOS+crop+A2J)"}
-    if engine is not None:
-        from hn_amd import ops
-        out = engine.forward_device(rgb.to(dev), depth.to(dev))
-        has = out.has_hand.bool().cpu()
-        kp = out.keypoints.cpu()
-        same_box = bool(has.all()) and crops_ref.shape[0] == n and torch.equal(out.crop_box.cpu(), crops_ref)
+    if engine is None:
+        imgs = [rgb[i] for i in range(n)]
+        handnet_ref.handnet_forward(imgs[:1], depth[:1], fcos_sd, a2j_sd, 3)  # warm-up
+        t0 = time.time()
+        for lo in range(0, n, 8):
+            handnet_ref.handnet_forward(imgs[lo:lo + 8], depth[lo:lo + 8], fcos_sd, a2j_sd, 3)
+        dt = time.time() - t0
+        return {"value": round(n / dt, 3), "unit": "frames/s", "cores": threads, "kind": "port",
+                "sample": f"{n} frames in batches of 8, full-pipeline oracle forward (torch CPU fp32, FCOS+crop+A2J)"}
+    # the same frames through the oracle (timed) and the HIP engine: where end-to-end parity can break
+    from hn_amd import ops
+    from oracle import parity
+    handnet_ref.handnet_forward([rgb[0]], depth[:1], fcos_sd, a2j_sd, 3)  # warm-up
+    stats, oracle_s, (g_kp, g_box, g_has, o_kp, o_box, o_has) = parity.pipeline_parity(
+        engine, rgb, depth, fcos_sd, a2j_sd, 3, chunk=8)
+    res = {"value": round(n / oracle_s, 3), "unit": "frames/s", "cores": threads, "kind": "port",
+           "sample": f"{n} frames (seeds 1000/2000) in batches of 8, full-pipeline oracle forward "
+                     "(torch CPU fp32, FCOS+crop+A2J)"}
+    eq = (g_box == o_box).all(dim=1) & g_has & o_has
+    if bool(eq.any()):
         paras = (617.343, 617.343, 312.42, 241.42)   # SURVEY 8d intrinsics for the millimetre figure
-        par = {"frames": n, "crop_boxes_identical": same_box,
-               "max_abs_keypoint_diff": float((kp - kp_ref).abs().max()), "tolerance": 1e-3}
-        if same_box:
-            xyz = ops.convert_joints(out.keypoints, out.crop_box, out.has_hand, paras).cpu()
-            xyz_ref = ops.convert_joints(kp_ref.to(dev), crops_ref.to(dev), out.has_hand, paras).cpu()
-            par["mm_epe"] = float((xyz - xyz_ref).norm(dim=-1).mean())
-        res["parity"] = par
+        valid = eq.to(torch.int32).to(dev)
+        xyz = ops.convert_joints(g_kp.to(dev), g_box.to(dev), valid, paras).cpu()
+        xyz_ref = ops.convert_joints(o_kp.to(dev), o_box.to(dev), valid, paras).cpu()
+        stats["mm_epe"] = float((xyz - xyz_ref)[eq].norm(dim=-1).mean())
+    res["parity"] = stats
     return res
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: start one rank per GPU with torch.distributed.run and
+    relay its output.  Runs BEFORE anything initialises HIP in this process (no torch.cuda.is_available(), no
+    library load): the parent only waits for the children and exits with their status -- it is never replaced by
+    another program."""
+    have = torch.cuda.device_count()          # does not initialise the GPU on this image
+    if not args.share_gpu and have < args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but only {have} GPU(s) are visible "
+                         "(--share-gpu --dist-backend gloo rehearses the plumbing on one)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    print(f"[bench] launching {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    sys.exit(subprocess.run(cmd).returncode)
 
 
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     from hn_amd import dist as hdist
     if args.share_gpu:
         os.environ["LOCAL_RANK"] = "0"
     rank, local, world = hdist.init_from_env(args.dist_backend if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as "
+                         f"{args.gpus} GPUs")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -259,13 +331,16 @@ def main():
     step, info, sds = build_workload(args, dev, rank)
     batch = info["batch_per_gpu"]
 
+    gathered = {"rows": None}
+
     def full_step():
         out = step()
         if world > 1 and args.workload == "pipeline":
             if args.dist_backend == "gloo":  # rehearsal only: gloo gathers host tensors
-                hdist.gather_results(out.keypoints.cpu(), out.crop_box.cpu(), out.has_hand.cpu(), per_rank=batch)
+                g = hdist.gather_results(out.keypoints.cpu(), out.crop_box.cpu(), out.has_hand.cpu(), per_rank=batch)
             else:
-                hdist.gather_results(out.keypoints, out.crop_box, out.has_hand, per_rank=batch)
+                g = hdist.gather_results(out.keypoints, out.crop_box, out.has_hand, per_rank=batch)
+            gathered["rows"] = g[3]
         return out
 
     def fence():
@@ -287,9 +362,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # what the collective really spanned: ranks seen by an actual all_gather_into_tensor (not the --gpus flag)
+    rccl_ranks = world
+    if world > 1 and gathered["rows"] is not None:
+        rccl_ranks = int(gathered["rows"].numel()) // batch
+        if rccl_ranks != world or not bool(gathered["rows"].all()):
+            raise SystemExit(f"all-gather returned {gathered['rows'].numel()} rows for {world} ranks x {batch} frames")
     roof = None
     if not args.no_roofline and not args.graph:
-        roof = roofline_leg(step, max(1, min(args.steps, 3)))
+        roof = roofline_leg(step, max(1, min(args.steps, 3)), 1e3 * elapsed / args.steps)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, sds, info.get("engine"), dev)
@@ -308,7 +389,8 @@ def main():
                     "reference architectures, hn_amd.synth seed 0)",
             "config": {"workload": info["name"], "batch_per_gpu": batch, "global_batch": batch * world,
                        "frame": {"a2j": "176x176 depth crop", "pose2mesh": "21 x 2-D joints"}.get(args.workload, "640x480 RGB-D"),
-                       "parallelism": f"frames sharded over {world} GPU(s), all-gather of per-frame results",
+                       "parallelism": f"frames sharded over {world} GPU(s), one all-gather of per-frame records per step",
+                       "collective_backend": (dist.get_backend() if world > 1 else None), "rccl_ranks": rccl_ranks,
                        "gflop_per_unit": round(info["gflop_per_unit"], 3), "hipgraph": bool(args.graph)},
             "algorithmic_tflops": round(value * info["gflop_per_unit"] / 1e3, 2),
             "roofline": roof, "cpu_baseline": cpu,

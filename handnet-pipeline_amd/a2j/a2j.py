@@ -8,9 +8,16 @@ the CPU (the reference ends with `.data.cpu()`, a2j/a2j.py:229).  Callers keep w
     model.load_state_dict(torch.load(path, map_location="cpu")["model"], strict=False)
     jt_uvd = model(depth)[0]                                  # a2j_infer.py:25-28,58-60
 
+`A2JModelLightning` (a2j/a2j.py:252-366) is provided for what the callers use it for -- `load_from_checkpoint(path)`
+of a Lightning `.ckpt` (handnet_pipeline.py:28-29; commented alternative in a2j_infer.py:26, a2j_mesh.py:30) and
+`forward` -- so that `from a2j.a2j import A2JModelLightning` (a2j_infer.py:12, a2j_mesh.py:15,
+handnet_pipeline/handnet_pipeline.py:8) resolves; its training / test hooks raise.
 Training (`gt is not None`) is out of scope and raises.
 """
 from __future__ import annotations
+
+import inspect
+import os
 
 import numpy as np
 import torch
@@ -23,8 +30,6 @@ from hn_amd.state import EngineOwner, build_state_tree
 class A2JModel(EngineOwner):
     def __init__(self, num_classes, crop_height, crop_width, is_3D=True, is_RGBD=False, spatial_factor=0.5):
         super().__init__()
-        if not is_3D:
-            raise NotImplementedError("only the is_3D=True model of the reference's inference path is provided")
         self.is_3D = is_3D
         self.is_RGBD = is_RGBD
         self.num_classes = num_classes
@@ -32,11 +37,19 @@ class A2JModel(EngineOwner):
         # The reference starts from ImageNet weights fetched over the network
         # (a2j/a2j.py:188); offline, the state starts from the deterministic synthetic
         # checkpoint and is normally overwritten by load_state_dict().
-        tree = build_state_tree(synth.make_a2j_state_dict(seed=0, num_joints=num_classes, rgbd=is_RGBD))
+        sd = synth.make_a2j_state_dict(seed=0, num_joints=num_classes, rgbd=is_RGBD)
+        if not is_3D:  # a2j/a2j.py:219-220: no depth branch
+            sd = {k: v for k, v in sd.items() if not k.startswith("DepthRegressionModel.")}
+        tree = build_state_tree(sd)
         for name, child in tree.named_children():
             self.add_module(name, child)
 
     def engine(self) -> A2JEngine:
+        if not self.is_3D:
+            # Same failure as the reference: A2JModel builds post_process with its default is_3D=True
+            # (a2j/a2j.py:223), so a two-head forward dies unpacking (cls, reg) into three names (a2j/anchor.py:59).
+            raise ValueError("not enough values to unpack (expected 3, got 2) -- the reference's is_3D=False "
+                             "forward fails the same way (a2j/a2j.py:223, a2j/anchor.py:58-59)")
         dev = self._require_gpu()
         if self._engine is None:
             sd = {k: v.detach().cpu() for k, v in self.state_dict().items()}
@@ -51,6 +64,63 @@ class A2JModel(EngineOwner):
         if gt is not None:
             raise NotImplementedError("training losses (a2j/anchor.py:84-152) are outside the inference hot path")
         return self.forward_device(x).cpu()
+
+
+class A2JModelLightning(EngineOwner):
+    """Inference-side stand-in for the reference's LightningModule (a2j/a2j.py:252-366): same constructor
+    arguments, `.a2j` = the HIP-backed A2JModel, state_dict keys `a2j.*` (the layout of a Lightning checkpoint's
+    `state_dict`), `load_from_checkpoint`, `forward`.  pytorch-lightning is not needed (and not installed here)."""
+
+    def __init__(self, num_classes: int = 21, crop_height: int = 176, crop_width: int = 176, is_3D: bool = True,
+                 is_RGBD: bool = False, spatial_factor: float = 0.5, display_freq: int = 5000,
+                 output_dir: str = "models/a2j"):
+        super().__init__()
+        self.hparams = dict(num_classes=num_classes, crop_height=crop_height, crop_width=crop_width, is_3D=is_3D,
+                            is_RGBD=is_RGBD, spatial_factor=spatial_factor, display_freq=display_freq,
+                            output_dir=output_dir)
+        self.a2j = A2JModel(num_classes, crop_height, crop_width, is_3D, is_RGBD, spatial_factor)
+        # the reference ctor unconditionally loads this file (a2j/a2j.py:278); offline it is absent, and
+        # load_from_checkpoint overwrites the weights anyway
+        pre = "models/a2j_dexycb_1/a2j_25.pth"
+        if os.path.exists(pre):
+            self.a2j.load_state_dict(torch.load(pre, map_location="cpu")["model"], strict=False)
+        self.rgbd = is_RGBD
+        self.display_freq = display_freq
+        self.output_dir = output_dir
+
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, map_location=None, hparams_file=None, strict: bool = True, **kwargs):
+        """LightningModule.load_from_checkpoint: constructor arguments come from the file's `hyper_parameters`
+        (save_hyperparameters, a2j/a2j.py:276) overridden by kwargs; weights from `state_dict` (keys `a2j.*`)."""
+        ckpt = torch.load(checkpoint_path, map_location="cpu")
+        if "state_dict" not in ckpt:
+            raise KeyError(f"{checkpoint_path} is not a Lightning checkpoint (no 'state_dict'); plain A2J files "
+                           "are loaded with A2JModel.load_state_dict(ckpt['model'])")
+        hp = dict(ckpt.get("hyper_parameters", {}))
+        hp.update(kwargs)
+        accepted = set(inspect.signature(cls.__init__).parameters) - {"self"}
+        model = cls(**{k: v for k, v in hp.items() if k in accepted})
+        sd = ckpt["state_dict"]
+        own = set(model.state_dict().keys())
+        model.load_state_dict({k: v for k, v in sd.items() if k in own or strict}, strict=strict)
+        if map_location is not None and str(map_location) != "cpu":
+            model = model.to(map_location)
+        return model
+
+    def engine(self):
+        return self.a2j.engine()
+
+    def forward(self, x, gt=None):
+        return self.a2j(x, gt)
+
+    def forward_device(self, x, valid=None):
+        return self.a2j.forward_device(x, valid)
+
+    def _no_training(self, *a, **k):
+        raise NotImplementedError("training / evaluation hooks of A2JModelLightning (a2j/a2j.py:283-366) are outside "
+                                  "the inference hot path")
+
+    training_step = test_step = test_epoch_end = configure_optimizers = _no_training
 
 
 def convert_joints(jt_uvd_pred, jt_uvd_gt, box, paras, cropWidth, cropHeight):

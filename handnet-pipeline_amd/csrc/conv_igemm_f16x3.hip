@@ -15,8 +15,8 @@
 //   weights      fp16 [Cout][(Cin/32)*R*S][2][32] -- the same run structure along k; k tiles are
 //                ordered channel block OUTER, tap (r,s) INNER (weights.split_f16x3).
 //
-// Kernel (v5).  rocprof ablations of v2 (fp32 activations split in the loader; kept for
-// reference in conv_igemm_f16x3_v2.hip.txt) showed the loader's conversion VALU (+27 %) and
+// Kernel (v5).  rocprof ablations of v2 (fp32 activations split in the loader; git history,
+// commit 4caba32) showed the loader's conversion VALU (+27 %) and
 // its ds_write_b128 traffic (+15 %) to be the largest costs, so since v3 there is neither:
 //   * both operands are staged global -> LDS by LDS-DMA (global_load_lds_dwordx4): no VGPR
 //     staging, no VALU, no ds_write.  One wave instruction moves 8 rows x 128 B; the gather
@@ -88,6 +88,7 @@ struct ConvParams16 {
   float* split_ws;
   int64_t split_ws_bytes;
   int tiles_m, tiles_n, nblocks;
+  int* range_flag;    // f16x3 range contract (hn_range_check_enable): set to 1 when an S32 output value cannot be split
 };
 
 constexpr int BK = 32;    // k values per tile
@@ -160,6 +161,10 @@ __device__ __forceinline__ void epi_finish8(const ConvParams16& p, int m, int n,
   for (int e = 0; e < 8; ++e)
     if (n + e < p.relu_cols) v[e] = fmaxf(v[e], 0.f);
   if (p.out_split) {
+    if (p.range_flag) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) hn::range_note(p.range_flag, v[e]);
+    }
     f16x8 hi, lo;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -644,6 +649,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
         }
         if (n < p.relu_cols) v = fmaxf(v, 0.f);
         if (p.out_split) {
+          if (p.range_flag) hn::range_note(p.range_flag, v);
           _Float16* q = y16 + (long)m * p.ys + (n >> 5) * 64 + (n & 31);
           const _Float16 h = (_Float16)v;
           q[0] = h;
@@ -820,6 +826,7 @@ static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, c
               ((uintptr_t)y % 16 == 0) && (bias == nullptr || (uintptr_t)bias % 16 == 0) &&
               (residual == nullptr || (uintptr_t)residual % 16 == 0);
   p.tiles_m = p.tiles_n = p.nblocks = 0;
+  p.range_flag = hn::range_flag_ptr();
   p.gn_partial = gn_partial;
   p.split_ws = (float*)workspace;
   p.split_ws_bytes = workspace ? workspace_bytes : 0;
@@ -865,7 +872,7 @@ static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, c
   hipStream_t st = (hipStream_t)stream;
   switch (hn_conv2d_f16x3_pick_tile(&tile_desc)) {
     case HN_TILE_128x128: return launch16<128, 128, 2, 2, 2>(p, st);
-    // LDS stage counts from an in-pipeline sweep (tools/stage_sweep.py): extra stages only pay
+    // LDS stage counts from an in-pipeline sweep (round-1 commit 5dc48dd): extra stages only pay
     // where they do not cost occupancy
     case HN_TILE_128x64: return launch16<128, 64, 2, 2, 2>(p, st);
     case HN_TILE_64x64: return launch16<64, 64, 2, 2, 3>(p, st);
@@ -912,6 +919,7 @@ extern "C" int hn_conv_stem_f16x3(const void* x16, int n, int ph, int pw, int pa
   p.rs = 0;
   p.vec_epi = (cout % 8 == 0) && ((uintptr_t)y % 16 == 0) && (bias == nullptr || (uintptr_t)bias % 16 == 0);
   p.tiles_m = p.tiles_n = p.nblocks = 0;
+  p.range_flag = hn::range_flag_ptr();
   hipStream_t st = (hipStream_t)stream;
   if (cout <= 32) return launch16<128, 32, 4, 1, 3>(p, st);
   if (cout <= 64) return launch16<128, 64, 2, 2, 2>(p, st);

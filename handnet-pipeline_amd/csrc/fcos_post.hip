@@ -34,15 +34,34 @@ __device__ __forceinline__ void src_index(float scale, int dst, int in_size, int
   l0 = 1.f - l1;
 }
 
+// Batches of differently sized images (torchvision batch_images, fcos_utils/fcos.py:702-709): image `img` is
+// its own [3][h][w] buffer srcs[img] with geometry geom[img] = {h, w, oh, ow}; every image is resized on its own
+// and lands in the top-left corner of the common zero-padded canvas.  Null tables = one dense [n][3][h][w] batch.
+struct ImageGeom {
+  const float* const* srcs;
+  const int* geom;
+};
+
+__device__ __forceinline__ const float* image_geometry(const ImageGeom& g, const float* src, int img, int& h, int& w,
+                                                       int& oh, int& ow, float& scale_h, float& scale_w) {
+  if (!g.geom) return src + (long)img * 3 * h * w;
+  const int* q = g.geom + img * 4;
+  h = q[0]; w = q[1]; oh = q[2]; ow = q[3];
+  scale_h = (float)h / (float)oh;
+  scale_w = (float)w / (float)ow;
+  return g.srcs[img];
+}
+
 __global__ __launch_bounds__(256) void fcos_preprocess_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                               int n, int h, int w, int oh, int ow, int ph, int pw,
-                                                              float scale_h, float scale_w, Norm3 nm) {
+                                                              float scale_h, float scale_w, Norm3 nm, ImageGeom g) {
   const long total = (long)n * ph * pw;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int ox = (int)(i % pw);
     const long t = i / pw;
     const int oy = (int)(t % ph);
     const int img = (int)(t / ph);
+    const float* base = image_geometry(g, src, img, h, w, oh, ow, scale_h, scale_w);
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
     if (oy < oh && ox < ow) {
       int y0, y1, x0, x1;
@@ -51,7 +70,7 @@ __global__ __launch_bounds__(256) void fcos_preprocess_kernel(const float* __res
       src_index(scale_w, ox, w, x0, x1, wx0, wx1);
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float* pl = src + ((long)img * 3 + c) * h * w;
+        const float* pl = base + (long)c * h * w;
         const float m = nm.mean[c], s = nm.stdv[c];
         const float v00 = (pl[(long)y0 * w + x0] - m) / s, v01 = (pl[(long)y0 * w + x1] - m) / s;
         const float v10 = (pl[(long)y1 * w + x0] - m) / s, v11 = (pl[(long)y1 * w + x1] - m) / s;
@@ -71,7 +90,8 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void fcos_preprocess_split_kernel(const float* __restrict__ src,
                                                                     _Float16* __restrict__ dst, int n, int h, int w,
                                                                     int oh, int ow, int ph, int pw, int b,
-                                                                    float scale_h, float scale_w, Norm3 nm) {
+                                                                    float scale_h, float scale_w, Norm3 nm,
+                                                                    int* range_flag, ImageGeom g) {
   const int hb = ph + 2 * b, wb = pw + 2 * b;
   const long total = (long)n * hb * wb;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -79,6 +99,7 @@ __global__ __launch_bounds__(256) void fcos_preprocess_split_kernel(const float*
     const long t = i / wb;
     const int oy = (int)(t % hb) - b;
     const int img = (int)(t / hb);
+    const float* base = image_geometry(g, src, img, h, w, oh, ow, scale_h, scale_w);
     float o[3] = {0.f, 0.f, 0.f};
     if ((unsigned)oy < (unsigned)oh && (unsigned)ox < (unsigned)ow) {
       int y0, y1, x0, x1;
@@ -87,7 +108,7 @@ __global__ __launch_bounds__(256) void fcos_preprocess_split_kernel(const float*
       src_index(scale_w, ox, w, x0, x1, wx0, wx1);
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float* pl = src + ((long)img * 3 + c) * h * w;
+        const float* pl = base + (long)c * h * w;
         const float m = nm.mean[c], s = nm.stdv[c];
         const float v00 = (pl[(long)y0 * w + x0] - m) / s, v01 = (pl[(long)y0 * w + x1] - m) / s;
         const float v10 = (pl[(long)y1 * w + x0] - m) / s, v11 = (pl[(long)y1 * w + x1] - m) / s;
@@ -99,6 +120,7 @@ __global__ __launch_bounds__(256) void fcos_preprocess_split_kernel(const float*
     f16x4 hi, lo;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
+      if (range_flag) hn::range_note(range_flag, o[c]);
       hi[c] = (_Float16)o[c];
       lo[c] = (_Float16)(o[c] - (float)hi[c]);
     }
@@ -279,6 +301,7 @@ struct NmsArgs {
   int cap;
   double thr;  // torchvision passes iou_threshold as a C++ double (0.3, not 0.3f)
   float ratio_h, ratio_w;
+  const float* ratios;   // optional per-image [n][2] = (ratio_h, ratio_w) (batches of differently sized images)
   int rescale;           // multiply output boxes by the ratios
   char* scratch;
   long scratch_stride;   // bytes per image
@@ -446,8 +469,9 @@ __global__ __launch_bounds__(1024) void nms_kernel(const NmsArgs a) {
         if (a.det_boxes) {
           float ox1 = raw[0], oy1 = raw[1], ox2 = raw[2], oy2 = raw[3];
           if (a.rescale) {
-            ox1 = ox1 * a.ratio_w; ox2 = ox2 * a.ratio_w;
-            oy1 = oy1 * a.ratio_h; oy2 = oy2 * a.ratio_h;
+            const float rh = a.ratios ? a.ratios[img * 2] : a.ratio_h, rw = a.ratios ? a.ratios[img * 2 + 1] : a.ratio_w;
+            ox1 = ox1 * rw; ox2 = ox2 * rw;
+            oy1 = oy1 * rh; oy2 = oy2 * rh;
           }
           a.det_boxes[o * 4 + 0] = ox1; a.det_boxes[o * 4 + 1] = oy1;
           a.det_boxes[o * 4 + 2] = ox2; a.det_boxes[o * 4 + 3] = oy2;
@@ -563,38 +587,54 @@ long nms_scratch_stride(int cap) {
 
 }  // namespace
 
-extern "C" int hn_fcos_preprocess_f32(const float* src, float* dst, int n, int h, int w, int oh, int ow, int ph,
-                                      int pw, const float mean[3], const float stdv[3], void* stream) {
-  HN_CHECK_ARG(src && dst && mean && stdv, "hn_fcos_preprocess_f32: null pointer");
-  HN_CHECK_ARG(n > 0 && h > 0 && w > 0 && oh > 0 && ow > 0 && ph >= oh && pw >= ow, "bad dims");
+static int preprocess_run(const float* src, const float* const* srcs, const int32_t* geom, void* dst, int split, int n,
+                          int h, int w, int oh, int ow, int ph, int pw, int border, const float mean[3],
+                          const float stdv[3], void* stream) {
   Norm3 nm;
   for (int c = 0; c < 3; ++c) {
     nm.mean[c] = mean[c];
     nm.stdv[c] = stdv[c];
   }
-  const float scale_h = (float)h / (float)oh, scale_w = (float)w / (float)ow;
-  const long total = (long)n * ph * pw;
-  hipLaunchKernelGGL(fcos_preprocess_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, src, dst,
-                     n, h, w, oh, ow, ph, pw, scale_h, scale_w, nm);
-  HN_CHECK_LAUNCH("fcos_preprocess_kernel");
+  ImageGeom g;
+  g.srcs = srcs;
+  g.geom = geom;
+  const float scale_h = geom ? 1.f : (float)h / (float)oh, scale_w = geom ? 1.f : (float)w / (float)ow;
+  if (split) {
+    const long total = (long)n * (ph + 2 * border) * (pw + 2 * border);
+    hipLaunchKernelGGL(fcos_preprocess_split_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       (_Float16*)dst, n, h, w, oh, ow, ph, pw, border, scale_h, scale_w, nm, hn::range_flag_ptr(), g);
+    HN_CHECK_LAUNCH("fcos_preprocess_split_kernel");
+  } else {
+    const long total = (long)n * ph * pw;
+    hipLaunchKernelGGL(fcos_preprocess_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       (float*)dst, n, h, w, oh, ow, ph, pw, scale_h, scale_w, nm, g);
+    HN_CHECK_LAUNCH("fcos_preprocess_kernel");
+  }
   return HN_OK;
+}
+
+extern "C" int hn_fcos_preprocess_f32(const float* src, float* dst, int n, int h, int w, int oh, int ow, int ph,
+                                      int pw, const float mean[3], const float stdv[3], void* stream) {
+  HN_CHECK_ARG(src && dst && mean && stdv, "hn_fcos_preprocess_f32: null pointer");
+  HN_CHECK_ARG(n > 0 && h > 0 && w > 0 && oh > 0 && ow > 0 && ph >= oh && pw >= ow, "bad dims");
+  return preprocess_run(src, nullptr, nullptr, dst, 0, n, h, w, oh, ow, ph, pw, 0, mean, stdv, stream);
 }
 
 extern "C" int hn_fcos_preprocess_split(const float* src, void* dst16, int n, int h, int w, int oh, int ow, int ph,
                                         int pw, int border, const float mean[3], const float stdv[3], void* stream) {
   HN_CHECK_ARG(src && dst16 && mean && stdv, "hn_fcos_preprocess_split: null pointer");
   HN_CHECK_ARG(n > 0 && h > 0 && w > 0 && oh > 0 && ow > 0 && ph >= oh && pw >= ow && border >= 0, "bad dims");
-  Norm3 nm;
-  for (int c = 0; c < 3; ++c) {
-    nm.mean[c] = mean[c];
-    nm.stdv[c] = stdv[c];
-  }
-  const float scale_h = (float)h / (float)oh, scale_w = (float)w / (float)ow;
-  const long total = (long)n * (ph + 2 * border) * (pw + 2 * border);
-  hipLaunchKernelGGL(fcos_preprocess_split_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, src,
-                     (_Float16*)dst16, n, h, w, oh, ow, ph, pw, border, scale_h, scale_w, nm);
-  HN_CHECK_LAUNCH("fcos_preprocess_split_kernel");
-  return HN_OK;
+  return preprocess_run(src, nullptr, nullptr, dst16, 1, n, h, w, oh, ow, ph, pw, border, mean, stdv, stream);
+}
+
+// A batch of differently sized images (torchvision batch_images): srcs = DEVICE array of n device pointers to
+// [3][h_i][w_i] images, geom = DEVICE int32 [n][4] = {h_i, w_i, oh_i, ow_i} (oh_i <= ph, ow_i <= pw: the caller
+// has checked that, the kernel clips to the canvas).  split = 0: fp32 [n][ph][pw][4] canvas; 1: the stem image.
+extern "C" int hn_fcos_preprocess_list(const float* const* srcs, const int32_t* geom, void* dst, int split, int n, int ph,
+                                       int pw, int border, const float mean[3], const float stdv[3], void* stream) {
+  HN_CHECK_ARG(srcs && geom && dst && mean && stdv, "hn_fcos_preprocess_list: null pointer");
+  HN_CHECK_ARG(n > 0 && ph > 0 && pw > 0 && border >= 0 && (split == 0 || split == 1), "bad dims");
+  return preprocess_run(nullptr, srcs, geom, dst, split, n, 1, 1, 1, 1, ph, pw, split ? border : 0, mean, stdv, stream);
 }
 
 extern "C" int hn_fcos_candidates(const hn_fcos_levels* lv, int n, int num_classes, float score_thresh,
@@ -658,11 +698,11 @@ extern "C" int64_t hn_fcos_nms_scratch_bytes(int n, int cap) {
   return (int64_t)n * nms_scratch_stride(cap);
 }
 
-extern "C" int hn_fcos_nms(const float* cand_boxes, const float* cand_scores, const int32_t* cand_labels,
-                           const int32_t* cand_sides, const int32_t* cand_level, const int32_t* cand_count, int n,
-                           int cap, double iou_thresh, float ratio_h, float ratio_w, void* scratch, float* det_boxes,
-                           float* det_scores, int32_t* det_labels, int32_t* det_sides, int32_t* det_level,
-                           int32_t* det_keep, int32_t* det_count, void* stream) {
+static int fcos_nms_run(const float* cand_boxes, const float* cand_scores, const int32_t* cand_labels,
+                        const int32_t* cand_sides, const int32_t* cand_level, const int32_t* cand_count, int n, int cap,
+                        double iou_thresh, float ratio_h, float ratio_w, const float* ratios, void* scratch,
+                        float* det_boxes, float* det_scores, int32_t* det_labels, int32_t* det_sides,
+                        int32_t* det_level, int32_t* det_keep, int32_t* det_count, void* stream) {
   HN_CHECK_ARG(cand_boxes && cand_scores && cand_labels && cand_sides && cand_level && cand_count && scratch,
                "hn_fcos_nms: null input");
   HN_CHECK_ARG(det_boxes && det_scores && det_labels && det_sides && det_level && det_count, "hn_fcos_nms: null output");
@@ -670,12 +710,36 @@ extern "C" int hn_fcos_nms(const float* cand_boxes, const float* cand_scores, co
   NmsArgs a;
   a.boxes = cand_boxes; a.scores = cand_scores; a.labels = cand_labels; a.sides = cand_sides; a.level = cand_level;
   a.count = cand_count; a.k_fixed = 0; a.cap = cap; a.thr = iou_thresh; a.ratio_h = ratio_h; a.ratio_w = ratio_w;
+  a.ratios = ratios;
   a.rescale = 1; a.scratch = (char*)scratch; a.scratch_stride = nms_scratch_stride(cap); a.pad_cap = pow2_at_least(cap);
   a.det_boxes = det_boxes; a.det_scores = det_scores; a.det_labels = det_labels; a.det_sides = det_sides;
   a.det_level = det_level; a.det_keep = det_keep; a.det_count = det_count;
   hipLaunchKernelGGL(nms_kernel, dim3(n), dim3(1024), 0, (hipStream_t)stream, a);
   HN_CHECK_LAUNCH("nms_kernel");
   return HN_OK;
+}
+
+extern "C" int hn_fcos_nms(const float* cand_boxes, const float* cand_scores, const int32_t* cand_labels,
+                           const int32_t* cand_sides, const int32_t* cand_level, const int32_t* cand_count, int n,
+                           int cap, double iou_thresh, float ratio_h, float ratio_w, void* scratch, float* det_boxes,
+                           float* det_scores, int32_t* det_labels, int32_t* det_sides, int32_t* det_level,
+                           int32_t* det_keep, int32_t* det_count, void* stream) {
+  return fcos_nms_run(cand_boxes, cand_scores, cand_labels, cand_sides, cand_level, cand_count, n, cap, iou_thresh,
+                      ratio_h, ratio_w, nullptr, scratch, det_boxes, det_scores, det_labels, det_sides, det_level,
+                      det_keep, det_count, stream);
+}
+
+// Same with one (ratio_h, ratio_w) pair per image: ratios = DEVICE fp32 [n][2] (resize_boxes of a batch whose
+// images differ in size, fcos_utils/fcos.py:661-669,770-783).
+extern "C" int hn_fcos_nms_ratios(const float* cand_boxes, const float* cand_scores, const int32_t* cand_labels,
+                                  const int32_t* cand_sides, const int32_t* cand_level, const int32_t* cand_count, int n,
+                                  int cap, double iou_thresh, const float* ratios, void* scratch, float* det_boxes,
+                                  float* det_scores, int32_t* det_labels, int32_t* det_sides, int32_t* det_level,
+                                  int32_t* det_keep, int32_t* det_count, void* stream) {
+  HN_CHECK_ARG(ratios, "hn_fcos_nms_ratios: null ratios");
+  return fcos_nms_run(cand_boxes, cand_scores, cand_labels, cand_sides, cand_level, cand_count, n, cap, iou_thresh, 1.f,
+                      1.f, ratios, scratch, det_boxes, det_scores, det_labels, det_sides, det_level, det_keep, det_count,
+                      stream);
 }
 
 extern "C" int hn_nms(const float* boxes, const float* scores, int k, double iou_thresh, void* scratch, int32_t* keep,
@@ -688,7 +752,7 @@ extern "C" int hn_nms(const float* boxes, const float* scores, int k, double iou
   }
   NmsArgs a;
   a.boxes = boxes; a.scores = scores; a.labels = nullptr; a.sides = nullptr; a.level = nullptr; a.count = nullptr;
-  a.k_fixed = k; a.cap = k; a.thr = iou_thresh; a.ratio_h = a.ratio_w = 1.f; a.rescale = 0;
+  a.k_fixed = k; a.cap = k; a.thr = iou_thresh; a.ratio_h = a.ratio_w = 1.f; a.ratios = nullptr; a.rescale = 0;
   a.scratch = (char*)scratch; a.scratch_stride = nms_scratch_stride(k); a.pad_cap = pow2_at_least(k);
   a.det_boxes = nullptr; a.det_scores = nullptr; a.det_labels = nullptr; a.det_sides = nullptr; a.det_level = nullptr;
   a.det_keep = keep; a.det_count = num_keep;

@@ -12,6 +12,8 @@ namespace hn {
 // thread-local error text returned by hn_last_error()
 char* err_buf();
 int fail(int code, const char* fmt, ...);
+// device address of the sticky f16x3 range flag of the current device, or nullptr while the check is off
+int* range_flag_ptr();
 
 #define HN_CHECK_ARG(cond, ...)                          \
   do {                                                   \
@@ -34,5 +36,11 @@ int fail(int code, const char* fmt, ...);
   } while (0)
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// f16x3 range contract: a value that is to be split into fp16 hi + lo must be finite and within the fp16 range
+// (hi = fp16(v) is +-inf beyond 65504).  `flag` is null unless hn_range_check_enable(1) was called.
+__device__ __forceinline__ void range_note(int* flag, float v) {
+  if (!(fabsf(v) <= 65504.f)) *flag = 1;
+}
 
 }  // namespace hn

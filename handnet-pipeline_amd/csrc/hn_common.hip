@@ -1,9 +1,28 @@
-// Error reporting, ABI version, device facts and HIP-event timing helpers.
+// Error reporting, ABI version, device facts, HIP-event timing helpers, the f16x3 range-contract flag and the
+// in-kernel shader-clock sampler.
 #include "hn_common.h"
 
 #include <string.h>
 
+// Sticky per-device flag of the f16x3 range contract (hn_range_check_enable): set by any producer of split
+// (hi + lo fp16) data that meets a value outside the fp16 range or a non-finite one.
+__device__ int g_range_flag;
+static int g_range_check_on = 0;
+
 namespace hn {
+
+int* range_flag_ptr() {
+  if (!g_range_check_on) return nullptr;
+  static int* ptrs[64] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!ptrs[dev]) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_range_flag)) != hipSuccess) return nullptr;
+    ptrs[dev] = (int*)p;
+  }
+  return ptrs[dev];
+}
 
 char* err_buf() {
   static thread_local char buf[512] = {0};
@@ -60,5 +79,50 @@ extern "C" int hn_event_elapsed_ms(void* start, void* stop, float* ms) {
   HN_CHECK_ARG(ms, "hn_event_elapsed_ms: null");
   HN_CHECK_HIP(hipEventSynchronize((hipEvent_t)stop));
   HN_CHECK_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return HN_OK;
+}
+
+// ---- f16x3 range contract (debug switch) ----
+extern "C" int hn_range_check_enable(int on) {
+  g_range_check_on = on ? 1 : 0;
+  return HN_OK;
+}
+
+extern "C" int hn_range_check_fetch(int* flag, int reset, void* stream) {
+  HN_CHECK_ARG(flag, "hn_range_check_fetch: null");
+  void* p = nullptr;
+  HN_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(g_range_flag)));
+  HN_CHECK_HIP(hipMemcpyAsync(flag, p, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HN_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  if (reset) {
+    HN_CHECK_HIP(hipMemsetAsync(p, 0, sizeof(int), (hipStream_t)stream));
+    HN_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  }
+  return HN_OK;
+}
+
+// ---- shader clock under load ----
+// One wave compares s_memtime (shader cycles) with s_memrealtime (100 MHz) over `micros` microseconds.  Launched
+// on a side stream while the kernels of interest run, it reads the clock the chip actually holds under that load
+// (MI355X_MICROARCH.md, DVFS give-back (6)).  The loop ends after a bounded number of real-time ticks.
+namespace {
+__global__ __launch_bounds__(64) void clock_sample_kernel(unsigned long long ticks, float* mhz) {
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+  unsigned long long r1 = r0;
+  for (long guard = 0; guard < (1L << 26) && r1 - r0 < ticks; ++guard) {
+    __builtin_amdgcn_s_sleep(64);
+    r1 = __builtin_amdgcn_s_memrealtime();
+  }
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) mhz[0] = (float)((double)(c1 - c0) / ((double)(r1 - r0) * 0.01));
+}
+}  // namespace
+
+extern "C" int hn_clock_sample(int micros, float* mhz, void* stream) {
+  HN_CHECK_ARG(mhz, "hn_clock_sample: null");
+  HN_CHECK_ARG(micros > 0 && micros <= 2000000, "hn_clock_sample: micros must be in 1..2e6");
+  hipLaunchKernelGGL(clock_sample_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)micros * 100ull, mhz);
+  HN_CHECK_LAUNCH("clock_sample_kernel");
   return HN_OK;
 }

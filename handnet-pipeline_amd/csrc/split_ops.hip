@@ -32,7 +32,7 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, f16x8& hi
 __global__ __launch_bounds__(256) void affine_split_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, int relu, long npix,
                                                            int hw, int c, int xs, int as,
-                                                           _Float16* __restrict__ y, int ys) {
+                                                           _Float16* __restrict__ y, int ys, int* range_flag) {
   const int c8 = c >> 3;
   const long total = npix * c8;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -56,6 +56,13 @@ __global__ __launch_bounds__(256) void affine_split_kernel(const float* __restri
       for (int e = 0; e < 4; ++e) {
         a[e] = fmaxf(a[e], 0.f);
         b[e] = fmaxf(b[e], 0.f);
+      }
+    }
+    if (range_flag) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        hn::range_note(range_flag, a[e]);
+        hn::range_note(range_flag, b[e]);
       }
     }
     f16x8 hi, lo;
@@ -156,7 +163,7 @@ extern "C" int hn_affine_split_f32(const float* x, const float* scale, const flo
   HN_CHECK_ARG(xs >= c && xs % 4 == 0 && as >= c && as % 4 == 0 && ys >= 2 * c && ys % 64 == 0, "bad strides");
   const long npix = (long)n * hw;
   hipLaunchKernelGGL(affine_split_kernel, dim3(grid_for(npix * (c / 8))), dim3(256), 0, (hipStream_t)stream, x, scale,
-                     shift, relu, npix, hw, c, xs, as, (_Float16*)y16, ys);
+                     shift, relu, npix, hw, c, xs, as, (_Float16*)y16, ys, hn::range_flag_ptr());
   HN_CHECK_LAUNCH("affine_split_kernel");
   return HN_OK;
 }

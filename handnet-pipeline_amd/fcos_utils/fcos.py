@@ -54,8 +54,11 @@ class FCOS(EngineOwner):
         if self.training or targets is not None:
             raise NotImplementedError("training (fcos.py:543-570 losses) is outside the inference hot path")
         if len({tuple(i.shape) for i in images}) != 1:
-            raise NotImplementedError("all images of a batch must share one size (the demo feeds 480x640 frames)")
-        batch = torch.stack([i.float() for i in images])
+            # torchvision batch_images (fcos.py:702-709): every image is resized on its own, padded to the common
+            # canvas, and its boxes are scaled back by its own ratios
+            batch = [i.float() for i in images]
+        else:
+            batch = torch.stack([i.float() for i in images])
         if self.ext:
             det, _, contacts, dxdymags = self.engine().detect_ext(batch)
         else:

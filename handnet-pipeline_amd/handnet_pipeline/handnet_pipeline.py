@@ -8,7 +8,7 @@ Constructor and call contract of handnet_pipeline/handnet_pipeline.py:38-116:
   keypoints   FloatTensor [N,21,3] on the CPU (zero rows for frames without a hand)
   depth_batch [K,1,176,176] on the model device, K = frames with a hand
   crops       [K,4] int64 on the model device (padded, clamped x1,y1,x2,y2)
-  no frame with a hand: (zeros[N,21,3], zeros_like(depth_images), zeros[N,4] float32)
+  no frame with a hand: (zeros[N,21,3], zeros_like(depth_images), zeros[N,4] float32 on the CPU)
   is_detect or is_3D: returns None (the reference has no such branch either).
 
 Documented deviations: a batch that MIXES frames with and without a hand raises in the
@@ -21,9 +21,9 @@ import torch
 
 from a2j.a2j import A2JModel
 from fcos_utils.fcos import FCOS
+from a2j.a2j import A2JModelLightning
 from hn_amd.pipeline import HandNetEngine
 from hn_amd.state import EngineOwner
-from hn_amd.weights import strip_prefix
 
 
 def load_pretrained_fcos(args, reload_detector=False, num_classes=2):
@@ -37,20 +37,14 @@ def load_pretrained_fcos(args, reload_detector=False, num_classes=2):
 
 
 def load_pretrained_a2j(args, reload_a2j=False, RGBD=False):
-    """Reference (handnet_pipeline.py:25-36): RGBD or a '.ckpt' path -> Lightning checkpoint (weights under
-    state_dict with prefix 'a2j.', a2j/a2j.py:277), always loaded; else A2JModel + optional {"model": sd}."""
-    path = str(getattr(args, "pretrained_a2j", ""))
-    checkpoint = None
-    if "ckpt" in path or (RGBD and reload_a2j):
-        # Lightning restores the constructor arguments saved in the file (a2j/a2j.py:276), so the
-        # checkpoint, not the RGBD flag, decides the stem width
-        checkpoint = torch.load(path, map_location="cpu")
-        RGBD = bool(checkpoint.get("hyper_parameters", {}).get("is_RGBD", RGBD))
-    a2j = A2JModel(21, crop_height=176, crop_width=176, is_RGBD=RGBD)
-    if checkpoint is not None:
-        a2j.load_state_dict(strip_prefix(checkpoint["state_dict"], "a2j."), strict=False)
-    elif reload_a2j:
-        checkpoint = torch.load(path, map_location="cpu")
+    """handnet_pipeline.py:25-36: RGBD or a path containing 'ckpt' -> Lightning checkpoint through
+    A2JModelLightning.load_from_checkpoint (the file's hyper_parameters decide the stem width); else A2JModel +
+    optional {"model": sd}."""
+    if RGBD or "ckpt" in str(args.pretrained_a2j):
+        return A2JModelLightning.load_from_checkpoint(args.pretrained_a2j).eval()
+    a2j = A2JModel(21, crop_height=176, crop_width=176, is_RGBD=False)
+    if reload_a2j:
+        checkpoint = torch.load(args.pretrained_a2j, map_location="cpu")
         a2j.load_state_dict(checkpoint["model"], strict=False)
     for p in a2j.parameters():
         p.requires_grad = False
@@ -66,13 +60,17 @@ class HandNet(EngineOwner):
         self.detector = load_pretrained_fcos(args, reload_detector, num_classes)
         self.detector.eval()
         self.a2j = load_pretrained_a2j(args, reload_a2j, RGBD)
-        self.RGBD = bool(self.a2j.is_RGBD)
+        # the reference keeps the caller's flag (handnet_pipeline.py:55); a Lightning checkpoint knows its own stem
+        self.RGBD = bool(self.a2j.rgbd) if isinstance(self.a2j, A2JModelLightning) else bool(RGBD)
         self.num_classes = num_classes
 
     def engine(self) -> HandNetEngine:
         self._require_gpu()
-        if self._engine is None:
-            self._engine = HandNetEngine(self.detector.engine(), self.a2j.engine(), self.num_classes)
+        fcos, a2j = self.detector.engine(), self.a2j.engine()
+        # the sub-modules rebuild their engines when THEIR weights change (net.detector.load_state_dict(...)):
+        # never keep running a holder of stale ones
+        if self._engine is None or self._engine.fcos is not fcos or self._engine.a2j is not a2j:
+            self._engine = HandNetEngine(fcos, a2j, self.num_classes)
         return self._engine
 
     def enable_graph(self, on: bool = True):
@@ -105,9 +103,8 @@ class HandNet(EngineOwner):
         mask = out.has_hand.bool()
         final_results = out.keypoints.cpu()          # the reference returns keypoints on the CPU
         mask_cpu = mask.cpu()
-        if not bool(mask_cpu.any()):
-            return (torch.zeros((n, 21, 3)), torch.zeros_like(depth_images),
-                    torch.zeros((n, 4), device=depth_images.device))
+        if not bool(mask_cpu.any()):  # handnet_pipeline.py:107-108: the crops placeholder is a CPU float tensor
+            return torch.zeros((n, 21, 3)), torch.zeros_like(depth_images), torch.zeros((n, 4))
         sel = out.crops_nhwc[mask]
         depth_batch = (sel.permute(0, 3, 1, 2) if self.RGBD else sel[..., 0].unsqueeze(1)).contiguous()
         crops = out.crop_box[mask]

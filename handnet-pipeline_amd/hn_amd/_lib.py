@@ -6,12 +6,13 @@ fails (or a call returns non-zero) a RuntimeError is raised.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import threading
 from pathlib import Path
 
 from . import build as _build
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, TILE_256x128, TILE_64x128 = range(7)
 HN_FCOS_MAX_LEVELS = 5
@@ -58,6 +59,9 @@ SIGNATURES = {
     "hn_event_destroy": (C.c_int, [VP]),
     "hn_event_record": (C.c_int, [VP, VP]),
     "hn_event_elapsed_ms": (C.c_int, [VP, VP, c_f32p]),
+    "hn_clock_sample": (C.c_int, [C.c_int, VP, VP]),
+    "hn_range_check_enable": (C.c_int, [C.c_int]),
+    "hn_range_check_fetch": (C.c_int, [c_i32p, C.c_int, VP]),
     "hn_conv2d_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), VP, VP, VP, VP, VP, VP, VP, VP]),
     "hn_conv2d_pick_tile": (C.c_int, [C.POINTER(ConvDesc)]),
     "hn_conv2d_nhwc_f16x3": (C.c_int, [C.POINTER(ConvDesc), VP, VP, VP, VP, VP, VP]),
@@ -78,12 +82,14 @@ SIGNATURES = {
     "hn_cheby3_basis_split": (C.c_int, [VP, VP, VP, C.c_int, VP, VP, VP, C.c_int, C.c_int, C.c_int, VP]),
     "hn_feat_interp_add_f32": (C.c_int, [VP, VP, VP, C.c_int64, C.c_int, C.c_int, C.c_int, VP]),
     "hn_fcos_preprocess_split": (C.c_int, [VP, VP] + [C.c_int] * 8 + [c_f32p, c_f32p, VP]),
+    "hn_fcos_preprocess_list": (C.c_int, [VP, VP, VP] + [C.c_int] * 5 + [c_f32p, c_f32p, VP]),
     "hn_conv_stem_f16x3": (C.c_int, [VP] + [C.c_int] * 7 + [VP, VP, C.c_int, VP, C.c_int, VP]),
     "hn_fcos_candidates": (C.c_int, [C.POINTER(FcosLevels), C.c_int, C.c_int, C.c_float,
                                      VP, VP, VP, VP, VP, VP, VP, C.c_int, VP]),
     "hn_fcos_ext_gather": (C.c_int, [C.POINTER(FcosLevels), C.POINTER(VP), VP, VP, VP, C.c_int, C.c_int, VP, VP, VP]),
     "hn_fcos_nms_scratch_bytes": (C.c_int64, [C.c_int, C.c_int]),
     "hn_fcos_nms": (C.c_int, [VP] * 6 + [C.c_int, C.c_int, C.c_double, C.c_float, C.c_float] + [VP] * 9),
+    "hn_fcos_nms_ratios": (C.c_int, [VP] * 6 + [C.c_int, C.c_int, C.c_double, VP] + [VP] * 9),
     "hn_nms": (C.c_int, [VP, VP, C.c_int, C.c_double, VP, VP, VP, VP]),
     "hn_crop_resize": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, VP] + [C.c_int] * 7 + [VP, VP, VP, VP]),
     "hn_pack_depth_nhwc": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, VP]),
@@ -96,7 +102,10 @@ _lib = None
 
 
 def lib_path() -> Path:
-    return _build.LIB_PATH
+    """The in-tree library; HN_LIB_PATH selects another build (ablation / probe variants under tools/) without
+    touching the product file."""
+    override = os.environ.get("HN_LIB_PATH")
+    return Path(override) if override else _build.LIB_PATH
 
 
 def load(build_if_missing: bool = True) -> C.CDLL:
@@ -107,7 +116,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
             return _lib
         path = lib_path()
         if not path.exists():
-            if not build_if_missing:
+            if not build_if_missing or path != _build.LIB_PATH:
                 raise RuntimeError(f"{path} is missing; run `python __graft_entry__.py build`")
             _build.build_library()
         lib = C.CDLL(str(path))

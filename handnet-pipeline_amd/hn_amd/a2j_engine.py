@@ -1,9 +1,11 @@
 """A2J pose network on MI355X: dilated ResNet-50 trunk + 3 conv heads + anchor aggregation.
 
-Mirrors (arithmetically) a2j/a2j.py:194-250 of the reference; every convolution runs as
-hn_conv2d_nhwc_f32 with BatchNorm folded, ReLU / residual fused in the epilogue, NHWC
-activations resident in HBM.  The regression and depth heads read the same x4, so their
-first layers run as ONE 2048 -> 512 conv (wider N tile, x4 gathered once).
+Mirrors (arithmetically) a2j/a2j.py:194-250 of the reference.  Default precision "f16x3": every convolution with
+Cin % 32 == 0 runs hn_conv2d_nhwc_f16x3(_ws / _grouped) on S32 split activations (BatchNorm folded, ReLU /
+residual fused in the epilogue, split-K for the 11x11 layers), the stem (Cin 1 or 4) runs the exact f32-MFMA
+kernel hn_conv2d_nhwc_f32; precision "f32" keeps everything on the latter.  The regression and depth heads read
+the same x4, so their first layers run as ONE 2048 -> 512 conv, and layers 2-4 / the outputs of the three heads
+are one grouped launch each.
 """
 from __future__ import annotations
 
@@ -27,6 +29,7 @@ class A2JEngine:
             raise ValueError("precision must be 'f32' or 'f16x3'")
         self.precision = precision
         sd = strip_prefix(state_dict, "a2j.")
+        ops.clear_plan_caches()   # plans are keyed by weight addresses; a rebuilt engine starts clean
         self.device = torch.device(device)
         self.joints = num_joints
         self.rgbd = rgbd
@@ -130,6 +133,7 @@ class A2JEngine:
         dep = self._conv(d, self.dep_out, relu=False, out_f32=True)
         return cls, reg, dep
 
+    @ops.device_guarded
     def forward_nhwc(self, x, valid=None, return_heads=False):
         x3, x4 = self.trunk(x)
         cls, reg, dep = self.heads(x3, x4)
@@ -140,6 +144,7 @@ class A2JEngine:
             return out, (x3, x4), (cls, reg, dep)
         return out
 
+    @ops.device_guarded
     def forward(self, depth, valid=None):
         """depth [K,1,H,W] (or [K,4,H,W] for RGBD) fp32 on the GPU -> [K,J,3] on the GPU."""
         if depth.dim() != 4:

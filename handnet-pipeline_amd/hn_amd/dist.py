@@ -1,6 +1,6 @@
 """Multi-GPU inference: frames are independent, so a batch is sharded contiguously over the
 ranks (one process per GPU, full weight replica each) and the only exchange is ONE
-all-gather of fixed-size per-frame records per step (RCCL over xGMI on the GPU box, gloo
+all-gather (a single collective call) of fixed-size per-frame records per step (RCCL over xGMI on the GPU box, gloo
 in the CPU tests).  No collective sits on the data path of the networks themselves.
 
 Per-frame record: keypoints [21,3] fp32 + padded crop box [4] int64 + has_hand flag --
@@ -37,12 +37,35 @@ def shard_bounds(total: int, rank: int, world: int) -> tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+# one fixed-size record per frame, packed so that ONE all-gather moves everything:
+#   bytes   0..31   padded crop box, 4 x int64
+#   bytes  32..35   has_hand (int32)        bytes 36..39  row-is-a-real-frame (int32)
+#   bytes  40..     keypoints, J*3 x fp32
+_HEAD = 40
+_BUFFERS = {}
+
+
+def _record_bytes(j3: int) -> int:
+    return (_HEAD + 4 * j3 + 7) // 8 * 8
+
+
+def _buffers(per_rank, world, rec, dev):
+    """Send / receive buffers are reused from step to step (no allocation on the timed path)."""
+    key = (per_rank, world, rec, str(dev))
+    buf = _BUFFERS.get(key)
+    if buf is None:
+        send = torch.zeros((per_rank, rec), device=dev, dtype=torch.uint8)
+        recv = torch.zeros((world * per_rank, rec), device=dev, dtype=torch.uint8) if world > 1 else send
+        buf = _BUFFERS[key] = (send, recv)
+    return buf
+
+
 def gather_results(keypoints: torch.Tensor, crop_box: torch.Tensor, has_hand: torch.Tensor,
                    per_rank: int | None = None, group=None):
-    """All-gather one step's per-frame results.
+    """All-gather one step's per-frame results with ONE collective.
 
     keypoints [b,J,3] fp32, crop_box [b,4] int64, has_hand [b] int32 (this rank's frames,
-    b <= per_rank).  Shards are padded to `per_rank` rows so a plain all-gather suffices;
+    b <= per_rank).  Shards are padded to `per_rank` records so a plain all-gather suffices;
     returns (keypoints [W*per_rank,J,3], crop_box [W*per_rank,4], has_hand [W*per_rank],
     valid [W*per_rank] bool) on every rank, in global frame order.
     """
@@ -52,22 +75,23 @@ def gather_results(keypoints: torch.Tensor, crop_box: torch.Tensor, has_hand: to
     if b > per_rank:
         raise ValueError("shard larger than per_rank")
     dev = keypoints.device
-    j3 = keypoints.shape[1] * keypoints.shape[2]
-    fl = torch.zeros((per_rank, j3), device=dev, dtype=torch.float32)
-    fl[:b] = keypoints.reshape(b, j3)
-    meta = torch.zeros((per_rank, 6), device=dev, dtype=torch.int64)
-    meta[:b, :4] = crop_box
-    meta[:b, 4] = has_hand.to(torch.int64)
-    meta[:b, 5] = 1  # row is a real frame
+    j, three = keypoints.shape[1], keypoints.shape[2]
+    j3 = j * three
+    rec = _record_bytes(j3)
+    send, recv = _buffers(per_rank, world, rec, dev)
+    if b < per_rank:
+        send[b:].zero_()
+    send[:b, :32] = crop_box.to(torch.int64).contiguous().view(torch.uint8).reshape(b, 32)
+    flags = torch.stack([has_hand.to(torch.int32), torch.ones_like(has_hand, dtype=torch.int32)], dim=1)
+    send[:b, 32:_HEAD] = flags.contiguous().view(torch.uint8).reshape(b, 8)
+    send[:b, _HEAD:_HEAD + 4 * j3] = keypoints.to(torch.float32).reshape(b, j3).contiguous().view(torch.uint8)
     if world > 1:
-        fl_all = torch.empty((world * per_rank, j3), device=dev, dtype=torch.float32)
-        meta_all = torch.empty((world * per_rank, 6), device=dev, dtype=torch.int64)
-        dist.all_gather_into_tensor(fl_all, fl, group=group)
-        dist.all_gather_into_tensor(meta_all, meta, group=group)
-    else:
-        fl_all, meta_all = fl, meta
-    kp = fl_all.reshape(world * per_rank, keypoints.shape[1], keypoints.shape[2])
-    return kp, meta_all[:, :4], meta_all[:, 4].to(torch.int32), meta_all[:, 5].bool()
+        dist.all_gather_into_tensor(recv, send, group=group)
+    rows = world * per_rank
+    box = recv[:, :32].contiguous().view(torch.int64).reshape(rows, 4)
+    fl = recv[:, 32:_HEAD].contiguous().view(torch.int32).reshape(rows, 2)
+    kp = recv[:, _HEAD:_HEAD + 4 * j3].contiguous().view(torch.float32).reshape(rows, j, three)
+    return kp, box, fl[:, 0].contiguous(), fl[:, 1].bool()
 
 
 def compact_gathered(kp, crop_box, has_hand, valid):

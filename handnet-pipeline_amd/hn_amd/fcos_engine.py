@@ -1,15 +1,20 @@
 """FCOS hand detector on MI355X: ResNet-34-FPN + GroupNorm towers + on-device post-process.
 
-Arithmetic follows fcos_utils/fcos.py:675-767 of the reference (eval branch):
-  transform (torchvision GeneralizedRCNNTransform)   -> hn_fcos_preprocess_f32 (NHWC, C=4)
-  resnet34 body + FrozenBatchNorm (folded) + FPN      -> hn_conv2d_nhwc_f32 (+ residual /
-                                                         nearest-2x top-down add epilogues)
-  4 x (conv3x3 + GroupNorm(32) + ReLU) towers          -> conv writes raw output, GN statistics
-                                                         become per-(image,channel) scale/shift
-                                                         applied by the NEXT conv on load
+Arithmetic follows fcos_utils/fcos.py:675-767 of the reference (eval branch); default precision "f16x3":
+  transform (torchvision GeneralizedRCNNTransform)   -> hn_fcos_preprocess_split (the stem's split fp16 image;
+                                                         hn_fcos_preprocess_list for mixed-size batches)
+  resnet34 body + FrozenBatchNorm (folded) + FPN      -> hn_conv_stem_f16x3, hn_conv2d_nhwc_f16x3(_ws / _grouped)
+                                                         on S32 split activations (+ residual / nearest-2x
+                                                         top-down add epilogues)
+  4 x (conv3x3 + GroupNorm(32) + ReLU) towers          -> grouped conv launches write the raw fp32 output AND the
+                                                         GroupNorm partial sums; hn_groupnorm_finalize_rows32
+                                                         builds per-(image, channel) scale/shift tables,
+                                                         hn_affine_split_f32 applies them (+ReLU) and emits the
+                                                         next conv's S32 input
   cls_logits+hand_lr / bbox_reg+ctrness               -> one Cout=C+2 and one Cout=5 conv
-  score/threshold/decode/compaction, batched NMS      -> hn_fcos_candidates, hn_fcos_nms
-Everything stays on the device; nothing here synchronises with the host.
+  score/threshold/decode/compaction, batched NMS      -> hn_fcos_candidates, hn_fcos_nms(_ratios)
+precision "f32" keeps every convolution on the exact f32-MFMA kernel (hn_conv2d_nhwc_f32; GroupNorm applied on
+load by the next conv).  Everything stays on the device; nothing here synchronises with the host.
 """
 from __future__ import annotations
 
@@ -45,6 +50,7 @@ class FCOSEngine:
             raise ValueError("precision must be 'f32' or 'f16x3'")
         self.precision = precision
         sd = state_dict
+        ops.clear_plan_caches()   # plans are keyed by weight addresses; a rebuilt engine starts clean
         dev = torch.device(device)
         self.device = dev
         self.num_classes = num_classes
@@ -303,31 +309,59 @@ class FCOSEngine:
             outs.append((cls_lr, reg_ctr, ext))
         return outs
 
+    def list_geometry(self, images):
+        """torchvision batch_images for a list of [3,h_i,w_i] images: per-image (h, w, oh, ow) and the common
+        canvas (max resized size rounded up to 32), fcos_utils/fcos.py:702-709."""
+        geom = []
+        for img in images:
+            if img.dim() != 3 or img.shape[0] != 3:
+                raise ValueError("expected a list of [3,H,W] images")
+            h, w = int(img.shape[1]), int(img.shape[2])
+            geom.append((h, w) + resized_size(h, w, self.min_size, self.max_size))
+        ph = int(math.ceil(max(g[2] for g in geom) / 32) * 32)
+        pw = int(math.ceil(max(g[3] for g in geom) / 32) * 32)
+        return geom, ph, pw
+
+    @ops.device_guarded
     def forward_heads(self, images):
-        """images [N,3,H,W] fp32 0..1 on the GPU -> per-level head tensors + geometry."""
-        if images.dim() != 4 or images.shape[1] != 3:
-            raise ValueError("expected [N,3,H,W]")
-        n, _, h, w = images.shape
-        oh, ow, ph, pw = self.geometry(h, w)
-        pre = ops.fcos_preprocess_split if self.precision == "f16x3" else ops.fcos_preprocess
-        x = pre(images.float().contiguous(), oh, ow, ph, pw, IMAGE_MEAN, IMAGE_STD)
+        """images [N,3,H,W] fp32 0..1 on the GPU (or a list of [3,h_i,w_i] images of different sizes)
+        -> per-level head tensors + geometry."""
+        if not torch.is_tensor(images):
+            geom, ph, pw = self.list_geometry(images)
+            x = ops.fcos_preprocess_list(images, geom, ph, pw, IMAGE_MEAN, IMAGE_STD, split=self.precision == "f16x3")
+            oh, ow = [g[2] for g in geom], [g[3] for g in geom]
+        else:
+            if images.dim() != 4 or images.shape[1] != 3:
+                raise ValueError("expected [N,3,H,W]")
+            n, _, h, w = images.shape
+            oh, ow, ph, pw = self.geometry(h, w)
+            pre = ops.fcos_preprocess_split if self.precision == "f16x3" else ops.fcos_preprocess
+            x = pre(images.float().contiguous(), oh, ow, ph, pw, IMAGE_MEAN, IMAGE_STD)
         feats = self.backbone(x)
         outs = self.heads(feats)
         strides = [ph // f.shape[1] for f in feats]
         self._ext_levels = [o[2] for o in outs] if self.ext else None
         return [o[0] for o in outs], [o[1] for o in outs], strides, (oh, ow, ph, pw)
 
+    @ops.device_guarded
     def detect(self, images, cand=None, det=None, nms_scratch=None):
-        """Full detector on the device -> ops.Detections (fixed capacity, score-ordered)."""
-        n, _, h, w = images.shape
+        """Full detector on the device -> ops.Detections (fixed capacity, score-ordered).  images: [N,3,H,W], or a
+        list of [3,h_i,w_i] tensors of different sizes (each resized on its own, boxes rescaled per image)."""
         cls_lr, reg_ctr, strides, (oh, ow, ph, pw) = self.forward_heads(images)
         cand = ops.fcos_candidates(cls_lr, reg_ctr, strides, self.num_classes, SCORE_THRESH, out=cand)
         # resize_boxes (fcos.py:770-783): fp32 tensor / fp32 tensor
+        if not torch.is_tensor(images):
+            hs = torch.tensor([float(i.shape[1]) for i in images]) / torch.tensor([float(v) for v in oh])
+            ws = torch.tensor([float(i.shape[2]) for i in images]) / torch.tensor([float(v) for v in ow])
+            ratios = torch.stack([hs, ws], dim=1).contiguous().to(self.device)
+            return ops.fcos_nms(cand, NMS_THRESH, 1.0, 1.0, scratch=nms_scratch, out=det, ratios=ratios), cand
+        n, _, h, w = images.shape
         ratio_h = (torch.tensor(float(h)) / torch.tensor(float(oh))).item()
         ratio_w = (torch.tensor(float(w)) / torch.tensor(float(ow))).item()
         det = ops.fcos_nms(cand, NMS_THRESH, ratio_h, ratio_w, scratch=nms_scratch, out=det)
         return det, cand
 
+    @ops.device_guarded
     def detect_ext(self, images):
         """ext=True detector: (Detections, Candidates, contacts [N,cap] int32, dxdymags [N,cap,3])."""
         if not self.ext:

@@ -29,9 +29,53 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def _check_device(t: torch.Tensor, name="tensor"):
+    """Launches go to the CURRENT device's stream: a tensor of another GPU would be a memory fault (or silently
+    run on the wrong device under peer access).  The engines enter `on_device(self.device)`; direct callers of
+    these wrappers must make the tensor's device current (torch.cuda.device / set_device)."""
+    if _cur_device is not None and t.device.index != _cur_device():
+        raise RuntimeError(f"{name} lives on cuda:{t.device.index} but the current device is cuda:{_cur_device()}; "
+                           "wrap the call in `with torch.cuda.device(tensor.device):`")
+
+
+class on_device:
+    """`with on_device(dev):` -- make `dev` current for the block (no-op, and no torch.cuda.device object, when
+    it already is: the hot path stays free of the context-manager cost)."""
+
+    __slots__ = ("idx", "ctx")
+
+    def __init__(self, dev):
+        self.idx = torch.device(dev).index
+        self.ctx = None
+
+    def __enter__(self):
+        if self.idx is not None and (_cur_device is None or _cur_device() != self.idx):
+            self.ctx = torch.cuda.device(self.idx)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+            self.ctx = None
+        return False
+
+
+def device_guarded(fn):
+    """Method decorator: run with `self.device` as the current device."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *a, **k):
+        with on_device(self.device):
+            return fn(self, *a, **k)
+    return wrapper
+
+
 def _req(t: torch.Tensor, dtype=torch.float32, name="tensor"):
     if not t.is_cuda:
         raise RuntimeError(f"{name} must live on the GPU (no CPU fallback in handnet-pipeline_amd)")
+    _check_device(t, name)
     if t.dtype != dtype:
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
     if not t.is_contiguous():
@@ -58,6 +102,7 @@ def _pixel_stride(t: torch.Tensor, name: str) -> int:
     xs[:, :, :, b0:b1]).  Returns the pixel stride in elements (floats or halfs)."""
     if not t.is_cuda:
         raise RuntimeError(f"{name} must live on the GPU (no CPU fallback in handnet-pipeline_amd)")
+    _check_device(t, name)
     n, h, w = t.shape[:3]
     ps = t.stride(2)
     if is_split(t):
@@ -137,6 +182,13 @@ CONV_PROFILE = None
 TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x64", 4: "128x32", 5: "256x128", 6: "64x128", 7: "32x64", 8: "256x64", 9: "256x128w8"}
 
 
+def clear_plan_caches():
+    """Drop the cached conv descriptors / launch plans (they are keyed by weight addresses: engines call this when
+    they are rebuilt, so that a recycled address can never meet a stale plan and the caches stay bounded)."""
+    _CONV_PLANS.clear()
+    _DESC_TEMPLATES.clear()
+
+
 # split-K workspace: one fp32 buffer per (device, stream) -- a convolution only uses it between its own two
 # launches, and launches on one stream are ordered
 CONV_WORKSPACE_BYTES = 32 << 20
@@ -190,7 +242,9 @@ def conv2d_nhwc(x, w, bias=None, *, stride=1, pad=0, dil=1, relu=False, relu_col
     plan_key = None
     if (out is None and in_scale is None and w16 is not None and gn_partial is None and CONV_PROFILE is None
             and x.dtype == torch.float16 and x.is_cuda):
-        plan_key = (x.device.index, x.shape, x.stride(), w.data_ptr(), w16.data_ptr(), None if bias is None else bias.data_ptr(),
+        _check_device(x, "x")
+        plan_key = (x.device.index, x.shape, x.stride(), w.data_ptr(), tuple(w.shape), w16.data_ptr(),
+                    None if bias is None else bias.data_ptr(),
                     stride, pad, dil, relu, relu_cols, tile, out_split, res_upsample, splitk, SPLITK, SPLITK_EAGER,
                     None if residual is None else (residual.shape, residual.stride(), residual.dtype))
         plan = _CONV_PLANS.get(plan_key)
@@ -480,6 +534,36 @@ def fcos_preprocess_split(images, oh, ow, ph, pw, mean, std, border=3, out=None)
     return out
 
 
+def fcos_preprocess_list(images, geom, ph, pw, mean, std, split=True, border=3):
+    """Differently sized images (torchvision batch_images): images = list of fp32 GPU [3,h_i,w_i] tensors,
+    geom = [(h_i, w_i, oh_i, ow_i)] -> the common canvas (stem image when split, else fp32 [N,ph,pw,4])."""
+    lib = _lib.load()
+    n = len(images)
+    if n == 0 or len(geom) != n:
+        raise ValueError("need one geometry row per image")
+    keep = []
+    for i, (img, (h, w, oh, ow)) in enumerate(zip(images, geom)):
+        img = _req(img.float().contiguous(), name=f"images[{i}]")
+        if tuple(img.shape) != (3, h, w) or oh > ph or ow > pw or min(h, w, oh, ow) <= 0:
+            raise ValueError(f"images[{i}]: shape {tuple(img.shape)} does not match its geometry {(h, w, oh, ow)} "
+                             f"or exceeds the canvas {(ph, pw)}")
+        keep.append(img)
+    dev = keep[0].device
+    ptrs = torch.tensor([t.data_ptr() for t in keep], dtype=torch.int64).to(dev)
+    gtab = torch.tensor([list(g) for g in geom], dtype=torch.int32).to(dev)
+    if split:
+        out = torch.empty((2, n, ph + 2 * border, pw + 2 * border, 4), device=dev, dtype=torch.float16)
+    else:
+        out = torch.empty((n, ph, pw, 4), device=dev, dtype=torch.float32)
+    m = (C.c_float * 3)(*[float(v) for v in mean])
+    s = (C.c_float * 3)(*[float(v) for v in std])
+    check(lib.hn_fcos_preprocess_list(ptr(ptrs), ptr(gtab), ptr(out), 1 if split else 0, n, ph, pw, border, m, s,
+                                      _stream()), "hn_fcos_preprocess_list")
+    # the kernel reads `keep` / the tables asynchronously: tie their lifetime to the output
+    out._hn_sources = (keep, ptrs, gtab)
+    return out
+
+
 def conv_stem_split(x16, w16, bias, cout, r=7, stride=2, relu=True, out_split=True, algo_cin=3, out=None):
     """Stem conv on the f16x3 kernel.  x16: stem image from fcos_preprocess_split (border = r // 2);
     w16: weights.pack_stem_split(...).w16.  -> [N, oh, ow, cout] fp32 or S32."""
@@ -596,14 +680,27 @@ def fcos_ext_gather(ext, det: "Detections", cand: Candidates):
     return contacts, dxdymags
 
 
-def fcos_nms(cand: Candidates, iou_thresh, ratio_h, ratio_w, scratch=None, out: Detections | None = None):
+def fcos_nms(cand: Candidates, iou_thresh, ratio_h, ratio_w, scratch=None, out: Detections | None = None,
+             ratios=None):
+    """ratios: optional fp32 GPU [N,2] = (ratio_h, ratio_w) per image (batches of differently sized images);
+    otherwise the scalar pair applies to every image."""
     lib = _lib.load()
     n, cap = cand.scores.shape
+    _check_device(cand.scores, "candidates")
     need = lib.hn_fcos_nms_scratch_bytes(n, cap)
     if scratch is None or scratch.numel() < need:
         scratch = torch.empty((need,), device=cand.scores.device, dtype=torch.uint8)
     if out is None:
         out = alloc_detections(n, cap, cand.scores.device)
+    if ratios is not None:
+        _req(ratios, name="ratios")
+        if tuple(ratios.shape) != (n, 2):
+            raise ValueError("ratios must be [N,2]")
+        check(lib.hn_fcos_nms_ratios(ptr(cand.boxes), ptr(cand.scores), ptr(cand.labels), ptr(cand.sides),
+                                     ptr(cand.level), ptr(cand.count), n, cap, float(iou_thresh), ptr(ratios),
+                                     ptr(scratch), ptr(out.boxes), ptr(out.scores), ptr(out.labels), ptr(out.sides),
+                                     ptr(out.level), ptr(out.keep), ptr(out.count), _stream()), "hn_fcos_nms_ratios")
+        return out
     check(lib.hn_fcos_nms(ptr(cand.boxes), ptr(cand.scores), ptr(cand.labels), ptr(cand.sides), ptr(cand.level),
                           ptr(cand.count), n, cap, float(iou_thresh), float(ratio_h), float(ratio_w), ptr(scratch),
                           ptr(out.boxes), ptr(out.scores), ptr(out.labels), ptr(out.sides), ptr(out.level),
@@ -696,6 +793,32 @@ def convert_joints(kp, crop_box, valid=None, paras=None, crop=176, out=None):
         pp = (C.c_float * 4)(*[float(v) for v in paras])
     check(lib.hn_convert_joints_f32(ptr(kp), ptr(crop_box), ptr(valid), n, j, float(crop), float(crop), pp, ptr(out),
                                     _stream()), "hn_convert_joints_f32")
+    return out
+
+
+def range_check_enable(on=True):
+    """f16x3 range contract (see include/handnet_hip.h): split producers launched from now on flag values that
+    cannot be represented as fp16 hi + lo (|v| > 65504 or non-finite)."""
+    check(_lib.load().hn_range_check_enable(1 if on else 0), "hn_range_check_enable")
+
+
+def range_check_fetch(reset=True) -> bool:
+    """True if a split producer met an out-of-range / non-finite value since the last reset (synchronises)."""
+    flag = C.c_int32(0)
+    check(_lib.load().hn_range_check_fetch(C.byref(flag), 1 if reset else 0, _stream()), "hn_range_check_fetch")
+    return bool(flag.value)
+
+
+class RangeError(RuntimeError):
+    """An activation left the dynamic range the f16x3 split format supports."""
+
+
+def clock_sample(micros, out=None, stream=None):
+    """Enqueue the one-wave shader-clock sampler (MHz -> out[0], fp32 GPU) on `stream` (default: current)."""
+    if out is None:
+        out = torch.zeros((1,), device=torch.device("cuda", _cur_device() if _cur_device else 0), dtype=torch.float32)
+    st = _stream() if stream is None else stream.cuda_stream
+    check(_lib.load().hn_clock_sample(int(micros), ptr(out), st), "hn_clock_sample")
     return out
 
 

@@ -10,6 +10,8 @@ from __future__ import annotations
 
 from dataclasses import dataclass
 
+import os
+
 import torch
 
 from . import ops
@@ -31,24 +33,39 @@ class HandNetOutput:
 
 class HandNetEngine:
     def __init__(self, fcos: FCOSEngine, a2j: A2JEngine, num_classes: int):
+        if fcos.device != a2j.device:
+            raise ValueError(f"detector on {fcos.device} but A2J on {a2j.device}")
         self.fcos, self.a2j, self.num_classes = fcos, a2j, num_classes
+        self.device = fcos.device
         self._graphs = {}
+        # f16x3 range contract as a debug switch: every split producer flags values outside the fp16 range and
+        # forward_device raises instead of returning inf / NaN keypoints (costs one device -> host sync per call)
+        self.check_range = os.environ.get("HN_CHECK_RANGE", "0") == "1"
 
-    def forward_device(self, images: torch.Tensor, depth: torch.Tensor) -> HandNetOutput:
-        """images [N,3,H,W] 0..1, depth [N,1,H,W] metres (RGBD model: [N,4,H,W] = RGB + depth), fp32 on the GPU."""
+    @ops.device_guarded
+    def forward_device(self, images, depth: torch.Tensor) -> HandNetOutput:
+        """images [N,3,H,W] 0..1 (or a list of [3,h_i,w_i] tensors of different sizes), depth [N,1,H,W] metres
+        (RGBD model: [N,4,H,W] = RGB + depth), fp32 on the GPU."""
         want_c = 4 if self.a2j.rgbd else 1
-        if depth.dim() != 4 or depth.shape[1] != want_c or depth.shape[0] != images.shape[0]:
+        if depth.dim() != 4 or depth.shape[1] != want_c or depth.shape[0] != len(images):
             raise ValueError(f"depth_images must be [N,{want_c},H,W] matching images"
                              + (" (RGB + depth, ros_demo.py:268-270)" if self.a2j.rgbd else ""))
+        if self.check_range:
+            ops.range_check_enable(True)
+            ops.range_check_fetch(reset=True)
         det, cand = self.fcos.detect(images)
         crop_box, has_hand, crops = ops.crop_resize(det, self.num_classes - 1, depth.float().contiguous(), CROP, 4,
                                                     reorder_bgr=self.a2j.rgbd)
         kp = self.a2j.forward_nhwc(crops, valid=has_hand)
+        if self.check_range and ops.range_check_fetch(reset=True):
+            raise ops.RangeError("an activation left the fp16 range (|v| > 65504 or non-finite) on the f16x3 path: "
+                                 "results would be inf/NaN.  Run the engines with precision='f32' for this model")
         return HandNetOutput(kp, crops, crop_box, has_hand, det, cand)
 
     # -------------------------------------------------------------------------------
     # hipGraph replay for a fixed batch shape (launch-bound at small batch)
     # -------------------------------------------------------------------------------
+    @ops.device_guarded
     def graphed(self, images: torch.Tensor, depth: torch.Tensor):
         """Returns (run, static_images, static_depth, static_output): copy new inputs into the
         static tensors and call run() to replay the captured step."""

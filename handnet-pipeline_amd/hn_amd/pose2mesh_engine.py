@@ -135,6 +135,7 @@ class Pose2MeshEngine:
                 x = ops.feat_interp_add(xin.contiguous(), x.contiguous(), up=1)
         return x
 
+    @ops.device_guarded
     def graphed(self, pose2d):
         """hipGraph replay for a fixed batch size (the forward is ~76 short launches, i.e. launch-bound):
         returns (run, static_input, (mesh, pose3d)); copy new joints into static_input and call run()."""
@@ -156,6 +157,7 @@ class Pose2MeshEngine:
         g, s_in, out = self._graphs[key]
         return g.replay, s_in, out
 
+    @ops.device_guarded
     def forward(self, pose2d):
         """pose2d [B,J,2] fp32 on the GPU -> (cam_mesh [B,V0,3], pose3d [B,J,3]), both on the GPU."""
         if pose2d.dim() != 3 or pose2d.shape[1:] != (self.num_joint, 2):

@@ -43,6 +43,17 @@ class ConvW:
         return self.cout * r * s * (real_cin or self.cin)
 
 
+F16_MAX = 65504.0
+
+
+def check_split_range(w: torch.Tensor, what: str) -> None:
+    """f16x3 range contract for weights: hi = fp16(w) must be finite (BatchNorm folding can blow a filter up by
+    gamma / sqrt(var + eps)).  Checked once at load, on the host; such a model needs precision='f32'."""
+    if w.numel() and not bool(torch.isfinite(w).all() and w.abs().max() <= F16_MAX):
+        raise ValueError(f"{what}: values outside the fp16 range (|w| max {float(w.abs().max()):.3g} > {F16_MAX}) or "
+                         "non-finite -- the f16x3 split format cannot hold them; build the engine with precision='f32'")
+
+
 def split_f16x3(w: torch.Tensor) -> torch.Tensor:
     """[Cout,R,S,Cin] fp32 -> fp16 [Cout, (Cin/32)*R*S, 2, 32]: k tiles ordered 32-channel block
     OUTER / filter tap INNER (the order the f16x3 kernel walks K, chosen for L2 reuse of the input);
@@ -50,6 +61,7 @@ def split_f16x3(w: torch.Tensor) -> torch.Tensor:
     cout, r, s, cin = w.shape
     if cin % 32:
         raise ValueError("split_f16x3 needs Cin to be a multiple of 32")
+    check_split_range(w, "filter bank")
     tiles = w.float().reshape(cout, r * s, cin // 32, 32).permute(0, 2, 1, 3).reshape(cout, -1, 32)
     hi = tiles.half()
     lo = (tiles - hi.float()).half()

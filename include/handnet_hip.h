@@ -33,7 +33,7 @@ extern "C" {
 #define HN_ERR_HIP 2
 
 /* ABI version; bumped whenever a struct below changes. */
-#define HN_ABI_VERSION 19
+#define HN_ABI_VERSION 20
 int hn_abi_version(void);
 const char* hn_last_error(void);
 
@@ -45,6 +45,20 @@ int hn_event_create(void** ev);
 int hn_event_destroy(void* ev);
 int hn_event_record(void* ev, void* stream);
 int hn_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
+
+/* Shader clock UNDER LOAD: one wave compares s_memtime with s_memrealtime for `micros` microseconds and writes
+ * the MHz figure to *mhz (device float).  Launch it on a side stream while the kernels of interest run
+ * (bench.py roofline leg: roofline.clock_mhz); the sampling loop is bounded by real time. */
+int hn_clock_sample(int micros, float* mhz, void* stream);
+
+/* ---- f16x3 range contract (debug switch; engines: HN_CHECK_RANGE=1) -------------------------------------
+ * A value that is stored in the split format must be finite and |v| <= 65504 (hi = fp16(v) would be +-inf).
+ * hn_range_check_enable(1) makes every later launch of a split PRODUCER (f16x3 conv epilogue / split-K tail,
+ * hn_affine_split_f32, hn_fcos_preprocess_split / _list) set a sticky per-device flag when it meets such a
+ * value; hn_range_check_fetch copies it to *flag (host), optionally clearing it, and synchronises `stream`.
+ * Weight banks are checked on the host when they are split (hn_amd.weights.split_f16x3 raises). */
+int hn_range_check_enable(int on);
+int hn_range_check_fetch(int* flag /* host */, int reset, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Convolution (implicit GEMM on f32 / f16 MFMA), fused epilogue.
@@ -204,6 +218,13 @@ int hn_fcos_preprocess_f32(const float* src, float* dst, int n, int h, int w,
 int hn_fcos_preprocess_split(const float* src, void* dst16, int n, int h, int w, int oh, int ow,
                              int ph, int pw, int border, const float mean[3], const float stdv[3],
                              void* stream);
+/* Batches of differently sized images (torchvision batch_images, fcos_utils/fcos.py:702-709): srcs = DEVICE
+ * array of n device pointers to [3][h_i][w_i] images, geom = DEVICE int32 [n][4] = {h_i, w_i, oh_i, ow_i};
+ * each image is resized on its own into the top-left corner of the common zero canvas.
+ * split = 0: dst = fp32 [n][ph][pw][4]; split = 1: dst = the stem image (border as above). */
+int hn_fcos_preprocess_list(const float* const* srcs, const int32_t* geom, void* dst, int split, int n,
+                            int ph, int pw, int border, const float mean[3], const float stdv[3],
+                            void* stream);
 int hn_conv_stem_f16x3(const void* x16, int n, int ph, int pw, int pad, int r, int stride, int cout,
                        const void* w16, const float* bias, int relu, void* y, int out_split,
                        void* stream);
@@ -256,6 +277,14 @@ int hn_fcos_nms(const float* cand_boxes, const float* cand_scores, const int32_t
                 float* det_boxes /* [n][cap][4] */, float* det_scores, int32_t* det_labels,
                 int32_t* det_sides, int32_t* det_level, int32_t* det_keep /* cand index */,
                 int32_t* det_count /* [n] */, void* stream);
+
+/* hn_fcos_nms with one (ratio_h, ratio_w) pair per image: ratios = DEVICE fp32 [n][2] (resize_boxes of a
+ * batch whose images differ in size, fcos_utils/fcos.py:661-669). */
+int hn_fcos_nms_ratios(const float* cand_boxes, const float* cand_scores, const int32_t* cand_labels,
+                       const int32_t* cand_sides, const int32_t* cand_level, const int32_t* cand_count,
+                       int n, int cap, double iou_thresh, const float* ratios, void* scratch,
+                       float* det_boxes, float* det_scores, int32_t* det_labels, int32_t* det_sides,
+                       int32_t* det_level, int32_t* det_keep, int32_t* det_count, void* stream);
 
 /* Stand-alone NMS with torchvision.ops.nms semantics (tests / callers with own boxes). */
 int hn_nms(const float* boxes, const float* scores, int k, double iou_thresh,

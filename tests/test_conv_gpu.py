@@ -442,3 +442,66 @@ def test_conv_f16x3_grouped_members_of_different_spatial_size():
         for x, y in zip(xs, ys):
             ref = ops.conv2d_nhwc(x, cw.w, cw.bias, pad=1, relu_cols=rc, w16=cw.w16, splitk=False)
             assert y.shape == ref.shape and torch.equal(y, ref)
+
+
+# ---- f16x3 range contract (include/handnet_hip.h: hn_range_check_enable / _fetch) ----
+def test_f16x3_range_contract_flags_overflow_instead_of_returning_inf():
+    """|v| > 65504 cannot be split (hi = fp16(v) = inf).  With the debug switch on, every split producer raises
+    the sticky flag: the fp32 -> S32 pass, and a conv epilogue that writes S32."""
+    from hn_amd import ops
+    from hn_amd.weights import split_f16x3
+    ops.range_check_enable(True)
+    try:
+        assert ops.range_check_fetch(reset=True) in (False, True)      # clear whatever earlier tests left
+        x = _rand((1, 9, 9, 64), 71, 1.0).cuda()
+        ops.to_split(x)
+        assert ops.range_check_fetch() is False
+        big = x.clone()
+        big[0, 4, 4, 7] = 1.0e5
+        xs = ops.to_split(big)
+        assert ops.range_check_fetch() is True                          # flagged ...
+        assert not torch.isfinite(ops.from_split(xs)).all()             # ... because the data really is inf
+        assert ops.range_check_fetch() is False                         # sticky flag was reset by the fetch
+        nan = x.clone()
+        nan[0, 0, 0, 0] = float("nan")
+        ops.to_split(nan)
+        assert ops.range_check_fetch() is True
+        # conv epilogue: in-range operands, out-of-range S32 OUTPUT (64 channels x 9 taps x 40 x 40 = 9e5)
+        wt = torch.full((64, 3, 3, 64), 40.0)
+        xin = ops.to_split(torch.full((1, 9, 9, 64), 40.0, device="cuda"))
+        assert ops.range_check_fetch() is False
+        y32 = ops.conv2d_nhwc(xin, wt.cuda(), None, pad=1, w16=split_f16x3(wt).cuda(), out_split=False)
+        assert ops.range_check_fetch() is False and torch.isfinite(y32).all()   # fp32 output is fine
+        ops.conv2d_nhwc(xin, wt.cuda(), None, pad=1, w16=split_f16x3(wt).cuda(), out_split=True)
+        assert ops.range_check_fetch() is True
+    finally:
+        ops.range_check_enable(False)
+    ops.to_split(big)                                                    # switch off: nothing is recorded
+    ops.range_check_enable(True)
+    try:
+        assert ops.range_check_fetch() is False
+    finally:
+        ops.range_check_enable(False)
+
+
+def test_f16x3_wide_dynamic_range_keeps_precision():
+    """Log-uniform magnitudes over nine decades (1e-6 .. 1e3) in activations and 1e-4 .. 1e1 in weights: error
+    <= 2e-5 of the output scale against fp64 (the stored value's error is max(2^-22 |v|, 2^-25): tiny values lose
+    relative precision but cannot hurt an output dominated by the large ones)."""
+    from hn_amd import ops
+    from hn_amd.weights import split_f16x3
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(72)
+    mag = 10.0 ** (torch.rand((2, 20, 20, 128), generator=g) * 9.0 - 6.0)
+    x = mag * torch.sign(torch.randn((2, 20, 20, 128), generator=g))
+    wmag = 10.0 ** (torch.rand((64, 3, 3, 128), generator=g) * 5.0 - 4.0)
+    wt = wmag * torch.sign(torch.randn((64, 3, 3, 128), generator=g))
+    ref = ops_ref.conv2d_nhwc(x.double(), wt.double(), None, 1, 1, 1)
+    ops.range_check_enable(True)
+    try:
+        ops.range_check_fetch()
+        y = ops.conv2d_nhwc(x.cuda(), wt.cuda(), None, pad=1, w16=split_f16x3(wt).cuda()).cpu()
+        assert ops.range_check_fetch() is False
+    finally:
+        ops.range_check_enable(False)
+    assert float((y.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())

@@ -86,3 +86,25 @@ def test_single_process_gather_is_identity():
     assert gk.shape == (5, 21, 3) and valid.tolist() == [True, True, True, False, False]
     ck, cb, ch = compact_gathered(gk, gb, gh, valid)
     assert torch.equal(ck, kp) and torch.equal(cb, box) and torch.equal(ch, has)
+
+
+def test_gather_is_one_collective_with_reused_buffers(monkeypatch):
+    """The timed path issues ONE all_gather_into_tensor per step and allocates its buffers once."""
+    import torch.distributed as dist
+    from hn_amd import dist as hdist
+    calls = []
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_world_size", lambda group=None: 2)
+
+    def fake_gather(out, inp, group=None):
+        calls.append((out.data_ptr(), inp.data_ptr()))
+        out[: inp.shape[0]] = inp
+        out[inp.shape[0]:] = inp
+    monkeypatch.setattr(dist, "all_gather_into_tensor", fake_gather)
+    kp, box, has = torch.rand((3, 21, 3)), torch.randint(0, 600, (3, 4)), torch.tensor([1, 0, 1], dtype=torch.int32)
+    for _ in range(3):
+        gk, gb, gh, valid = hdist.gather_results(kp, box, has, per_rank=4)
+    assert len(calls) == 3 and len(set(calls)) == 1
+    assert gk.shape == (8, 21, 3) and torch.equal(gk[:3], kp) and torch.equal(gk[4:7], kp)
+    assert torch.equal(gb[4:7], box) and gh.tolist() == [1, 0, 1, 0, 1, 0, 1, 0]
+    assert valid.tolist() == [True, True, True, False] * 2

@@ -1,0 +1,70 @@
+"""N > 1 on the real engine (GPU box): two ranks sharing cuda:0 (gloo rehearsal; an 8-GPU node is not available to
+the tests) must reproduce the single-process batch, and `bench.py --gpus 2` must launch its own two ranks."""
+import json
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+REPO = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_ranks_equal_single_process_batch(tmp_path, fcos_sd, a2j_sd):
+    """2 ranks x 16 frames == 1 rank x 32 frames through HandNetEngine: crop boxes and has_hand bit-for-bit,
+    keypoints <= 1e-4 (a 16-frame batch may pick other conv tiles / split-K plans, i.e. another fp32 summation
+    order, than the 32-frame batch)."""
+    from hn_amd import synth
+    from hn_amd.a2j_engine import A2JEngine
+    from hn_amd.fcos_engine import FCOSEngine
+    from hn_amd.pipeline import HandNetEngine
+    total, world = 32, 2
+    port = _free_port()
+    out_file = tmp_path / "gathered.pt"
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(REPO / "tests" / "dist_worker.py"), str(total), "gloo",
+                                       str(out_file)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    kp, box, has, w = torch.load(out_file)
+    assert w == world and kp.shape == (total, 21, 3)
+    eng = HandNetEngine(FCOSEngine(fcos_sd, 3, device="cuda"), A2JEngine(a2j_sd, device="cuda"), 3)
+    ref = eng.forward_device(synth.make_rgb(total, seed=1000).cuda(), synth.make_depth(total, seed=2000).cuda())
+    assert torch.equal(box, ref.crop_box.cpu())
+    assert torch.equal(has, ref.has_hand.cpu())
+    assert (kp - ref.keypoints.cpu()).abs().max().item() <= 1e-4
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` without a torchrun environment starts two ranks itself (never a silent
+    single-GPU run) and rank 0 prints one JSON line with n_gpus = 2."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--share-gpu", "--dist-backend", "gloo",
+                        "--steps", "2", "--warmup", "1", "--batch", "4", "--no-cpu-baseline", "--no-roofline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 8 and line["config"]["rccl_ranks"] == 2
+    assert line["config"]["collective_backend"] == "gloo" and line["value"] > 0
+
+
+def test_bench_refuses_world_size_mismatch():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stdout + r.stderr)

@@ -165,6 +165,75 @@ def test_batched_nms_bit_exact(k):
     assert torch.equal(det.labels[0, :n].cpu().long(), labels[ref_keep])
 
 
+def _nms_case(name):
+    """Edge fixtures for the greedy pass (inputs only; expectations come from oracle/nms_ref.c)."""
+    import zlib
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 10000)
+    if name == "zero_area":
+        # degenerate boxes: area 0 -> IoU of two of them is 0/0 = NaN, which is NOT > 0.3: nothing suppressed by
+        # them, and a zero-area box inside a real one has IoU 0
+        b, s, l = _random_boxes(200, 7)
+        b[::5, 2] = b[::5, 0]            # zero width
+        b[3::7, 3] = b[3::7, 1]          # zero height
+        b[10] = b[15] = torch.tensor([50.0, 50.0, 50.0, 50.0])   # identical points
+        return b, s, l
+    if name == "identical_across_tile":
+        # 70 copies of ONE box with ONE score and one class: they straddle the 64-candidate tile boundary of the
+        # greedy pass; exactly the lowest index survives.  Then 70 more with distinct classes (all survive).
+        b = torch.tensor([[10.0, 20.0, 90.0, 120.0]]).repeat(140, 1)
+        s = torch.full((140,), 0.875)
+        l = torch.cat([torch.zeros(70, dtype=torch.long), torch.arange(70) % 3 + 3])
+        return b, s, l
+    if name in ("ties_2049", "ties_4097"):
+        k = int(name.split("_")[1])
+        b, s, l = _random_boxes(k, 11 + k, spread=900.0)
+        s = (torch.randint(0, 40, (k,), generator=g).float() / 64.0 + 0.3)   # ~40 distinct scores: long tie runs
+        return b, s, l
+    if name == "one_class_1001":
+        b, s, l = _random_boxes(1001, 33)
+        return b, s, torch.full((1001,), 2, dtype=torch.long)
+    if name == "tie_run_over_tiles":
+        # 200 overlapping boxes sharing one score: order within the run must be ascending index across tiles
+        b, s, l = _random_boxes(200, 5, spread=60.0, size=80.0)
+        return b, torch.full((200,), 0.75), torch.zeros(200, dtype=torch.long)
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("name", ["zero_area", "identical_across_tile", "ties_2049", "ties_4097", "one_class_1001",
+                                  "tie_run_over_tiles"])
+def test_batched_nms_edge_fixtures(name):
+    """Survivor indices bit-exact vs oracle/nms_ref.c on the inputs where a greedy NMS can go wrong: NaN IoUs,
+    equal (score, box) runs across the 64-candidate tiles, K just past the LDS sort capacity (2048) and past 4096
+    with score ties (global-memory sort path + per-class torchvision path), and a single-class K = 1001."""
+    from hn_amd import ops
+    from oracle import fcos_ref
+    boxes, scores, labels = _nms_case(name)
+    k = boxes.shape[0]
+    ref_keep = fcos_ref.batched_nms(boxes, scores, labels, 0.3)
+    cand = ops.alloc_candidates(1, k, "cuda")
+    cand.boxes[0] = boxes.cuda()
+    cand.scores[0] = scores.cuda()
+    cand.labels[0] = labels.int().cuda()
+    cand.count[0] = k
+    det = ops.fcos_nms(cand, 0.3, 1.0, 1.0)
+    n = int(det.count[0])
+    assert n == len(ref_keep), (n, len(ref_keep))
+    assert torch.equal(det.keep[0, :n].cpu().long(), ref_keep)
+    assert torch.equal(det.boxes[0, :n].cpu(), boxes[ref_keep])
+    if name == "identical_across_tile":
+        assert ref_keep[0] == 0 and n == 1 + 3   # one survivor of the 70 clones + one per distinct class
+
+
+def test_plain_nms_zero_area_and_ties():
+    from hn_amd import ops
+    from oracle import fcos_ref
+    for name in ("zero_area", "tie_run_over_tiles"):
+        boxes, scores, _ = _nms_case(name)
+        ref = fcos_ref.nms(boxes, scores, 0.3)
+        got = ops.nms(boxes.cuda(), scores.cuda(), 0.3).cpu()
+        assert torch.equal(got, ref), name
+
+
 def test_nms_ties_and_threshold_boundary():
     from hn_amd import ops
     from oracle import fcos_ref
@@ -281,3 +350,38 @@ def test_other_frame_size_wide(fcos_sd, engine):
         j = int(d.argmin())
         matched += int(d[j] < 1e-2 and labels[j] == l)
     assert len(ref["labels"]) > 20 and matched >= 0.98 * len(ref["labels"]) and k <= 1.02 * len(ref["labels"]) + 1
+
+
+def test_mixed_size_image_list(fcos_sd):
+    """torchvision batch_images (fcos_utils/fcos.py:702-709): a list of differently sized images is resized per
+    image, padded to the common canvas and rescaled per image.  480x640 + 360x640 vs the oracle."""
+    from fcos_utils.fcos import FCOS
+    from hn_amd import ops, synth
+    from hn_amd.fcos_engine import IMAGE_MEAN, IMAGE_STD
+    from oracle import fcos_ref
+    a = synth.make_rgb(1, seed=1000)[0]
+    b = synth.make_rgb(1, seed=1001)[0][:, :360, :].contiguous()
+    imgs = [a, b]
+    dets, inter = fcos_ref.fcos_forward(imgs, fcos_sd, 3, return_intermediates=True)
+    model = FCOS(num_classes=3, ext=False)
+    model.load_state_dict(fcos_sd, strict=False)
+    model = model.cuda().eval()
+    eng = model.engine()
+    geom, ph, pw = eng.list_geometry(imgs)
+    assert [g[2:] for g in geom] == [tuple(s) for s in inter["image_sizes"]]
+    assert (ph, pw) == tuple(inter["x"].shape[-2:])
+    # staged: the canvas itself (fp32 mode of the list kernel) against the oracle's transform
+    canvas = ops.fcos_preprocess_list([i.cuda() for i in imgs], geom, ph, pw, IMAGE_MEAN, IMAGE_STD, split=False)
+    ref = inter["x"].permute(0, 2, 3, 1)
+    assert (canvas[..., :3].cpu() - ref).abs().max().item() < 1e-5
+    assert float(canvas[..., 3].abs().max()) == 0.0
+    with torch.inference_mode():
+        out = model([i.cuda() for i in imgs])
+    assert len(out) == 2
+    for got, want in zip(out, dets):
+        k = want["scores"].numel()
+        assert abs(got["scores"].numel() - k) <= max(1, k // 50)
+        if got["scores"].numel() == k:
+            same = (got["labels"].cpu() == want["labels"]) & ((got["boxes"].cpu() - want["boxes"]).abs().max(dim=1)[0] < 0.01)
+            assert same.float().mean().item() >= 0.98
+            assert (got["scores"].cpu() - want["scores"]).abs().max().item() < 1e-4

@@ -233,3 +233,108 @@ def test_pipeline_batch32_permutation_invariance(handnet):
     assert torch.equal(a.has_hand[perm], b.has_hand) and torch.equal(a.crop_box[perm], b.crop_box)
     assert torch.equal(a.detections.count[perm], b.detections.count)
     assert (a.keypoints[perm] - b.keypoints).abs().max().item() < 1e-4
+
+
+def test_convert_joints_matches_reference_golden(golden_dir):
+    """hn_convert_joints_f32 against outputs of the reference's own a2j.a2j.convert_joints + uvd2xyz
+    (tests/golden/make_golden_joints.py imports them): camera xyz in mm and the paras=None image-uvd branch."""
+    from hn_amd import ops
+    g = np.load(golden_dir / "convert_joints.npz")
+    kp, box = torch.from_numpy(g["pred"]).cuda(), torch.from_numpy(g["box"]).cuda()
+    uvd = ops.convert_joints(kp, box, None, None).cpu().numpy()
+    assert np.abs(uvd - g["uvd_img"]).max() < 2e-4            # pixels (|u| <= 640)
+    for i in range(kp.shape[0]):
+        xyz = ops.convert_joints(kp[i:i + 1], box[i:i + 1], None, tuple(float(v) for v in g["paras"][i])).cpu().numpy()[0]
+        assert np.abs(xyz - g["xyz_pred"][i]).max() < 1e-2, i  # millimetres on |x| <= 1600
+    valid = torch.tensor([1, 0] * (kp.shape[0] // 2), dtype=torch.int32).cuda()
+    z = ops.convert_joints(kp, box, valid, None).cpu().numpy()
+    assert np.abs(z[1::2]).max() == 0.0 and np.abs(z[0::2] - g["uvd_img"][0::2]).max() < 2e-4
+
+
+def test_no_detection_branch_matches_reference_contract(fcos_sd, a2j_sd):
+    """handnet_pipeline.py:107-108: nothing passes 0.7 -> (zeros[N,21,3] CPU, zeros_like(depth_images),
+    zeros[N,4] float32 on the CPU)."""
+    import types
+    from handnet_pipeline.handnet_pipeline import HandNet
+    from hn_amd import synth
+    net = HandNet(types.SimpleNamespace(pretrained_fcos="-", pretrained_a2j="-"), num_classes=3)
+    sd = dict(fcos_sd)
+    for k in ("head.classification_head.cls_logits.bias", "head.regression_head.bbox_ctrness.bias"):
+        sd[k] = torch.full_like(sd[k], -20.0)        # every score far below 0.7
+    net.detector.load_state_dict(sd, strict=False)
+    net.a2j.load_state_dict(a2j_sd, strict=False)
+    net = net.cuda().eval()
+    rgb, depth = synth.make_rgb(2, seed=1000), synth.make_depth(2, seed=2000).cuda()
+    with torch.inference_mode():
+        kp, db, crops = net([rgb[0].cuda(), rgb[1].cuda()], depth_images=depth)
+    assert kp.device.type == "cpu" and kp.shape == (2, 21, 3) and float(kp.abs().max()) == 0.0
+    assert db.shape == depth.shape and db.device == depth.device and float(db.abs().max()) == 0.0
+    assert crops.device.type == "cpu" and crops.dtype == torch.float32 and crops.shape == (2, 4)
+    # ros_demo.py:294 tests detections.max() == 0 for "no hand"
+    assert crops.max() == 0
+
+
+def test_handnet_follows_submodule_weight_reload(fcos_sd, a2j_sd):
+    """net.detector.load_state_dict(...) AFTER a first forward must not leave HandNet on stale engines."""
+    import types
+    from handnet_pipeline.handnet_pipeline import HandNet
+    from hn_amd import synth
+    net = HandNet(types.SimpleNamespace(pretrained_fcos="-", pretrained_a2j="-"), num_classes=3)
+    net.detector.load_state_dict(fcos_sd, strict=False)
+    net.a2j.load_state_dict(a2j_sd, strict=False)
+    net = net.cuda().eval()
+    rgb, depth = synth.make_rgb(1, seed=1000), synth.make_depth(1, seed=2000).cuda()
+    with torch.inference_mode():
+        kp0, _, _ = net([rgb[0].cuda()], depth_images=depth)
+        e0 = net.engine()
+        net.a2j.load_state_dict(synth.make_a2j_state_dict(seed=5), strict=False)
+        kp1, _, _ = net([rgb[0].cuda()], depth_images=depth)
+    assert net.engine() is not e0 and net.engine().a2j is net.a2j.engine()
+    assert (kp1 - kp0).abs().max() > 1e-3
+
+
+def test_many_frame_crop_box_parity(fcos_sd, a2j_sd):
+    """Where end-to-end parity can actually break: 128 fresh frames (seeds 1000 / 2000 streams) through HIP and
+    the oracle.  Integer crop boxes must be identical on every frame unless the flip is explained by a coordinate
+    or score sitting within float noise of its decision boundary (listed by oracle.parity); keypoints on the
+    equal-box frames stay < 1e-3."""
+    from hn_amd import synth
+    from hn_amd.a2j_engine import A2JEngine
+    from hn_amd.fcos_engine import FCOSEngine
+    from hn_amd.pipeline import HandNetEngine
+    from oracle import parity
+    torch.set_num_threads(min(16, torch.get_num_threads() or 16))
+    n = 128
+    rgb, depth = synth.make_rgb(n, seed=1000), synth.make_depth(n, seed=2000)
+    eng = HandNetEngine(FCOSEngine(fcos_sd, 3, device="cuda"), A2JEngine(a2j_sd, device="cuda"), 3)
+    stats, oracle_s, _ = parity.pipeline_parity(eng, rgb, depth, fcos_sd, a2j_sd, 3, chunk=8)
+    print(f"[parity] {stats['crop_box_equal_frames']}/{n} equal crop boxes, max |dkp| {stats['max_abs_keypoint_diff']:.2e}, "
+          f"oracle {oracle_s:.1f} s, flips: {stats['flips']}")
+    assert stats["frames_with_hand"] == n
+    assert stats["keypoints_within_tolerance"], stats["max_abs_keypoint_diff"]
+    # every flip must be a boundary case: same detection, a coordinate within 1e-3 px of an integer
+    for f in stats["flips"]:
+        assert f["cause"].startswith("same detection") and f["min_dist_to_integer"] < 1e-3, f
+    assert stats["crop_box_equality_rate"] >= 0.98
+
+
+def test_engine_range_check_raises_on_overflowing_activations(fcos_sd, a2j_sd):
+    """HN_CHECK_RANGE=1 (HandNetEngine.check_range): a depth map in millimetres x 1000 drives A2J activations
+    past 65504 -> RangeError instead of inf / NaN keypoints; ordinary inputs pass with the check on."""
+    from hn_amd import ops, synth
+    from hn_amd.a2j_engine import A2JEngine
+    from hn_amd.fcos_engine import FCOSEngine
+    from hn_amd.pipeline import HandNetEngine
+    eng = HandNetEngine(FCOSEngine(fcos_sd, 3, device="cuda"), A2JEngine(a2j_sd, device="cuda"), 3)
+    eng.check_range = True
+    rgb, depth = synth.make_rgb(2, seed=1000).cuda(), synth.make_depth(2, seed=2000).cuda()
+    try:
+        out = eng.forward_device(rgb, depth)
+        assert torch.isfinite(out.keypoints).all()
+        with pytest.raises(ops.RangeError):
+            eng.forward_device(rgb, depth * 1.0e6)
+        eng.check_range = False
+        bad = eng.forward_device(rgb, depth * 1.0e6)          # what the check protects from
+        assert not torch.isfinite(bad.keypoints).all()
+    finally:
+        ops.range_check_enable(False)
