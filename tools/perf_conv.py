@@ -39,11 +39,32 @@ if prec == "f16x3":
 for _ in range(3):
     ops.conv2d_nhwc(x, wt, b, **kw)
 torch.cuda.synchronize()
+# shader clock (in-kernel sampler on a side stream) and socket power (rocm-smi) WHILE the loop runs
+import subprocess, threading
+side = torch.cuda.Stream()
+clock = torch.zeros((1,), device="cuda")
+power = []
+def _smi():
+    import time
+    time.sleep(0.25)
+    try:
+        out = subprocess.run(["rocm-smi", "--showpower"], capture_output=True, text=True, timeout=20).stdout
+        power.extend(l.split(":")[-1].strip() for l in out.splitlines() if "Socket Graphics" in l)
+    except Exception:
+        pass
+th = threading.Thread(target=_smi)
+if iters >= 400:
+    th.start()
 t = ops.HipTimer()
 t.start()
-for _ in range(iters):
+for i in range(iters):
+    if i == iters // 4:
+        ops.clock_sample(200000 if iters >= 400 else 2000, out=clock, stream=side)
     ops.conv2d_nhwc(x, wt, b, **kw)
 t.stop()
 ms = t.elapsed_ms() / iters
+if iters >= 400:
+    th.join()
 fl = 2.0 * n * oh * ow * cout * r * r * cin
-print(f"{prec} tile={tile} {n}x{h}x{w}x{cin}->{cout} r{r} s{stride} d{dil} aff{affine} osplit{osplit}: {ms*1e3:.1f} us  {fl/ms/1e9:.1f} TFLOP/s")
+pw = power[0] if power else "?"
+print(f"{prec} tile={tile} {n}x{h}x{w}x{cin}->{cout} r{r} s{stride} d{dil} aff{affine} osplit{osplit}: {ms*1e3:.1f} us  {fl/ms/1e9:.1f} TFLOP/s  clock {float(clock.item()):.0f} MHz  power {pw} W")
