@@ -89,6 +89,12 @@ struct ConvParams16 {
   int64_t split_ws_bytes;
   int tiles_m, tiles_n, nblocks;
   int* range_flag;    // f16x3 range contract (hn_range_check_enable): set to 1 when an S32 output value cannot be split
+  // v6 operand addressing (BUF kernels): both operands are fetched through buffer descriptors, so a DMA's address is
+  // <descriptor base> + <per-lane 32-bit offset, loop-invariant> + <wave-uniform SGPR offset of the k tile>, and a
+  // padding tap is a lane whose offset has bit 31 set: the hardware range check returns zeros for it.
+  unsigned a_records; // bytes covered by the A descriptor (< 2^31 so that bit 31 is out of range)
+  unsigned b_records;
+  unsigned ga_records[HN_CONV_MAX_GROUP];
 };
 
 constexpr int BK = 32;    // k values per tile
@@ -233,7 +239,7 @@ struct HalfSched {
   }
 };
 
-template <int BM, int BN, int WM, int WN, int NBUF>
+template <int BM, int BN, int WM, int WN, int NBUF, bool BUF>
 __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const ConvParams16 p) {
   static_assert(NBUF >= 2 && NBUF <= 6, "2..6 LDS stages");
   // Grouped launch: workgroup z works on member z -- its own tensors and, for FPN levels, its own spatial size.
@@ -247,7 +253,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
     void* y;
     float* gn_partial;
     int H, W, pitch, OH, OW, M, nblocks;
-  } o = {p.x, p.w, p.bias, p.y, p.gn_partial, p.H, p.W, p.pitch, p.OH, p.OW, p.M, p.nblocks};
+    unsigned a_records;
+  } o = {p.x, p.w, p.bias, p.y, p.gn_partial, p.H, p.W, p.pitch, p.OH, p.OW, p.M, p.nblocks, p.a_records};
   if (p.groups > 1) {
     const int gz = (int)blockIdx.z;
 #define HN_GROUP_SEL(arr) \
@@ -266,6 +273,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
     o.OH = HN_GROUP_SEL(gOH);
     o.OW = HN_GROUP_SEL(gOW);
     o.M = HN_GROUP_SEL(gM);
+    o.a_records = HN_GROUP_SEL(ga_records);
 #undef HN_GROUP_SEL
   }
   constexpr int NT = WM * WN * 64;
@@ -295,8 +303,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
 
   // ---- DMA geometry: lane -> (row = tid >> 3 within a pass, LDS position pos = tid & 7) ----
   const int drow = tid >> 3, dpos = tid & 7;
+  // !BUF (fallback for tensors of 2 GB and more): 64-bit per-lane pointers, bounds checks and a zero page per tap
   int a_ih0[A_IT], a_iw0[A_IT], a_cc[A_IT];  // a_cc: chunk offset inside the zero page
   const _Float16* a_row[A_IT];  // address of (img, ih0, iw0, channel 0) + swizzled chunk; may lie outside the image
+  const _Float16* b_ptr[B_IT];
+  // BUF: loop-invariant 32-bit byte offsets from the descriptor bases + one bit per filter tap that is SET when the tap
+  // falls outside the image for this lane's pixel (tap index = r * S + s <= 31)
+  unsigned a_off[A_IT], a_inv[A_IT], b_off[B_IT];
 #pragma unroll
   for (int it = 0; it < A_IT; ++it) {
     const int row = drow + it * ROWS_PASS;
@@ -305,21 +318,44 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
     const int img = m / ohow;
     const int rem = m - img * ohow;
     const int oh = rem / o.OW, ow = rem - oh * o.OW;
-    a_ih0[it] = oh * p.stride - p.pad;
-    a_iw0[it] = ow * p.stride - p.pad;
+    const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
     const int chunk = dpos ^ swz(row);  // source chunk that belongs at this LDS position: 0-3 hi run, 4-7 lo run
-    a_cc[it] = chunk * 8;
-    a_row[it] = o.x + (((long)img * o.H + a_ih0[it]) * o.pitch + a_iw0[it]) * p.xs + (chunk & 3) * 8 +
-                (chunk >> 2) * p.lo_off;
+    if constexpr (BUF) {
+      a_off[it] = (unsigned)(((((long)img * o.H + oh * p.stride) * o.pitch + ow * p.stride) * p.xs + (chunk & 3) * 8 +
+                              (chunk >> 2) * p.lo_off) * 2);
+      unsigned inv = 0;
+      for (int r = 0; r < p.R; ++r) {
+        const unsigned rbad = (unsigned)(ih0 + r * p.dil) >= (unsigned)o.H ? 1u : 0u;
+        for (int sx = 0; sx < p.S; ++sx) {
+          const unsigned bad = rbad | ((unsigned)(iw0 + sx * p.dil) >= (unsigned)o.W ? 1u : 0u);
+          inv |= bad << (r * p.S + sx);
+        }
+      }
+      a_inv[it] = inv;
+    } else {
+      a_ih0[it] = ih0;
+      a_iw0[it] = iw0;
+      a_cc[it] = chunk * 8;
+      a_row[it] = o.x + (((long)img * o.H + ih0) * o.pitch + iw0) * p.xs + (chunk & 3) * 8 + (chunk >> 2) * p.lo_off;
+    }
   }
-  const _Float16* b_ptr[B_IT];
 #pragma unroll
   for (int it = 0; it < B_IT; ++it) {
     const int row = drow + it * ROWS_PASS;
     int n = n0 + row;
     n = n < p.Cout ? n : p.Cout - 1;  // columns >= Cout are never stored
-    b_ptr[it] = o.w + (long)n * p.Ktot * 2 + (dpos ^ swz(row)) * 8;
+    if constexpr (BUF)
+      b_off[it] = (unsigned)(((long)n * p.Ktot * 2 + (dpos ^ swz(row)) * 8) * 2);
+    else
+      b_ptr[it] = o.w + (long)n * p.Ktot * 2 + (dpos ^ swz(row)) * 8;
   }
+  // buffer descriptors (wave-uniform by construction: kernel arguments / blockIdx.z selects)
+  // the A descriptor starts pad rows + pad columns BEFORE the member's first pixel, so that a_off (computed from the
+  // un-padded coordinates oh * stride, ow * stride) is never negative; the pitch is the member's own
+  const long a_shift = BUF ? ((long)p.pad * o.pitch + p.pad) * p.xs * 2 : 0;
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<const char*>(o.x) - a_shift), 0, (int)o.a_records, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)o.w, 0, (int)p.b_records, 0x00020000);
   // wave-uniform LDS row base of this wave's 8-row group inside a pass
   const int grp_row = __builtin_amdgcn_readfirstlane(wave) * 8;
 
@@ -334,15 +370,38 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
   int load_t = t_begin, cur_cb = t_begin / (p.R * p.S);
   int cur_r = (t_begin - cur_cb * p.R * p.S) / p.S, cur_s = t_begin - cur_cb * p.R * p.S - cur_r * p.S;
 
-  // one DMA instruction (8 rows x 128 B per wave): A piece `it` gathers im2col rows, B piece `it` weight rows
-  auto dma_a_piece = [&](int it, _Float16* Ad, int dr, int ds, long uoff) {
-    const bool ok = (unsigned)(a_ih0[it] + dr) < (unsigned)o.H && (unsigned)(a_iw0[it] + ds) < (unsigned)o.W;
-    const _Float16* src = ok ? a_row[it] + uoff : g_zero_page16 + a_cc[it];  // padding taps read zeros
-    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(Ad + (it * ROWS_PASS + grp_row) * ROWH), 16, 0, 0);
+  // one DMA instruction (8 rows x 128 B per wave): A piece `it` gathers im2col rows, B piece `it` weight rows.
+  // BUF: `uoff` / `boff` are the wave-uniform BYTE offsets of the k tile (SGPR soffset), `sh` = 31 - tap index; the
+  // lane's own part is two VALU instructions (shift its invalid-tap bit to bit 31, OR it into the offset) -- no
+  // compares, no 64-bit address arithmetic, no zero page: the range check of the descriptor supplies the zeros.
+  auto dma_a_piece = [&](int it, _Float16* Ad, int dr, int ds, long uoff, int sh) {
+    lds_void* dst = (lds_void*)(Ad + (it * ROWS_PASS + grp_row) * ROWH);
+    if constexpr (BUF) {
+      const unsigned voff = ((a_inv[it] << sh) & 0x80000000u) | a_off[it];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, dst, 16, (int)voff, (int)uoff, 0, 0);
+    } else {
+      const bool ok = (unsigned)(a_ih0[it] + dr) < (unsigned)o.H && (unsigned)(a_iw0[it] + ds) < (unsigned)o.W;
+      const _Float16* src = ok ? a_row[it] + uoff : g_zero_page16 + a_cc[it];  // padding taps read zeros
+      __builtin_amdgcn_global_load_lds((gbl_void*)src, dst, 16, 0, 0);
+    }
   };
   auto dma_b_piece = [&](int it, _Float16* Bd, long boff) {
-    __builtin_amdgcn_global_load_lds((gbl_void*)(b_ptr[it] + boff), (lds_void*)(Bd + (it * ROWS_PASS + grp_row) * ROWH),
-                                     16, 0, 0);
+    lds_void* dst = (lds_void*)(Bd + (it * ROWS_PASS + grp_row) * ROWH);
+    if constexpr (BUF)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, dst, 16, (int)b_off[it], (int)boff, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds((gbl_void*)(b_ptr[it] + boff), dst, 16, 0, 0);
+  };
+  // wave-uniform offsets of the k tile the loader is at (halfs for the pointer form, bytes for the descriptor form)
+  auto tile_offsets = [&](long& uoff, long& boff, int& sh) {
+    const int dr = cur_r * p.dil, ds = cur_s * p.dil;
+    uoff = ((long)dr * o.pitch + ds) * p.xs + (long)cur_cb * (2 * BK);
+    boff = (long)load_t * (2 * BK);
+    sh = 31 - (cur_r * p.S + cur_s);
+    if constexpr (BUF) {
+      uoff *= 2;
+      boff *= 2;
+    }
   };
   // branch-free advance of (tap, channel block) to the next k tile: keeps the hot loop one basic block
   // saturates at the last tile: the pipeline keeps issuing (redundant, never read) loads of it past the end
@@ -360,12 +419,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
   };
   auto dma_tile = [&](int buf) {
     const int dr = cur_r * p.dil, ds = cur_s * p.dil;
-    const long uoff = ((long)dr * o.pitch + ds) * p.xs + (long)cur_cb * (2 * BK);  // wave-uniform
+    long uoff, boff;
+    int sh;
+    tile_offsets(uoff, boff, sh);
     _Float16* Ad = As + buf * A_BUF;
     _Float16* Bd = Bs + buf * B_BUF;
 #pragma unroll
-    for (int it = 0; it < A_IT; ++it) dma_a_piece(it, Ad, dr, ds, uoff);
-    const long boff = (long)load_t * (2 * BK);
+    for (int it = 0; it < A_IT; ++it) dma_a_piece(it, Ad, dr, ds, uoff, sh);
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) dma_b_piece(it, Bd, boff);
     advance_tile();
@@ -452,8 +512,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     const int dr = cur_r * p.dil, ds = cur_s * p.dil;
-    const long uoff = ((long)dr * o.pitch + ds) * p.xs + (long)cur_cb * (2 * BK);
-    const long boff = (long)load_t * (2 * BK);
+    long uoff, boff;
+    int sh;
+    tile_offsets(uoff, boff, sh);
     _Float16* Ad = As + cs * A_BUF;
     _Float16* Bd = Bs + cs * B_BUF;
     const unsigned anx_hi = a_rd_hi + ns * (A_BUF * 2), anx_lo = a_rd_lo + ns * (A_BUF * 2);
@@ -464,7 +525,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
         constexpr int q = decltype(Q)::value;
         if constexpr (S2::slot(q) == k) {
           if constexpr (q < A_IT) {
-            dma_a_piece(q, Ad, dr, ds, uoff);
+            dma_a_piece(q, Ad, dr, ds, uoff, sh);
           } else if constexpr (q < DPT) {
             dma_b_piece(q - A_IT, Bd, boff);
           } else if constexpr (q < DPT + 2 * TH) {
@@ -662,8 +723,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
   }
 }
 
-template <int BM, int BN, int WM, int WN, int NBUF>
-int launch16(const ConvParams16& p0, hipStream_t st) {
+template <int BM, int BN, int WM, int WN, int NBUF, bool BUF>
+int launch16_impl(const ConvParams16& p0, hipStream_t st) {
   ConvParams16 p = p0;
   p.tiles_m = hn::cdiv(p.M, BM);
   p.tiles_n = hn::cdiv(p.Cout, BN);
@@ -698,7 +759,7 @@ int launch16(const ConvParams16& p0, hipStream_t st) {
       grid_x = grid_x > p.gnblocks[g] ? grid_x : p.gnblocks[g];
     }
   }
-  hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, NBUF>), dim3(grid_x, p.splits, p.groups > 1 ? p.groups : 1),
+  hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, NBUF, BUF>), dim3(grid_x, p.splits, p.groups > 1 ? p.groups : 1),
                      dim3(WM * WN * 64), 0, st, p);
   HN_CHECK_LAUNCH("conv_igemm_f16x3_kernel");
   if (p.splits > 1) {
@@ -708,6 +769,35 @@ int launch16(const ConvParams16& p0, hipStream_t st) {
     HN_CHECK_LAUNCH("splitk_reduce_kernel");
   }
   return HN_OK;
+}
+
+// Operand extents for the buffer descriptors of the v6 addressing.  Falls back to the pointer-form kernel (one
+// instantiation, 128x128) when an operand spans 2 GB or more (bit 31 of an offset must stay out of range) or the
+// filter has more than 32 taps.
+template <int BM, int BN, int WM, int WN, int NBUF>
+int launch16(const ConvParams16& p0, hipStream_t st) {
+  ConvParams16 p = p0;
+  const int64_t lim = (int64_t)1 << 31;
+  auto extent = [&](int h, int pitch) {
+    // bytes the A descriptor covers: it starts pad rows + pad columns before x (kernel: a_shift) and ends at the last
+    // pixel's lo run (an upper bound for channel slices: the range check only has to keep bit 31 outside)
+    return ((int64_t)p.N * h * pitch * p.xs + (p.lo_off > 32 ? p.lo_off : 0)) * 2 +
+           ((int64_t)p.pad * pitch + p.pad) * p.xs * 2;
+  };
+  bool ok = p.R * p.S <= 32 && (int64_t)p.Cout * p.Ktot * 4 < lim;
+  int64_t ea = extent(p.H, p.pitch);
+  ok = ok && ea < lim;
+  p.a_records = (unsigned)(ok ? ea : 0);
+  p.b_records = (unsigned)(ok ? (int64_t)p.Cout * p.Ktot * 4 : 0);
+  for (int g = 0; g < HN_CONV_MAX_GROUP; ++g) p.ga_records[g] = 0;
+  if (p.groups > 1)
+    for (int g = 0; g < p.groups; ++g) {
+      ea = extent(p.gH[g], p.gW[g]);
+      ok = ok && ea < lim;
+      p.ga_records[g] = (unsigned)(ea < lim ? ea : 0);
+    }
+  if (ok) return launch16_impl<BM, BN, WM, WN, NBUF, true>(p, st);
+  return launch16_impl<128, 128, 2, 2, 2, false>(p, st);
 }
 
 int64_t nblocks16(const hn_conv_desc* d, int bm, int bn) {
