@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--precision", choices=["f16x3", "f32"], default="f16x3",
                     help="f16x3: split-fp16 operands on the f16 MFMA (fp32-grade results); f32: exact f32 MFMA")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
+    ap.add_argument("--native", action="store_true",
+                    help="drive the step through the model-level C ABI (C++ layer graphs, csrc/model.hip) instead of "
+                         "the Python engines; same launches, same results")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=32,
@@ -137,7 +140,16 @@ def build_workload(args, dev, rank):
     eng = HandNetEngine(fcos, a2j, 3)
     info.update(unit="frames/s", gflop_per_unit=2 * (fcos.macs_per_frame() + a2j.macs_per_crop()) / 1e9,
                 name="Full HandNet pipeline (FCOS -> crop -> A2J), 640x480 RGB-D (BASELINE config 4)", engine=eng)
-    if args.graph:
+    if args.native:
+        from hn_amd.native_model import NativeModel
+        from hn_amd.pipeline import HandNetOutput
+        native = NativeModel(fcos_sd, a2j_sd, num_classes=3, device=dev)
+        info["native"] = native
+
+        def step():
+            kp, box, has = native.handnet(rgb, depth)
+            return HandNetOutput(kp, None, box, has, None, None)
+    elif args.graph:
         run, _, _, out = eng.graphed(rgb, depth)
 
         def step():
@@ -369,7 +381,7 @@ def main():
         if rccl_ranks != world or not bool(gathered["rows"].all()):
             raise SystemExit(f"all-gather returned {gathered['rows'].numel()} rows for {world} ranks x {batch} frames")
     roof = None
-    if not args.no_roofline and not args.graph:
+    if not args.no_roofline and not args.graph and not args.native:
         roof = roofline_leg(step, max(1, min(args.steps, 3)), 1e3 * elapsed / args.steps)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -391,7 +403,8 @@ def main():
                        "frame": {"a2j": "176x176 depth crop", "pose2mesh": "21 x 2-D joints"}.get(args.workload, "640x480 RGB-D"),
                        "parallelism": f"frames sharded over {world} GPU(s), one all-gather of per-frame records per step",
                        "collective_backend": (dist.get_backend() if world > 1 else None), "rccl_ranks": rccl_ranks,
-                       "gflop_per_unit": round(info["gflop_per_unit"], 3), "hipgraph": bool(args.graph)},
+                       "gflop_per_unit": round(info["gflop_per_unit"], 3), "hipgraph": bool(args.graph),
+                       "host": "C++ layer graph (model-level C ABI)" if args.native else "Python engines (op-level C ABI)"},
             "algorithmic_tflops": round(value * info["gflop_per_unit"] / 1e3, 2),
             "roofline": roof, "cpu_baseline": cpu,
         }

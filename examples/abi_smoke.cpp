@@ -1,5 +1,8 @@
-// A host that is NOT Python: binds include/handnet_hip.h directly (plain pointers, sizes, one POD struct), runs
-// a split-fp16 convolution and an NMS through the C ABI and checks both against host loops.
+// A host that is NOT Python: binds include/handnet_hip.h directly (plain pointers, sizes, POD structs), runs
+// a split-fp16 convolution and an NMS through the op-level C ABI and checks both against host loops; given a model
+// blob (argv[1], written by tests/test_abi_gpu.py: a reference-layout A2J state_dict, seeded crops and the keypoints the
+// REFERENCE produced for them) it also runs a whole A2J forward through the model-level ABI
+// (hn_create / hn_load_weight / hn_finalize / hn_a2j_forward / hn_destroy) and checks it against that fixture.
 //   hipcc --offload-arch=gfx950 -Iinclude examples/abi_smoke.cpp -Lhandnet-pipeline_amd/csrc -lhandnet_hip -o abi_smoke
 // Exit code 0 and "abi_smoke ok" on success.
 #include <hip/hip_runtime.h>
@@ -33,7 +36,57 @@ static float frand(unsigned& s) {  // deterministic LCG in [-1, 1)
   return (float)((s >> 8) & 0xFFFF) / 32768.0f - 1.0f;
 }
 
-int main() {
+// blob: "HNB1", int32 tensors, then per tensor {int32 name_len, name, int32 ndim, int64 shape[ndim], float data[]},
+// then int32 k, h, w, float crops[k*h*w], int32 joints, float expected[k*joints*3]
+static int run_a2j_model(const char* path, hipStream_t st) {
+  FILE* f = std::fopen(path, "rb");
+  if (!f) { std::fprintf(stderr, "cannot open %s\n", path); return 10; }
+  auto rd = [&](void* dst, size_t bytes) { return std::fread(dst, 1, bytes, f) == bytes; };
+  char magic[4];
+  int32_t count = 0;
+  if (!rd(magic, 4) || std::memcmp(magic, "HNB1", 4) != 0 || !rd(&count, 4)) return 11;
+  hn_model_config cfg;
+  std::memset(&cfg, 0, sizeof(cfg));
+  cfg.parts = HN_MODEL_A2J; cfg.num_classes = 3; cfg.num_joints = 21;
+  hn_model* m = nullptr;
+  HN_OK_OR_DIE(hn_create(&cfg, &m));
+  std::vector<float> buf;
+  for (int i = 0; i < count; ++i) {
+    int32_t len = 0, ndim = 0;
+    if (!rd(&len, 4)) return 12;
+    std::vector<char> name(len + 1, 0);
+    int64_t shape[4] = {0, 0, 0, 0};
+    if (!rd(name.data(), len) || !rd(&ndim, 4) || ndim > 4 || !rd(shape, 8 * (size_t)ndim)) return 12;
+    size_t numel = 1;
+    for (int d = 0; d < ndim; ++d) numel *= (size_t)shape[d];
+    buf.resize(numel);
+    if (!rd(buf.data(), numel * 4)) return 12;
+    HN_OK_OR_DIE(hn_load_weight(m, name.data(), buf.data(), shape, ndim));
+  }
+  HN_OK_OR_DIE(hn_finalize(m));
+  int32_t k = 0, h = 0, w = 0, joints = 0;
+  if (!rd(&k, 4) || !rd(&h, 4) || !rd(&w, 4)) return 13;
+  std::vector<float> crops((size_t)k * h * w);
+  if (!rd(crops.data(), crops.size() * 4) || !rd(&joints, 4)) return 13;
+  std::vector<float> expect((size_t)k * joints * 3), got(expect.size());
+  if (!rd(expect.data(), expect.size() * 4)) return 13;
+  std::fclose(f);
+  float *dc, *dk;
+  HIP_OK(hipMalloc(&dc, crops.size() * 4));
+  HIP_OK(hipMalloc(&dk, got.size() * 4));
+  HIP_OK(hipMemcpy(dc, crops.data(), crops.size() * 4, hipMemcpyHostToDevice));
+  for (int rep = 0; rep < 2; ++rep)   // the second call re-uses the plan and the arena: no allocation
+    HN_OK_OR_DIE(hn_a2j_forward(m, dc, k, h, w, nullptr, dk, st));
+  HIP_OK(hipStreamSynchronize(st));
+  HIP_OK(hipMemcpy(got.data(), dk, got.size() * 4, hipMemcpyDeviceToHost));
+  double err = 0.0;
+  for (size_t i = 0; i < got.size(); ++i) err = std::fmax(err, std::fabs((double)got[i] - expect[i]));
+  std::printf("a2j model forward (%d crops, C++ layer graph): max |keypoint - reference| %.3g (bound 1e-3)\n", k, err);
+  HN_OK_OR_DIE(hn_destroy(m));
+  return err < 1e-3 ? 0 : 14;
+}
+
+int main(int argc, char** argv) {
   if (hn_abi_version() != HN_ABI_VERSION) {
     std::fprintf(stderr, "ABI mismatch: header %d, library %d\n", HN_ABI_VERSION, hn_abi_version());
     return 1;
@@ -124,6 +177,10 @@ int main() {
   // a bad argument must fail loudly, not crash
   d.cin = 48;
   if (hn_conv2d_nhwc_f16x3(&d, dx16, dw16, db, nullptr, dy, st) == 0 || std::strlen(hn_last_error()) == 0) return 6;
+  if (argc > 1) {
+    const int rc = run_a2j_model(argv[1], st);
+    if (rc) return rc;
+  }
   std::printf("abi_smoke ok\n");
   return 0;
 }

@@ -1,0 +1,827 @@
+// Model-level C ABI: the layer graphs of the FCOS detector, the A2J pose network and the HandNet glue in C++, on top of
+// the op-level entry points of this library.  A host that is not Python binds these (hn_create /
+// hn_load_weight / hn_fcos_forward / hn_a2j_forward / hn_destroy); the Python engines (hn_amd/*_engine.py) issue the
+// same launches with the same descriptors, so both hosts produce bit-identical results
+// (tests/test_model_abi_gpu.py).
+//
+//   hn_create        configuration -> handle
+//   hn_load_weight   one entry of a REFERENCE-layout state_dict, fp32 host data, by name
+//   hn_finalize      BatchNorm / FrozenBatchNorm folding in fp64 (fcos.py:737 body; a2j/resnet.py:35,67-71), NCHW -> [Cout][R][S][Cin]
+//                    repacking, hi/lo fp16 splitting, upload (the only place weights are allocated)
+//   hn_fcos_forward  fcos_utils/fcos.py:675-767 (eval)      hn_a2j_forward   a2j/a2j.py:243-250
+//   hn_handnet_forward  handnet_pipeline/handnet_pipeline.py:58-116
+// Default precision (f16x3) only; the ext=True heads and the f32 mode stay op-level / Python.
+// Memory: activations live in one arena per model that is sized by a dry pass over the graph and (re)allocated only
+// when a forward needs more than any earlier one -- steady-state calls neither allocate nor synchronise.
+#include "hn_common.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+constexpr double kBnEps = 1e-5;
+constexpr int kCrop = 176;
+constexpr int64_t kConvWorkspaceBytes = 32ll << 20;  // split-K workspace, as hn_amd/ops.py
+
+struct HostT {
+  std::vector<float> v;
+  std::vector<int64_t> shape;
+};
+
+// packed convolution: w [cout][r][s][cin] fp32 (cin padded to 4), optional bias, optional split bank
+struct ConvW {
+  int cout = 0, r = 0, s = 0, cin = 0, stride = 1, pad = 0, dil = 1;
+  std::vector<float> hw, hb;          // host copies (until upload)
+  std::vector<_Float16> hw16;
+  bool has_bias = false;
+  float* w = nullptr;
+  float* bias = nullptr;
+  _Float16* w16 = nullptr;
+};
+
+struct T {  // device activation: dense NHWC fp32, or S32 split ([n][h][w][c/32][2][32] fp16); ps = pixel stride in elements
+  char* p = nullptr;
+  int n = 0, h = 0, w = 0, c = 0, ps = 0;
+  bool split = false;
+};
+
+struct Arena {
+  char* base = nullptr;
+  size_t cap = 0, off = 0;
+  bool dry = false;
+  char* take(size_t bytes) {
+    const size_t a = (off + 255) & ~(size_t)255;
+    off = a + bytes;
+    return (dry ? (char*)0x1000 : base) + a;
+  }
+};
+
+}  // namespace
+
+struct hn_model {
+  hn_model_config cfg;
+  std::map<std::string, HostT> sd;
+  bool finalized = false;
+  std::vector<void*> owned;  // device allocations of the weights
+  // ---- A2J ----
+  ConvW a_stem;
+  struct Bneck { ConvW c1, c2, c3, ds; bool has_ds = false; int layer = 0; };
+  std::vector<Bneck> a_blocks;
+  ConvW a_cls[4], a_reg[3], a_dep[3], a_regdep1, a_cls_out, a_reg_out, a_dep_out;
+  // ---- FCOS ----
+  ConvW f_stem16;  // w16 = [64][7][2][32] stem rows, bias
+  struct Basic { ConvW c1, c2, ds; bool has_ds = false; int layer = 0; bool last = false; };
+  std::vector<Basic> f_blocks;
+  ConvW f_inner[3], f_layer[3], f_tower0, f_cls_t[3], f_reg_t[3], f_cls_out, f_reg_out;
+  float* f_gn0_gamma = nullptr; float* f_gn0_beta = nullptr;  // [512]
+  float* f_gn_gamma[3] = {nullptr, nullptr, nullptr}; float* f_gn_beta[3] = {nullptr, nullptr, nullptr};  // [512] cls | reg
+  // ---- run-time state ----
+  Arena arena;
+  std::map<std::string, size_t> plan;  // arena bytes per (entry, n, h, w)
+};
+
+namespace {
+
+#define HN_TRY(expr)            \
+  do {                          \
+    const int st_ = (expr);     \
+    if (st_ != HN_OK) return st_; \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------------------------
+// weight packing (host, fp64) -- restates hn_amd/weights.py
+// ------------------------------------------------------------------------------------------------------------------
+const HostT* find(const hn_model* m, const std::string& k) {
+  auto it = m->sd.find(k);
+  return it == m->sd.end() ? nullptr : &it->second;
+}
+
+int need(const hn_model* m, const std::string& k, const HostT** out, int ndim) {
+  const HostT* t = find(m, k);
+  if (!t) return hn::fail(HN_ERR_ARG, "weight '%s' was not loaded", k.c_str());
+  if ((int)t->shape.size() != ndim) return hn::fail(HN_ERR_ARG, "weight '%s' has %d dims, expected %d", k.c_str(), (int)t->shape.size(), ndim);
+  *out = t;
+  return HN_OK;
+}
+
+// (Frozen)BatchNorm eval: y = x * scale + shift
+int bn_scale_shift(const hn_model* m, const std::string& name, std::vector<double>& scale, std::vector<double>& shift) {
+  const HostT *w, *b, *rm, *rv;
+  HN_TRY(need(m, name + ".weight", &w, 1));
+  HN_TRY(need(m, name + ".bias", &b, 1));
+  HN_TRY(need(m, name + ".running_mean", &rm, 1));
+  HN_TRY(need(m, name + ".running_var", &rv, 1));
+  const size_t c = w->v.size();
+  scale.resize(c);
+  shift.resize(c);
+  for (size_t i = 0; i < c; ++i) {
+    scale[i] = (double)w->v[i] / sqrt((double)rv->v[i] + kBnEps);
+    shift[i] = (double)b->v[i] - (double)rm->v[i] * scale[i];
+  }
+  return HN_OK;
+}
+
+// hi = fp16(v), lo = fp16(v - hi); bank [cout][(cin/32)*r*s][2][32], k tiles channel-block outer / tap inner
+int split_bank(const std::vector<float>& w, int cout, int r, int s, int cin, std::vector<_Float16>& out, const char* what) {
+  if (cin % 32) return hn::fail(HN_ERR_ARG, "%s: split bank needs cin %% 32 == 0", what);
+  const int taps = r * s, cbs = cin / 32;
+  out.resize((size_t)cout * cbs * taps * 64);
+  for (int o = 0; o < cout; ++o)
+    for (int cb = 0; cb < cbs; ++cb)
+      for (int t = 0; t < taps; ++t) {
+        const float* src = &w[((size_t)o * taps + t) * cin + cb * 32];
+        _Float16* dst = &out[(((size_t)o * cbs + cb) * taps + t) * 64];
+        for (int e = 0; e < 32; ++e) {
+          const float v = src[e];
+          if (!(fabsf(v) <= 65504.f))
+            return hn::fail(HN_ERR_ARG, "%s: value %g outside the fp16 range (f16x3 range contract); this model needs the f32 mode", what, (double)v);
+          const _Float16 h = (_Float16)v;
+          dst[e] = h;
+          dst[32 + e] = (_Float16)(v - (float)h);
+        }
+      }
+  return HN_OK;
+}
+
+// weight [cout][cin][r][s] (torch) (+ bias) (+ BN) -> ConvW; sum_cin collapses the input channels (A2J stem, a2j/a2j.py:199)
+int pack_conv(const hn_model* m, const std::string& wname, const std::string& bname, const std::string& bnname, int stride,
+              int pad, int dil, bool sum_cin, ConvW& cw) {
+  const HostT* w;
+  HN_TRY(need(m, wname, &w, 4));
+  const int cout = (int)w->shape[0], cin0 = (int)w->shape[1], r = (int)w->shape[2], s = (int)w->shape[3];
+  const int cin = sum_cin ? 1 : cin0;
+  const int cp = (cin + 3) / 4 * 4;
+  std::vector<double> scale, shift;
+  const bool bn = !bnname.empty();
+  if (bn) HN_TRY(bn_scale_shift(m, bnname, scale, shift));
+  const HostT* b = nullptr;
+  if (!bname.empty()) HN_TRY(need(m, bname, &b, 1));
+  cw.cout = cout; cw.r = r; cw.s = s; cw.cin = cp; cw.stride = stride; cw.pad = pad; cw.dil = dil;
+  cw.hw.assign((size_t)cout * r * s * cp, 0.f);
+  for (int o = 0; o < cout; ++o)
+    for (int y = 0; y < r; ++y)
+      for (int x = 0; x < s; ++x)
+        for (int c = 0; c < cin; ++c) {
+          double v = 0.0;
+          if (sum_cin) {
+            for (int cc = 0; cc < cin0; ++cc) v += (double)w->v[(((size_t)o * cin0 + cc) * r + y) * s + x];
+          } else {
+            v = (double)w->v[(((size_t)o * cin0 + c) * r + y) * s + x];
+          }
+          if (bn) v *= scale[o];
+          cw.hw[(((size_t)o * r + y) * s + x) * cp + c] = (float)v;
+        }
+  cw.has_bias = bn || b;
+  if (cw.has_bias) {
+    cw.hb.resize(cout);
+    for (int o = 0; o < cout; ++o) {
+      double v = b ? (double)b->v[o] : 0.0;
+      if (bn) v = b ? v * scale[o] + shift[o] : shift[o];
+      cw.hb[o] = (float)v;
+    }
+  }
+  if (cp % 32 == 0) HN_TRY(split_bank(cw.hw, cout, r, s, cp, cw.hw16, wname.c_str()));
+  return HN_OK;
+}
+
+int concat_cout(const ConvW& a, const ConvW& b, ConvW& out, const char* what) {
+  if (a.r != b.r || a.s != b.s || a.cin != b.cin || a.stride != b.stride || a.pad != b.pad || a.dil != b.dil)
+    return hn::fail(HN_ERR_ARG, "%s: stacked convolutions differ in geometry", what);
+  out = a;
+  out.cout = a.cout + b.cout;
+  out.hw.insert(out.hw.end(), b.hw.begin(), b.hw.end());
+  out.has_bias = a.has_bias || b.has_bias;
+  if (out.has_bias) {
+    out.hb.assign(out.cout, 0.f);
+    for (int i = 0; i < a.cout && a.has_bias; ++i) out.hb[i] = a.hb[i];
+    for (int i = 0; i < b.cout && b.has_bias; ++i) out.hb[a.cout + i] = b.hb[i];
+  }
+  out.hw16.clear();
+  if (out.cin % 32 == 0) HN_TRY(split_bank(out.hw, out.cout, out.r, out.s, out.cin, out.hw16, what));
+  return HN_OK;
+}
+
+// R x R stem (cin <= 4) for hn_conv_stem_f16x3: each filter ROW is one 32-deep k tile, k = kx*4 + c
+int pack_stem_split(const hn_model* m, const std::string& wname, const std::string& bnname, ConvW& cw) {
+  const HostT* w;
+  HN_TRY(need(m, wname, &w, 4));
+  const int cout = (int)w->shape[0], cin = (int)w->shape[1], r = (int)w->shape[2], s = (int)w->shape[3];
+  if (r != s || r > 8 || cin > 4) return hn::fail(HN_ERR_ARG, "stem filter must be R x R with R <= 8 and Cin <= 4");
+  std::vector<double> scale, shift;
+  HN_TRY(bn_scale_shift(m, bnname, scale, shift));
+  std::vector<float> rows((size_t)cout * r * 32, 0.f);
+  for (int o = 0; o < cout; ++o)
+    for (int ky = 0; ky < r; ++ky)
+      for (int kx = 0; kx < r; ++kx)
+        for (int c = 0; c < cin; ++c)
+          rows[((size_t)o * r + ky) * 32 + kx * 4 + c] = (float)((double)w->v[(((size_t)o * cin + c) * r + ky) * s + kx] * scale[o]);
+  cw.cout = cout; cw.r = r; cw.s = r; cw.cin = 4; cw.stride = 2; cw.pad = r / 2; cw.dil = 1;
+  cw.has_bias = true;
+  cw.hb.resize(cout);
+  for (int o = 0; o < cout; ++o) cw.hb[o] = (float)shift[o];
+  return split_bank(rows, cout, r, 1, 32, cw.hw16, wname.c_str());
+}
+
+int upload(hn_model* m, ConvW& cw) {
+  auto put = [&](const void* src, size_t bytes, void** dst) -> int {
+    HN_CHECK_HIP(hipMalloc(dst, bytes));
+    m->owned.push_back(*dst);
+    HN_CHECK_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    return HN_OK;
+  };
+  if (!cw.hw.empty()) HN_TRY(put(cw.hw.data(), cw.hw.size() * 4, (void**)&cw.w));
+  if (cw.has_bias) HN_TRY(put(cw.hb.data(), cw.hb.size() * 4, (void**)&cw.bias));
+  if (!cw.hw16.empty()) HN_TRY(put(cw.hw16.data(), cw.hw16.size() * 2, (void**)&cw.w16));
+  cw.hw.clear(); cw.hw.shrink_to_fit();
+  cw.hw16.clear(); cw.hw16.shrink_to_fit();
+  return HN_OK;
+}
+
+int upload_vec(hn_model* m, const std::vector<float>& v, float** dst) {
+  HN_CHECK_HIP(hipMalloc((void**)dst, v.size() * 4));
+  m->owned.push_back(*dst);
+  HN_CHECK_HIP(hipMemcpy(*dst, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+  return HN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// graph execution helpers (mirror hn_amd/ops.py: same descriptors -> same kernels -> same bits)
+// ------------------------------------------------------------------------------------------------------------------
+struct Ctx {
+  hn_model* m;
+  void* stream;
+  bool dry;
+  char* ws;  // split-K workspace
+};
+
+T alloc(Ctx& cx, int n, int h, int w, int c, bool split) {
+  T t;
+  t.n = n; t.h = h; t.w = w; t.c = c; t.split = split;
+  t.ps = split ? 2 * c : c;
+  t.p = cx.m->arena.take((size_t)n * h * w * c * 4);  // S32 has the same bytes as fp32
+  return t;
+}
+
+char* alloc_bytes(Ctx& cx, size_t bytes) { return cx.m->arena.take(bytes); }
+
+inline void out_size(int h, int w, int r, int s, int stride, int pad, int dil, int& oh, int& ow) {
+  oh = (h + 2 * pad - dil * (r - 1) - 1) / stride + 1;
+  ow = (w + 2 * pad - dil * (s - 1) - 1) / stride + 1;
+}
+
+hn_conv_desc make_desc(const T& x, const ConvW& cw, int relu_cols) {
+  hn_conv_desc d;
+  memset(&d, 0, sizeof(d));
+  d.n = x.n; d.h = x.h; d.w = x.w; d.cin = cw.cin; d.cout = cw.cout; d.r = cw.r; d.s = cw.s;
+  d.stride = cw.stride; d.pad = cw.pad; d.dil = cw.dil;
+  int oh, ow;
+  out_size(x.h, x.w, cw.r, cw.s, cw.stride, cw.pad, cw.dil, oh, ow);
+  d.oh = oh; d.ow = ow;
+  d.relu_cols = relu_cols;
+  d.in_pix_stride = x.ps == (x.split ? 2 * cw.cin : cw.cin) ? 0 : x.ps;
+  return d;
+}
+
+// one f16x3 convolution with the split-K workspace (ops.conv2d_nhwc with w16): S32 in, S32 or fp32 out
+int conv16(Ctx& cx, const T& x, const ConvW& cw, bool relu, bool out_split, const T* res, bool res_up, T& y) {
+  if (!x.split || x.c != cw.cin) return hn::fail(HN_ERR_ARG, "model graph: conv input mismatch (c %d vs cin %d)", x.c, cw.cin);
+  hn_conv_desc d = make_desc(x, cw, relu ? cw.cout : 0);
+  y = alloc(cx, x.n, d.oh, d.ow, cw.cout, out_split);
+  d.out_split = out_split ? 1 : 0;
+  if (res) {
+    d.res_mode = res_up ? 2 : 1;
+    if (res_up) { d.res_h = res->h; d.res_w = res->w; }
+    d.res_split = res->split ? 1 : 0;
+    d.res_pix_stride = res->ps;
+  }
+  d.splitk = 1;
+  if (cx.dry) return HN_OK;
+  return hn_conv2d_nhwc_f16x3_ws(&d, x.p, cw.w16, cw.bias, res ? res->p : nullptr, y.p, cx.ws, kConvWorkspaceBytes, cx.stream);
+}
+
+// channel-block slice of an S32 tensor (no copy)
+T slice_blocks(const T& x, int b0, int b1) {
+  T s = x;
+  s.p = x.p + (size_t)b0 * 64 * 2;
+  s.c = (b1 - b0) * 32;
+  return s;
+}
+
+struct GroupSpec {
+  int count = 0;
+  T x[HN_CONV_MAX_GROUP];
+  const ConvW* w[HN_CONV_MAX_GROUP];
+  char* y[HN_CONV_MAX_GROUP];           // output base (already offset to the member's channel)
+  float* gn[HN_CONV_MAX_GROUP];
+};
+
+// ops.conv2d_nhwc_grouped: members share channels / filter / batch / pixel strides; outputs given by the caller
+int conv_grouped(Ctx& cx, const GroupSpec& g, int relu_cols, bool out_split, int out_pix_stride, int gn_units) {
+  const ConvW& c0 = *g.w[0];
+  hn_conv_desc d = make_desc(g.x[0], c0, relu_cols);
+  d.out_split = out_split ? 1 : 0;
+  d.out_pix_stride = out_pix_stride == (out_split ? 2 : 1) * c0.cout ? 0 : out_pix_stride;
+  d.splitk = -1;
+  hn_conv_group grp;
+  memset(&grp, 0, sizeof(grp));
+  grp.count = g.count;
+  grp.gn_units = gn_units;
+  for (int i = 0; i < g.count; ++i) {
+    grp.x16[i] = g.x[i].p; grp.w16[i] = g.w[i]->w16; grp.bias[i] = g.w[i]->bias; grp.y[i] = g.y[i];
+    grp.gn_partial[i] = g.gn[i];
+    grp.h[i] = g.x[i].h; grp.w[i] = g.x[i].w;
+  }
+  if (cx.dry) return HN_OK;
+  return hn_conv2d_nhwc_f16x3_grouped(&d, &grp, cx.stream);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// A2J (hn_amd/a2j_engine.py)
+// ------------------------------------------------------------------------------------------------------------------
+int a2j_graph(Ctx& cx, const T& crops /* fp32 [k][176][176][4] */, const int32_t* valid, float* keypoints) {
+  hn_model* m = cx.m;
+  const int k = crops.n;
+  // stem: exact f32-MFMA kernel (Cin 4), S32 output
+  hn_conv_desc d = make_desc(crops, m->a_stem, m->a_stem.cout);
+  d.out_split = 1;
+  T x = alloc(cx, k, d.oh, d.ow, 64, true);
+  if (!cx.dry) HN_TRY(hn_conv2d_nhwc_f32(&d, (const float*)crops.p, m->a_stem.w, m->a_stem.bias, nullptr, nullptr, nullptr, (float*)x.p, cx.stream));
+  {
+    const int oh = (x.h + 2 - 3) / 2 + 1, ow = (x.w + 2 - 3) / 2 + 1;
+    T p = alloc(cx, k, oh, ow, 64, true);
+    if (!cx.dry) HN_TRY(hn_maxpool3x3s2_s32(x.p, p.p, k, x.h, x.w, 64, oh, ow, cx.stream));
+    x = p;
+  }
+  T x3;
+  for (size_t i = 0; i < m->a_blocks.size(); ++i) {
+    auto& b = m->a_blocks[i];
+    T o, o2, idn, y;
+    HN_TRY(conv16(cx, x, b.c1, true, true, nullptr, false, o));
+    HN_TRY(conv16(cx, o, b.c2, true, true, nullptr, false, o2));
+    if (b.has_ds) HN_TRY(conv16(cx, x, b.ds, false, true, nullptr, false, idn));
+    else idn = x;
+    HN_TRY(conv16(cx, o2, b.c3, true, true, &idn, false, y));
+    x = y;
+    const bool last_of_layer = i + 1 == m->a_blocks.size() || m->a_blocks[i + 1].layer != b.layer;
+    if (b.layer == 3 && last_of_layer) x3 = x;
+  }
+  const T x4 = x;
+  // heads (grouped launches, a2j_engine.heads)
+  T c, rd;
+  HN_TRY(conv16(cx, x3, m->a_cls[0], true, true, nullptr, false, c));
+  HN_TRY(conv16(cx, x4, m->a_regdep1, true, true, nullptr, false, rd));
+  T r = slice_blocks(rd, 0, 8), dd = slice_blocks(rd, 8, 16);
+  {
+    T c2;
+    HN_TRY(conv16(cx, c, m->a_cls[1], true, true, nullptr, false, c2));
+    c = c2;
+    GroupSpec g;
+    g.count = 2;
+    T r2 = alloc(cx, k, r.h, r.w, 256, true), d2 = alloc(cx, k, r.h, r.w, 256, true);
+    g.x[0] = r; g.x[1] = dd; g.w[0] = &m->a_reg[0]; g.w[1] = &m->a_dep[0];
+    g.y[0] = r2.p; g.y[1] = d2.p; g.gn[0] = g.gn[1] = nullptr;
+    HN_TRY(conv_grouped(cx, g, 256, true, 512, 0));
+    r = r2; dd = d2;
+  }
+  for (int i = 1; i <= 2; ++i) {
+    GroupSpec g;
+    g.count = 3;
+    T c2 = alloc(cx, k, c.h, c.w, 256, true), r2 = alloc(cx, k, c.h, c.w, 256, true), d2 = alloc(cx, k, c.h, c.w, 256, true);
+    g.x[0] = c; g.x[1] = r; g.x[2] = dd;
+    g.w[0] = &m->a_cls[i + 1]; g.w[1] = &m->a_reg[i]; g.w[2] = &m->a_dep[i];
+    g.y[0] = c2.p; g.y[1] = r2.p; g.y[2] = d2.p; g.gn[0] = g.gn[1] = g.gn[2] = nullptr;
+    HN_TRY(conv_grouped(cx, g, 256, true, 512, 0));
+    c = c2; r = r2; dd = d2;
+  }
+  const int aj = m->a_cls_out.cout;
+  T cls = alloc(cx, k, c.h, c.w, aj, false), dep = alloc(cx, k, c.h, c.w, aj, false), reg;
+  {
+    GroupSpec g;
+    g.count = 2;
+    g.x[0] = c; g.x[1] = dd; g.w[0] = &m->a_cls_out; g.w[1] = &m->a_dep_out;
+    g.y[0] = cls.p; g.y[1] = dep.p; g.gn[0] = g.gn[1] = nullptr;
+    HN_TRY(conv_grouped(cx, g, 0, false, aj, 0));
+  }
+  HN_TRY(conv16(cx, r, m->a_reg_out, false, false, nullptr, false, reg));
+  if (cx.dry) return HN_OK;
+  return hn_a2j_aggregate_f32((const float*)cls.p, (const float*)reg.p, (const float*)dep.p, valid, k, c.h, c.w,
+                              m->cfg.num_joints, 16, keypoints, cx.stream);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// FCOS (hn_amd/fcos_engine.py, default f16x3 path with lock-step grouped heads)
+// ------------------------------------------------------------------------------------------------------------------
+struct Geometry {
+  int oh, ow, ph, pw;
+};
+
+// torchvision GeneralizedRCNNTransform.resize: float / tensor = tensor.reciprocal() * float in fp32, then
+// floor(size * scale) in double
+Geometry geometry(const hn_model_config& c, int h, int w) {
+  const float inv_min = 1.0f / (float)(h < w ? h : w), inv_max = 1.0f / (float)(h < w ? w : h);
+  const float a = inv_min * (float)c.min_size, b = inv_max * (float)c.max_size;
+  const double scale = (double)(a < b ? a : b);
+  Geometry g;
+  g.oh = (int)((double)h * scale);
+  g.ow = (int)((double)w * scale);
+  g.ph = (g.oh + 31) / 32 * 32;
+  g.pw = (g.ow + 31) / 32 * 32;
+  return g;
+}
+
+struct FcosOut {
+  float* boxes; float* scores; int32_t *labels, *sides, *level, *count;
+  int cap;
+};
+
+int fcos_graph(Ctx& cx, const float* rgb, int n, int h, int w, const FcosOut& out) {
+  hn_model* m = cx.m;
+  const Geometry g = geometry(m->cfg, h, w);
+  if (out.cap != (int)hn_fcos_capacity(m, h, w))
+    return hn::fail(HN_ERR_ARG, "detection arrays must have hn_fcos_capacity(m, %d, %d) = %d rows per image (got %d)", h, w,
+                    (int)hn_fcos_capacity(m, h, w), out.cap);
+  const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+  const int border = 3;
+  char* img16 = alloc_bytes(cx, (size_t)2 * n * (g.ph + 2 * border) * (g.pw + 2 * border) * 4 * 2);
+  if (!cx.dry) HN_TRY(hn_fcos_preprocess_split(rgb, img16, n, h, w, g.oh, g.ow, g.ph, g.pw, border, mean, stdv, cx.stream));
+  int sh, sw;
+  out_size(g.ph + 2 * border, g.pw + 2 * border, 7, 7, 2, 0, 1, sh, sw);
+  T x = alloc(cx, n, sh, sw, 64, true);
+  if (!cx.dry)
+    HN_TRY(hn_conv_stem_f16x3(img16, n, g.ph, g.pw, border, 7, 2, 64, m->f_stem16.w16, m->f_stem16.bias, 1, x.p, 1, cx.stream));
+  {
+    const int oh = (x.h + 2 - 3) / 2 + 1, ow = (x.w + 2 - 3) / 2 + 1;
+    T p = alloc(cx, n, oh, ow, 64, true);
+    if (!cx.dry) HN_TRY(hn_maxpool3x3s2_s32(x.p, p.p, n, x.h, x.w, 64, oh, ow, cx.stream));
+    x = p;
+  }
+  T feats_c[3];
+  int nf = 0;
+  for (auto& b : m->f_blocks) {
+    T o, idn, y;
+    HN_TRY(conv16(cx, x, b.c1, true, true, nullptr, false, o));
+    if (b.has_ds) HN_TRY(conv16(cx, x, b.ds, false, true, nullptr, false, idn));
+    else idn = x;
+    HN_TRY(conv16(cx, o, b.c2, true, true, &idn, false, y));
+    x = y;
+    if (b.last && b.layer >= 2) feats_c[nf++] = x;
+  }
+  T lat5, lat4, lat3;
+  HN_TRY(conv16(cx, feats_c[2], m->f_inner[2], false, true, nullptr, false, lat5));
+  HN_TRY(conv16(cx, feats_c[1], m->f_inner[1], false, true, &lat5, true, lat4));
+  HN_TRY(conv16(cx, feats_c[0], m->f_inner[0], false, true, &lat4, true, lat3));
+  const T lat[3] = {lat3, lat4, lat5};
+  const int L = 3;
+  T feats[3];
+  {
+    GroupSpec gs;
+    gs.count = L;
+    for (int l = 0; l < L; ++l) {
+      feats[l] = alloc(cx, n, lat[l].h, lat[l].w, 256, true);
+      gs.x[l] = lat[l]; gs.w[l] = &m->f_layer[l]; gs.y[l] = feats[l].p; gs.gn[l] = nullptr;
+    }
+    HN_TRY(conv_grouped(cx, gs, 0, true, 512, 0));
+  }
+  // ---- heads in lock-step over levels and towers (FCOSEngine.heads_grouped) ----
+  int hw[3];
+  float* parts[3];
+  for (int l = 0; l < L; ++l) {
+    hw[l] = feats[l].h * feats[l].w;
+    if (hw[l] < 32) return hn::fail(HN_ERR_ARG, "image %dx%d too small for the grouped FCOS heads (a level has %d points)", h, w, hw[l]);
+    parts[l] = (float*)alloc_bytes(cx, (size_t)hn_groupnorm_rows32_scratch_floats((int64_t)n * hw[l], 512) * 4);
+  }
+  auto new_t = [&](T* t) {
+    for (int l = 0; l < L; ++l) t[l] = alloc(cx, n, feats[l].h, feats[l].w, 512, false);
+  };
+  T t[3];
+  new_t(t);
+  {
+    GroupSpec gs;
+    gs.count = L;
+    for (int l = 0; l < L; ++l) { gs.x[l] = feats[l]; gs.w[l] = &m->f_tower0; gs.y[l] = t[l].p; gs.gn[l] = parts[l]; }
+    HN_TRY(conv_grouped(cx, gs, 0, false, 512, 64));
+  }
+  float *scale[3], *shift[3];
+  for (int l = 0; l < L; ++l) {
+    scale[l] = (float*)alloc_bytes(cx, (size_t)n * 512 * 4);
+    shift[l] = (float*)alloc_bytes(cx, (size_t)n * 512 * 4);
+  }
+  auto finalize = [&](const float* gamma, const float* beta) -> int {
+    if (cx.dry) return HN_OK;
+    for (int l = 0; l < L; ++l)
+      HN_TRY(hn_groupnorm_finalize_rows32(parts[l], gamma, beta, n, hw[l], 512, 64, 1e-5f, scale[l], shift[l], cx.stream));
+    return HN_OK;
+  };
+  auto activate = [&](T* a) -> int {  // GroupNorm affine + ReLU + split: S32 [n][h][w][16][2][32], cls blocks 0-7, reg 8-15
+    for (int l = 0; l < L; ++l) {
+      a[l] = alloc(cx, n, t[l].h, t[l].w, 512, true);
+      if (!cx.dry)
+        HN_TRY(hn_affine_split_f32((const float*)t[l].p, scale[l], shift[l], 1, n, hw[l], 512, 512, 512, a[l].p, 1024, cx.stream));
+    }
+    return HN_OK;
+  };
+  HN_TRY(finalize(m->f_gn0_gamma, m->f_gn0_beta));
+  T a[3];
+  for (int layer = 0; layer < 3; ++layer) {
+    HN_TRY(activate(a));
+    new_t(t);
+    GroupSpec gs;
+    gs.count = 2 * L;
+    for (int l = 0; l < L; ++l) {
+      gs.x[l] = slice_blocks(a[l], 0, 8); gs.w[l] = &m->f_cls_t[layer]; gs.y[l] = t[l].p; gs.gn[l] = parts[l];
+      gs.x[L + l] = slice_blocks(a[l], 8, 16); gs.w[L + l] = &m->f_reg_t[layer]; gs.y[L + l] = t[l].p + 256 * 4;
+      gs.gn[L + l] = (float*)((char*)parts[l] + 16 * 32);
+    }
+    HN_TRY(conv_grouped(cx, gs, 0, false, 512, 64));
+    HN_TRY(finalize(m->f_gn_gamma[layer], m->f_gn_beta[layer]));
+  }
+  HN_TRY(activate(a));
+  hn_fcos_levels lv;
+  memset(&lv, 0, sizeof(lv));
+  lv.num_levels = L;
+  T cls_lr[3], reg_ctr[3];
+  {
+    GroupSpec gc, gr;
+    gc.count = gr.count = L;
+    const int ccls = m->f_cls_out.cout;
+    for (int l = 0; l < L; ++l) {
+      cls_lr[l] = alloc(cx, n, a[l].h, a[l].w, ccls, false);
+      reg_ctr[l] = alloc(cx, n, a[l].h, a[l].w, 5, false);
+      gc.x[l] = slice_blocks(a[l], 0, 8); gc.w[l] = &m->f_cls_out; gc.y[l] = cls_lr[l].p; gc.gn[l] = nullptr;
+      gr.x[l] = slice_blocks(a[l], 8, 16); gr.w[l] = &m->f_reg_out; gr.y[l] = reg_ctr[l].p; gr.gn[l] = nullptr;
+      lv.h[l] = a[l].h; lv.w[l] = a[l].w; lv.stride[l] = g.ph / a[l].h;
+      lv.cls_lr[l] = (const float*)cls_lr[l].p; lv.reg_ctr[l] = (const float*)reg_ctr[l].p;
+    }
+    HN_TRY(conv_grouped(cx, gc, 0, false, ccls, 0));
+    HN_TRY(conv_grouped(cx, gr, 4, false, 5, 0));
+  }
+  const int cap = hw[0] + hw[1] + hw[2];
+  if (out.cap != cap) return hn::fail(HN_ERR_ARG, "internal: %d anchor points but capacity %d", cap, out.cap);
+  float* cb = (float*)alloc_bytes(cx, (size_t)n * cap * 16);
+  float* cs = (float*)alloc_bytes(cx, (size_t)n * cap * 4);
+  int32_t* cl = (int32_t*)alloc_bytes(cx, (size_t)n * cap * 4);
+  int32_t* cd = (int32_t*)alloc_bytes(cx, (size_t)n * cap * 4);
+  int32_t* cv = (int32_t*)alloc_bytes(cx, (size_t)n * cap * 4);
+  int32_t* cc = (int32_t*)alloc_bytes(cx, (size_t)n * 4);
+  int32_t* keep = (int32_t*)alloc_bytes(cx, (size_t)n * cap * 4);
+  char* scratch = alloc_bytes(cx, (size_t)hn_fcos_nms_scratch_bytes(n, cap));
+  if (cx.dry) return HN_OK;
+  HN_TRY(hn_fcos_candidates(&lv, n, m->cfg.num_classes, 0.7f /* fcos.py:600 */, cb, cs, cl, cd, cv, nullptr, cc, cap, cx.stream));
+  // resize_boxes (fcos.py:770-783): fp32 / fp32
+  const float ratio_h = (float)h / (float)g.oh, ratio_w = (float)w / (float)g.ow;
+  return hn_fcos_nms(cb, cs, cl, cd, cv, cc, n, cap, 0.3 /* fcos.py:635 */, ratio_h, ratio_w, scratch, out.boxes, out.scores,
+                     out.labels, out.sides, out.level, keep, out.count, cx.stream);
+}
+
+// dry pass (sizes the arena) + real pass
+template <class F>
+int run_planned(hn_model* m, const std::string& key, void* stream, F&& graph) {
+  HN_CHECK_ARG(m && m->finalized, "model is not finalized (hn_finalize)");
+  auto it = m->plan.find(key);
+  size_t bytes;
+  if (it == m->plan.end()) {
+    Ctx dry{m, stream, true, nullptr};
+    m->arena.dry = true;
+    m->arena.off = 0;
+    (void)m->arena.take(kConvWorkspaceBytes);
+    HN_TRY(graph(dry));
+    bytes = m->arena.off + 256;
+    m->plan[key] = bytes;
+  } else {
+    bytes = it->second;
+  }
+  if (bytes > m->arena.cap) {  // first call with a larger problem: the one place a forward allocates (and synchronises)
+    HN_CHECK_HIP(hipDeviceSynchronize());
+    if (m->arena.base) HN_CHECK_HIP(hipFree(m->arena.base));
+    m->arena.base = nullptr;
+    m->arena.cap = 0;
+    HN_CHECK_HIP(hipMalloc((void**)&m->arena.base, bytes));
+    m->arena.cap = bytes;
+  }
+  m->arena.dry = false;
+  m->arena.off = 0;
+  Ctx cx{m, stream, false, nullptr};
+  cx.ws = m->arena.take(kConvWorkspaceBytes);
+  return graph(cx);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" int hn_create(const hn_model_config* cfg, hn_model** out) {
+  HN_CHECK_ARG(cfg && out, "hn_create: null pointer");
+  HN_CHECK_ARG(cfg->parts & (HN_MODEL_FCOS | HN_MODEL_A2J), "hn_create: parts must name HN_MODEL_FCOS and / or HN_MODEL_A2J");
+  HN_CHECK_ARG(cfg->num_classes >= 1 && cfg->num_classes <= 64 && cfg->num_joints >= 1, "bad class / joint count");
+  hn_model* m = new hn_model();
+  m->cfg = *cfg;
+  if (m->cfg.min_size <= 0) m->cfg.min_size = 800;     // fcos.py:460-461
+  if (m->cfg.max_size <= 0) m->cfg.max_size = 1333;
+  *out = m;
+  return HN_OK;
+}
+
+extern "C" int hn_load_weight(hn_model* m, const char* name, const float* data, const int64_t* shape, int ndim) {
+  HN_CHECK_ARG(m && name && data && (shape || ndim == 0), "hn_load_weight: null pointer");
+  HN_CHECK_ARG(!m->finalized, "hn_load_weight after hn_finalize");
+  HN_CHECK_ARG(ndim >= 0 && ndim <= 4, "weights have 0..4 dims");
+  std::string key(name);
+  if (key.rfind("a2j.", 0) == 0) key = key.substr(4);  // Lightning checkpoints prefix A2J with 'a2j.' (a2j/a2j.py:277)
+  HostT t;
+  int64_t numel = 1;
+  for (int i = 0; i < ndim; ++i) {
+    HN_CHECK_ARG(shape[i] > 0, "bad shape");
+    t.shape.push_back(shape[i]);
+    numel *= shape[i];
+  }
+  t.v.assign(data, data + numel);
+  m->sd[key] = std::move(t);
+  return HN_OK;
+}
+
+extern "C" int hn_finalize(hn_model* m) {
+  HN_CHECK_ARG(m && !m->finalized, "hn_finalize: null or already finalized");
+  if (m->cfg.parts & HN_MODEL_A2J) {
+    const std::string p = "Backbone.model.";
+    HN_TRY(pack_conv(m, p + "conv1.weight", "", p + "bn1", 2, 3, 1, !m->cfg.rgbd, m->a_stem));
+    const int planes[4] = {64, 128, 256, 512}, blocks[4] = {3, 4, 6, 3}, strides[4] = {1, 2, 2, 1}, dils[4] = {1, 1, 1, 2};
+    (void)planes;
+    for (int li = 1; li <= 4; ++li)
+      for (int b = 0; b < blocks[li - 1]; ++b) {
+        const std::string q = p + "layer" + std::to_string(li) + "." + std::to_string(b) + ".";
+        const int st = b == 0 ? strides[li - 1] : 1, dl = b == 0 ? 1 : dils[li - 1];  // a2j/resnet.py:133-147
+        hn_model::Bneck k;
+        k.layer = li;
+        HN_TRY(pack_conv(m, q + "conv1.weight", "", q + "bn1", 1, 0, 1, false, k.c1));
+        HN_TRY(pack_conv(m, q + "conv2.weight", "", q + "bn2", st, dl, dl, false, k.c2));
+        HN_TRY(pack_conv(m, q + "conv3.weight", "", q + "bn3", 1, 0, 1, false, k.c3));
+        k.has_ds = find(m, q + "downsample.0.weight") != nullptr;
+        if (k.has_ds) HN_TRY(pack_conv(m, q + "downsample.0.weight", "", q + "downsample.1", st, 0, 1, false, k.ds));
+        m->a_blocks.push_back(std::move(k));
+      }
+    auto head = [&](const std::string& name, ConvW* convs4, ConvW& outc) -> int {
+      for (int i = 1; i <= 4; ++i) {
+        const std::string c = name + ".conv" + std::to_string(i), bn = name + ".bn" + std::to_string(i);
+        HN_TRY(pack_conv(m, c + ".weight", c + ".bias", bn, 1, 1, 1, false, convs4[i - 1]));
+      }
+      return pack_conv(m, name + ".output.weight", name + ".output.bias", "", 1, 1, 1, false, outc);
+    };
+    ConvW reg4[4], dep4[4];
+    HN_TRY(head("classificationModel", m->a_cls, m->a_cls_out));
+    HN_TRY(head("regressionModel", reg4, m->a_reg_out));
+    HN_TRY(head("DepthRegressionModel", dep4, m->a_dep_out));
+    HN_TRY(concat_cout(reg4[0], dep4[0], m->a_regdep1, "A2J regression+depth conv1"));
+    for (int i = 0; i < 3; ++i) { m->a_reg[i] = reg4[i + 1]; m->a_dep[i] = dep4[i + 1]; }
+    HN_CHECK_ARG(m->a_cls_out.cout == 16 * m->cfg.num_joints, "checkpoint does not match num_joints");
+    HN_TRY(upload(m, m->a_stem));
+    for (auto& k : m->a_blocks) {
+      HN_TRY(upload(m, k.c1)); HN_TRY(upload(m, k.c2)); HN_TRY(upload(m, k.c3));
+      if (k.has_ds) HN_TRY(upload(m, k.ds));
+    }
+    for (int i = 0; i < 4; ++i) HN_TRY(upload(m, m->a_cls[i]));
+    for (int i = 0; i < 3; ++i) { HN_TRY(upload(m, m->a_reg[i])); HN_TRY(upload(m, m->a_dep[i])); }
+    HN_TRY(upload(m, m->a_regdep1)); HN_TRY(upload(m, m->a_cls_out)); HN_TRY(upload(m, m->a_reg_out)); HN_TRY(upload(m, m->a_dep_out));
+  }
+  if (m->cfg.parts & HN_MODEL_FCOS) {
+    const std::string p = "backbone.body.";
+    HN_TRY(pack_stem_split(m, p + "conv1.weight", p + "bn1", m->f_stem16));
+    const int blocks[4] = {3, 4, 6, 3}, strides[4] = {1, 2, 2, 2};
+    for (int li = 1; li <= 4; ++li)
+      for (int b = 0; b < blocks[li - 1]; ++b) {
+        const std::string q = p + "layer" + std::to_string(li) + "." + std::to_string(b) + ".";
+        const int st = b == 0 ? strides[li - 1] : 1;
+        hn_model::Basic k;
+        k.layer = li;
+        k.last = b == blocks[li - 1] - 1;
+        HN_TRY(pack_conv(m, q + "conv1.weight", "", q + "bn1", st, 1, 1, false, k.c1));
+        HN_TRY(pack_conv(m, q + "conv2.weight", "", q + "bn2", 1, 1, 1, false, k.c2));
+        k.has_ds = find(m, q + "downsample.0.weight") != nullptr;
+        if (k.has_ds) HN_TRY(pack_conv(m, q + "downsample.0.weight", "", q + "downsample.1", st, 0, 1, false, k.ds));
+        m->f_blocks.push_back(std::move(k));
+      }
+    const std::string f = "backbone.fpn.";
+    for (int i = 0; i < 3; ++i) {
+      const std::string a = f + "inner_blocks." + std::to_string(i), b = f + "layer_blocks." + std::to_string(i);
+      HN_TRY(pack_conv(m, a + ".weight", a + ".bias", "", 1, 0, 1, false, m->f_inner[i]));
+      HN_TRY(pack_conv(m, b + ".weight", b + ".bias", "", 1, 1, 1, false, m->f_layer[i]));
+    }
+    const std::string c = "head.classification_head", r = "head.regression_head";
+    auto tconv = [&](const std::string& t, int i, ConvW& cw) {
+      const std::string n = t + ".conv." + std::to_string(3 * i);
+      return pack_conv(m, n + ".weight", n + ".bias", "", 1, 1, 1, false, cw);
+    };
+    ConvW c0, r0;
+    HN_TRY(tconv(c, 0, c0));
+    HN_TRY(tconv(r, 0, r0));
+    HN_TRY(concat_cout(c0, r0, m->f_tower0, "FCOS tower layer 0"));
+    for (int i = 1; i < 4; ++i) { HN_TRY(tconv(c, i, m->f_cls_t[i - 1])); HN_TRY(tconv(r, i, m->f_reg_t[i - 1])); }
+    auto gn = [&](int i, const char* k, std::vector<float>& v) -> int {  // cls | reg stacked
+      v.clear();
+      for (const std::string* t : {&c, &r}) {
+        const HostT* x;
+        HN_TRY(need(m, *t + ".conv." + std::to_string(3 * i + 1) + "." + k, &x, 1));
+        v.insert(v.end(), x->v.begin(), x->v.end());
+      }
+      return HN_OK;
+    };
+    std::vector<float> v;
+    HN_TRY(gn(0, "weight", v)); HN_TRY(upload_vec(m, v, &m->f_gn0_gamma));
+    HN_TRY(gn(0, "bias", v)); HN_TRY(upload_vec(m, v, &m->f_gn0_beta));
+    for (int i = 1; i < 4; ++i) {
+      HN_TRY(gn(i, "weight", v)); HN_TRY(upload_vec(m, v, &m->f_gn_gamma[i - 1]));
+      HN_TRY(gn(i, "bias", v)); HN_TRY(upload_vec(m, v, &m->f_gn_beta[i - 1]));
+    }
+    ConvW cl, lr, br, bc;
+    HN_TRY(pack_conv(m, c + ".cls_logits.weight", c + ".cls_logits.bias", "", 1, 1, 1, false, cl));
+    HN_TRY(pack_conv(m, c + ".hand_lr_layer.weight", c + ".hand_lr_layer.bias", "", 1, 1, 1, false, lr));
+    HN_TRY(pack_conv(m, r + ".bbox_reg.weight", r + ".bbox_reg.bias", "", 1, 1, 1, false, br));
+    HN_TRY(pack_conv(m, r + ".bbox_ctrness.weight", r + ".bbox_ctrness.bias", "", 1, 1, 1, false, bc));
+    HN_TRY(concat_cout(cl, lr, m->f_cls_out, "FCOS cls_logits+hand_lr"));
+    HN_TRY(concat_cout(br, bc, m->f_reg_out, "FCOS bbox_reg+ctrness"));
+    HN_CHECK_ARG(m->f_cls_out.cout == m->cfg.num_classes + 2, "checkpoint does not match num_classes");
+    HN_TRY(upload(m, m->f_stem16));
+    for (auto& k : m->f_blocks) {
+      HN_TRY(upload(m, k.c1)); HN_TRY(upload(m, k.c2));
+      if (k.has_ds) HN_TRY(upload(m, k.ds));
+    }
+    for (int i = 0; i < 3; ++i) {
+      HN_TRY(upload(m, m->f_inner[i])); HN_TRY(upload(m, m->f_layer[i])); HN_TRY(upload(m, m->f_cls_t[i])); HN_TRY(upload(m, m->f_reg_t[i]));
+    }
+    HN_TRY(upload(m, m->f_tower0)); HN_TRY(upload(m, m->f_cls_out)); HN_TRY(upload(m, m->f_reg_out));
+  }
+  m->sd.clear();
+  m->finalized = true;
+  return HN_OK;
+}
+
+extern "C" int64_t hn_fcos_capacity(const hn_model* m, int h, int w) {
+  if (!m || h <= 0 || w <= 0) return 0;
+  const Geometry g = geometry(m->cfg, h, w);
+  return (int64_t)(g.ph / 8) * (g.pw / 8) + (int64_t)(g.ph / 16) * (g.pw / 16) + (int64_t)(g.ph / 32) * (g.pw / 32);
+}
+
+extern "C" int hn_a2j_forward(hn_model* m, const float* crops, int k, int h, int w, const int32_t* valid, float* keypoints,
+                              void* stream) {
+  HN_CHECK_ARG(m && crops && keypoints, "hn_a2j_forward: null pointer");
+  HN_CHECK_ARG(m->cfg.parts & HN_MODEL_A2J, "model was created without HN_MODEL_A2J");
+  HN_CHECK_ARG(!m->cfg.rgbd, "RGB-D crops are NHWC inside the pipeline: use hn_handnet_forward");
+  HN_CHECK_ARG(k > 0 && h >= 32 && w >= 32, "bad crop batch");
+  const std::string key = "a2j:" + std::to_string(k) + "x" + std::to_string(h) + "x" + std::to_string(w);
+  return run_planned(m, key, stream, [&](Ctx& cx) -> int {
+    T x;
+    x.n = k; x.h = h; x.w = w; x.c = 4; x.ps = 4; x.split = false;
+    x.p = cx.m->arena.take((size_t)k * h * w * 16);
+    if (!cx.dry) HN_TRY(hn_pack_depth_nhwc(crops, (float*)x.p, k, h * w, 4, cx.stream));
+    return a2j_graph(cx, x, valid, keypoints);
+  });
+}
+
+extern "C" int hn_fcos_forward(hn_model* m, const float* rgb, int n, int h, int w, float* det_boxes, float* det_scores,
+                               int32_t* det_labels, int32_t* det_sides, int32_t* det_level, int32_t* det_count, int cap,
+                               void* stream) {
+  HN_CHECK_ARG(m && rgb && det_boxes && det_scores && det_labels && det_sides && det_level && det_count, "hn_fcos_forward: null pointer");
+  HN_CHECK_ARG(m->cfg.parts & HN_MODEL_FCOS, "model was created without HN_MODEL_FCOS");
+  HN_CHECK_ARG(n > 0 && h > 0 && w > 0, "bad image batch");
+  const std::string key = "fcos:" + std::to_string(n) + "x" + std::to_string(h) + "x" + std::to_string(w);
+  const FcosOut out{det_boxes, det_scores, det_labels, det_sides, det_level, det_count, cap};
+  return run_planned(m, key, stream, [&](Ctx& cx) -> int { return fcos_graph(cx, rgb, n, h, w, out); });
+}
+
+extern "C" int hn_handnet_forward(hn_model* m, const float* rgb, const float* depth, int n, int h, int w, float* keypoints,
+                                  int64_t* crop_box, int32_t* has_hand, void* stream) {
+  HN_CHECK_ARG(m && rgb && depth && keypoints && crop_box && has_hand, "hn_handnet_forward: null pointer");
+  HN_CHECK_ARG((m->cfg.parts & (HN_MODEL_FCOS | HN_MODEL_A2J)) == (HN_MODEL_FCOS | HN_MODEL_A2J), "model needs both HN_MODEL_FCOS and HN_MODEL_A2J");
+  HN_CHECK_ARG(n > 0 && h > 0 && w > 0, "bad image batch");
+  const int cap = (int)hn_fcos_capacity(m, h, w);
+  const std::string key = "handnet:" + std::to_string(n) + "x" + std::to_string(h) + "x" + std::to_string(w);
+  return run_planned(m, key, stream, [&](Ctx& cx) -> int {
+    FcosOut out;
+    out.cap = cap;
+    out.boxes = (float*)alloc_bytes(cx, (size_t)n * cap * 16);
+    out.scores = (float*)alloc_bytes(cx, (size_t)n * cap * 4);
+    out.labels = (int32_t*)alloc_bytes(cx, (size_t)n * cap * 4);
+    out.sides = (int32_t*)alloc_bytes(cx, (size_t)n * cap * 4);
+    out.level = (int32_t*)alloc_bytes(cx, (size_t)n * cap * 4);
+    out.count = (int32_t*)alloc_bytes(cx, (size_t)n * 4);
+    HN_TRY(fcos_graph(cx, rgb, n, h, w, out));
+    T crops;
+    crops.n = n; crops.h = kCrop; crops.w = kCrop; crops.c = 4; crops.ps = 4; crops.split = false;
+    crops.p = alloc_bytes(cx, (size_t)n * kCrop * kCrop * 16);
+    if (!cx.dry)
+      HN_TRY(hn_crop_resize(out.boxes, out.labels, out.count, cap, m->cfg.num_classes - 1, depth, n, m->cfg.rgbd ? 4 : 1,
+                            m->cfg.rgbd ? 1 : 0, h, w, kCrop, 4, crop_box, has_hand, (float*)crops.p, cx.stream));
+    return a2j_graph(cx, crops, has_hand, keypoints);
+  });
+}
+
+extern "C" int hn_destroy(hn_model* m) {
+  if (!m) return HN_OK;
+  for (void* p : m->owned) (void)hipFree(p);
+  if (m->arena.base) (void)hipFree(m->arena.base);
+  delete m;
+  return HN_OK;
+}

@@ -12,7 +12,7 @@ from pathlib import Path
 
 from . import build as _build
 
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, TILE_256x128, TILE_64x128 = range(7)
 HN_FCOS_MAX_LEVELS = 5
@@ -37,6 +37,13 @@ class ConvGroup(C.Structure):  # == struct hn_conv_group
                 ("bias", C.c_void_p * CONV_MAX_GROUP), ("y", C.c_void_p * CONV_MAX_GROUP),
                 ("gn_partial", C.c_void_p * CONV_MAX_GROUP), ("h", C.c_int32 * CONV_MAX_GROUP),
                 ("w", C.c_int32 * CONV_MAX_GROUP), ("gn_units", C.c_int32)]
+
+
+class ModelConfig(C.Structure):  # == struct hn_model_config
+    _fields_ = [(k, C.c_int32) for k in ("parts", "num_classes", "num_joints", "rgbd", "min_size", "max_size")]
+
+
+MODEL_FCOS, MODEL_A2J = 1, 2
 
 
 class FcosLevels(C.Structure):
@@ -94,6 +101,14 @@ SIGNATURES = {
     "hn_crop_resize": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, VP] + [C.c_int] * 7 + [VP, VP, VP, VP]),
     "hn_pack_depth_nhwc": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, VP]),
     "hn_a2j_aggregate_f32": (C.c_int, [VP, VP, VP, VP] + [C.c_int] * 5 + [VP, VP]),
+    "hn_create": (C.c_int, [C.POINTER(ModelConfig), C.POINTER(VP)]),
+    "hn_load_weight": (C.c_int, [VP, C.c_char_p, VP, c_i64p, C.c_int]),
+    "hn_finalize": (C.c_int, [VP]),
+    "hn_fcos_capacity": (C.c_int64, [VP, C.c_int, C.c_int]),
+    "hn_fcos_forward": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int] + [VP] * 6 + [C.c_int, VP]),
+    "hn_a2j_forward": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, VP, VP, VP]),
+    "hn_handnet_forward": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP]),
+    "hn_destroy": (C.c_int, [VP]),
     "hn_convert_joints_f32": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_float, C.c_float, c_f32p, VP, VP]),
 }
 

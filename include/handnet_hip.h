@@ -33,7 +33,7 @@ extern "C" {
 #define HN_ERR_HIP 2
 
 /* ABI version; bumped whenever a struct below changes. */
-#define HN_ABI_VERSION 20
+#define HN_ABI_VERSION 21
 int hn_abi_version(void);
 const char* hn_last_error(void);
 
@@ -351,6 +351,55 @@ int hn_cheby3_basis_split(const int32_t* indptr, const int32_t* indices, const f
                           void* stream);
 int hn_feat_interp_add_f32(const float* xin, const float* y, float* out, int64_t rows, int fi, int fo,
                            int up, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Model-level entry points: the layer graphs of the detector, the pose network and the HandNet glue in C++
+ * (csrc/model.hip), for hosts that are not Python.  They issue exactly the launches the Python engines issue
+ * (hn_amd/fcos_engine.py, a2j_engine.py, pipeline.py), so both hosts give bit-identical results.
+ *   hn_create          configuration -> handle
+ *   hn_load_weight     one entry of a REFERENCE-layout state_dict ("backbone.body.conv1.weight",
+ *                      "head.classification_head.conv.0.weight", "Backbone.model.layer1.0.bn1.running_var", ...;
+ *                      a leading "a2j." is stripped, a2j/a2j.py:277), fp32 HOST data in torch layout; unknown names
+ *                      are kept and ignored (strict=False, handnet_pipeline.py:20,33)
+ *   hn_finalize        folds (Frozen)BatchNorm in fp64, repacks to [Cout][R][S][Cin], splits into fp16 hi/lo banks
+ *                      (fails if a folded weight leaves the fp16 range), uploads.  Allocates and synchronises.
+ *   hn_fcos_forward    fcos_utils/fcos.py:675-767 (eval, ext=False): rgb [n][3][h][w] fp32 0..1 on the device ->
+ *                      score-ordered detections, fixed capacity cap = hn_fcos_capacity(m, h, w) rows per image:
+ *                      det_boxes [n][cap][4] (original-image pixels), det_scores / det_labels / det_sides /
+ *                      det_level [n][cap], det_count [n]
+ *   hn_a2j_forward     a2j/a2j.py:243-250: crops [k][1][h][w] fp32 metres -> keypoints [k][J][3] (u, v, d) on the
+ *                      device (the reference's .cpu() is the caller's copy); rows with valid[i] == 0 are zeros
+ *   hn_handnet_forward handnet_pipeline/handnet_pipeline.py:58-116: rgb [n][3][h][w] + depth [n][1][h][w] (RGB-D
+ *                      model: [n][4][h][w]) -> keypoints [n][J][3], crop_box [n][4] int64 (padded, clamped
+ *                      x1,y1,x2,y2), has_hand [n]; frames without a hand give zero rows (deviations)
+ * All tensors are device pointers borrowed from the caller; work is enqueued on `stream`.  Activations live in one
+ * arena per model, sized by a dry pass over the graph: a forward allocates (and synchronises the device) only when
+ * it needs more memory than any earlier call of this model; steady-state calls do neither.  One model must not be
+ * used from two host threads at once (the reference callable is not re-entered either, ros_demo.py:240-257).
+ * ------------------------------------------------------------------------------------ */
+#define HN_MODEL_FCOS 1
+#define HN_MODEL_A2J 2
+typedef struct hn_model_config {
+  int32_t parts;        /* HN_MODEL_FCOS | HN_MODEL_A2J */
+  int32_t num_classes;  /* FCOS classes (ros_demo.py:374 uses 3); hand class = num_classes - 1 */
+  int32_t num_joints;   /* 21 */
+  int32_t rgbd;         /* 1: 4-channel A2J stem + RGB-D crops with the [2,1,0,3] permutation */
+  int32_t min_size, max_size; /* GeneralizedRCNNTransform sizes; 0 = 800 / 1333 (fcos.py:460-461) */
+} hn_model_config;
+typedef struct hn_model hn_model;
+
+int hn_create(const hn_model_config* cfg, hn_model** out);
+int hn_load_weight(hn_model* m, const char* name, const float* host_data, const int64_t* shape, int ndim);
+int hn_finalize(hn_model* m);
+int64_t hn_fcos_capacity(const hn_model* m, int h, int w);
+int hn_fcos_forward(hn_model* m, const float* rgb, int n, int h, int w, float* det_boxes, float* det_scores,
+                    int32_t* det_labels, int32_t* det_sides, int32_t* det_level, int32_t* det_count, int cap,
+                    void* stream);
+int hn_a2j_forward(hn_model* m, const float* crops, int k, int h, int w, const int32_t* valid /* or NULL */,
+                   float* keypoints, void* stream);
+int hn_handnet_forward(hn_model* m, const float* rgb, const float* depth, int n, int h, int w, float* keypoints,
+                       int64_t* crop_box, int32_t* has_hand, void* stream);
+int hn_destroy(hn_model* m);
 
 #ifdef __cplusplus
 }

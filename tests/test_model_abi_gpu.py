@@ -1,0 +1,83 @@
+"""Model-level C ABI (hn_create / hn_load_weight / hn_finalize / hn_*_forward / hn_destroy): the C++ layer graphs
+must reproduce the Python engines bit for bit (same launches, same descriptors), and fail loudly on bad use."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def native(fcos_sd, a2j_sd):
+    from hn_amd.native_model import NativeModel
+    m = NativeModel(fcos_sd, a2j_sd, num_classes=3)
+    yield m
+    m.close()
+
+
+def test_handnet_forward_equals_python_engine(native, fcos_sd, a2j_sd):
+    from hn_amd import synth
+    from hn_amd.a2j_engine import A2JEngine
+    from hn_amd.fcos_engine import FCOSEngine
+    from hn_amd.pipeline import HandNetEngine
+    eng = HandNetEngine(FCOSEngine(fcos_sd, 3, device="cuda"), A2JEngine(a2j_sd, device="cuda"), 3)
+    for n, seed in ((2, 1000), (5, 1100), (2, 1000)):          # a larger batch re-sizes the arena; then a plan hit
+        rgb, depth = synth.make_rgb(n, seed=seed).cuda(), synth.make_depth(n, seed=seed + 1000).cuda()
+        ref = eng.forward_device(rgb, depth)
+        kp, box, has = native.handnet(rgb, depth)
+        assert torch.equal(box, ref.crop_box) and torch.equal(has, ref.has_hand)
+        assert torch.equal(kp, ref.keypoints)                    # bit-identical: the same kernels in the same order
+
+
+def test_fcos_forward_equals_python_engine(native, fcos_sd):
+    from hn_amd import synth
+    from hn_amd.fcos_engine import FCOSEngine
+    eng = FCOSEngine(fcos_sd, 3, device="cuda")
+    rgb = synth.make_rgb(2, seed=1000).cuda()
+    det, _ = eng.detect(rgb)
+    boxes, scores, labels, sides, level, count = native.fcos(rgb)
+    assert native.fcos_capacity(480, 640) == 17850 == det.scores.shape[1]
+    assert torch.equal(count, det.count)
+    for i, k in enumerate(count.tolist()):
+        assert k > 0
+        assert torch.equal(boxes[i, :k], det.boxes[i, :k]) and torch.equal(scores[i, :k], det.scores[i, :k])
+        assert torch.equal(labels[i, :k], det.labels[i, :k]) and torch.equal(sides[i, :k], det.sides[i, :k])
+        assert torch.equal(level[i, :k], det.level[i, :k])
+
+
+def test_a2j_forward_equals_python_engine_and_golden(native, a2j_sd, golden_dir):
+    from hn_amd import synth
+    from hn_amd.a2j_engine import A2JEngine
+    eng = A2JEngine(a2j_sd, device="cuda")
+    x = synth.make_crops(3, 176, seed=3000).cuda()
+    assert torch.equal(native.a2j(x), eng.forward(x))
+    valid = torch.tensor([1, 0, 1], dtype=torch.int32, device="cuda")
+    kp = native.a2j(x, valid)
+    assert float(kp[1].abs().max()) == 0.0 and torch.equal(kp[0], eng.forward(x)[0])
+    g = np.load(golden_dir / "a2j_forward.npz")                  # the reference's own output on the same seeded crops
+    x2 = synth.make_crops(2, 176, seed=int(g["input_seed"])).cuda()
+    assert np.abs(native.a2j(x2).cpu().numpy() - g["keypoints"]).max() < 1e-3
+
+
+def test_model_abi_errors_are_loud(a2j_sd):
+    from hn_amd import _lib
+    from hn_amd.native_model import NativeModel
+    lib = _lib.load()
+    sd = {k: v for k, v in a2j_sd.items() if k != "Backbone.model.layer2.0.bn1.running_var"}
+    with pytest.raises(RuntimeError, match="layer2.0.bn1.running_var"):
+        NativeModel(None, sd)
+    m = NativeModel(None, a2j_sd)
+    try:
+        with pytest.raises(RuntimeError, match="HN_MODEL_FCOS"):
+            m.fcos(torch.zeros((1, 3, 480, 640), device="cuda"))
+        t = torch.zeros(4)
+        st = lib.hn_load_weight(m._h, b"x", t.data_ptr(), (C.c_int64 * 1)(4), 1)
+        assert st != 0 and b"after hn_finalize" in lib.hn_last_error()
+    finally:
+        m.close()
+    big = dict(a2j_sd)
+    big["regressionModel.conv2.weight"] = a2j_sd["regressionModel.conv2.weight"] * 1e6   # leaves the fp16 range once folded
+    with pytest.raises(RuntimeError, match="fp16 range"):
+        NativeModel(None, big)
