@@ -102,7 +102,13 @@ class A2JModelLightning(EngineOwner):
         model = cls(**{k: v for k, v in hp.items() if k in accepted})
         sd = ckpt["state_dict"]
         own = set(model.state_dict().keys())
-        model.load_state_dict({k: v for k, v in sd.items() if k in own or strict}, strict=strict)
+        # strict (Lightning's default) = every weight of THIS module must be in the file; entries this inference-only
+        # module does not carry (the anchor / threshold buffers of A2J_loss and post_process, a2j/anchor.py:48-49,88-90,
+        # optimizer-side state) are ignored
+        missing = sorted(k for k in own if k not in sd and not k.endswith("num_batches_tracked"))
+        if strict and missing:
+            raise KeyError(f"{checkpoint_path}: state_dict lacks {len(missing)} entries, e.g. {missing[:3]}")
+        model.load_state_dict({k: v for k, v in sd.items() if k in own}, strict=False)
         if map_location is not None and str(map_location) != "cpu":
             model = model.to(map_location)
         return model

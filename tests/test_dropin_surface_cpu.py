@@ -70,6 +70,18 @@ def test_lightning_checkpoint_round_trip(tmp_path, a2j_rgbd_sd):
     assert all(k.startswith("a2j.") for k in got)
     k = "a2j.Backbone.model.conv1.weight"
     assert got[k].shape[1] == 4 and torch.equal(got[k], a2j_rgbd_sd[k[4:]])
+    # a real Lightning file also carries the anchor / threshold buffers of A2J_loss and post_process: ignored;
+    # a file that lacks one of OUR weights fails under strict (Lightning's default)
+    extra = torch.load(path)
+    extra["state_dict"]["a2j.post_process.all_anchors"] = torch.zeros(1936, 2)
+    extra["state_dict"]["a2j.criterion.thres"] = torch.tensor([16.0, 32.0])
+    torch.save(extra, tmp_path / "extra.ckpt")
+    assert A2JModelLightning.load_from_checkpoint(str(tmp_path / "extra.ckpt")).rgbd
+    del extra["state_dict"]["a2j.regressionModel.output.weight"]
+    torch.save(extra, tmp_path / "short.ckpt")
+    with pytest.raises(KeyError, match="regressionModel.output.weight"):
+        A2JModelLightning.load_from_checkpoint(str(tmp_path / "short.ckpt"))
+    assert A2JModelLightning.load_from_checkpoint(str(tmp_path / "short.ckpt"), strict=False).rgbd
     with pytest.raises(NotImplementedError):
         m.training_step(None, 0)
     with pytest.raises(KeyError):      # a plain {"model": sd} file is not a Lightning checkpoint
