@@ -70,6 +70,9 @@ def parse():
                          "the Python engines; same launches, same results")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-clock-sample", action="store_true",
+                    help="skip the one-wave in-kernel clock sampler of the roofline leg (it runs beside the step on a side "
+                         "stream and would show up as a long kernel in rocprofv3 --stats)")
     ap.add_argument("--cpu-frames", type=int, default=32,
                     help="frames in the bounded CPU sample (also the frames of the HIP-vs-oracle parity figures)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
@@ -160,7 +163,7 @@ def build_workload(args, dev, rank):
     return step, info, (fcos_sd, a2j_sd)
 
 
-def roofline_leg(step, steps, ms_per_step):
+def roofline_leg(step, steps, ms_per_step, sample_clock=True):
     """Bracket every conv launch with HIP events (on the launch stream) for `steps` steps; a one-wave sampler on a
     side stream reads the shader clock the chip holds meanwhile."""
     from hn_amd import ops
@@ -170,7 +173,8 @@ def roofline_leg(step, steps, ms_per_step):
     ops.CONV_PROFILE = []
     try:
         step()                                    # chip under load before the sampling window opens
-        ops.clock_sample(max(1000, int(0.8 * 1e3 * ms_per_step * steps)), out=clock, stream=side)
+        if sample_clock:
+            ops.clock_sample(max(1000, int(0.8 * 1e3 * ms_per_step * steps)), out=clock, stream=side)
         for _ in range(steps):
             step()
         torch.cuda.synchronize()
@@ -208,7 +212,7 @@ def roofline_leg(step, steps, ms_per_step):
         "kernel": kernel,
         # shader clock sampled in-kernel while the instrumented steps ran, and the same fraction against the MFMA
         # peak AT that clock (the nominal peak assumes 2400 MHz; under this load the chip holds less)
-        "clock_mhz": round(clock_mhz, 1),
+        "clock_mhz": round(clock_mhz, 1) if clock_mhz > 0 else None,
         "frac_at_clock": round(achieved / (peak * clock_mhz / 2400.0), 4) if clock_mhz > 0 else None,
         "mfma_issued_frac_at_clock": round(issued / (peak * clock_mhz / 2400.0), 4) if clock_mhz > 0 else None,
         "mfma_issued_tflops": round(issued, 2),
@@ -382,7 +386,7 @@ def main():
             raise SystemExit(f"all-gather returned {gathered['rows'].numel()} rows for {world} ranks x {batch} frames")
     roof = None
     if not args.no_roofline and not args.graph and not args.native:
-        roof = roofline_leg(step, max(1, min(args.steps, 3)), 1e3 * elapsed / args.steps)
+        roof = roofline_leg(step, max(1, min(args.steps, 3)), 1e3 * elapsed / args.steps, not args.no_clock_sample)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, sds, info.get("engine"), dev)

@@ -224,6 +224,29 @@ def test_batched_nms_edge_fixtures(name):
         assert ref_keep[0] == 0 and n == 1 + 3   # one survivor of the 70 clones + one per distinct class
 
 
+def test_batched_nms_at_full_capacity():
+    """Maximum size: EVERY anchor point of a 480x640 frame is a candidate (K = capacity = 17850, the global-memory sort
+    path with a 32768-key bitonic network and the per-class torchvision path), two images in one launch with
+    different counts; survivor indices bit-exact vs oracle/nms_ref.c."""
+    from hn_amd import ops
+    from oracle import fcos_ref
+    cap = 17850
+    boxes, scores, labels = _random_boxes(cap, 77, spread=1000.0, size=90.0)
+    counts = [cap, cap - 4097]
+    cand = ops.alloc_candidates(2, cap, "cuda")
+    for i, k in enumerate(counts):
+        cand.boxes[i, :k] = boxes[:k].cuda()
+        cand.scores[i, :k] = scores[:k].cuda()
+        cand.labels[i, :k] = labels[:k].int().cuda()
+        cand.count[i] = k
+    det = ops.fcos_nms(cand, 0.3, 1.0, 1.0)
+    for i, k in enumerate(counts):
+        ref_keep = fcos_ref.batched_nms(boxes[:k], scores[:k], labels[:k], 0.3)
+        n = int(det.count[i])
+        assert n == len(ref_keep) and n > 500
+        assert torch.equal(det.keep[i, :n].cpu().long(), ref_keep)
+
+
 def test_plain_nms_zero_area_and_ties():
     from hn_amd import ops
     from oracle import fcos_ref

@@ -31,6 +31,28 @@ def test_handnet_forward_equals_python_engine(native, fcos_sd, a2j_sd):
         assert torch.equal(kp, ref.keypoints)                    # bit-identical: the same kernels in the same order
 
 
+def test_rgbd_handnet_forward_equals_python_engine(fcos_sd, a2j_rgbd_sd):
+    """RGB-D variant through the C++ graph: 4-channel A2J stem, 4-channel crops with the [2,1,0,3] permutation
+    (handnet_pipeline.py:102), depth_images = cat([rgb, depth]) as ros_demo.py:268-270 passes them."""
+    from hn_amd import synth
+    from hn_amd.a2j_engine import A2JEngine
+    from hn_amd.fcos_engine import FCOSEngine
+    from hn_amd.native_model import NativeModel
+    from hn_amd.pipeline import HandNetEngine
+    eng = HandNetEngine(FCOSEngine(fcos_sd, 3, device="cuda"), A2JEngine(a2j_rgbd_sd, rgbd=True, device="cuda"), 3)
+    m = NativeModel(fcos_sd, a2j_rgbd_sd, num_classes=3, rgbd=True)
+    try:
+        rgb, depth = synth.make_rgb(3, seed=1000).cuda(), synth.make_depth(3, seed=2000).cuda()
+        rgbd = torch.cat([rgb, depth], 1).contiguous()
+        ref = eng.forward_device(rgb, rgbd)
+        kp, box, has = m.handnet(rgb, rgbd)
+        assert torch.equal(box, ref.crop_box) and torch.equal(has, ref.has_hand) and torch.equal(kp, ref.keypoints)
+        with pytest.raises(RuntimeError, match="hn_handnet_forward"):
+            m.a2j(depth[:, :, :176, :176].contiguous())      # the A2J-only entry takes 1-channel crops
+    finally:
+        m.close()
+
+
 def test_fcos_forward_equals_python_engine(native, fcos_sd):
     from hn_amd import synth
     from hn_amd.fcos_engine import FCOSEngine

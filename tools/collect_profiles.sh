@@ -11,7 +11,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline"
 python3 $R/bench.py > $O/bench_default.log 2>&1; tail -1 $O/bench_default.log > $O/bench_pipeline_b32.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B > $O/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B --no-clock-sample > $O/bench_under_rocprof.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $B --no-roofline > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- $B --no-roofline > /dev/null 2>&1
 python3 $R/tools/layer_table.py f16x3 32 2>&1 | grep -v amdgpu.ids > $O/layer_table_b32.txt
