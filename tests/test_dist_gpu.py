@@ -68,3 +68,34 @@ def test_bench_refuses_world_size_mismatch():
     r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stdout + r.stderr)
+
+
+def test_bench_line_contract():
+    """The one JSON line of the driver contract: metric / value / unit / n_gpus / steps / warmup / ms_per_step /
+    higher_is_better / scaling / vs_baseline / dtype / data / config.workload, plus the roofline and cpu_baseline
+    objects with their required keys; clock sampled in-kernel; parity figures over the CPU sample."""
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "2",
+                        "--cpu-frames", "2"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["vs_baseline"] is None
+    assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 2 * 2 / (d["ms_per_step"] * 2e-3)) < 0.02 * d["value"]
+    roof = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel", "clock_mhz"):
+        assert k in roof, k
+    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == 2500.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    assert 400.0 < roof["clock_mhz"] < 2600.0                       # s_memtime / s_memrealtime under load
+    assert roof["traffic"] is None and "launches/step" in roof["traffic_source"]   # batch 2 != the profiled batch 32
+    cpu = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample", "parity"):
+        assert k in cpu, k
+    assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["parity"]["frames"] == 2
+    assert cpu["parity"]["keypoints_within_tolerance"] is True
