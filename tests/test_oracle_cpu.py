@@ -1,6 +1,7 @@
 """CPU tests: the oracle reproduces the golden vectors that the imported reference produced
 (tests/golden/make_golden*.py), plus hand-checkable facts from SURVEY.md appendix A."""
 import numpy as np
+import pytest
 import torch
 
 from hn_amd import synth
@@ -174,3 +175,19 @@ def test_pose2mesh_oracle_reproduces_reference_golden(golden_dir):
     assert mesh.shape == (3, graphs[0].shape[0], 3) and pose3d.shape == (3, 21, 3)
     assert np.abs(pose3d.numpy() - g["pose3d"]).max() <= 1e-3          # values ~1e2 (millimetres)
     assert np.abs(mesh.numpy() - g["mesh"]).max() <= 1e-4
+
+
+def test_frozen_bn_matches_published_copy_of_torchvision_class(fcos_sd):
+    """torchvision itself is absent from the image, but HF transformers ships a verbatim copy of its
+    FrozenBatchNorm2d ("Copy-paste from torchvision.misc.ops", transformers/models/detr/modeling_detr.py) with the
+    eps of torchvision >= 0.5: the oracle's _frozen_bn (ResNet-34 body of the FCOS detector, fcos.py:476,737) must
+    reproduce it bit for bit on the synthetic checkpoint's statistics."""
+    detr = pytest.importorskip("transformers.models.detr.modeling_detr")
+    name = "backbone.body.layer2.0.bn1"
+    c = fcos_sd[name + ".weight"].numel()
+    m = detr.DetrFrozenBatchNorm2d(c)
+    with torch.no_grad():
+        for k in ("weight", "bias", "running_mean", "running_var"):
+            getattr(m, k).copy_(fcos_sd[f"{name}.{k}"])
+    x = torch.randn((2, c, 9, 7), generator=torch.Generator().manual_seed(4))
+    assert torch.equal(fcos_ref._frozen_bn(x, fcos_sd, name), m(x))
