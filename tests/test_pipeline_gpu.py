@@ -340,3 +340,32 @@ def test_engine_range_check_raises_on_overflowing_activations(fcos_sd, a2j_sd):
         assert not torch.isfinite(bad.keypoints).all() or rel > 1e-2, rel
     finally:
         ops.range_check_enable(False)
+
+
+def test_handnet_default_two_class_detector_matches_oracle(a2j_sd):
+    """The constructor default is num_classes=2 (handnet_pipeline.py:47; hand class = 1): Cout = 4 head outputs,
+    two-way argmax in the candidate kernel.  Crop boxes identical to the oracle, keypoints < 1e-3; also through the
+    C++ layer graph (bit-identical to the Python engine)."""
+    from handnet_pipeline.handnet_pipeline import HandNet
+    from hn_amd import synth
+    from hn_amd.native_model import NativeModel
+    from oracle import handnet_ref
+    fsd = synth.make_fcos_state_dict(0, 2)
+    net = HandNet(types.SimpleNamespace(pretrained_fcos="-", pretrained_a2j="-"))          # num_classes=2 default
+    assert net.num_classes == 2
+    net.detector.load_state_dict(fsd, strict=False)
+    net.a2j.load_state_dict(a2j_sd, strict=False)
+    net = net.cuda().eval()
+    rgb, depth = synth.make_rgb(3, seed=1000), synth.make_depth(3, seed=2000)
+    with torch.inference_mode():
+        kp, db, crops = net([r.cuda() for r in rgb], depth_images=depth.cuda())
+    rkp, rdb, rcrops = handnet_ref.handnet_forward([r for r in rgb], depth, fsd, a2j_sd, 2)
+    assert torch.equal(crops.cpu(), rcrops) and torch.equal(db.cpu(), rdb)
+    assert (kp - rkp).abs().max().item() < 1e-3
+    m = NativeModel(fsd, a2j_sd, num_classes=2)
+    try:
+        nkp, nbox, nhas = m.handnet(rgb.cuda(), depth.cuda())
+        out = net.forward_device(rgb.cuda(), depth.cuda())
+        assert torch.equal(nkp, out.keypoints) and torch.equal(nbox, out.crop_box) and torch.equal(nhas, out.has_hand)
+    finally:
+        m.close()
