@@ -10,7 +10,7 @@
 //                    repacking, hi/lo fp16 splitting, upload (the only place weights are allocated)
 //   hn_fcos_forward  fcos_utils/fcos.py:675-767 (eval)      hn_a2j_forward   a2j/a2j.py:243-250
 //   hn_handnet_forward  handnet_pipeline/handnet_pipeline.py:58-116
-// Default precision (f16x3) only; the ext=True heads and the f32 mode stay op-level / Python.
+// Default precision (f16x3) only; the exact-f32 mode and mixed-size image lists stay op-level / Python.
 // Memory: activations live in one arena per model that is sized by a dry pass over the graph and (re)allocated only
 // when a forward needs more than any earlier one -- steady-state calls neither allocate nor synchronise.
 #include "hn_common.h"
@@ -77,7 +77,7 @@ struct hn_model {
   ConvW f_stem16;  // w16 = [64][7][2][32] stem rows, bias
   struct Basic { ConvW c1, c2, ds; bool has_ds = false; int layer = 0; bool last = false; };
   std::vector<Basic> f_blocks;
-  ConvW f_inner[3], f_layer[3], f_tower0, f_cls_t[3], f_reg_t[3], f_cls_out, f_reg_out;
+  ConvW f_inner[3], f_layer[3], f_tower0, f_cls_t[3], f_reg_t[3], f_cls_out, f_reg_out, f_ext_out;  // f_ext_out: cfg.ext only
   float* f_gn0_gamma = nullptr; float* f_gn0_beta = nullptr;  // [512]
   float* f_gn_gamma[3] = {nullptr, nullptr, nullptr}; float* f_gn_beta[3] = {nullptr, nullptr, nullptr};  // [512] cls | reg
   // ---- run-time state ----
@@ -437,6 +437,8 @@ Geometry geometry(const hn_model_config& c, int h, int w) {
 struct FcosOut {
   float* boxes; float* scores; int32_t *labels, *sides, *level, *count;
   int cap;
+  int32_t* contacts = nullptr;  // ext=True outputs (fcos.py:637-647), optional
+  float* dxdymags = nullptr;
 };
 
 int fcos_graph(Ctx& cx, const float* rgb, int n, int h, int w, const FcosOut& out) {
@@ -544,7 +546,7 @@ int fcos_graph(Ctx& cx, const float* rgb, int n, int h, int w, const FcosOut& ou
   hn_fcos_levels lv;
   memset(&lv, 0, sizeof(lv));
   lv.num_levels = L;
-  T cls_lr[3], reg_ctr[3];
+  T cls_lr[3], reg_ctr[3], ext_lv[3];
   {
     GroupSpec gc, gr;
     gc.count = gr.count = L;
@@ -558,6 +560,15 @@ int fcos_graph(Ctx& cx, const float* rgb, int n, int h, int w, const FcosOut& ou
       lv.cls_lr[l] = (const float*)cls_lr[l].p; lv.reg_ctr[l] = (const float*)reg_ctr[l].p;
     }
     HN_TRY(conv_grouped(cx, gc, 0, false, ccls, 0));
+    if (out.contacts) {  // ext heads: relu(hand_dydx_layer)[3] | hand_contact_state_layer[5] from the cls tower (fcos.py:255-264)
+      GroupSpec ge;
+      ge.count = L;
+      for (int l = 0; l < L; ++l) {
+        ext_lv[l] = alloc(cx, n, a[l].h, a[l].w, 8, false);
+        ge.x[l] = slice_blocks(a[l], 0, 8); ge.w[l] = &m->f_ext_out; ge.y[l] = ext_lv[l].p; ge.gn[l] = nullptr;
+      }
+      HN_TRY(conv_grouped(cx, ge, 3, false, 8, 0));
+    }
     HN_TRY(conv_grouped(cx, gr, 4, false, 5, 0));
   }
   const int cap = hw[0] + hw[1] + hw[2];
@@ -569,13 +580,19 @@ int fcos_graph(Ctx& cx, const float* rgb, int n, int h, int w, const FcosOut& ou
   int32_t* cv = (int32_t*)alloc_bytes(cx, (size_t)n * cap * 4);
   int32_t* cc = (int32_t*)alloc_bytes(cx, (size_t)n * 4);
   int32_t* keep = (int32_t*)alloc_bytes(cx, (size_t)n * cap * 4);
+  int32_t* point = out.contacts ? (int32_t*)alloc_bytes(cx, (size_t)n * cap * 4) : nullptr;
   char* scratch = alloc_bytes(cx, (size_t)hn_fcos_nms_scratch_bytes(n, cap));
   if (cx.dry) return HN_OK;
-  HN_TRY(hn_fcos_candidates(&lv, n, m->cfg.num_classes, 0.7f /* fcos.py:600 */, cb, cs, cl, cd, cv, nullptr, cc, cap, cx.stream));
+  HN_TRY(hn_fcos_candidates(&lv, n, m->cfg.num_classes, 0.7f /* fcos.py:600 */, cb, cs, cl, cd, cv, point, cc, cap, cx.stream));
   // resize_boxes (fcos.py:770-783): fp32 / fp32
   const float ratio_h = (float)h / (float)g.oh, ratio_w = (float)w / (float)g.ow;
-  return hn_fcos_nms(cb, cs, cl, cd, cv, cc, n, cap, 0.3 /* fcos.py:635 */, ratio_h, ratio_w, scratch, out.boxes, out.scores,
-                     out.labels, out.sides, out.level, keep, out.count, cx.stream);
+  HN_TRY(hn_fcos_nms(cb, cs, cl, cd, cv, cc, n, cap, 0.3 /* fcos.py:635 */, ratio_h, ratio_w, scratch, out.boxes, out.scores,
+                     out.labels, out.sides, out.level, keep, out.count, cx.stream));
+  if (out.contacts) {
+    const float* ext_ptrs[HN_FCOS_MAX_LEVELS] = {(const float*)ext_lv[0].p, (const float*)ext_lv[1].p, (const float*)ext_lv[2].p, nullptr, nullptr};
+    HN_TRY(hn_fcos_ext_gather(&lv, ext_ptrs, keep, point, out.count, n, cap, out.contacts, out.dxdymags, cx.stream));
+  }
+  return HN_OK;
 }
 
 // dry pass (sizes the arena) + real pass
@@ -743,6 +760,14 @@ extern "C" int hn_finalize(hn_model* m) {
     HN_TRY(concat_cout(cl, lr, m->f_cls_out, "FCOS cls_logits+hand_lr"));
     HN_TRY(concat_cout(br, bc, m->f_reg_out, "FCOS bbox_reg+ctrness"));
     HN_CHECK_ARG(m->f_cls_out.cout == m->cfg.num_classes + 2, "checkpoint does not match num_classes");
+    if (m->cfg.ext) {
+      ConvW dx, ct;
+      HN_TRY(pack_conv(m, c + ".hand_dydx_layer.weight", c + ".hand_dydx_layer.bias", "", 1, 1, 1, false, dx));
+      HN_TRY(pack_conv(m, c + ".hand_contact_state_layer.weight", c + ".hand_contact_state_layer.bias", "", 1, 1, 1, false, ct));
+      HN_TRY(concat_cout(dx, ct, m->f_ext_out, "FCOS ext heads"));
+      HN_CHECK_ARG(m->f_ext_out.cout == 8, "ext heads must have 3 + 5 output channels");
+      HN_TRY(upload(m, m->f_ext_out));
+    }
     HN_TRY(upload(m, m->f_stem16));
     for (auto& k : m->f_blocks) {
       HN_TRY(upload(m, k.c1)); HN_TRY(upload(m, k.c2));
@@ -787,7 +812,21 @@ extern "C" int hn_fcos_forward(hn_model* m, const float* rgb, int n, int h, int 
   HN_CHECK_ARG(m->cfg.parts & HN_MODEL_FCOS, "model was created without HN_MODEL_FCOS");
   HN_CHECK_ARG(n > 0 && h > 0 && w > 0, "bad image batch");
   const std::string key = "fcos:" + std::to_string(n) + "x" + std::to_string(h) + "x" + std::to_string(w);
-  const FcosOut out{det_boxes, det_scores, det_labels, det_sides, det_level, det_count, cap};
+  FcosOut out{det_boxes, det_scores, det_labels, det_sides, det_level, det_count, cap};
+  return run_planned(m, key, stream, [&](Ctx& cx) -> int { return fcos_graph(cx, rgb, n, h, w, out); });
+}
+
+extern "C" int hn_fcos_forward_ext(hn_model* m, const float* rgb, int n, int h, int w, float* det_boxes, float* det_scores,
+                                   int32_t* det_labels, int32_t* det_sides, int32_t* det_level, int32_t* det_count,
+                                   int32_t* det_contacts, float* det_dxdymags, int cap, void* stream) {
+  HN_CHECK_ARG(m && rgb && det_boxes && det_scores && det_labels && det_sides && det_level && det_count && det_contacts && det_dxdymags,
+               "hn_fcos_forward_ext: null pointer");
+  HN_CHECK_ARG((m->cfg.parts & HN_MODEL_FCOS) && m->cfg.ext, "model was created without HN_MODEL_FCOS / ext = 1");
+  HN_CHECK_ARG(n > 0 && h > 0 && w > 0, "bad image batch");
+  const std::string key = "fcos_ext:" + std::to_string(n) + "x" + std::to_string(h) + "x" + std::to_string(w);
+  FcosOut out{det_boxes, det_scores, det_labels, det_sides, det_level, det_count, cap};
+  out.contacts = det_contacts;
+  out.dxdymags = det_dxdymags;
   return run_planned(m, key, stream, [&](Ctx& cx) -> int { return fcos_graph(cx, rgb, n, h, w, out); });
 }
 

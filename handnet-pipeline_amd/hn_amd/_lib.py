@@ -12,7 +12,7 @@ from pathlib import Path
 
 from . import build as _build
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, TILE_256x128, TILE_64x128 = range(7)
 HN_FCOS_MAX_LEVELS = 5
@@ -40,7 +40,7 @@ class ConvGroup(C.Structure):  # == struct hn_conv_group
 
 
 class ModelConfig(C.Structure):  # == struct hn_model_config
-    _fields_ = [(k, C.c_int32) for k in ("parts", "num_classes", "num_joints", "rgbd", "min_size", "max_size")]
+    _fields_ = [(k, C.c_int32) for k in ("parts", "num_classes", "num_joints", "rgbd", "min_size", "max_size", "ext")]
 
 
 MODEL_FCOS, MODEL_A2J = 1, 2
@@ -106,6 +106,7 @@ SIGNATURES = {
     "hn_finalize": (C.c_int, [VP]),
     "hn_fcos_capacity": (C.c_int64, [VP, C.c_int, C.c_int]),
     "hn_fcos_forward": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int] + [VP] * 6 + [C.c_int, VP]),
+    "hn_fcos_forward_ext": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int] + [VP] * 8 + [C.c_int, VP]),
     "hn_a2j_forward": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, VP, VP, VP]),
     "hn_handnet_forward": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP]),
     "hn_destroy": (C.c_int, [VP]),

@@ -18,7 +18,7 @@ from .ops import _stream, on_device
 
 class NativeModel:
     def __init__(self, fcos_sd=None, a2j_sd=None, num_classes=3, num_joints=21, rgbd=False, device="cuda",
-                 min_size=0, max_size=0):
+                 min_size=0, max_size=0, ext=False):
         if fcos_sd is None and a2j_sd is None:
             raise ValueError("give a FCOS and / or an A2J state_dict (reference layouts, SURVEY A.6)")
         self.device = torch.device(device)
@@ -28,7 +28,7 @@ class NativeModel:
         self.num_classes, self.num_joints, self.rgbd = num_classes, num_joints, rgbd
         parts = (_lib.MODEL_FCOS if fcos_sd is not None else 0) | (_lib.MODEL_A2J if a2j_sd is not None else 0)
         cfg = _lib.ModelConfig(parts=parts, num_classes=num_classes, num_joints=num_joints, rgbd=1 if rgbd else 0,
-                               min_size=min_size, max_size=max_size)
+                               min_size=min_size, max_size=max_size, ext=1 if ext else 0)
         h = C.c_void_p()
         check(self.lib.hn_create(C.byref(cfg), C.byref(h)), "hn_create")
         self._h = h
@@ -73,6 +73,20 @@ class NativeModel:
                    torch.zeros((n,), **i32))
             check(self.lib.hn_fcos_forward(self._h, ptr(rgb), n, h, w, *[ptr(t) for t in out], cap, _stream()),
                   "hn_fcos_forward")
+        return out
+
+    def fcos_ext(self, rgb):
+        """ext=True detector: fcos() outputs + (contacts [N,cap] int32, dxdymags [N,cap,3])"""
+        rgb = rgb.float().contiguous()
+        n, _, h, w = rgb.shape
+        cap = self.fcos_capacity(h, w)
+        with on_device(self.device):
+            i32 = dict(device=self.device, dtype=torch.int32)
+            out = (torch.zeros((n, cap, 4), device=self.device), torch.zeros((n, cap), device=self.device),
+                   torch.zeros((n, cap), **i32), torch.zeros((n, cap), **i32), torch.zeros((n, cap), **i32),
+                   torch.zeros((n,), **i32), torch.zeros((n, cap), **i32), torch.zeros((n, cap, 3), device=self.device))
+            check(self.lib.hn_fcos_forward_ext(self._h, ptr(rgb), n, h, w, *[ptr(t) for t in out], cap, _stream()),
+                  "hn_fcos_forward_ext")
         return out
 
     def a2j(self, crops, valid=None):

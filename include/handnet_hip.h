@@ -33,7 +33,7 @@ extern "C" {
 #define HN_ERR_HIP 2
 
 /* ABI version; bumped whenever a struct below changes. */
-#define HN_ABI_VERSION 21
+#define HN_ABI_VERSION 22
 int hn_abi_version(void);
 const char* hn_last_error(void);
 
@@ -363,7 +363,7 @@ int hn_feat_interp_add_f32(const float* xin, const float* y, float* out, int64_t
  *                      are kept and ignored (strict=False, handnet_pipeline.py:20,33)
  *   hn_finalize        folds (Frozen)BatchNorm in fp64, repacks to [Cout][R][S][Cin], splits into fp16 hi/lo banks
  *                      (fails if a folded weight leaves the fp16 range), uploads.  Allocates and synchronises.
- *   hn_fcos_forward    fcos_utils/fcos.py:675-767 (eval, ext=False): rgb [n][3][h][w] fp32 0..1 on the device ->
+ *   hn_fcos_forward    fcos_utils/fcos.py:675-767 (eval; hn_fcos_forward_ext adds the ext=True outputs): rgb [n][3][h][w] fp32 0..1 on the device ->
  *                      score-ordered detections, fixed capacity cap = hn_fcos_capacity(m, h, w) rows per image:
  *                      det_boxes [n][cap][4] (original-image pixels), det_scores / det_labels / det_sides /
  *                      det_level [n][cap], det_count [n]
@@ -385,6 +385,8 @@ typedef struct hn_model_config {
   int32_t num_joints;   /* 21 */
   int32_t rgbd;         /* 1: 4-channel A2J stem + RGB-D crops with the [2,1,0,3] permutation */
   int32_t min_size, max_size; /* GeneralizedRCNNTransform sizes; 0 = 800 / 1333 (fcos.py:460-461) */
+  int32_t ext;          /* 1: also load the ext=True heads (hand_dydx_layer, hand_contact_state_layer; the FCOS class
+                           default, fcos.py:255-264) for hn_fcos_forward_ext */
 } hn_model_config;
 typedef struct hn_model hn_model;
 
@@ -395,6 +397,11 @@ int64_t hn_fcos_capacity(const hn_model* m, int h, int w);
 int hn_fcos_forward(hn_model* m, const float* rgb, int n, int h, int w, float* det_boxes, float* det_scores,
                     int32_t* det_labels, int32_t* det_sides, int32_t* det_level, int32_t* det_count, int cap,
                     void* stream);
+/* ext=True detections (fcos.py:637-647): additionally det_contacts [n][cap] (argmax of the contact state) and
+ * det_dxdymags [n][cap][3] (magnitude, 0.1 * unit dx, 0.1 * unit dy) per kept detection. */
+int hn_fcos_forward_ext(hn_model* m, const float* rgb, int n, int h, int w, float* det_boxes, float* det_scores,
+                        int32_t* det_labels, int32_t* det_sides, int32_t* det_level, int32_t* det_count,
+                        int32_t* det_contacts, float* det_dxdymags, int cap, void* stream);
 int hn_a2j_forward(hn_model* m, const float* crops, int k, int h, int w, const int32_t* valid /* or NULL */,
                    float* keypoints, void* stream);
 int hn_handnet_forward(hn_model* m, const float* rgb, const float* depth, int n, int h, int w, float* keypoints,

@@ -69,6 +69,33 @@ def test_fcos_forward_equals_python_engine(native, fcos_sd):
         assert torch.equal(level[i, :k], det.level[i, :k])
 
 
+def test_fcos_ext_forward_equals_python_engine():
+    """ext=True (the FCOS class default, trainval_net_fcos.py --test-only): contact state and dxdy magnitudes of the
+    kept detections through the C++ graph == the Python engine."""
+    from hn_amd import synth
+    from hn_amd.fcos_engine import FCOSEngine
+    from hn_amd.native_model import NativeModel
+    sd = synth.make_fcos_state_dict(0, 3, ext=True)
+    eng = FCOSEngine(sd, 3, device="cuda", ext=True)
+    rgb = synth.make_rgb(2, seed=1000).cuda()
+    det, _, contacts, dxdymags = eng.detect_ext(rgb)
+    m = NativeModel(sd, None, num_classes=3, ext=True)
+    try:
+        boxes, scores, labels, sides, level, count, ncon, ndx = m.fcos_ext(rgb)
+        assert torch.equal(count, det.count)
+        for i, k in enumerate(count.tolist()):
+            assert k > 0 and torch.equal(boxes[i, :k], det.boxes[i, :k]) and torch.equal(labels[i, :k], det.labels[i, :k])
+            assert torch.equal(ncon[i, :k], contacts[i, :k]) and torch.equal(ndx[i, :k], dxdymags[i, :k])
+        plain = NativeModel(synth.make_fcos_state_dict(0, 3), None, num_classes=3)
+        try:
+            with pytest.raises(RuntimeError, match="ext = 1"):
+                plain.fcos_ext(rgb)
+        finally:
+            plain.close()
+    finally:
+        m.close()
+
+
 def test_a2j_forward_equals_python_engine_and_golden(native, a2j_sd, golden_dir):
     from hn_amd import synth
     from hn_amd.a2j_engine import A2JEngine
