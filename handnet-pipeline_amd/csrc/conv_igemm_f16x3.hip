@@ -92,6 +92,10 @@ struct ConvParams16 {
   // v6 operand addressing (BUF kernels): both operands are fetched through buffer descriptors, so a DMA's address is
   // <descriptor base> + <per-lane 32-bit offset, loop-invariant> + <wave-uniform SGPR offset of the k tile>, and a
   // padding tap is a lane whose offset has bit 31 set: the hardware range check returns zeros for it.
+  // exact division of a row index m < 2^31 by OH*OW and by OW with one v_mul_hi (host-computed magic numbers): the
+  // per-lane pixel decomposition in the prologue cost ~25 VALU per division, 2 divisions per DMA piece
+  unsigned mg_ohow, sh_ohow, mg_ow, sh_ow;
+  unsigned gmg_ohow[HN_CONV_MAX_GROUP], gsh_ohow[HN_CONV_MAX_GROUP], gmg_ow[HN_CONV_MAX_GROUP], gsh_ow[HN_CONV_MAX_GROUP];
   unsigned a_records; // bytes covered by the A descriptor (< 2^31 so that bit 31 is out of range)
   unsigned b_records;
   unsigned ga_records[HN_CONV_MAX_GROUP];
@@ -101,6 +105,11 @@ constexpr int BK = 32;    // k values per tile
 constexpr int ROWH = 64;  // halfs per LDS row (hi 32 | lo 32) = 128 bytes
 
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+
+// floor(n / d) for 0 <= n < 2^31 with the host's magic pair (see magic_u31): d == 1 is encoded as mg == 0
+__device__ __forceinline__ int fastdiv(int n, unsigned mg, unsigned sh) {
+  return mg ? (int)(__umulhi((unsigned)n, mg) >> sh) : n;
+}
 
 // Issue plan of the second half of a k step.  MFMA k (term-major: term = k / (TM*TH), row tile i, column
 // tile jj) is preceded by the memory instructions whose slot is k.  Instruction list q: the DPT LDS-DMA pieces of
@@ -253,28 +262,37 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
     void* y;
     float* gn_partial;
     int H, W, pitch, OH, OW, M, nblocks;
-    unsigned a_records;
-  } o = {p.x, p.w, p.bias, p.y, p.gn_partial, p.H, p.W, p.pitch, p.OH, p.OW, p.M, p.nblocks, p.a_records};
+    unsigned a_records, mg_ohow, sh_ohow, mg_ow, sh_ow;
+  } o = {p.x, p.w, p.bias, p.y, p.gn_partial, p.H, p.W, p.pitch, p.OH, p.OW, p.M, p.nblocks, p.a_records,
+         p.mg_ohow, p.sh_ohow, p.mg_ow, p.sh_ow};
   if (p.groups > 1) {
+    // The member's fields are read straight from the kernel-argument SEGMENT (constant address space) with the uniform
+    // index blockIdx.z: scalar loads with an SGPR offset.  (Indexing the by-value parameter `p` dynamically would copy
+    // the whole block to scratch; constant-index select chains over all six members -- the round-1 form -- kept ~500
+    // bytes of member tables live in SGPRs: 376-528 spilled SGPRs, i.e. ~630 v_writelane / v_readlane per workgroup
+    // in the prologue of EVERY convolution, grouped or not.)
+    typedef __attribute__((address_space(4))) const ConvParams16 KArgs;
+    KArgs* kp = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     const int gz = (int)blockIdx.z;
-#define HN_GROUP_SEL(arr) \
-  (gz == 0 ? p.arr[0] : gz == 1 ? p.arr[1] : gz == 2 ? p.arr[2] : gz == 3 ? p.arr[3] : gz == 4 ? p.arr[4] : p.arr[5])
-    static_assert(HN_CONV_MAX_GROUP == 6, "select chain covers six members");
-    o.nblocks = HN_GROUP_SEL(gnblocks);
+    static_assert(HN_CONV_MAX_GROUP == 6, "member tables hold six entries");
+    o.nblocks = kp->gnblocks[gz];
     if ((int)blockIdx.x >= o.nblocks) return;
-    o.x = HN_GROUP_SEL(gx);
-    o.w = HN_GROUP_SEL(gw);
-    o.bias = HN_GROUP_SEL(gbias);
-    o.y = HN_GROUP_SEL(gy);
-    o.gn_partial = HN_GROUP_SEL(ggn);
-    o.H = HN_GROUP_SEL(gH);
-    o.W = HN_GROUP_SEL(gW);
+    o.x = kp->gx[gz];
+    o.w = kp->gw[gz];
+    o.bias = kp->gbias[gz];
+    o.y = kp->gy[gz];
+    o.gn_partial = kp->ggn[gz];
+    o.H = kp->gH[gz];
+    o.W = kp->gW[gz];
     o.pitch = o.W;
-    o.OH = HN_GROUP_SEL(gOH);
-    o.OW = HN_GROUP_SEL(gOW);
-    o.M = HN_GROUP_SEL(gM);
-    o.a_records = HN_GROUP_SEL(ga_records);
-#undef HN_GROUP_SEL
+    o.OH = kp->gOH[gz];
+    o.OW = kp->gOW[gz];
+    o.M = kp->gM[gz];
+    o.a_records = kp->ga_records[gz];
+    o.mg_ohow = kp->gmg_ohow[gz];
+    o.sh_ohow = kp->gsh_ohow[gz];
+    o.mg_ow = kp->gmg_ow[gz];
+    o.sh_ow = kp->gsh_ow[gz];
   }
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;  // 16x16 MFMA tiles per wave
@@ -315,20 +333,24 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
     const int row = drow + it * ROWS_PASS;
     int m = m0 + row;
     m = m < o.M ? m : o.M - 1;  // rows >= M are never stored
-    const int img = m / ohow;
+    const int img = fastdiv(m, o.mg_ohow, o.sh_ohow);
     const int rem = m - img * ohow;
-    const int oh = rem / o.OW, ow = rem - oh * o.OW;
+    const int oh = fastdiv(rem, o.mg_ow, o.sh_ow), ow = rem - oh * o.OW;
     const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
     const int chunk = dpos ^ swz(row);  // source chunk that belongs at this LDS position: 0-3 hi run, 4-7 lo run
     if constexpr (BUF) {
       a_off[it] = (unsigned)(((((long)img * o.H + oh * p.stride) * o.pitch + ow * p.stride) * p.xs + (chunk & 3) * 8 +
                               (chunk >> 2) * p.lo_off) * 2);
+      // tap (r, s) is invalid iff its row or its column is: R + S tests instead of R * S.  col_bits has bit s set for
+      // a bad column; a bad row sets the whole S-bit field of that row.  (No padding => nothing to test.)
       unsigned inv = 0;
-      for (int r = 0; r < p.R; ++r) {
-        const unsigned rbad = (unsigned)(ih0 + r * p.dil) >= (unsigned)o.H ? 1u : 0u;
-        for (int sx = 0; sx < p.S; ++sx) {
-          const unsigned bad = rbad | ((unsigned)(iw0 + sx * p.dil) >= (unsigned)o.W ? 1u : 0u);
-          inv |= bad << (r * p.S + sx);
+      if (p.pad > 0) {
+        unsigned col_bits = 0;
+        for (int sx = 0; sx < p.S; ++sx) col_bits |= ((unsigned)(iw0 + sx * p.dil) >= (unsigned)o.W ? 1u : 0u) << sx;
+        const unsigned row_full = (1u << p.S) - 1u;
+        for (int r = 0; r < p.R; ++r) {
+          const unsigned bits = (unsigned)(ih0 + r * p.dil) >= (unsigned)o.H ? row_full : col_bits;
+          inv |= bits << (r * p.S);
         }
       }
       a_inv[it] = inv;
@@ -771,12 +793,31 @@ int launch16_impl(const ConvParams16& p0, hipStream_t st) {
   return HN_OK;
 }
 
+// mg / sh such that floor(n / d) == umulhi(n, mg) >> sh for every 0 <= n < 2^31 (d >= 2); d == 1 -> mg = 0 (identity).
+// With k = ceil(log2 d) and mg = ceil(2^(31+k) / d): mg * d - 2^(31+k) < d <= 2^k, and n * that < 2^(31+k), so the
+// quotient is exact.
+static void magic_u31(unsigned d, unsigned& mg, unsigned& sh) {
+  if (d <= 1) { mg = 0; sh = 0; return; }
+  unsigned k = 0;
+  while ((1ull << k) < d) ++k;
+  const unsigned long long pw = 1ull << (31 + k);
+  mg = (unsigned)((pw + d - 1) / d);
+  sh = k - 1;   // umulhi drops 32 bits: total shift 31 + k
+}
+
 // Operand extents for the buffer descriptors of the v6 addressing.  Falls back to the pointer-form kernel (one
 // instantiation, 128x128) when an operand spans 2 GB or more (bit 31 of an offset must stay out of range) or the
 // filter has more than 32 taps.
 template <int BM, int BN, int WM, int WN, int NBUF>
 int launch16(const ConvParams16& p0, hipStream_t st) {
   ConvParams16 p = p0;
+  magic_u31((unsigned)(p.OH * p.OW), p.mg_ohow, p.sh_ohow);
+  magic_u31((unsigned)p.OW, p.mg_ow, p.sh_ow);
+  for (int g = 0; g < HN_CONV_MAX_GROUP; ++g) {
+    const bool on = p.groups > 1 && g < p.groups;
+    magic_u31(on ? (unsigned)(p.gOH[g] * p.gOW[g]) : 1u, p.gmg_ohow[g], p.gsh_ohow[g]);
+    magic_u31(on ? (unsigned)p.gOW[g] : 1u, p.gmg_ow[g], p.gsh_ow[g]);
+  }
   const int64_t lim = (int64_t)1 << 31;
   auto extent = [&](int h, int pitch) {
     // bytes the A descriptor covers: it starts pad rows + pad columns before x (kernel: a_shift) and ends at the last
