@@ -172,9 +172,14 @@ __device__ __forceinline__ void epi_finish8(const ConvParams16& p, int m, int n,
       }
     }
   }
+  if (p.relu_cols >= p.Cout) {  // the usual case (all columns): wave-uniform, 8 v_max
 #pragma unroll
-  for (int e = 0; e < 8; ++e)
-    if (n + e < p.relu_cols) v[e] = fmaxf(v[e], 0.f);
+    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+  } else if (p.relu_cols > 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (n + e < p.relu_cols) v[e] = fmaxf(v[e], 0.f);
+  }
   if (p.out_split) {
     if (p.range_flag) {
 #pragma unroll
@@ -339,8 +344,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
     const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
     const int chunk = dpos ^ swz(row);  // source chunk that belongs at this LDS position: 0-3 hi run, 4-7 lo run
     if constexpr (BUF) {
-      a_off[it] = (unsigned)(((((long)img * o.H + oh * p.stride) * o.pitch + ow * p.stride) * p.xs + (chunk & 3) * 8 +
-                              (chunk >> 2) * p.lo_off) * 2);
+      // every term stays below the descriptor's extent (< 2^31 bytes, checked on the host): 32-bit arithmetic
+      a_off[it] = (((unsigned)(img * o.H + oh * p.stride) * (unsigned)o.pitch + (unsigned)(ow * p.stride)) * (unsigned)p.xs +
+                   (unsigned)((chunk & 3) * 8) + (unsigned)(chunk >> 2) * (unsigned)p.lo_off) * 2u;
       // tap (r, s) is invalid iff its row or its column is: R + S tests instead of R * S.  col_bits has bit s set for
       // a bad column; a bad row sets the whole S-bit field of that row.  (No padding => nothing to test.)
       unsigned inv = 0;
@@ -367,7 +373,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
     int n = n0 + row;
     n = n < p.Cout ? n : p.Cout - 1;  // columns >= Cout are never stored
     if constexpr (BUF)
-      b_off[it] = (unsigned)(((long)n * p.Ktot * 2 + (dpos ^ swz(row)) * 8) * 2);
+      b_off[it] = ((unsigned)n * (unsigned)p.Ktot * 2u + (unsigned)((dpos ^ swz(row)) * 8)) * 2u;
     else
       b_ptr[it] = o.w + (long)n * p.Ktot * 2 + (dpos ^ swz(row)) * 8;
   }
@@ -628,6 +634,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
     constexpr int GROUPS = PW / 8;    // 8-channel groups per row
     __syncthreads();                  // every wave is done with the operand tiles in LDS
     float* patch = reinterpret_cast<float*>(smem) + wave * (32 * PWP);
+    // a lane handles the SAME 8-channel group in every iteration of every pass (64 % GROUPS == 0): its bias is loaded once
+    static_assert(64 % GROUPS == 0, "lane -> channel group must not depend on the iteration");
+    const int n_lane = n0 + wn * (BN / WN) + (lane % GROUPS) * 8;
+    f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = {0.f, 0.f, 0.f, 0.f};
+    if (q.bias && n_lane < p.Cout) {
+      bias0 = *reinterpret_cast<const f32x4*>(q.bias + n_lane);
+      bias1 = *reinterpret_cast<const f32x4*>(q.bias + n_lane + 4);
+    }
 #pragma unroll
     for (int i = 0; i < TM; i += 2) {  // 32 rows (two 16-row tiles) per pass
 #pragma unroll
@@ -643,29 +657,21 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
       // (a group touches at most two images when OH*OW >= 32): [sum, sumsq] of image A, then of image A+1
       float gsum[4] = {0.f, 0.f, 0.f, 0.f};
       const int m_grp = m0 + wm * (BM / WM) + i * 16;
-      const int m_split = (m_grp / ohow + 1) * ohow;  // first row of the next image
+      const int m_split = (fastdiv(m_grp < o.M ? m_grp : o.M - 1, o.mg_ohow, o.sh_ohow) + 1) * ohow;  // first row of the next image
 #pragma unroll
       for (int k = 0; k < (32 * GROUPS) / 64; ++k) {
         const int qq = lane + 64 * k;
         const int prow = qq / GROUPS, g = qq - prow * GROUPS;
         const int m = m0 + wm * (BM / WM) + i * 16 + prow;
-        const int n = n0 + wn * (BN / WN) + g * 8;
+        const int n = n_lane;
         const f32x4 c0 = *reinterpret_cast<const f32x4*>(&patch[prow * PWP + g * 8]);
         const f32x4 c1 = *reinterpret_cast<const f32x4*>(&patch[prow * PWP + g * 8 + 4]);
         if (m >= o.M || n >= p.Cout) continue;
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = c0[e];
-          v[4 + e] = c1[e];
-        }
-        if (q.bias) {
-          const f32x4 b0 = *reinterpret_cast<const f32x4*>(q.bias + n), b1 = *reinterpret_cast<const f32x4*>(q.bias + n + 4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[e] += b0[e];
-            v[4 + e] += b1[e];
-          }
+        for (int e = 0; e < 4; ++e) {   // + 0 when there is no bias (exact)
+          v[e] = c0[e] + bias0[e];
+          v[4 + e] = c1[e] + bias1[e];
         }
         if (q.gn_partial) {
           float s1 = 0.f, s2 = 0.f;
