@@ -147,8 +147,12 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // residual add, ReLU on a column prefix and the 16-byte store of 8 consecutive channels n..n+7 of output
 // pixel m (fp32 or S32); shared by the conv epilogue and the split-K reduction
-__device__ __forceinline__ void epi_finish8(const ConvParams16& p, int m, int n, float (&v)[8], int ohow) {
-  if (p.res_mode) {
+__device__ __forceinline__ void epi_finish8(const ConvParams16& p, int m, int n, float (&v)[8], int ohow,
+                                            const f16x8* pre_hi = nullptr, const f16x8* pre_lo = nullptr) {
+  if (pre_hi) {  // S32 residual of the same shape, fetched by the caller ahead of time
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += (float)(*pre_hi)[e] + (float)(*pre_lo)[e];
+  } else if (p.res_mode) {
     long rpix = m;
     if (p.res_mode == 2) {
       const int img = m / ohow;
@@ -351,12 +355,20 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
       // a bad column; a bad row sets the whole S-bit field of that row.  (No padding => nothing to test.)
       unsigned inv = 0;
       if (p.pad > 0) {
-        unsigned col_bits = 0;
-        for (int sx = 0; sx < p.S; ++sx) col_bits |= ((unsigned)(iw0 + sx * p.dil) >= (unsigned)o.W ? 1u : 0u) << sx;
-        const unsigned row_full = (1u << p.S) - 1u;
-        for (int r = 0; r < p.R; ++r) {
-          const unsigned bits = (unsigned)(ih0 + r * p.dil) >= (unsigned)o.H ? row_full : col_bits;
-          inv |= bits << (r * p.S);
+        if (p.R == 3 && p.S == 3) {  // wave-uniform: the usual filter, fully unrolled (no loop control per piece)
+          const unsigned uw = (unsigned)o.W, uh = (unsigned)o.H;
+          const unsigned col_bits = ((unsigned)iw0 >= uw ? 1u : 0u) | ((unsigned)(iw0 + p.dil) >= uw ? 2u : 0u) |
+                                    ((unsigned)(iw0 + 2 * p.dil) >= uw ? 4u : 0u);
+          inv = ((unsigned)ih0 >= uh ? 7u : col_bits) | (((unsigned)(ih0 + p.dil) >= uh ? 7u : col_bits) << 3) |
+                (((unsigned)(ih0 + 2 * p.dil) >= uh ? 7u : col_bits) << 6);
+        } else {
+          unsigned col_bits = 0;
+          for (int sx = 0; sx < p.S; ++sx) col_bits |= ((unsigned)(iw0 + sx * p.dil) >= (unsigned)o.W ? 1u : 0u) << sx;
+          const unsigned row_full = (1u << p.S) - 1u;
+          for (int r = 0; r < p.R; ++r) {
+            const unsigned bits = (unsigned)(ih0 + r * p.dil) >= (unsigned)o.H ? row_full : col_bits;
+            inv |= bits << (r * p.S);
+          }
         }
       }
       a_inv[it] = inv;
@@ -642,6 +654,29 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
       bias0 = *reinterpret_cast<const f32x4*>(q.bias + n_lane);
       bias1 = *reinterpret_cast<const f32x4*>(q.bias + n_lane + 4);
     }
+    // S32 residual of the output's own shape (every ResNet block): ALL of this lane's 16-byte pieces are requested
+    // here, before the first transpose, so the passes below wait for ONE memory latency instead of one per pass
+    // (in-kernel stamps: the epilogue of a 256x64 layer1 workgroup took 23.0k cycles with a residual, 11.2k without)
+    constexpr int EK = (32 * GROUPS) / 64;          // iterations per pass
+    constexpr bool PREF = (TM / 2) * EK <= 8;       // <= 64 VGPRs of prefetched residual (the fragments are dead by now)
+    f16x8 rpre_h[PREF ? (TM / 2) * EK : 1], rpre_l[PREF ? (TM / 2) * EK : 1];
+    const bool use_pre = PREF && q.res_mode == 1 && q.res_split;
+    if constexpr (PREF) {
+      if (use_pre) {
+#pragma unroll
+        for (int i = 0; i < TM; i += 2)
+#pragma unroll
+          for (int k = 0; k < EK; ++k) {
+            const int prow = (lane + 64 * k) / GROUPS;
+            int m = m0 + wm * (BM / WM) + i * 16 + prow;
+            m = m < o.M ? m : o.M - 1;
+            const int n = n_lane < p.Cout ? n_lane : 0;
+            const _Float16* q16 = res16 + (long)m * q.rs + (n >> 5) * 64 + (n & 31);
+            rpre_h[(i / 2) * EK + k] = *reinterpret_cast<const f16x8*>(q16);
+            rpre_l[(i / 2) * EK + k] = *reinterpret_cast<const f16x8*>(q16 + 32);
+          }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < TM; i += 2) {  // 32 rows (two 16-row tiles) per pass
 #pragma unroll
@@ -686,7 +721,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
           gsum[2] += second ? s1 : 0.f;
           gsum[3] += second ? s2 : 0.f;
         }
-        epi_finish8(q, m, n, v, ohow);
+        if constexpr (PREF) {
+          if (use_pre) epi_finish8(q, m, n, v, ohow, &rpre_h[(i / 2) * EK + k], &rpre_l[(i / 2) * EK + k]);
+          else epi_finish8(q, m, n, v, ohow);
+        } else {
+          epi_finish8(q, m, n, v, ohow);
+        }
       }
       if (q.gn_partial) {
         // lanes with equal (lane % GROUPS) hold the same channel unit: fixed-order butterfly over the rows
