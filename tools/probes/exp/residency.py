@@ -41,3 +41,5 @@ for c in np.unique(cu):
 res = np.array(res); gaps = np.array(gaps)
 print(f"average resident workgroups per CU: {res.mean():.2f} (min {res.min():.2f}, max {res.max():.2f})")
 print(f"slot hand-over (next start - earlier end, two slots per CU): median {np.median(gaps):.0f} ticks, p10 {np.percentile(gaps,10):.0f}, p90 {np.percentile(gaps,90):.0f}")
+
+# (s_memtime counters are not synchronised between CUs: only per-CU differences are meaningful)
