@@ -26,7 +26,8 @@ assert lib.hn_debug_read_stamps(buf, 8 * nb) == 0
 a = np.frombuffer(buf, dtype=np.uint64).reshape(nb, 8).astype(np.int64)
 a = a[a[:, 0] > 0]
 d = np.diff(a[:, :7], axis=1)
-names = ["index math", "first tile (DMA latency)", "frag preload", "k loop", "epilogue issue", "store drain"]
+import os
+names = ["index math", "first tile (DMA latency)", "frag preload", "k loop", "epilogue issue", "store drain"] if not os.environ.get("EPI") else ["barrier", "pass0 write+wait", "pass0 compute+store", "pass1 write+wait", "pass1 compute+store", "store drain"]
 print(f"tile {tile} {n}x{h}x{w}x{cin}->{cout} r{r} residual={res}: {len(a)} workgroups stamped; median cycles per phase")
 for i, nm in enumerate(names):
     print(f"  {nm:26s} {np.median(d[:, i]):9.0f}   (p10 {np.percentile(d[:, i], 10):.0f}, p90 {np.percentile(d[:, i], 90):.0f})")
