@@ -1,7 +1,13 @@
-"""Winograd F(2x2,3x3) split-domain conv: correctness against an fp64 convolution and timing against the direct f16x3 kernel."""
+"""Winograd F(2x2,3x3) split-domain conv prototypes: correctness against an fp64 convolution and timing against the
+direct f16x3 kernel.  WINO_LIB = one of the libraries built by build.sh (default libwino_v1.so); v2 takes fp32 input.
+    python tools/probes/wino/wino.py [bench | tower | iters]"""
 import ctypes as C
 import os
 import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+os.environ["HN_LIB_PATH"] = os.environ.get("WINO_LIB", os.path.join(HERE, "libwino_v1.so"))
+V2 = "_v2" in os.environ["HN_LIB_PATH"]
 
 import numpy as np
 import torch
@@ -55,10 +61,11 @@ def check(n, h, wd, cin, cout, relu=False, res=None, out_split=False, seed=0):
     if relu:
         ref = ref.relu()
     xs = ops.to_split(x.cuda())
+    xg = x.cuda() if V2 else xs
     rr = None
     if r is not None:
         rr = ops.to_split(r.cuda()) if res == "split" else r.cuda()
-    y = wino(xs, pack(w), w.shape, b.cuda(), relu, rr, out_split)
+    y = wino(xg, pack(w), w.shape, b.cuda(), relu, rr, out_split)
     if out_split:
         y = ops.from_split(y)
     err = (y.double().cpu() - ref).abs().max().item()
@@ -93,7 +100,8 @@ def bench(n, h, wd, cin, cout, iters=40):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / iters
 
-    tw = run(lambda: wino(xs, u, w.shape, b, True))
+    xin = x if V2 else xs
+    tw = run(lambda: wino(xin, u, w.shape, b, True))
     td = run(lambda: ops.conv2d_nhwc(xs, wg, b, pad=1, relu=True, w16=w16))
     print(f"bench n={n} {h}x{wd} {cin}->{cout}: wino {tw*1e3:.0f} us = {flop/tw/1e9:.0f} TFLOP/s | direct {td*1e3:.0f} us = "
           f"{flop/td/1e9:.0f} TFLOP/s", flush=True)
@@ -112,7 +120,7 @@ if __name__ == "__main__":
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(25)]
             ev[0].record()
             for i in range(24):
-                wino(xs, u, w.shape, b, True)
+                wino(x if V2 else xs, u, w.shape, b, True)
                 ev[i + 1].record()
             torch.cuda.synchronize()
             print("iters us:", " ".join(f"{ev[i].elapsed_time(ev[i+1])*1e3:.0f}" for i in range(24)), flush=True)
@@ -121,6 +129,8 @@ if __name__ == "__main__":
     check(2, 20, 30, 64, 128, relu=True)
     check(2, 25, 34, 96, 256, relu=True, res="f32")
     check(1, 13, 17, 64, 128, res="split", out_split=True)
+    check(3, 100, 136, 256, 128, relu=True)
+    check(1, 9, 200, 32, 128)
     if len(sys.argv) > 1 and sys.argv[1] == "bench":
         for nn in (2, 4, 8, 16, 32):
             bench(nn, 100, 136, 256, 256)

@@ -20,7 +20,7 @@
 //      fragment order (1 KB per wave instruction, no LDS: nobody else uses this wave's frequencies).
 // After the last chunk the waves reduce along j in registers, exchange the 4 x 2 partial planes through LDS, finish
 // along i and run the usual epilogue tail per (pixel, 8 channels): bias, residual, ReLU, fp32 or S32 store.
-#include "hn_common.h"
+#include "../../../handnet-pipeline_amd/csrc/hn_common.h"
 
 namespace {
 
