@@ -14,12 +14,14 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
-    """torchrun-style env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*) -> (rank, local_rank, world)."""
+def init_from_env(backend: str | None = None, force: bool = False) -> tuple[int, int, int]:
+    """torchrun-style env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*) -> (rank, local_rank, world).
+    A process group is created for world > 1, or for a single rank when `force` is set (then gather_results() still
+    goes through the collective: the one-GPU rehearsal of the RCCL path)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -51,11 +53,12 @@ def _record_bytes(j3: int) -> int:
 
 def _buffers(per_rank, world, rec, dev):
     """Send / receive buffers are reused from step to step (no allocation on the timed path)."""
-    key = (per_rank, world, rec, str(dev))
+    grouped = world > 1 or dist.is_initialized()
+    key = (per_rank, world, rec, str(dev), grouped)
     buf = _BUFFERS.get(key)
     if buf is None:
         send = torch.zeros((per_rank, rec), device=dev, dtype=torch.uint8)
-        recv = torch.zeros((world * per_rank, rec), device=dev, dtype=torch.uint8) if world > 1 else send
+        recv = torch.zeros((world * per_rank, rec), device=dev, dtype=torch.uint8) if grouped else send
         buf = _BUFFERS[key] = (send, recv)
     return buf
 
@@ -85,7 +88,7 @@ def gather_results(keypoints: torch.Tensor, crop_box: torch.Tensor, has_hand: to
     flags = torch.stack([has_hand.to(torch.int32), torch.ones_like(has_hand, dtype=torch.int32)], dim=1)
     send[:b, 32:_HEAD] = flags.contiguous().view(torch.uint8).reshape(b, 8)
     send[:b, _HEAD:_HEAD + 4 * j3] = keypoints.to(torch.float32).reshape(b, j3).contiguous().view(torch.uint8)
-    if world > 1:
+    if world > 1 or dist.is_initialized():  # a single-rank group still runs the collective (RCCL rehearsal on one GPU)
         dist.all_gather_into_tensor(recv, send, group=group)
     rows = world * per_rank
     box = recv[:, :32].contiguous().view(torch.int64).reshape(rows, 4)

@@ -28,7 +28,7 @@ def main():
     from hn_amd.pipeline import HandNetEngine
     if backend == "gloo":
         os.environ["LOCAL_RANK"] = "0"
-    rank, local, world = hdist.init_from_env(backend)
+    rank, local, world = hdist.init_from_env(backend, force=True)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     eng = HandNetEngine(FCOSEngine(synth.make_fcos_state_dict(0, 3), 3, device=dev),

@@ -88,6 +88,32 @@ def test_single_process_gather_is_identity():
     assert torch.equal(ck, kp) and torch.equal(cb, box) and torch.equal(ch, has)
 
 
+def test_single_rank_group_still_runs_the_collective(tmp_path):
+    """With a process group of one rank gather_results() goes through all_gather_into_tensor (the one-GPU RCCL
+    rehearsal of tests/test_dist_gpu.py relies on it) and returns the same records."""
+    import torch.distributed as dist
+    from hn_amd.dist import compact_gathered, gather_results
+    dist.init_process_group("gloo", init_method=f"file://{tmp_path}/pg", rank=0, world_size=1)
+    try:
+        kp, box, has = torch.rand((3, 21, 3)), torch.randint(0, 600, (3, 4)), torch.tensor([1, 0, 1], dtype=torch.int32)
+        seen = []
+        real = dist.all_gather_into_tensor
+
+        def spy(out, inp, group=None):
+            seen.append(out.data_ptr() != inp.data_ptr())
+            return real(out, inp, group=group)
+        dist.all_gather_into_tensor = spy
+        try:
+            gk, gb, gh, valid = gather_results(kp, box, has, per_rank=4)
+        finally:
+            dist.all_gather_into_tensor = real
+        assert seen == [True]
+        ck, cb, ch = compact_gathered(gk, gb, gh, valid)
+        assert torch.equal(ck, kp) and torch.equal(cb, box) and torch.equal(ch, has)
+    finally:
+        dist.destroy_process_group()
+
+
 def test_gather_is_one_collective_with_reused_buffers(monkeypatch):
     """The timed path issues ONE all_gather_into_tensor per step and allocates its buffers once."""
     import torch.distributed as dist

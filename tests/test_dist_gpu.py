@@ -48,6 +48,29 @@ def test_two_ranks_equal_single_process_batch(tmp_path, fcos_sd, a2j_sd):
     assert (kp - ref.keypoints.cpu()).abs().max().item() <= 1e-4
 
 
+def test_rccl_single_rank_gather(tmp_path, fcos_sd, a2j_sd):
+    """The RCCL leg on the one GPU this box has: a single-rank "nccl" process group (ncclCommInitRank on the device,
+    all_gather_into_tensor of the packed uint8 records on the current stream) around the real engine; what comes back
+    equals the in-process result bit for bit."""
+    from hn_amd import synth
+    from hn_amd.a2j_engine import A2JEngine
+    from hn_amd.fcos_engine import FCOSEngine
+    from hn_amd.pipeline import HandNetEngine
+    total = 8
+    out_file = tmp_path / "gathered_rccl.pt"
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(REPO / "tests" / "dist_worker.py"), str(total), "nccl", str(out_file)], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout
+    kp, box, has, w = torch.load(out_file)
+    assert w == 1 and kp.shape == (total, 21, 3)
+    eng = HandNetEngine(FCOSEngine(fcos_sd, 3, device="cuda"), A2JEngine(a2j_sd, device="cuda"), 3)
+    ref = eng.forward_device(synth.make_rgb(total, seed=1000).cuda(), synth.make_depth(total, seed=2000).cuda())
+    assert torch.equal(box, ref.crop_box.cpu()) and torch.equal(has, ref.has_hand.cpu())
+    assert torch.equal(kp, ref.keypoints.cpu())
+
+
 def test_bench_launches_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` without a torchrun environment starts two ranks itself (never a silent
     single-GPU run) and rank 0 prints one JSON line with n_gpus = 2."""
