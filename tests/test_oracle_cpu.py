@@ -191,3 +191,43 @@ def test_frozen_bn_matches_published_copy_of_torchvision_class(fcos_sd):
             getattr(m, k).copy_(fcos_sd[f"{name}.{k}"])
     x = torch.randn((2, c, 9, 7), generator=torch.Generator().manual_seed(4))
     assert torch.equal(fcos_ref._frozen_bn(x, fcos_sd, name), m(x))
+
+
+def test_resnet34_body_matches_third_party_basic_block_resnet(fcos_sd):
+    """Row a4, third-party pin for the whole trunk INCLUDING layer4 (torchvision is absent from the image): Hugging
+    Face's ResNetModel in its "basic" configuration (depths 3-4-6-3, stride on the first 3x3 of a stage, 1x1 + BN
+    shortcut, 7x7/2 stem + 3x3/2 max-pool) is the torchvision resnet34 architecture that fcos.py:737 builds.  With the
+    synthetic checkpoint's weights copied in, its four stage outputs must equal the oracle's C2..C5 (eval-mode
+    BatchNorm vs the folded FrozenBN form: a few ulps per layer)."""
+    tr = pytest.importorskip("transformers")
+    cfg = tr.ResNetConfig(num_channels=3, embedding_size=64, hidden_sizes=[64, 128, 256, 512], depths=[3, 4, 6, 3],
+                          layer_type="basic", hidden_act="relu", downsample_in_first_stage=False)
+    m = tr.ResNetModel(cfg).eval()
+    p = "backbone.body."
+    new = {}
+
+    def bn(dst, src):
+        for k in ("weight", "bias", "running_mean", "running_var"):
+            new[f"{dst}.{k}"] = fcos_sd[f"{src}.{k}"]
+    new["embedder.embedder.convolution.weight"] = fcos_sd[p + "conv1.weight"]
+    bn("embedder.embedder.normalization", p + "bn1")
+    for li, blocks in enumerate((3, 4, 6, 3), start=1):
+        for b in range(blocks):
+            src, dst = f"{p}layer{li}.{b}.", f"encoder.stages.{li - 1}.layers.{b}."
+            for i in (1, 2):
+                new[f"{dst}layer.{i - 1}.convolution.weight"] = fcos_sd[f"{src}conv{i}.weight"]
+                bn(f"{dst}layer.{i - 1}.normalization", f"{src}bn{i}")
+            if f"{src}downsample.0.weight" in fcos_sd:
+                new[f"{dst}shortcut.convolution.weight"] = fcos_sd[f"{src}downsample.0.weight"]
+                bn(f"{dst}shortcut.normalization", f"{src}downsample.1")
+    missing, unexpected = m.load_state_dict(new, strict=False)
+    assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing), (missing, unexpected)
+    x = torch.randn((2, 3, 96, 128), generator=torch.Generator().manual_seed(11))
+    with torch.no_grad():
+        theirs = m(x, output_hidden_states=True).hidden_states[1:]
+        ours = fcos_ref.body(x, fcos_sd)
+    assert len(theirs) == 4
+    for name, a, b in zip(("C2", "C3", "C4", "C5"), ours, theirs):
+        assert a.shape == b.shape, name
+        scale = b.abs().max().item()
+        assert (a - b).abs().max().item() <= 1e-5 * max(scale, 1.0), name
