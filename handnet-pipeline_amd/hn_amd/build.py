@@ -62,11 +62,15 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
 
     with ThreadPoolExecutor(max_workers=min(6, len(sources) or 1)) as ex:
         objs = list(ex.map(compile_one, sources))
-    if force or _newer(objs, LIB_PATH):
+    # relink also when the SET of objects changed (a source file added or removed leaves every mtime older than the library)
+    manifest = objdir / "linked_objects.txt"
+    wanted = "\n".join(o.name for o in objs)
+    if force or _newer(objs, LIB_PATH) or not manifest.exists() or manifest.read_text() != wanted:
         cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB_PATH)] + [str(o) for o in objs]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        manifest.write_text(wanted)
     return LIB_PATH
 
 
