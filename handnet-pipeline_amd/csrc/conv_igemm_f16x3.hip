@@ -96,6 +96,10 @@ struct ConvParams16 {
   // per-lane pixel decomposition in the prologue cost ~25 VALU per division, 2 divisions per DMA piece
   unsigned mg_ohow, sh_ohow, mg_ow, sh_ow;
   unsigned gmg_ohow[HN_CONV_MAX_GROUP], gsh_ohow[HN_CONV_MAX_GROUP], gmg_ow[HN_CONV_MAX_GROUP], gsh_ow[HN_CONV_MAX_GROUP];
+  // row-shared A operand (RS kernels, 3x3 / stride 1 / pad 1): exact division by W + 1 and by H for the slot -> pixel map
+  unsigned mg_w1, sh_w1, mg_h, sh_h;
+  unsigned gmg_w1[HN_CONV_MAX_GROUP], gsh_w1[HN_CONV_MAX_GROUP], gmg_h[HN_CONV_MAX_GROUP], gsh_h[HN_CONV_MAX_GROUP];
+  int rs_ok;          // host: the row-shared A kernel may be used (set by conv16_run, refined in launch16)
   unsigned a_records; // bytes covered by the A descriptor (< 2^31 so that bit 31 is out of range)
   unsigned b_records;
   unsigned ga_records[HN_CONV_MAX_GROUP];
@@ -257,9 +261,19 @@ struct HalfSched {
   }
 };
 
-template <int BM, int BN, int WM, int WN, int NBUF, bool BUF>
-__global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const ConvParams16 p) {
+// RS ("row-shared A", 3x3 / stride 1 / pad 1 / dilation 1 only): the three taps of a filter ROW read the same pixels
+// shifted by one, so the A operand of a (channel block, filter row) is staged ONCE as a wide tile and the k steps s = 0, 1, 2
+// read their fragments from it at slot offsets -1 / 0 / +1 -- a third of the L2 -> LDS traffic of the A operand, which is what
+// holds the clock down at the power cap (tools/probes/exp/halo2.sh: +17 % on the tower layer with that traffic removed).
+// Slot j of the wide tile holds the pixel with PADDED linear index u0 + j, where a padded image row has W + 1 entries and
+// entry W is a gap that the DMA zero-fills (descriptor range check): the left neighbour of a pixel with ow = 0 and the right
+// neighbour of one with ow = W - 1 are then the gap, with no per-tap masking of fragments.  Vertical padding and the slots
+// past the tensor are per-lane invalid bits of the DMA piece, one per filter row.
+template <int BM, int BN, int WM, int WN, int NBUF, bool BUF, bool RS = false>
+__global__ __launch_bounds__(WM* WN * 64)
+void conv_igemm_f16x3_kernel(const ConvParams16 p) {
   static_assert(NBUF >= 2 && NBUF <= 6, "2..6 LDS stages");
+  static_assert(!RS || (BUF && NBUF == 2), "row-shared A needs the descriptor form and the 2-stage pipeline");
   // Grouped launch: workgroup z works on member z -- its own tensors and, for FPN levels, its own spatial size.
   // Only these fields differ per member; they live in a small local struct `o` (picked with constant-index
   // selects: a dynamic index into the kernel-argument arrays would send the whole parameter block through
@@ -271,9 +285,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
     void* y;
     float* gn_partial;
     int H, W, pitch, OH, OW, M, nblocks;
-    unsigned a_records, mg_ohow, sh_ohow, mg_ow, sh_ow;
+    unsigned a_records, mg_ohow, sh_ohow, mg_ow, sh_ow, mg_w1, sh_w1, mg_h, sh_h;
   } o = {p.x, p.w, p.bias, p.y, p.gn_partial, p.H, p.W, p.pitch, p.OH, p.OW, p.M, p.nblocks, p.a_records,
-         p.mg_ohow, p.sh_ohow, p.mg_ow, p.sh_ow};
+         p.mg_ohow, p.sh_ohow, p.mg_ow, p.sh_ow, p.mg_w1, p.sh_w1, p.mg_h, p.sh_h};
   if (p.groups > 1) {
     // The member's fields are read straight from the kernel-argument SEGMENT (constant address space) with the uniform
     // index blockIdx.z: scalar loads with an SGPR offset.  (Indexing the by-value parameter `p` dynamically would copy
@@ -302,6 +316,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
     o.sh_ohow = kp->gsh_ohow[gz];
     o.mg_ow = kp->gmg_ow[gz];
     o.sh_ow = kp->gsh_ow[gz];
+    if constexpr (RS) {
+      o.mg_w1 = kp->gmg_w1[gz];
+      o.sh_w1 = kp->gsh_w1[gz];
+      o.mg_h = kp->gmg_h[gz];
+      o.sh_h = kp->gsh_h[gz];
+    }
   }
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;  // 16x16 MFMA tiles per wave
@@ -309,10 +329,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
   constexpr int TH = TN / 2;                            // column tiles per half step
   constexpr int ROWS_PASS = NT / 8;  // 8 lanes (16 B each) cover one 128-byte row
   static_assert(BM % ROWS_PASS == 0 && BN % ROWS_PASS == 0, "tile rows must be a multiple of NT/8");
-  constexpr int A_IT = BM / ROWS_PASS, B_IT = BN / ROWS_PASS;
-  constexpr int A_BUF = BM * ROWH, B_BUF = BN * ROWH;  // halfs per buffer
-  __shared__ __attribute__((aligned(1024))) _Float16 smem[NBUF * (A_BUF + B_BUF)];
-  _Float16* As = smem;                 // [stage][BM][64]
+  constexpr int A_ROWS = RS ? BM + ROWS_PASS : BM;  // RS: BM + 2 neighbours + up to ROWS_PASS - 2 gap slots
+  constexpr int A_IT = A_ROWS / ROWS_PASS, B_IT = BN / ROWS_PASS;
+  constexpr int A_BUF = A_ROWS * ROWH, B_BUF = BN * ROWH;  // halfs per buffer
+  // the RS stages exceed the 64 KB a static array may have: dynamic LDS there (launch16_impl sets the size)
+  extern __shared__ __attribute__((aligned(1024))) _Float16 smem_dyn[];
+  __shared__ __attribute__((aligned(1024))) _Float16 smem_static[RS ? 8 : NBUF * (A_BUF + B_BUF)];
+  _Float16* smem = RS ? smem_dyn : smem_static;
+  _Float16* As = smem;                 // [stage][A_ROWS][64]
   _Float16* Bs = smem + NBUF * A_BUF;  // [stage][BN][64]
 
   int lid;
@@ -337,9 +361,31 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
   // BUF: loop-invariant 32-bit byte offsets from the descriptor bases + one bit per filter tap that is SET when the tap
   // falls outside the image for this lane's pixel (tap index = r * S + s <= 31)
   unsigned a_off[A_IT], a_inv[A_IT], b_off[B_IT];
+  // RS: padded linear index of the slot in front of the tile's first pixel (may be -1)
+  int rs_u0 = 0;
+  if constexpr (RS) {
+    const int mw = fastdiv(m0, o.mg_ow, o.sh_ow);
+    rs_u0 = mw * (o.W + 1) + (m0 - mw * o.W) - 1;
+  }
 #pragma unroll
   for (int it = 0; it < A_IT; ++it) {
     const int row = drow + it * ROWS_PASS;
+    if constexpr (RS) {
+      const int u = rs_u0 + row;
+      const int uc = u < 0 ? 0 : u;
+      const int rowi = fastdiv(uc, o.mg_w1, o.sh_w1);        // global image-row index (img * H + oh)
+      const int owp = uc - rowi * (o.W + 1);
+      const int img = fastdiv(rowi, o.mg_h, o.sh_h);
+      const int oh = rowi - img * o.H;
+      const bool pix_ok = u >= 0 && owp < o.W && rowi < p.N * o.H;
+      const int chunk = dpos ^ swz(row);
+      a_off[it] = pix_ok ? (((unsigned)rowi * (unsigned)o.pitch + (unsigned)owp) * (unsigned)p.xs + (unsigned)((chunk & 3) * 8) +
+                            (unsigned)(chunk >> 2) * (unsigned)p.lo_off) * 2u
+                         : 0u;
+      // bit r: filter row r reads image row oh + r - 1
+      a_inv[it] = !pix_ok ? 7u : (oh == 0 ? 1u : 0u) | (oh == o.H - 1 ? 4u : 0u);
+      continue;
+    }
     int m = m0 + row;
     m = m < o.M ? m : o.M - 1;  // rows >= M are never stored
     const int img = fastdiv(m, o.mg_ohow, o.sh_ohow);
@@ -392,7 +438,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
   // buffer descriptors (wave-uniform by construction: kernel arguments / blockIdx.z selects)
   // the A descriptor starts pad rows + pad columns BEFORE the member's first pixel, so that a_off (computed from the
   // un-padded coordinates oh * stride, ow * stride) is never negative; the pitch is the member's own
-  const long a_shift = BUF ? ((long)p.pad * o.pitch + p.pad) * p.xs * 2 : 0;
+  // (RS: one row up only -- the slot map takes care of the columns)
+  const long a_shift = RS ? (long)o.pitch * p.xs * 2 : BUF ? ((long)p.pad * o.pitch + p.pad) * p.xs * 2 : 0;
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(reinterpret_cast<const char*>(o.x) - a_shift), 0, (int)o.a_records, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)o.w, 0, (int)p.b_records, 0x00020000);
@@ -457,6 +504,29 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
     cur_r = wr ? 0 : r1;
     cur_cb += wr;
   };
+  // RS: the A loader walks (channel block, filter row) pairs on its own, two row tiles ahead of the MFMAs
+  int a_r = 0, a_cb = t_begin / (p.R * p.S), a_q = 0;
+  const int a_qn = (t_end - t_begin) / 3;
+  auto rs_a_offsets = [&](long& uoff, int& sh) {
+    uoff = (((long)a_r * o.pitch) * p.xs + (long)a_cb * (2 * BK)) * 2;
+    sh = 31 - a_r;
+  };
+  auto rs_a_advance = [&]() {  // saturates at the last row tile, like advance_tile
+    const int adv = a_q + 1 < a_qn ? 1 : 0;
+    a_q += adv;
+    const int r1 = a_r + adv;
+    const int wr = r1 == 3 ? 1 : 0;
+    a_r = wr ? 0 : r1;
+    a_cb += wr;
+  };
+  auto rs_dma_a_tile = [&](int stage) {
+    long uoff;
+    int sh;
+    rs_a_offsets(uoff, sh);
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) dma_a_piece(it, As + stage * A_BUF, 0, 0, uoff, sh);
+    rs_a_advance();
+  };
   auto dma_tile = [&](int buf) {
     const int dr = cur_r * p.dil, ds = cur_s * p.dil;
     long uoff, boff;
@@ -464,8 +534,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
     tile_offsets(uoff, boff, sh);
     _Float16* Ad = As + buf * A_BUF;
     _Float16* Bd = Bs + buf * B_BUF;
+    if constexpr (!RS) {
 #pragma unroll
-    for (int it = 0; it < A_IT; ++it) dma_a_piece(it, Ad, dr, ds, uoff, sh);
+      for (int it = 0; it < A_IT; ++it) dma_a_piece(it, Ad, dr, ds, uoff, sh);
+    }
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) dma_b_piece(it, Bd, boff);
     advance_tile();
@@ -509,6 +581,27 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
   constexpr int TILE_OFF = 16 * ROWH * 2;
   const unsigned a_rd_hi = lds_addr(As + a_rd[0][0]), a_rd_lo = lds_addr(As + a_rd[0][1]);
   const unsigned b_rd_hi = lds_addr(Bs + b_rd[0][0]), b_rd_lo = lds_addr(Bs + b_rd[0][1]);
+  // RS: fragment addresses per (row tile, tap s, plane): output row `row` sits in slot c = u(m0 + row) - u0, tap s reads
+  // slot c + s - 1; the swizzle follows the slot, so the three taps need their own addresses
+  // (kept as the centre slot per row tile; the three taps' addresses are rebuilt per step -- 4 VALU each -- because 24
+  // loop-invariant address registers do not fit next to the fragments at two workgroups per CU)
+  int a_c[RS ? TM : 1];
+  const unsigned as_base = lds_addr(As);
+  if constexpr (RS) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      int m = m0 + wm * (BM / WM) + i * 16 + (lane & 15);
+      m = m < o.M ? m : o.M - 1;
+      const int mw = fastdiv(m, o.mg_ow, o.sh_ow);
+      int c = mw * (o.W + 1) + (m - mw * o.W) - rs_u0;
+      a_c[i] = c < A_ROWS - 1 ? c : A_ROWS - 2;  // never taken when the host's gap bound holds
+    }
+  }
+  // LDS byte address of chunk (pl * 4 + lg) of slot a_c[i] + d in A stage `stage`
+  auto rs_addr = [&](int i, int d, int pl, int stage) {
+    const int slot = a_c[i] + d;
+    return as_base + (unsigned)(stage * (A_BUF * 2)) + (unsigned)(slot * (ROWH * 2)) + (unsigned)((((pl * 4 + lg) ^ swz(slot)) << 4));
+  };
   BFrag b0, b1;
   AFrag af;  // ONE set of A fragments: the next tile's are read into each register after its last use
   constexpr int DPT = A_IT + B_IT;  // DMA instructions each wave issues per k tile
@@ -590,6 +683,102 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
     });
     advance_tile();
   };
+  // RS step, phase PH = tap s of tile t: as step_main, except that (a) the A pieces are issued in phase 2 only -- the wide
+  // tile of row tile q + 2 into the A stage `aq` that row tile q has just finished with -- and (b) the next tile's A
+  // fragments come from the slot set of tap (PH + 1) % 3, in the other A stage after phase 2.  NBUF == 2: the mid-step
+  // wait is vmcnt(0), so the varying number of DMA instructions per step needs no accounting.
+  auto step_rs = [&](auto PHc, int cs, int ns, int aq) {
+    constexpr int PH = decltype(PHc)::value;
+    constexpr int NPH = (PH + 1) % 3;
+    constexpr int A_CNT = PH == 2 ? A_IT : 0;
+    constexpr int DPT_PH = A_CNT + B_IT;
+    using S3 = HalfSched<TM, TH, DPT_PH>;
+    const unsigned bcur_hi = b_rd_hi + cs * (B_BUF * 2), bcur_lo = b_rd_lo + cs * (B_BUF * 2);
+    static_for<0, TH>([&](auto JJ) {
+      constexpr int jj = decltype(JJ)::value;
+      lds_read_pinned<(TH + jj) * TILE_OFF>(b1.h[jj], bcur_hi);
+      lds_read_pinned<(TH + jj) * TILE_OFF>(b1.l[jj], bcur_lo);
+    });
+    static_for<0, S3::NM>([&](auto K) {
+      constexpr int k = decltype(K)::value;
+      constexpr int term = k / (TM * TH), i = (k / TH) % TM, jj = k % TH;
+      if constexpr (k == 0) lgkm_wait<TM + 2 * TH>();
+      if constexpr (term == 1 && jj == 0) lgkm_wait<2 * TH + (TM - 1 - i)>();
+      mfma_pinned(acc[i][jj], term == 0 ? af.l[i] : af.h[i], term == 1 ? b0.l[jj] : b0.h[jj]);
+    });
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    long uoff_b, boff, uoff_a = 0;
+    int sh_b, sh_a = 0;
+    tile_offsets(uoff_b, boff, sh_b);
+    if constexpr (PH == 2) rs_a_offsets(uoff_a, sh_a);
+    _Float16* Ad = As + aq * A_BUF;
+    _Float16* Bd = Bs + cs * B_BUF;
+    const int an = PH == 2 ? aq ^ 1 : aq;  // A stage of tile t + 1
+    unsigned anx[TM][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) anx[i][pl] = rs_addr(i, NPH - 1, pl, an);
+    const unsigned bnx_hi = b_rd_hi + ns * (B_BUF * 2), bnx_lo = b_rd_lo + ns * (B_BUF * 2);
+    static_for<0, S3::NM + 1>([&](auto K) {
+      constexpr int k = decltype(K)::value;
+      static_for<0, S3::NMEM>([&](auto Q) {
+        constexpr int q = decltype(Q)::value;
+        if constexpr (S3::slot(q) == k) {
+          if constexpr (q < A_CNT) {
+            dma_a_piece(q, Ad, 0, 0, uoff_a, sh_a);
+          } else if constexpr (q < DPT_PH) {
+            dma_b_piece(q - A_CNT, Bd, boff);
+          } else if constexpr (q < DPT_PH + 2 * TH) {
+            constexpr int jj = (q - DPT_PH) >> 1;
+            if constexpr ((q - DPT_PH) & 1)
+              lds_read_pinned<jj * TILE_OFF>(b0.l[jj], bnx_lo);
+            else
+              lds_read_pinned<jj * TILE_OFF>(b0.h[jj], bnx_hi);
+          } else if constexpr (q < DPT_PH + 2 * TH + TM) {
+            constexpr int i = q - DPT_PH - 2 * TH;
+            lds_read_pinned<0>(af.l[i], anx[i][1]);
+          } else {
+            constexpr int i = q - DPT_PH - 2 * TH - TM;
+            lds_read_pinned<0>(af.h[i], anx[i][0]);
+          }
+        }
+      });
+      if constexpr (k < S3::NM) {
+        constexpr int term = k / (TM * TH), i = (k / TH) % TM, jj = k % TH;
+        mfma_pinned(acc[i][TH + jj], term == 0 ? af.l[i] : af.h[i], term == 1 ? b1.l[jj] : b1.h[jj]);
+      }
+    });
+    advance_tile();
+    if constexpr (PH == 2) rs_a_advance();
+  };
+  if constexpr (RS) {
+    // prologue: row tile 0 + W tile 0 (waited for), then row tile 1 + W tile 1 in flight; fragments of tile 0 (tap 0)
+    rs_dma_a_tile(0);
+    dma_tile(0);
+    drain_and_barrier();
+    rs_dma_a_tile(1);
+    dma_tile(1);
+    static_for<0, TH>([&](auto JJ) {
+      constexpr int jj = decltype(JJ)::value;
+      lds_read_pinned<jj * TILE_OFF>(b0.h[jj], b_rd_hi);
+      lds_read_pinned<jj * TILE_OFF>(b0.l[jj], b_rd_lo);
+    });
+    static_for<0, TM>([&](auto I) { lds_read_pinned<0>(af.l[decltype(I)::value], rs_addr(decltype(I)::value, -1, 1, 0)); });
+    static_for<0, TM>([&](auto I) { lds_read_pinned<0>(af.h[decltype(I)::value], rs_addr(decltype(I)::value, -1, 0, 0)); });
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0), see below
+    // one row tile (3 k steps) per iteration; the W stage parity flips from one row tile to the next
+    int aq = 0, cs = 0;
+    for (int q3 = 0; q3 < a_qn; ++q3) {
+      step_rs(std::integral_constant<int, 0>{}, cs, cs ^ 1, aq);
+      step_rs(std::integral_constant<int, 1>{}, cs ^ 1, cs, aq);
+      step_rs(std::integral_constant<int, 2>{}, cs, cs ^ 1, aq);
+      cs ^= 1;
+      aq ^= 1;
+    }
+  } else {
   // prologue: tile 0 -> stage 0 (waited for); tiles 1..NBUF-1 are put in flight behind it
   dma_tile(0);
   drain_and_barrier();
@@ -612,6 +801,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
     cs = ns;
     ns = ns + 1 == NBUF ? 0 : ns + 1;
   }
+  }  // !RS
   // the pinned MFMAs / reads are opaque to the compiler's hazard and counter tracking: retire everything
   // before the epilogue touches the accumulators
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
@@ -827,8 +1017,29 @@ int launch16_impl(const ConvParams16& p0, hipStream_t st) {
       grid_x = grid_x > p.gnblocks[g] ? grid_x : p.gnblocks[g];
     }
   }
-  hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, NBUF, BUF>), dim3(grid_x, p.splits, p.groups > 1 ? p.groups : 1),
-                     dim3(WM * WN * 64), 0, st, p);
+  // Row-shared A operand: 3x3 / stride 1 / pad 1 / dilation 1 on a dense-row tensor, no split-K, and every (member's) image
+  // row long enough that the gap slots of a wide tile fit (a tile of BM + 1 pixels crosses at most BM / W + 1 row ends).
+  bool rs = false;
+  constexpr int RS_LDS_BYTES = NBUF * (BM + WM * WN * 8 + BN) * ROWH * 2;
+  if constexpr (BUF && NBUF == 2 && WM * WN == 4 && RS_LDS_BYTES <= 80 * 1024 - 2048) {  // two workgroups per CU must remain
+    constexpr int SPARE = (WM * WN * 8) - 2;  // A_ROWS - BM - 2 gap slots
+    rs = p.rs_ok && p.splits == 1 && (BM + 1) / p.W + 1 <= SPARE;
+    for (int g = 0; rs && p.groups > 1 && g < p.groups; ++g) rs = (BM + 1) / p.gW[g] + 1 <= SPARE;
+    if (rs) {
+      constexpr int LDS_BYTES = RS_LDS_BYTES;
+      static bool attr_set = false;
+      if (!attr_set) {
+        HN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_igemm_f16x3_kernel<BM, BN, WM, WN, NBUF, true, true>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, NBUF, true, true>),
+                         dim3(grid_x, 1, p.groups > 1 ? p.groups : 1), dim3(WM * WN * 64), LDS_BYTES, st, p);
+    }
+  }
+  if (!rs)
+    hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, NBUF, BUF>), dim3(grid_x, p.splits, p.groups > 1 ? p.groups : 1),
+                       dim3(WM * WN * 64), 0, st, p);
   HN_CHECK_LAUNCH("conv_igemm_f16x3_kernel");
   if (p.splits > 1) {
     const long total = (long)p.M * (p.Cout >> 3);
@@ -859,11 +1070,19 @@ int launch16(const ConvParams16& p0, hipStream_t st) {
   ConvParams16 p = p0;
   magic_u31((unsigned)(p.OH * p.OW), p.mg_ohow, p.sh_ohow);
   magic_u31((unsigned)p.OW, p.mg_ow, p.sh_ow);
+  magic_u31((unsigned)p.W + 1u, p.mg_w1, p.sh_w1);
+  magic_u31((unsigned)p.H, p.mg_h, p.sh_h);
   for (int g = 0; g < HN_CONV_MAX_GROUP; ++g) {
     const bool on = p.groups > 1 && g < p.groups;
     magic_u31(on ? (unsigned)(p.gOH[g] * p.gOW[g]) : 1u, p.gmg_ohow[g], p.gsh_ohow[g]);
     magic_u31(on ? (unsigned)p.gOW[g] : 1u, p.gmg_ow[g], p.gsh_ow[g]);
+    magic_u31(on ? (unsigned)p.gW[g] + 1u : 1u, p.gmg_w1[g], p.gsh_w1[g]);
+    magic_u31(on ? (unsigned)p.gH[g] : 1u, p.gmg_h[g], p.gsh_h[g]);
   }
+  // (the padded index of the last slot stays far below 2^31: M < 2^31 / (1 + 1/W) is implied by the extent check below
+  // for every xs >= 2)
+  p.rs_ok = p.rs_ok && p.R == 3 && p.S == 3 && p.stride == 1 && p.dil == 1 && p.pad == 1 && p.pitch == p.W && p.OH == p.H &&
+            p.OW == p.W && !getenv("HN_CONV_NO_RS");
   const int64_t lim = (int64_t)1 << 31;
   auto extent = [&](int h, int pitch) {
     // bytes the A descriptor covers: it starts pad rows + pad columns before x (kernel: a_shift) and ends at the last
@@ -1009,6 +1228,7 @@ static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, c
   p.split_ws_bytes = workspace ? workspace_bytes : 0;
   p.splitk_mode = d->splitk;
   p.groups = 1;
+  p.rs_ok = 1;
   p.gn_units = d->cout >> 3;
   hn_conv_desc tile_desc = *d;  // what the tile heuristic sees: for a group, all members' rows together
   if (group) {
@@ -1057,6 +1277,8 @@ static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, c
     case HN_TILE_64x128: return launch16<64, 128, 2, 2, 3>(p, st);
     case HN_TILE_256x128: return launch16<256, 128, 2, 2, 2>(p, st);
     case HN_TILE_32x64: return launch16<32, 64, 1, 2, 4>(p, st);
+    // (the row-shared A form does not fit two 256-row workgroups on a CU, and 128x64 with it -- 442 us on ResNet-34 layer1 --
+    // loses to 256x64 without: 421 us)
     case HN_TILE_256x64: return launch16<256, 64, 4, 1, 2>(p, st);
     case HN_TILE_256x128_W8: return launch16<256, 128, 4, 2, 2>(p, st);
     default: return hn::fail(HN_ERR_ARG, "unknown tile id %d", d->tile);
@@ -1096,6 +1318,7 @@ extern "C" int hn_conv_stem_f16x3(const void* x16, int n, int ph, int pw, int pa
   p.rs = 0;
   p.vec_epi = (cout % 8 == 0) && ((uintptr_t)y % 16 == 0) && (bias == nullptr || (uintptr_t)bias % 16 == 0);
   p.tiles_m = p.tiles_n = p.nblocks = 0;
+  p.rs_ok = 0;
   p.range_flag = hn::range_flag_ptr();
   hipStream_t st = (hipStream_t)stream;
   if (cout <= 32) return launch16<128, 32, 4, 1, 3>(p, st);

@@ -505,3 +505,70 @@ def test_f16x3_wide_dynamic_range_keeps_precision():
     finally:
         ops.range_check_enable(False)
     assert float((y.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+# ---- row-shared A operand (RS kernels): the A tile of a filter ROW is staged once, taps read it at slot offsets ----
+RS_CASES = [
+    # n, h, w, cin, cout: image rows shorter / longer than a tile, widths that put row ends at every slot phase,
+    # M not a multiple of the tile, one-row and one-column images, the tower / body shapes at small batch
+    (2, 100, 136, 64, 128), (1, 25, 34, 64, 128), (3, 13, 17, 32, 128), (2, 7, 131, 32, 64), (1, 9, 129, 64, 128),
+    (2, 64, 5, 32, 128), (1, 1, 300, 32, 128), (1, 300, 1, 32, 64), (4, 11, 11, 96, 128), (1, 50, 68, 256, 256),
+    (1, 3, 6, 32, 128),
+]
+
+
+@pytest.mark.parametrize("case", RS_CASES)
+@pytest.mark.parametrize("tile", [1, 2])
+def test_conv_f16x3_row_shared_a_is_bit_identical_to_per_tap_form(case, tile, monkeypatch):
+    """Same k order and same operands => the row-shared kernel must reproduce the per-tap kernel bit for bit (S32 and fp32
+    outputs, residual + ReLU), and both are fp32-grade against an fp64 convolution.  HN_CONV_NO_RS=1 selects the per-tap
+    form; cases whose rows are too short for the gap slots of a wide tile fall back to it on their own."""
+    from hn_amd import ops
+    from hn_amd.weights import split_f16x3
+    from oracle import ops_ref
+    n, h, w, cin, cout = case
+    x = _rand((n, h, w, cin), 31)
+    wt = _rand((cout, 3, 3, cin), 32, scale=(2.0 / (cin * 9)) ** 0.5)
+    b = _rand((cout,), 33, 0.1)
+    res = _rand((n, h, w, cout), 34)
+    xs, w16, rs32 = ops.to_split(x.cuda()), split_f16x3(wt).cuda(), ops.to_split(res.cuda())
+    outs = {}
+    for mode in ("rs", "per_tap"):
+        if mode == "per_tap":
+            monkeypatch.setenv("HN_CONV_NO_RS", "1")
+        else:
+            monkeypatch.delenv("HN_CONV_NO_RS", raising=False)
+        y32 = ops.conv2d_nhwc(xs, wt.cuda(), b.cuda(), pad=1, relu=True, tile=tile, w16=w16, splitk=False)
+        y16 = ops.conv2d_nhwc(xs, wt.cuda(), b.cuda(), pad=1, relu=True, residual=rs32, tile=tile, w16=w16, out_split=True,
+                              splitk=False)
+        outs[mode] = (y32, ops.from_split(y16))
+    assert torch.equal(outs["rs"][0], outs["per_tap"][0]), f"fp32 output differs, case {case} tile {tile}"
+    assert torch.equal(outs["rs"][1], outs["per_tap"][1]), f"S32 output differs, case {case} tile {tile}"
+    ref = ops_ref.conv2d_nhwc(x.double(), wt.double(), b.double(), 1, 1, 1, relu_cols=cout).float()
+    assert float((outs["rs"][0].cpu() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_conv_f16x3_row_shared_a_grouped_levels_and_gn_partials(monkeypatch):
+    """Grouped launch over FPN-like levels (three map sizes, one of them with rows shorter than the tile) with GroupNorm
+    partial sums in the epilogue: outputs and partial slabs equal the per-tap form bit for bit."""
+    from types import SimpleNamespace as NS
+    from hn_amd import ops
+    from hn_amd.weights import split_f16x3
+    g = torch.Generator().manual_seed(83)
+    n, cin, cout = 2, 64, 128
+    xs = [ops.to_split(torch.randn((n, h, w, cin), generator=g).cuda()) for h, w in ((40, 56), (20, 28), (10, 14))]
+    wt = torch.randn((cout, 3, 3, cin), generator=g) * (2.0 / (9 * cin)) ** 0.5
+    cw = NS(w=wt.cuda(), bias=torch.randn((cout,), generator=g).cuda(), w16=split_f16x3(wt).cuda())
+    got = {}
+    for mode in ("rs", "per_tap"):
+        if mode == "per_tap":
+            monkeypatch.setenv("HN_CONV_NO_RS", "1")
+        else:
+            monkeypatch.delenv("HN_CONV_NO_RS", raising=False)
+        parts = [torch.zeros(ops.gn_rows32_scratch_floats(x.shape[0] * x.shape[1] * x.shape[2], cout), device="cuda") for x in xs]
+        ys = ops.conv2d_nhwc_grouped(xs, [cw] * 3, pad=1, gn_partials=parts)
+        got[mode] = (ys, parts)
+    for a, b in zip(got["rs"][0], got["per_tap"][0]):
+        assert torch.equal(a, b)
+    for a, b in zip(got["rs"][1], got["per_tap"][1]):
+        assert torch.equal(a, b)
