@@ -1273,7 +1273,11 @@ static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, c
     // where they do not cost occupancy
     case HN_TILE_128x64: return launch16<128, 64, 2, 2, 2>(p, st);
     case HN_TILE_64x64: return launch16<64, 64, 2, 2, 3>(p, st);
-    case HN_TILE_128x32: return launch16<128, 32, 4, 1, 3>(p, st);
+    case HN_TILE_128x32:
+      // few output columns: the A operand is nearly all of the traffic, so the row-shared form (2 stages) is tried first
+      if (d->r == 3 && d->s == 3 && d->stride == 1 && d->dil == 1 && d->pad == 1 && !getenv("HN_CONV_NO_RS") && !getenv("HN_CONV_NO_RS32"))
+        return launch16<128, 32, 4, 1, 2>(p, st);
+      return launch16<128, 32, 4, 1, 3>(p, st);
     case HN_TILE_64x128: return launch16<64, 128, 2, 2, 3>(p, st);
     case HN_TILE_256x128: return launch16<256, 128, 2, 2, 2>(p, st);
     case HN_TILE_32x64: return launch16<32, 64, 1, 2, 4>(p, st);

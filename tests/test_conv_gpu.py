@@ -518,7 +518,7 @@ RS_CASES = [
 
 
 @pytest.mark.parametrize("case", RS_CASES)
-@pytest.mark.parametrize("tile", [1, 2])
+@pytest.mark.parametrize("tile", [1, 2, 4])
 def test_conv_f16x3_row_shared_a_is_bit_identical_to_per_tap_form(case, tile, monkeypatch):
     """Same k order and same operands => the row-shared kernel must reproduce the per-tap kernel bit for bit (S32 and fp32
     outputs, residual + ReLU), and both are fp32-grade against an fp64 convolution.  HN_CONV_NO_RS=1 selects the per-tap
@@ -572,3 +572,24 @@ def test_conv_f16x3_row_shared_a_grouped_levels_and_gn_partials(monkeypatch):
         assert torch.equal(a, b)
     for a, b in zip(got["rs"][1], got["per_tap"][1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("case", [(2, 25, 34, 64, 5), (1, 100, 136, 32, 5), (3, 13, 17, 32, 3)])
+def test_conv_f16x3_row_shared_a_few_output_channels(case, monkeypatch):
+    """The FCOS output convs (5 / 3 channels, scalar epilogue, 128x32 tile): row-shared == per-tap bit for bit, with a
+    partial ReLU as the regression + centerness head has it."""
+    from hn_amd import ops
+    from hn_amd.weights import split_f16x3
+    n, h, w, cin, cout = case
+    xs = ops.to_split(_rand((n, h, w, cin), 41).cuda())
+    wt = _rand((cout, 3, 3, cin), 42, scale=(2.0 / (cin * 9)) ** 0.5)
+    b = _rand((cout,), 43, 0.1).cuda()
+    w16 = split_f16x3(wt).cuda()
+    got = []
+    for no_rs in (False, True):
+        if no_rs:
+            monkeypatch.setenv("HN_CONV_NO_RS", "1")
+        else:
+            monkeypatch.delenv("HN_CONV_NO_RS", raising=False)
+        got.append(ops.conv2d_nhwc(xs, wt.cuda(), b, pad=1, relu_cols=cout - 1, w16=w16, splitk=False))
+    assert torch.equal(got[0], got[1])
