@@ -201,7 +201,7 @@ def roofline_leg(step, steps, ms_per_step, sample_clock=True):
     # f16x3 issues 3 f16 MFMAs per algorithmic MAC; `achieved` stays ALGORITHMIC FLOP/s and is
     # priced against the dense f16 MFMA peak (the issued-MFMA rate is reported next to it).
     peak = F16_MFMA_PEAK_TFLOPS if prec == "f16x3" else F32_MFMA_PEAK_TFLOPS
-    kernel = f"conv_igemm_{prec}_kernel<{ops.TILE_NAMES.get(tile, tile)}>"
+    kernel = f"conv_igemm_{prec}_kernel<{ops.tile_name(tile)}>"
     gf_launch = round(g["flop"] / g["launches"] / 1e9, 3)
     traffic, traffic_source = measured_traffic(kernel, gf_launch, g["launches"] // steps)
     issued = achieved * (3 if prec == "f16x3" else 1)
@@ -247,10 +247,11 @@ def measured_traffic(kernel, gflop_per_launch, launches_per_step):
                       f"{gflop_per_launch}")
     want = stamp["kernel"].replace("conv_igemm_", "").split("_kernel<")
     prec, tile = want[0], want[1].rstrip(">")
-    bm, bn = tile.split("x")
+    rs = tile.endswith("+rs")                      # the row-shared-A instantiation: last template argument true
+    bm, bn = tile.replace("+rs", "").split("x")
     needle = f"conv_igemm_{prec}_kernel<{bm}, {bn},"
     for name, k in rec["kernels"].items():
-        if needle in name:
+        if needle in name and (prec != "f16x3" or name.split(">")[0].rstrip().endswith("true" if rs else "false")):
             return k["hbm_bytes_per_launch"], f"profiles/{rec.get('tag')}_traffic.json (commit {rec.get('commit')})"
     return None, f"{rec.get('tag')}: no {needle} record"
 

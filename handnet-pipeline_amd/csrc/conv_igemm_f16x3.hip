@@ -1132,6 +1132,16 @@ extern "C" int hn_conv2d_f16x3_pick_tile(const hn_conv_desc* d) {
   return HN_TILE_64x64;
 }
 
+// mirrors the choice launch16 / launch16_impl make for a single-pass launch (split-K launches use the per-tap form)
+extern "C" int hn_conv2d_f16x3_uses_rs(const hn_conv_desc* d) {
+  if (!d || getenv("HN_CONV_NO_RS")) return 0;
+  if (!(d->r == 3 && d->s == 3 && d->stride == 1 && d->dil == 1 && d->pad == 1 && d->w > 0)) return 0;
+  const int tile = hn_conv2d_f16x3_pick_tile(d);
+  if (tile != HN_TILE_128x128 && tile != HN_TILE_128x64 && tile != HN_TILE_128x32) return 0;
+  if (tile == HN_TILE_128x32 && getenv("HN_CONV_NO_RS32")) return 0;
+  return (128 + 1) / d->w + 1 <= 30 ? 1 : 0;
+}
+
 static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, const float* bias, const void* residual,
                       void* y, float* gn_partial, void* workspace, int64_t workspace_bytes, void* stream,
                       const hn_conv_group* group = nullptr);

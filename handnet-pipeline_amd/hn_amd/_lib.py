@@ -12,7 +12,7 @@ from pathlib import Path
 
 from . import build as _build
 
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, TILE_256x128, TILE_64x128 = range(7)
 HN_FCOS_MAX_LEVELS = 5
@@ -76,6 +76,7 @@ SIGNATURES = {
     "hn_unsplit_f32": (C.c_int, [VP] + [C.c_int] * 4 + [VP, C.c_int, VP]),
     "hn_maxpool3x3s2_s32": (C.c_int, [VP, VP] + [C.c_int] * 6 + [VP]),
     "hn_conv2d_f16x3_pick_tile": (C.c_int, [C.POINTER(ConvDesc)]),
+    "hn_conv2d_f16x3_uses_rs": (C.c_int, [C.POINTER(ConvDesc)]),
     "hn_maxpool3x3s2_nhwc_f32": (C.c_int, [VP, VP] + [C.c_int] * 6 + [VP]),
     "hn_groupnorm_scratch_floats": (C.c_int64, [C.c_int] * 4),
     "hn_groupnorm_affine_f32": (C.c_int, [VP, VP, VP] + [C.c_int] * 4 + [C.c_float, VP, VP, VP, VP]),

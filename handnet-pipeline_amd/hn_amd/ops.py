@@ -180,6 +180,13 @@ def from_split(xs16, out=None):
 # on the launch stream and ((precision, tile id), algorithmic MACs, timer, shape) is appended.
 CONV_PROFILE = None
 TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x64", 4: "128x32", 5: "256x128", 6: "64x128", 7: "32x64", 8: "256x64", 9: "256x128w8"}
+TILE_RS = 0x100  # profile records: tile id | TILE_RS when the launch ran the row-shared-A instantiation of that tile
+
+
+def tile_name(tile) -> str:
+    """'128x128' / '128x128+rs' (the row-shared-A kernels are separate instantiations, i.e. separate profiler rows)."""
+    base = TILE_NAMES.get(tile & 0xFF, str(tile & 0xFF)) if isinstance(tile, int) else str(tile)
+    return base + ("+rs" if isinstance(tile, int) and tile & TILE_RS else "")
 
 
 def clear_plan_caches():
@@ -356,7 +363,7 @@ def conv2d_nhwc(x, w, bias=None, *, stride=1, pad=0, dil=1, relu=False, relu_col
         timer.stop()
         macs = n * d.oh * d.ow * cout * r * s * (algo_cin or cin)
         if use16:
-            kind = ("f16x3", lib.hn_conv2d_f16x3_pick_tile(C.byref(d)))
+            kind = ("f16x3", lib.hn_conv2d_f16x3_pick_tile(C.byref(d)) | (TILE_RS if lib.hn_conv2d_f16x3_uses_rs(C.byref(d)) else 0))
         else:
             kind = ("f32", lib.hn_conv2d_pick_tile(C.byref(d)))
         prof.append((kind, macs, timer, (n, h, wd, cin, cout, r, stride, dil)))
@@ -440,8 +447,11 @@ def conv2d_nhwc_grouped(xs, ws, *, pad=0, relu=False, relu_cols=None, out_split=
         timer.stop()
         rows = sum(n * oh * ow for oh, ow in sizes)
         tot = make_conv_desc(1, rows, 1, cin, cout, 1, 1)          # what the tile heuristic saw: all rows together
-        prof.append((("f16x3", lib.hn_conv2d_f16x3_pick_tile(C.byref(tot))), rows * cout * r * s * cin, timer,
-                     (1, rows, 1, cin, cout, r, 1, 1)))
+        tile = lib.hn_conv2d_f16x3_pick_tile(C.byref(tot))
+        q = ConvDesc.from_buffer_copy(d)                           # geometry of the launch, picked tile, narrowest member
+        q.tile, q.w = tile, min(ow for _, ow in sizes)
+        prof.append((("f16x3", tile | (TILE_RS if lib.hn_conv2d_f16x3_uses_rs(C.byref(q)) else 0)), rows * cout * r * s * cin,
+                     timer, (1, rows, 1, cin, cout, r, 1, 1)))
     return outs
 
 

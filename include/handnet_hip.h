@@ -33,7 +33,7 @@ extern "C" {
 #define HN_ERR_HIP 2
 
 /* ABI version; bumped whenever a struct below changes. */
-#define HN_ABI_VERSION 22
+#define HN_ABI_VERSION 23
 int hn_abi_version(void);
 const char* hn_last_error(void);
 
@@ -126,6 +126,12 @@ int hn_conv2d_nhwc_f16x3(const hn_conv_desc* d, const void* x16 /* S32 */, const
                          const float* bias, const void* residual /* fp32 or S32 */,
                          void* y /* fp32 or S32 (d->out_split) */, void* stream);
 int hn_conv2d_f16x3_pick_tile(const hn_conv_desc* d);
+/* 1 when a single-pass launch of this descriptor runs the row-shared-A kernels (3x3 / stride 1 / pad 1 / dilation 1 on the
+ * 128x128, 128x64 or 128x32 tile, image rows long enough for the gap slots; HN_CONV_NO_RS=1 turns them off): the A
+ * operand of a filter row is staged once and the three taps read it at slot offsets.  Same results bit for bit; the
+ * profilers' kernel names differ (template argument RS), which is what bench.py asks this for.  For a grouped launch pass
+ * the smallest member width in d->w and the picked tile in d->tile. */
+int hn_conv2d_f16x3_uses_rs(const hn_conv_desc* d);
 
 /* ---- S32 split activation format: fp16 [N][H][W][C/32][2][32] (hi[32] | lo[32] per block) ----
  * hn_affine_split_f32: fp32 NHWC -> S32; with scale/shift [n][c] it first applies

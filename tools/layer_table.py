@@ -37,4 +37,4 @@ tot = sum(v[1] for v in tab.values())
 print(f"# precision {prec} batch {batch}: conv total {tot/reps:.2f} ms/step")
 print(f"{'kind':10s} {'tile':8s} {'n,h,w,cin,cout,r,stride,dil':42s} {'calls/step':>10s} {'ms/step':>9s} {'%':>6s} {'TFLOP/s':>8s}")
 for (kind, shape), (calls, ms, flop) in sorted(tab.items(), key=lambda kv: -kv[1][1]):
-    print(f"{kind[0]:10s} {ops.TILE_NAMES.get(kind[1], str(kind[1])):8s} {str(shape):42s} {calls/reps:10.0f} {ms/reps:9.3f} {100*ms/tot:6.1f} {flop/ms/1e9:8.1f}")
+    print(f"{kind[0]:10s} {ops.tile_name(kind[1]):11s} {str(shape):42s} {calls/reps:10.0f} {ms/reps:9.3f} {100*ms/tot:6.1f} {flop/ms/1e9:8.1f}")

@@ -33,4 +33,4 @@ tot = sum(v[1] for v in tab.values())
 print(f"# conv total {tot/reps:.3f} ms/step (event-bracketed, includes launch gaps)")
 print(f"{'tile':8s} {'n,h,w,cin,cout,r,stride,dil':40s} {'calls':>5s} {'ms/step':>8s} {'%':>6s} {'TFLOP/s':>8s}")
 for (kind, shape), (calls, ms, flop) in sorted(tab.items(), key=lambda kv: -kv[1][1]):
-    print(f"{ops.TILE_NAMES.get(kind[1], str(kind[1])):8s} {str(shape):40s} {calls/reps:5.0f} {ms/reps:8.3f} {100*ms/tot:6.1f} {flop/ms/1e9:8.1f}")
+    print(f"{ops.tile_name(kind[1]):11s} {str(shape):40s} {calls/reps:5.0f} {ms/reps:8.3f} {100*ms/tot:6.1f} {flop/ms/1e9:8.1f}")
