@@ -1021,7 +1021,8 @@ int launch16_impl(const ConvParams16& p0, hipStream_t st) {
   // row long enough that the gap slots of a wide tile fit (a tile of BM + 1 pixels crosses at most BM / W + 1 row ends).
   bool rs = false;
   constexpr int RS_LDS_BYTES = NBUF * (BM + WM * WN * 8 + BN) * ROWH * 2;
-  if constexpr (BUF && NBUF == 2 && WM * WN == 4 && RS_LDS_BYTES <= 80 * 1024 - 2048) {  // two workgroups per CU must remain
+  // eight waves per CU must remain: two 4-wave workgroups or one 8-wave workgroup
+  if constexpr (BUF && NBUF == 2 && (WM * WN == 4 || WM * WN == 8) && RS_LDS_BYTES <= (WM * WN == 4 ? 80 : 160) * 1024 - 2048) {
     constexpr int SPARE = (WM * WN * 8) - 2;  // A_ROWS - BM - 2 gap slots
     rs = p.rs_ok && p.splits == 1 && (BM + 1) / p.W + 1 <= SPARE;
     for (int g = 0; rs && p.groups > 1 && g < p.groups; ++g) rs = (BM + 1) / p.gW[g] + 1 <= SPARE;
