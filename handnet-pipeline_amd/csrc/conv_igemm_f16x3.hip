@@ -1028,11 +1028,13 @@ int launch16_impl(const ConvParams16& p0, hipStream_t st) {
     for (int g = 0; rs && p.groups > 1 && g < p.groups; ++g) rs = (BM + 1) / p.gW[g] + 1 <= SPARE;
     if (rs) {
       constexpr int LDS_BYTES = RS_LDS_BYTES;
-      static bool attr_set = false;
-      if (!attr_set) {
+      static bool attr_set[64] = {};  // per device: the attribute belongs to the function's image on the current device
+      int dev = 0;
+      HN_CHECK_HIP(hipGetDevice(&dev));
+      if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         HN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_igemm_f16x3_kernel<BM, BN, WM, WN, NBUF, true, true>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
       }
       hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, NBUF, true, true>),
                          dim3(grid_x, 1, p.groups > 1 ? p.groups : 1), dim3(WM * WN * 64), LDS_BYTES, st, p);
