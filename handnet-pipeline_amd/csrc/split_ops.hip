@@ -73,6 +73,85 @@ __global__ __launch_bounds__(256) void affine_split_kernel(const float* __restri
   }
 }
 
+// The same pass for channel counts whose 8-channel groups divide the block (C = 32 .. 2048, powers of two): one image
+// per blockIdx.y, a lane keeps ONE channel group for its whole pixel loop, so the GroupNorm scale / shift of that group
+// are loaded once, the per-item index math is a shift (the generic kernel pays two 64-bit divisions per 32 bytes), two
+// pixels are in flight per iteration, and the streams bypass the caches (read once / written once).
+template <bool AFFINE, int NT, int UNR>   // NT bit 0: streaming loads, bit 1: streaming stores; UNR pixels in flight per lane
+__global__ __launch_bounds__(256) void affine_split_pow2_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, int relu, int hw, int c8_log2,
+                                                                int xs, int as, _Float16* __restrict__ y, int ys,
+                                                                int* range_flag) {
+  const int c8 = 1 << c8_log2;
+  const int grp = threadIdx.x & (c8 - 1), ch = grp * 8;
+  const int ppb = 256 >> c8_log2;                       // pixels per block and iteration
+  const int img = blockIdx.y;
+  f32x4 s0 = {1.f, 1.f, 1.f, 1.f}, s1 = s0, t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0;
+  if constexpr (AFFINE) {
+    const long o = (long)img * as + ch;
+    s0 = *reinterpret_cast<const f32x4*>(scale + o);
+    s1 = *reinterpret_cast<const f32x4*>(scale + o + 4);
+    t0 = *reinterpret_cast<const f32x4*>(shift + o);
+    t1 = *reinterpret_cast<const f32x4*>(shift + o + 4);
+  }
+  const float* xi = x + (long)img * hw * xs + ch;
+  _Float16* yi = y + (long)img * hw * ys + (ch >> 5) * 64 + (ch & 31);
+  const int step = gridDim.x * ppb;
+  auto load = [&](const float* q) {
+    if constexpr (NT & 1) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q));
+    else return *reinterpret_cast<const f32x4*>(q);
+  };
+  auto one = [&](f32x4 a, f32x4 b, int pix) {
+    if constexpr (AFFINE) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a[e] = a[e] * s0[e] + t0[e];
+        b[e] = b[e] * s1[e] + t1[e];
+      }
+    }
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a[e] = fmaxf(a[e], 0.f);
+        b[e] = fmaxf(b[e], 0.f);
+      }
+    }
+    if (range_flag) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        hn::range_note(range_flag, a[e]);
+        hn::range_note(range_flag, b[e]);
+      }
+    }
+    f16x8 hi, lo;
+    split8(a, b, hi, lo);
+    _Float16* dst = yi + (long)pix * ys;
+    if constexpr (NT & 2) {
+      __builtin_nontemporal_store(hi, reinterpret_cast<f16x8*>(dst));
+      __builtin_nontemporal_store(lo, reinterpret_cast<f16x8*>(dst + 32));
+    } else {
+      *reinterpret_cast<f16x8*>(dst) = hi;
+      *reinterpret_cast<f16x8*>(dst + 32) = lo;
+    }
+  };
+  int pix = blockIdx.x * ppb + (threadIdx.x >> c8_log2);
+  for (; pix + (UNR - 1) * step < hw; pix += UNR * step) {
+    f32x4 a[UNR], b[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const float* q = xi + (long)(pix + u * step) * xs;
+      a[u] = load(q);
+      b[u] = load(q + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) one(a[u], b[u], pix + u * step);
+  }
+  for (; pix < hw; pix += step) {
+    const float* q = xi + (long)pix * xs;
+    one(load(q), load(q + 4), pix);
+  }
+}
+
 __global__ __launch_bounds__(256) void unsplit_kernel(const _Float16* __restrict__ x, long npix, int c, int xs,
                                                       float* __restrict__ y, int ys) {
   const int c8 = c >> 3;
@@ -162,6 +241,33 @@ extern "C" int hn_affine_split_f32(const float* x, const float* scale, const flo
   const int ys = out_pix_stride ? out_pix_stride : 2 * c;
   HN_CHECK_ARG(xs >= c && xs % 4 == 0 && as >= c && as % 4 == 0 && ys >= 2 * c && ys % 64 == 0, "bad strides");
   const long npix = (long)n * hw;
+  const int c8 = c / 8;
+  if ((c8 & (c8 - 1)) == 0 && c8 <= 256 && n <= 65535 && !getenv("HN_SPLIT_GENERIC")) {
+    int lg = 0;
+    while ((1 << lg) < c8) ++lg;
+    const int ppb = 256 >> lg;
+    // enough blocks per image to fill the chip a few times over, two pixels per lane and iteration
+    int gx = hn::cdiv(hw, 2 * ppb);  // (the grid size is not sensitive: 64 .. 512 blocks per image within 2 %)
+    const int cap = hn::cdiv(16384, n);
+    gx = gx < cap ? gx : cap;
+    gx = gx > 0 ? gx : 1;
+    // Streaming stores + four pixels in flight for tensors that no cache level keeps anyway (level 0: 382 -> 313 us, level 1:
+    // 89 -> 73 us at batch 32); plain stores for small ones, which the next convolution finds in L2 / Infinity Cache
+    // (sweep of NT bits x pixels in flight, profiles/r02_apply_pass_sweep.txt; streaming LOADS cost 8 % everywhere).  In the pipeline: +0.9 % at batch 32 over the
+    // generic kernel, the same with either store form (tools/probes/exp/apply_ab.sh).
+    const bool big = (int64_t)npix * c * 4 >= ((int64_t)128 << 20);
+#define HN_SPLIT_LAUNCH(AFF, NTV, UNRV)                                                                                          \
+  hipLaunchKernelGGL((affine_split_pow2_kernel<AFF, NTV, UNRV>), dim3(gx, n), dim3(256), 0, (hipStream_t)stream, x, scale, shift, \
+                     relu, hw, lg, xs, as, (_Float16*)y16, ys, hn::range_flag_ptr())
+    if (scale) {
+      if (big) HN_SPLIT_LAUNCH(true, 2, 4); else HN_SPLIT_LAUNCH(true, 0, 2);
+    } else {
+      if (big) HN_SPLIT_LAUNCH(false, 2, 4); else HN_SPLIT_LAUNCH(false, 0, 2);
+    }
+#undef HN_SPLIT_LAUNCH
+    HN_CHECK_LAUNCH("affine_split_pow2_kernel");
+    return HN_OK;
+  }
   hipLaunchKernelGGL(affine_split_kernel, dim3(grid_for(npix * (c / 8))), dim3(256), 0, (hipStream_t)stream, x, scale,
                      shift, relu, npix, hw, c, xs, as, (_Float16*)y16, ys, hn::range_flag_ptr());
   HN_CHECK_LAUNCH("affine_split_kernel");

@@ -593,3 +593,29 @@ def test_conv_f16x3_row_shared_a_few_output_channels(case, monkeypatch):
             monkeypatch.delenv("HN_CONV_NO_RS", raising=False)
         got.append(ops.conv2d_nhwc(xs, wt.cuda(), b, pad=1, relu_cols=cout - 1, w16=w16, splitk=False))
     assert torch.equal(got[0], got[1])
+
+
+@pytest.mark.parametrize("shape", [(2, 9, 7, 64), (3, 25, 34, 512), (1, 1, 1, 32), (2, 37, 3, 256), (1, 50, 68, 2048), (2, 5, 5, 96)])
+def test_affine_split_group_stationary_kernel_equals_generic(shape, monkeypatch):
+    """hn_affine_split_f32 picks a channel-group-stationary kernel for power-of-two channel counts (one image per
+    blockIdx.y, scale / shift loaded once per lane, several pixels in flight): same bits as the generic kernel
+    (HN_SPLIT_GENERIC=1), with and without the affine, odd pixel counts, and a sliced (strided) input; C = 96 takes the
+    generic kernel on both sides."""
+    from hn_amd import ops
+    n, h, w, c = shape
+    x = _rand(shape, 61, 2.0).cuda()
+    sc, sh = (_rand((n, c), 62) * 0.5 + 1.0).cuda(), _rand((n, c), 63, 0.2).cuda()
+    wide = _rand((n, h, w, 2 * c), 64).cuda()
+    outs = []
+    for generic in (False, True):
+        if generic:
+            monkeypatch.setenv("HN_SPLIT_GENERIC", "1")
+        else:
+            monkeypatch.delenv("HN_SPLIT_GENERIC", raising=False)
+        outs.append((ops.to_split(x), ops.to_split(x, sc, sh, relu=True), ops.to_split(x, sc, sh, relu=False),
+                     ops.to_split(wide[..., c:], sc, sh, relu=True)))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    ref = torch.relu(x * sc[:, None, None, :] + sh[:, None, None, :]).cpu()
+    got = ops.from_split(outs[0][1]).cpu()
+    assert float((got - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
