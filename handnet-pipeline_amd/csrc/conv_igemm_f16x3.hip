@@ -1085,7 +1085,7 @@ int launch16(const ConvParams16& p0, hipStream_t st) {
   // (the padded index of the last slot stays far below 2^31: M < 2^31 / (1 + 1/W) is implied by the extent check below
   // for every xs >= 2)
   p.rs_ok = p.rs_ok && p.R == 3 && p.S == 3 && p.stride == 1 && p.dil == 1 && p.pad == 1 && p.pitch == p.W && p.OH == p.H &&
-            p.OW == p.W && !getenv("HN_CONV_NO_RS");
+            p.OW == p.W && !hn::env_flags().no_rs;
   const int64_t lim = (int64_t)1 << 31;
   auto extent = [&](int h, int pitch) {
     // bytes the A descriptor covers: it starts pad rows + pad columns before x (kernel: a_shift) and ends at the last
@@ -1137,11 +1137,11 @@ extern "C" int hn_conv2d_f16x3_pick_tile(const hn_conv_desc* d) {
 
 // mirrors the choice launch16 / launch16_impl make for a single-pass launch (split-K launches use the per-tap form)
 extern "C" int hn_conv2d_f16x3_uses_rs(const hn_conv_desc* d) {
-  if (!d || getenv("HN_CONV_NO_RS")) return 0;
+  if (!d || hn::env_flags().no_rs) return 0;
   if (!(d->r == 3 && d->s == 3 && d->stride == 1 && d->dil == 1 && d->pad == 1 && d->w > 0)) return 0;
   const int tile = hn_conv2d_f16x3_pick_tile(d);
   if (tile != HN_TILE_128x128 && tile != HN_TILE_128x64 && tile != HN_TILE_128x32) return 0;
-  if (tile == HN_TILE_128x32 && getenv("HN_CONV_NO_RS32")) return 0;
+  if (tile == HN_TILE_128x32 && hn::env_flags().no_rs32) return 0;
   return (128 + 1) / d->w + 1 <= 30 ? 1 : 0;
 }
 
@@ -1288,7 +1288,7 @@ static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, c
     case HN_TILE_64x64: return launch16<64, 64, 2, 2, 3>(p, st);
     case HN_TILE_128x32:
       // few output columns: the A operand is nearly all of the traffic, so the row-shared form (2 stages) is tried first
-      if (d->r == 3 && d->s == 3 && d->stride == 1 && d->dil == 1 && d->pad == 1 && !getenv("HN_CONV_NO_RS") && !getenv("HN_CONV_NO_RS32"))
+      if (d->r == 3 && d->s == 3 && d->stride == 1 && d->dil == 1 && d->pad == 1 && !hn::env_flags().no_rs && !hn::env_flags().no_rs32)
         return launch16<128, 32, 4, 1, 2>(p, st);
       return launch16<128, 32, 4, 1, 3>(p, st);
     case HN_TILE_64x128: return launch16<64, 128, 2, 2, 3>(p, st);

@@ -14,6 +14,12 @@ char* err_buf();
 int fail(int code, const char* fmt, ...);
 // device address of the sticky f16x3 range flag of the current device, or nullptr while the check is off
 int* range_flag_ptr();
+// A/B switches read from the environment ONCE (hn_reread_env() refreshes them): getenv per launch costs more host time
+// than the rest of a small launch's argument checks.
+struct EnvFlags {
+  bool no_rs, no_rs32, split_generic;
+};
+const EnvFlags& env_flags();
 
 #define HN_CHECK_ARG(cond, ...)                          \
   do {                                                   \

@@ -2,6 +2,8 @@
 // in-kernel shader-clock sampler.
 #include "hn_common.h"
 
+#include <stdlib.h>
+
 #include <string.h>
 
 // Sticky per-device flag of the f16x3 range contract (hn_range_check_enable): set by any producer of split
@@ -40,6 +42,26 @@ int fail(int code, const char* fmt, ...) {
 }  // namespace hn
 
 extern "C" int hn_abi_version(void) { return HN_ABI_VERSION; }
+
+namespace hn {
+static EnvFlags g_env;
+static bool g_env_read = false;
+static void read_env() {
+  g_env.no_rs = getenv("HN_CONV_NO_RS") != nullptr;
+  g_env.no_rs32 = getenv("HN_CONV_NO_RS32") != nullptr;
+  g_env.split_generic = getenv("HN_SPLIT_GENERIC") != nullptr;
+  g_env_read = true;
+}
+const EnvFlags& env_flags() {
+  if (!g_env_read) read_env();
+  return g_env;
+}
+}  // namespace hn
+
+extern "C" int hn_reread_env(void) {
+  hn::read_env();
+  return HN_OK;
+}
 
 extern "C" const char* hn_last_error(void) { return hn::err_buf(); }
 

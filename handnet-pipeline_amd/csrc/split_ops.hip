@@ -242,7 +242,7 @@ extern "C" int hn_affine_split_f32(const float* x, const float* scale, const flo
   HN_CHECK_ARG(xs >= c && xs % 4 == 0 && as >= c && as % 4 == 0 && ys >= 2 * c && ys % 64 == 0, "bad strides");
   const long npix = (long)n * hw;
   const int c8 = c / 8;
-  if ((c8 & (c8 - 1)) == 0 && c8 <= 256 && n <= 65535 && !getenv("HN_SPLIT_GENERIC")) {
+  if ((c8 & (c8 - 1)) == 0 && c8 <= 256 && n <= 65535 && !hn::env_flags().split_generic) {
     int lg = 0;
     while ((1 << lg) < c8) ++lg;
     const int ppb = 256 >> lg;

@@ -12,7 +12,7 @@ from pathlib import Path
 
 from . import build as _build
 
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, TILE_256x128, TILE_64x128 = range(7)
 HN_FCOS_MAX_LEVELS = 5
@@ -69,6 +69,7 @@ SIGNATURES = {
     "hn_clock_sample": (C.c_int, [C.c_int, VP, VP]),
     "hn_range_check_enable": (C.c_int, [C.c_int]),
     "hn_range_check_fetch": (C.c_int, [c_i32p, C.c_int, VP]),
+    "hn_reread_env": (C.c_int, []),
     "hn_conv2d_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), VP, VP, VP, VP, VP, VP, VP, VP]),
     "hn_conv2d_pick_tile": (C.c_int, [C.POINTER(ConvDesc)]),
     "hn_conv2d_nhwc_f16x3": (C.c_int, [C.POINTER(ConvDesc), VP, VP, VP, VP, VP, VP]),

@@ -806,6 +806,11 @@ def convert_joints(kp, crop_box, valid=None, paras=None, crop=176, out=None):
     return out
 
 
+def reread_env():
+    """The library reads its A/B switches (HN_CONV_NO_RS, HN_SPLIT_GENERIC, ...) once; call this after changing them."""
+    check(_lib.load().hn_reread_env(), "hn_reread_env")
+
+
 def range_check_enable(on=True):
     """f16x3 range contract (see include/handnet_hip.h): split producers launched from now on flag values that
     cannot be represented as fp16 hi + lo (|v| > 65504 or non-finite)."""

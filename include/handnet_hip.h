@@ -33,7 +33,7 @@ extern "C" {
 #define HN_ERR_HIP 2
 
 /* ABI version; bumped whenever a struct below changes. */
-#define HN_ABI_VERSION 23
+#define HN_ABI_VERSION 24
 int hn_abi_version(void);
 const char* hn_last_error(void);
 
@@ -59,6 +59,10 @@ int hn_clock_sample(int micros, float* mhz, void* stream);
  * Weight banks are checked on the host when they are split (hn_amd.weights.split_f16x3 raises). */
 int hn_range_check_enable(int on);
 int hn_range_check_fetch(int* flag /* host */, int reset, void* stream);
+
+/* The library's A/B switches (HN_CONV_NO_RS, HN_CONV_NO_RS32, HN_SPLIT_GENERIC: select the older kernel forms, results
+ * unchanged) are read from the environment once, at first use; a host that changes them later calls this. */
+int hn_reread_env(void);
 
 /* ------------------------------------------------------------------------------------
  * Convolution (implicit GEMM on f32 / f16 MFMA), fused epilogue.

@@ -507,6 +507,18 @@ def test_f16x3_wide_dynamic_range_keeps_precision():
     assert float((y.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
 
 
+@pytest.fixture(autouse=True)
+def _library_switches_follow_the_environment(monkeypatch):
+    """The library caches its A/B switches; tests that flip them call ops.reread_env() -- and here the cache is put back
+    in step with the restored environment when the test ends."""
+    yield
+    monkeypatch.undo()
+    import torch as _t
+    if _t.cuda.is_available():
+        from hn_amd import ops
+        ops.reread_env()
+
+
 # ---- row-shared A operand (RS kernels): the A tile of a filter ROW is staged once, taps read it at slot offsets ----
 RS_CASES = [
     # n, h, w, cin, cout: image rows shorter / longer than a tile, widths that put row ends at every slot phase,
@@ -538,6 +550,7 @@ def test_conv_f16x3_row_shared_a_is_bit_identical_to_per_tap_form(case, tile, mo
             monkeypatch.setenv("HN_CONV_NO_RS", "1")
         else:
             monkeypatch.delenv("HN_CONV_NO_RS", raising=False)
+        ops.reread_env()
         y32 = ops.conv2d_nhwc(xs, wt.cuda(), b.cuda(), pad=1, relu=True, tile=tile, w16=w16, splitk=False)
         y16 = ops.conv2d_nhwc(xs, wt.cuda(), b.cuda(), pad=1, relu=True, residual=rs32, tile=tile, w16=w16, out_split=True,
                               splitk=False)
@@ -565,6 +578,7 @@ def test_conv_f16x3_row_shared_a_grouped_levels_and_gn_partials(monkeypatch):
             monkeypatch.setenv("HN_CONV_NO_RS", "1")
         else:
             monkeypatch.delenv("HN_CONV_NO_RS", raising=False)
+        ops.reread_env()
         parts = [torch.zeros(ops.gn_rows32_scratch_floats(x.shape[0] * x.shape[1] * x.shape[2], cout), device="cuda") for x in xs]
         ys = ops.conv2d_nhwc_grouped(xs, [cw] * 3, pad=1, gn_partials=parts)
         got[mode] = (ys, parts)
@@ -591,6 +605,7 @@ def test_conv_f16x3_row_shared_a_few_output_channels(case, monkeypatch):
             monkeypatch.setenv("HN_CONV_NO_RS", "1")
         else:
             monkeypatch.delenv("HN_CONV_NO_RS", raising=False)
+        ops.reread_env()
         got.append(ops.conv2d_nhwc(xs, wt.cuda(), b, pad=1, relu_cols=cout - 1, w16=w16, splitk=False))
     assert torch.equal(got[0], got[1])
 
@@ -612,6 +627,7 @@ def test_affine_split_group_stationary_kernel_equals_generic(shape, monkeypatch)
             monkeypatch.setenv("HN_SPLIT_GENERIC", "1")
         else:
             monkeypatch.delenv("HN_SPLIT_GENERIC", raising=False)
+        ops.reread_env()
         outs.append((ops.to_split(x), ops.to_split(x, sc, sh, relu=True), ops.to_split(x, sc, sh, relu=False),
                      ops.to_split(wide[..., c:], sc, sh, relu=True)))
     for a, b in zip(*outs):
