@@ -39,6 +39,9 @@
 // shows 1400 W (the cap) and sclk 1.84 GHz instead of 2.4 (tools/probes/exp/clocks.sh), so the
 // clock-adjusted dense-f16 peak is ~1.9 PFLOP/s; ablations (no DMA: +22 %, no LDS reads: +23 %)
 // show data movement energy, not MFMA issue, is what is left.
+//   * v6: both operands through buffer descriptors (per-lane 32-bit offsets, padding by range check), see ConvParams16;
+//   * v7 ("RS"): 3x3 / stride 1 / pad 1 layers stage the A operand once per filter ROW as a wide tile with zero-filled gap
+//     slots at the image-row ends and read the three taps from it at slot offsets (see the kernel template's comment).
 // Epilogue: bias, residual (fp32 or S32), ReLU on a column prefix, output fp32 or S32.
 // Requires Cin % 32 == 0 (the 4-channel stems stay on the f32 kernel).
 #include "hn_common.h"
