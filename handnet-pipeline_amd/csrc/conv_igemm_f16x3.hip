@@ -1143,6 +1143,7 @@ extern "C" int hn_conv2d_f16x3_uses_rs(const hn_conv_desc* d) {
   if (!d || hn::env_flags().no_rs) return 0;
   if (!(d->r == 3 && d->s == 3 && d->stride == 1 && d->dil == 1 && d->pad == 1 && d->w > 0)) return 0;
   const int tile = hn_conv2d_f16x3_pick_tile(d);
+  if (tile == HN_TILE_256x64_W8 || tile == HN_TILE_256x128_W8) return (256 + 1) / d->w + 1 <= 62 ? 1 : 0;
   if (tile != HN_TILE_128x128 && tile != HN_TILE_128x64 && tile != HN_TILE_128x32) return 0;
   if (tile == HN_TILE_128x32 && hn::env_flags().no_rs32) return 0;
   return (128 + 1) / d->w + 1 <= 30 ? 1 : 0;
@@ -1301,6 +1302,7 @@ static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, c
     // loses to 256x64 without: 421 us)
     case HN_TILE_256x64: return launch16<256, 64, 4, 1, 2>(p, st);
     case HN_TILE_256x128_W8: return launch16<256, 128, 4, 2, 2>(p, st);
+    case HN_TILE_256x64_W8: return launch16<256, 64, 4, 2, 2>(p, st);
     default: return hn::fail(HN_ERR_ARG, "unknown tile id %d", d->tile);
   }
 }

@@ -179,7 +179,7 @@ def from_split(xs16, out=None):
 # bench.py's roofline leg: when set to a list, every conv launch is bracketed by HIP events
 # on the launch stream and ((precision, tile id), algorithmic MACs, timer, shape) is appended.
 CONV_PROFILE = None
-TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x64", 4: "128x32", 5: "256x128", 6: "64x128", 7: "32x64", 8: "256x64", 9: "256x128w8"}
+TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x64", 4: "128x32", 5: "256x128", 6: "64x128", 7: "32x64", 8: "256x64", 9: "256x128w8", 10: "256x64w8"}
 TILE_RS = 0x100  # profile records: tile id | TILE_RS when the launch ran the row-shared-A instantiation of that tile
 
 

@@ -109,6 +109,8 @@ typedef struct hn_conv_desc {
 #define HN_TILE_32x64 7   /* f16x3 only: 2-wave workgroups for small-M layers */
 #define HN_TILE_256x64 8  /* f16x3 only: Cout <= 64 layers with 64x64 wave tiles (4 waves stacked along M) */
 #define HN_TILE_256x128_W8 9 /* f16x3 only: 256x128 with 8 waves (64x64 wave tiles), one workgroup per CU */
+#define HN_TILE_256x64_W8 10 /* f16x3 only: 256x64 with 8 waves (64x32 wave tiles), one workgroup per CU: the form in which the
+                              * row-shared A operand fits for Cout <= 64 (W tile shared by 256 rows) */
 
 int hn_conv2d_nhwc_f32(const hn_conv_desc* d, const float* x, const float* w,
                        const float* bias /* [cout] or NULL */,
