@@ -881,6 +881,11 @@ void conv_igemm_f16x3_kernel(const ConvParams16 p) {
           for (int j = 0; j < TN; ++j) patch[prow * PWP + j * 16 + (lane & 15)] = acc[i + ii][j][r];
         }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // The bias / residual loads above retire HERE, once, in a form the compiler's counter model sees.  Otherwise it
+      // cannot tell at the joins below whether they are still in flight, and because loads and stores share vmcnt it
+      // puts s_waitcnt vmcnt(0) in front of the first bias use of EVERY iteration -- i.e. each iteration waited for
+      // the previous iteration's stores to be acknowledged by memory (~1 k cycles each, 8 per workgroup).
+      if (i == 0) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
       // GroupNorm statistics of this 32-row group, per 8-channel unit, split at the image boundary
       // (a group touches at most two images when OH*OW >= 32): [sum, sumsq] of image A, then of image A+1
       float gsum[4] = {0.f, 0.f, 0.f, 0.f};
