@@ -709,7 +709,10 @@ void conv_igemm_f16x3_kernel(const ConvParams16 p) {
       if constexpr (term == 1 && jj == 0) lgkm_wait<2 * TH + (TM - 1 - i)>();
       mfma_pinned(acc[i][jj], term == 0 ? af.l[i] : af.h[i], term == 1 ? b0.l[jj] : b0.h[jj]);
     });
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // Phase 0 follows the step that put a wide A tile in flight as its YOUNGEST DMA instructions (W pieces first, A pieces
+    // last, below): only the W tile of the next step has to be complete here, the A tile -- first read three steps from
+    // now, and coming from HBM rather than L2 -- stays in flight across this barrier and is retired by phase 1's wait.
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PH == 0 ? A_IT : 0) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     long uoff_b, boff, uoff_a = 0;
@@ -730,10 +733,10 @@ void conv_igemm_f16x3_kernel(const ConvParams16 p) {
       static_for<0, S3::NMEM>([&](auto Q) {
         constexpr int q = decltype(Q)::value;
         if constexpr (S3::slot(q) == k) {
-          if constexpr (q < A_CNT) {
-            dma_a_piece(q, Ad, 0, 0, uoff_a, sh_a);
+          if constexpr (q < B_IT) {
+            dma_b_piece(q, Bd, boff);
           } else if constexpr (q < DPT_PH) {
-            dma_b_piece(q - A_CNT, Bd, boff);
+            dma_a_piece(q - B_IT, Ad, 0, 0, uoff_a, sh_a);
           } else if constexpr (q < DPT_PH + 2 * TH) {
             constexpr int jj = (q - DPT_PH) >> 1;
             if constexpr ((q - DPT_PH) & 1)
@@ -762,8 +765,8 @@ void conv_igemm_f16x3_kernel(const ConvParams16 p) {
     rs_dma_a_tile(0);
     dma_tile(0);
     drain_and_barrier();
-    rs_dma_a_tile(1);
     dma_tile(1);
+    rs_dma_a_tile(1);  // youngest, like in phase 2 of the loop: phase 0's counted wait leaves exactly these in flight
     static_for<0, TH>([&](auto JJ) {
       constexpr int jj = decltype(JJ)::value;
       lds_read_pinned<jj * TILE_OFF>(b0.h[jj], b_rd_hi);

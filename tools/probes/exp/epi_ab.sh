@@ -10,6 +10,6 @@ for v in old new; do
   HN_LIB_PATH=$lib python tools/perf_conv.py f16x3 0 32 200 272 64 64 3 1 1 400 0 1 2>&1 | grep -v amdgpu.ids
   HN_LIB_PATH=$lib python tools/perf_conv.py f16x3 0 32 100 136 128 256 1 1 1 400 0 1 2>&1 | grep -v amdgpu.ids
   HN_LIB_PATH=$lib python bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-roofline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('pipeline b32', d['value'], d['ms_per_step'])"
-  HN_LIB_PATH=$lib python bench.py --workload a2j --steps 50 --warmup 10 --no-cpu-baseline --no-roofline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('a2j b64', d['value'], d['ms_per_step'])"
+  
 done
 done
