@@ -26,6 +26,11 @@ Extra objects in the line:
                 instrumented steps run.  `traffic` is the HBM byte count per launch from the committed
                 rocprofv3 PMC passes (profiles/traffic_latest.json) and is null unless that
                 collection was made at the same launches/step and FLOP/launch (`traffic_source`).
+                `stages` splits the instrumented steps by stage of the hot path (ResNet-34 body / FPN / towers /
+                head outputs / A2J trunk / A2J heads): ms per step, algorithmic TFLOP/s and fraction of the peak.
+  dropin        the same batch through the reference's own callable -- handnet_pipeline.HandNet.forward as
+                ros_demo.py:270-273 calls it (list of [3,H,W] images + depth_images, keypoints copied to the
+                CPU) -- at the bench batch and at batch 1 (the only batch size the reference's caller uses).
   cpu_baseline  the oracle (CPU restatement, kind "port") timed on this box's host cores on a
                 bounded sample of the same workload (rank 0, N == 1 only); the same frames go
                 through the HIP engine and the agreement is reported as `parity`.
@@ -70,6 +75,8 @@ def parse():
                          "the Python engines; same launches, same results")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true",
+                    help="skip the second figure: the same batch through the reference's callable HandNet.forward (+ batch 1)")
     ap.add_argument("--no-clock-sample", action="store_true",
                     help="skip the one-wave in-kernel clock sampler of the roofline leg (it runs beside the step on a side "
                          "stream and would show up as a long kernel in rocprofv3 --stats)")
@@ -174,7 +181,7 @@ def roofline_leg(step, steps, ms_per_step, sample_clock=True):
     try:
         step()                                    # chip under load before the sampling window opens
         if sample_clock:
-            ops.clock_sample(max(1000, int(0.8 * 1e3 * ms_per_step * steps)), out=clock, stream=side)
+            ops.clock_sample(min(2_000_000, max(1000, int(0.8 * 1e3 * ms_per_step * steps))), out=clock, stream=side)
         for _ in range(steps):
             step()
         torch.cuda.synchronize()
@@ -182,12 +189,17 @@ def roofline_leg(step, steps, ms_per_step, sample_clock=True):
     finally:
         ops.CONV_PROFILE = None
     clock_mhz = float(clock.item())
-    groups = {}
-    for kind, macs, timer, shape in recs:
+    groups, stages = {}, {}
+    for kind, macs, timer, shape, stage in recs:
         g = groups.setdefault(kind, {"ms": 0.0, "flop": 0.0, "launches": 0, "bytes": 0.0})
-        g["ms"] += timer.elapsed_ms()
+        ms = timer.elapsed_ms()
+        g["ms"] += ms
         g["flop"] += 2.0 * macs
         g["launches"] += 1
+        st = stages.setdefault(stage or "other", {"ms": 0.0, "flop": 0.0, "launches": 0})
+        st["ms"] += ms
+        st["flop"] += 2.0 * macs
+        st["launches"] += 1
         n, h, w, cin, cout, r, stride, _dil = shape
         # algorithmic bytes: input + filters + output, 4 bytes per value (fp32 or S32 hi+lo)
         g["bytes"] += 4.0 * (n * h * w * cin + cout * r * r * cin + n * (h // stride) * (w // stride) * cout)
@@ -223,6 +235,12 @@ def roofline_leg(step, steps, ms_per_step, sample_clock=True):
         "share_of_conv_time": round(g["ms"] / tot_ms, 3),
         "all_conv_achieved": round(tot_flop / (tot_ms * 1e-3) / 1e12, 2),
         "conv_ms_per_step": round(tot_ms / steps, 3),
+        # convolution launches of the instrumented steps by stage of the hot path (north_star: "fraction of the conv
+        # roofline on the ResNet stages"): HIP-event time per step, algorithmic TFLOP/s and the fraction of `peak`
+        "stages": {name: {"ms_per_step": round(v["ms"] / steps, 3), "launches_per_step": v["launches"] // steps,
+                          "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 1),
+                          "frac": round(v["flop"] / (v["ms"] * 1e-3) / 1e12 / peak, 4)}
+                   for name, v in stages.items() if v["ms"] > 0},
     }
 
 
@@ -238,6 +256,9 @@ def measured_traffic(kernel, gflop_per_launch, launches_per_step):
     stamp = rec.get("bench")
     if not stamp:
         return None, f"{f.name} ({rec.get('tag')}) carries no bench stamp"
+    if rec.get("kernel_source_sha16") != kernel_source_sha16():
+        return None, (f"{rec.get('tag')} (commit {rec.get('commit')}): collected for another revision of "
+                      "csrc/conv_igemm_f16x3.hip (data movement may differ)")
     if stamp.get("kernel") != kernel:
         return None, f"{rec.get('tag')}: collected for {stamp.get('kernel')}, this run's dominant kernel is {kernel}"
     if (stamp.get("launches_per_step") != launches_per_step
@@ -254,6 +275,46 @@ def measured_traffic(kernel, gflop_per_launch, launches_per_step):
         if needle in name and (prec != "f16x3" or name.split(">")[0].rstrip().endswith("true" if rs else "false")):
             return k["hbm_bytes_per_launch"], f"profiles/{rec.get('tag')}_traffic.json (commit {rec.get('commit')})"
     return None, f"{rec.get('tag')}: no {needle} record"
+
+
+def kernel_source_sha16():
+    """Identity of the dominant kernel's source: the HBM-traffic figure of an older revision is never paired with a run."""
+    import hashlib
+    return hashlib.sha256((REPO / "handnet-pipeline_amd" / "csrc" / "conv_igemm_f16x3.hip").read_bytes()).hexdigest()[:16]
+
+
+def dropin_leg(args, sds, dev, batch):
+    """The SAME workload through the reference's callable: handnet_pipeline.HandNet.forward exactly as ros_demo.py:270-273
+    calls it (a list of [3,H,W] images, depth_images=[N,1,H,W]; keypoints come back on the CPU, which is a device -> host
+    copy and a sync per call), at the bench batch and at batch 1 (the reference's caller never batches)."""
+    import types
+
+    from handnet_pipeline.handnet_pipeline import HandNet
+    from hn_amd import synth
+    fcos_sd, a2j_sd = sds
+    net = HandNet(types.SimpleNamespace(pretrained_fcos="-", pretrained_a2j="-"), num_classes=3)
+    net.detector.load_state_dict(fcos_sd, strict=False)
+    net.a2j.load_state_dict(a2j_sd, strict=False)
+    net = net.to(dev).eval()
+    out = {"call": "handnet_pipeline.HandNet.forward(list of [3,H,W], depth_images=[N,1,H,W]) -> (keypoints on the CPU, "
+                   "depth_batch, crops), ros_demo.py:270-273", "precision": args.precision}
+    for b, steps in ((batch, args.steps), (1, max(50, args.steps))):
+        rgb = synth.make_rgb(b, seed=1000).to(dev)
+        depth = synth.make_depth(b, seed=2000).to(dev)
+        images = [rgb[i] for i in range(b)]
+        with torch.inference_mode():
+            for _ in range(3):
+                net(images, depth_images=depth)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                kp, _db, _crops = net(images, depth_images=depth)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        assert kp.device.type == "cpu" and tuple(kp.shape) == (b, 21, 3)
+        out[f"batch{b}"] = {"frames_per_s": round(b * steps / dt, 2), "ms_per_call": round(1e3 * dt / steps, 3), "calls": steps}
+    del net
+    return out
 
 
 def cpu_baseline(args, sds, engine=None, dev=None):
@@ -388,6 +449,10 @@ def main():
     roof = None
     if not args.no_roofline and not args.graph and not args.native:
         roof = roofline_leg(step, max(1, min(args.steps, 3)), 1e3 * elapsed / args.steps, not args.no_clock_sample)
+    dropin = None
+    if (rank == 0 and world == 1 and args.workload == "pipeline" and not args.no_dropin and not args.native
+            and not args.graph):
+        dropin = dropin_leg(args, sds, dev, batch)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, sds, info.get("engine"), dev)
@@ -411,7 +476,7 @@ def main():
                        "gflop_per_unit": round(info["gflop_per_unit"], 3), "hipgraph": bool(args.graph),
                        "host": "C++ layer graph (model-level C ABI)" if args.native else "Python engines (op-level C ABI)"},
             "algorithmic_tflops": round(value * info["gflop_per_unit"] / 1e3, 2),
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "dropin": dropin, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

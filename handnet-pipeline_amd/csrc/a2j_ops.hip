@@ -212,3 +212,103 @@ extern "C" int hn_a2j_aggregate_f32(const float* cls, const float* reg, const fl
   HN_CHECK_LAUNCH("a2j_aggregate_kernel");
   return HN_OK;
 }
+
+// ---------------------------------------------------------------------------------------
+// Per-frame result records of the N > 1 all-gather (hn_amd/dist.py) and the always-on non-finite check
+// ---------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kRecHead = 40;  // 4 x int64 box, int32 has_hand, int32 row flag
+
+// one thread per 4-byte word of a record
+__global__ __launch_bounds__(256) void pack_records_kernel(const float* __restrict__ kp, const long long* __restrict__ box,
+                                                           const int* __restrict__ has, int n, int rows, int j3,
+                                                           int rec_words, unsigned* __restrict__ rec) {
+  const long total = (long)rows * rec_words;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / rec_words), w = (int)(i - (long)r * rec_words);
+    unsigned v = 0u;
+    if (r < n) {
+      if (w < 8) {
+        const long long b = box[(long)r * 4 + (w >> 1)];
+        v = (unsigned)((unsigned long long)b >> ((w & 1) * 32));
+      } else if (w == 8) {
+        v = (unsigned)has[r];
+      } else if (w == 9) {
+        v = 1u;
+      } else if (w - 10 < j3) {
+        v = __float_as_uint(kp[(long)r * j3 + (w - 10)]);
+      }
+    }
+    rec[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void unpack_records_kernel(const unsigned* __restrict__ rec, int rows, int j3, int rec_words,
+                                                             float* __restrict__ kp, long long* __restrict__ box,
+                                                             int* __restrict__ has, int* __restrict__ valid) {
+  const long total = (long)rows * rec_words;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / rec_words), w = (int)(i - (long)r * rec_words);
+    const unsigned v = rec[i];
+    if (w < 8) {
+      if ((w & 1) == 0) {
+        const unsigned hi = rec[i + 1];
+        box[(long)r * 4 + (w >> 1)] = (long long)(((unsigned long long)hi << 32) | v);
+      }
+    } else if (w == 8) {
+      has[r] = (int)v;
+    } else if (w == 9) {
+      valid[r] = (int)v;
+    } else if (w - 10 < j3) {
+      kp[(long)r * j3 + (w - 10)] = __uint_as_float(v);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void nonfinite_count_kernel(const float* __restrict__ x, long count, int* __restrict__ flag) {
+  int bad = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
+    bad += !(fabsf(x[i]) <= 3.402823466e38f) ? 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o);
+  if ((threadIdx.x & 63) == 0 && bad) atomicAdd(flag, bad);
+}
+
+}  // namespace
+
+extern "C" int hn_pack_records(const float* keypoints, const int64_t* crop_box, const int32_t* has_hand, int n, int rows,
+                               int joints, int rec_bytes, void* records, void* stream) {
+  HN_CHECK_ARG(records && (n == 0 || (keypoints && crop_box && has_hand)), "hn_pack_records: null pointer");
+  HN_CHECK_ARG(n >= 0 && rows >= n && joints > 0, "bad dims");
+  HN_CHECK_ARG(rec_bytes >= kRecHead + 12 * joints && rec_bytes % 8 == 0, "rec_bytes must be a multiple of 8 >= 40 + 12*joints");
+  if (rows == 0) return HN_OK;
+  const long total = (long)rows * (rec_bytes / 4);
+  const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+  hipLaunchKernelGGL(pack_records_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, keypoints, (const long long*)crop_box,
+                     has_hand, n, rows, joints * 3, rec_bytes / 4, (unsigned*)records);
+  HN_CHECK_LAUNCH("pack_records_kernel");
+  return HN_OK;
+}
+
+extern "C" int hn_unpack_records(const void* records, int rows, int joints, int rec_bytes, float* keypoints,
+                                 int64_t* crop_box, int32_t* has_hand, int32_t* valid, void* stream) {
+  HN_CHECK_ARG(records && keypoints && crop_box && has_hand && valid, "hn_unpack_records: null pointer");
+  HN_CHECK_ARG(rows >= 0 && joints > 0, "bad dims");
+  HN_CHECK_ARG(rec_bytes >= kRecHead + 12 * joints && rec_bytes % 8 == 0, "rec_bytes must be a multiple of 8 >= 40 + 12*joints");
+  if (rows == 0) return HN_OK;
+  const long total = (long)rows * (rec_bytes / 4);
+  const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+  hipLaunchKernelGGL(unpack_records_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const unsigned*)records, rows,
+                     joints * 3, rec_bytes / 4, keypoints, (long long*)crop_box, has_hand, valid);
+  HN_CHECK_LAUNCH("unpack_records_kernel");
+  return HN_OK;
+}
+
+extern "C" int hn_nonfinite_count_f32(const float* x, int64_t count, int32_t* flag, void* stream) {
+  HN_CHECK_ARG(x && flag && count >= 0, "hn_nonfinite_count_f32: bad arguments");
+  if (count == 0) return HN_OK;
+  const int grid = (int)((count + 255) / 256 < 256 ? (count + 255) / 256 : 256);
+  hipLaunchKernelGGL(nonfinite_count_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (long)count, flag);
+  HN_CHECK_LAUNCH("nonfinite_count_kernel");
+  return HN_OK;
+}

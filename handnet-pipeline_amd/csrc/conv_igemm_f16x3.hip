@@ -42,6 +42,8 @@
 //   * v6: both operands through buffer descriptors (per-lane 32-bit offsets, padding by range check), see ConvParams16;
 //   * v7 ("RS"): 3x3 / stride 1 / pad 1 layers stage the A operand once per filter ROW as a wide tile with zero-filled gap
 //     slots at the image-row ends and read the three taps from it at slot offsets (see the kernel template's comment).
+//   * v8 (round 3): MFMA operands swapped (lane = pixel, registers = channels) + v_permlane16_swap: the epilogue works from
+//     registers with 16-byte accesses, no LDS transposition, no barrier.
 // Epilogue: bias, residual (fp32 or S32), ReLU on a column prefix, output fp32 or S32.
 // Requires Cin % 32 == 0 (the 4-channel stems stay on the f32 kernel).
 #include "hn_common.h"
@@ -126,8 +128,12 @@ __device__ __forceinline__ int fastdiv(int n, unsigned mg, unsigned sh) {
 // memory clobber) neither other pinned MFMAs nor LDS reads / LDS-DMA move across it.  The builtin form let
 // the scheduler hoist fragment reads over the loop back-edge or sink MFMAs past the barrier, and the
 // allocator then rotated accumulators through copies (v_accvgpr_mov) in the hot loop.
+// Operand order (v8): the W fragment `b` is srcA and the activation fragment `a` is srcB (both fragments have the same
+// register layout: lane (r, g) holds row r, k = 8g..8g+7), so the accumulator holds D[channel 4*(lane>>4)+reg][pixel
+// lane&15] -- four consecutive CHANNELS of one pixel per lane, which is what lets the epilogue store 16-byte runs
+// without a transposition through LDS.  Same products, same k order: results are bit-identical to the a-b order.
 __device__ __forceinline__ void mfma_pinned(f32x4& c, const f16x8& a, const f16x8& b) {
-  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b) : "memory");
+  asm volatile("v_mfma_f32_16x16x32_f16 %0, %2, %1, %0" : "+a"(c) : "v"(a), "v"(b) : "memory");
 }
 
 // LDS read with a fixed place in the instruction stream; the compiler neither sees that it is asynchronous
@@ -272,8 +278,12 @@ struct HalfSched {
 // entry W is a gap that the DMA zero-fills (descriptor range check): the left neighbour of a pixel with ow = 0 and the right
 // neighbour of one with ow = W - 1 are then the gap, with no per-tap masking of fragments.  Vertical padding and the slots
 // past the tensor are per-lane invalid bits of the DMA piece, one per filter row.
+// Two waves per SIMD (two 4-wave workgroups or one 8-wave workgroup per CU) are part of the design: one workgroup's
+// prologue / epilogue runs under the other's MFMAs.  The second launch bound makes the register allocator keep to the
+// 256 registers per lane that allows (the v8 epilogue once came out at 194 + 64 = 260 on the 128x128 tile: one workgroup
+// per CU, -40 % on every short-k layer of that tile).  The 4-wave 256x128 sweep variant needs 128 accumulators: one wave.
 template <int BM, int BN, int WM, int WN, int NBUF, bool BUF, bool RS = false>
-__global__ __launch_bounds__(WM* WN * 64)
+__global__ __launch_bounds__(WM* WN * 64, (BM * BN / (WM * WN) > 64 * 64 ? 1 : 2))
 void conv_igemm_f16x3_kernel(const ConvParams16 p) {
   static_assert(NBUF >= 2 && NBUF <= 6, "2..6 LDS stages");
   static_assert(!RS || (BUF && NBUF == 2), "row-shared A needs the descriptor form and the 2-stage pipeline");
@@ -832,140 +842,155 @@ void conv_igemm_f16x3_kernel(const ConvParams16 p) {
   const _Float16* res16 = reinterpret_cast<const _Float16*>(q.res);
   float* y32 = reinterpret_cast<float*>(q.y);
   _Float16* y16 = reinterpret_cast<_Float16*>(q.y);
+  // v8 (round 3): the MFMAs run with SWAPPED operands (the W fragment as srcA, the activation fragment as srcB; the two
+  // fragment layouts are identical, so the main loop is unchanged), which makes a lane own output PIXEL (lane & 15) of a
+  // 16-row tile and, per column tile j, the four consecutive channels 16j + 4*(lane >> 4) + reg.  One v_permlane16_swap
+  // per register (gfx950) then exchanges 16-lane rows between the accumulators of two neighbouring column tiles, after
+  // which every lane holds EIGHT consecutive channels of its pixel: bias / residual are read and fp32 or S32 results
+  // written with 16-byte accesses straight from registers.  The round-1/2 epilogue got the same ownership by transposing
+  // every accumulator through LDS (64 ds_write_b32 + 16 ds_read_b128 per lane and a workgroup barrier, ~12.5-14 k cycles
+  // per 128x128 tile, profiles/r02_conv_phase_stamps.txt) -- for the short-k layers (ResNet-34 layer1, the stem, all of
+  // A2J) that was a third to a half of a workgroup's life.
+  const int px = lane & 15;
+  // channel offset of this lane inside a PAIR of column tiles after the row exchange (see swap8 below)
+  const int nsub = (lg & 1) * 16 + (lg >> 1) * 8;
+  const int n_wave = n0 + wn * (BN / WN);
+  // rows {1, 3} of x <-> rows {0, 2} of y (16-lane rows): lane (px, g) ends up with channels
+  //   pair base + 16 * (g & 1) + 8 * (g >> 1) + [0, 8)   as   x[0..3], y[0..3]
+  auto swap8 = [&](f32x4& x, f32x4& y) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      // (__float_as_uint, not __builtin_bit_cast: the latter on an ext-vector ELEMENT reads element 0 with this compiler)
+      const auto s = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[r]), __float_as_uint(y[r]), false, false);
+      x[r] = __uint_as_float(s[0]);
+      y[r] = __uint_as_float(s[1]);
+    }
+  };
   if (p.vec_epi) {
-    // Vector path (Cout % 8 == 0): every wave transposes its accumulators through a private
-    // LDS patch (32 rows x TN*16 columns per pass) so that each lane then owns 8 consecutive
-    // channels of one pixel: bias / residual are read and the result is written with 16-byte
-    // accesses (the raw MFMA layout would need 2-byte stores for S32 outputs).
-    constexpr int PW = TN * 16;       // patch width in floats
-    constexpr int PWP = PW + 4;       // padded pitch: the four 16-lane groups hit disjoint banks
-    constexpr int GROUPS = PW / 8;    // 8-channel groups per row
-    __syncthreads();                  // every wave is done with the operand tiles in LDS
-    float* patch = reinterpret_cast<float*>(smem) + wave * (32 * PWP);
-    // a lane handles the SAME 8-channel group in every iteration of every pass (64 % GROUPS == 0): its bias is loaded once
-    static_assert(64 % GROUPS == 0, "lane -> channel group must not depend on the iteration");
-    const int n_lane = n0 + wn * (BN / WN) + (lane % GROUPS) * 8;
-    f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = {0.f, 0.f, 0.f, 0.f};
-    if (q.bias && n_lane < p.Cout) {
-      bias0 = *reinterpret_cast<const f32x4*>(q.bias + n_lane);
-      bias1 = *reinterpret_cast<const f32x4*>(q.bias + n_lane + 4);
+    constexpr int NP = TN / 2;        // column-tile pairs per wave
+    f32x4 bias0[NP], bias1[NP];
+#pragma unroll
+    for (int jp = 0; jp < NP; ++jp) {
+      const int n = n_wave + jp * 32 + nsub;
+      bias0[jp] = f32x4{0.f, 0.f, 0.f, 0.f};
+      bias1[jp] = bias0[jp];
+      if (q.bias && n < p.Cout) {
+        bias0[jp] = *reinterpret_cast<const f32x4*>(q.bias + n);
+        bias1[jp] = *reinterpret_cast<const f32x4*>(q.bias + n + 4);
+      }
     }
     // S32 residual of the output's own shape (every ResNet block): ALL of this lane's 16-byte pieces are requested
-    // here, before the first transpose, so the passes below wait for ONE memory latency instead of one per pass
-    // (in-kernel stamps: the epilogue of a 256x64 layer1 workgroup took 23.0k cycles with a residual, 11.2k without)
-    constexpr int EK = (32 * GROUPS) / 64;          // iterations per pass
-    constexpr bool PREF = (TM / 2) * EK <= 8;       // <= 64 VGPRs of prefetched residual (the fragments are dead by now)
-    f16x8 rpre_h[PREF ? (TM / 2) * EK : 1], rpre_l[PREF ? (TM / 2) * EK : 1];
+    // here, before the first use, so the loop below waits for ONE memory latency
+    constexpr bool PREF = TM * NP <= 8;   // <= 64 VGPRs of prefetched residual (the fragments are dead by now)
+    f16x8 rpre_h[PREF ? TM * NP : 1], rpre_l[PREF ? TM * NP : 1];
     const bool use_pre = PREF && q.res_mode == 1 && q.res_split;
     if constexpr (PREF) {
       if (use_pre) {
 #pragma unroll
-        for (int i = 0; i < TM; i += 2)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int k = 0; k < EK; ++k) {
-            const int prow = (lane + 64 * k) / GROUPS;
-            int m = m0 + wm * (BM / WM) + i * 16 + prow;
+          for (int jp = 0; jp < NP; ++jp) {
+            int m = m0 + wm * (BM / WM) + i * 16 + px;
             m = m < o.M ? m : o.M - 1;
-            const int n = n_lane < p.Cout ? n_lane : 0;
+            int n = n_wave + jp * 32 + nsub;
+            n = n < p.Cout ? n : 0;
             const _Float16* q16 = res16 + (long)m * q.rs + (n >> 5) * 64 + (n & 31);
-            rpre_h[(i / 2) * EK + k] = *reinterpret_cast<const f16x8*>(q16);
-            rpre_l[(i / 2) * EK + k] = *reinterpret_cast<const f16x8*>(q16 + 32);
+            rpre_h[i * NP + jp] = *reinterpret_cast<const f16x8*>(q16);
+            rpre_l[i * NP + jp] = *reinterpret_cast<const f16x8*>(q16 + 32);
           }
       }
     }
+    // The bias / residual loads above retire HERE, once, in a form the compiler's counter model sees.  Otherwise it
+    // cannot tell at the joins below whether they are still in flight, and because loads and stores share vmcnt it
+    // puts s_waitcnt vmcnt(0) in front of later bias uses -- i.e. a store batch would wait for the previous batch's
+    // stores to be acknowledged by memory (~1 k cycles each).
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 #pragma unroll
-    for (int i = 0; i < TM; i += 2) {  // 32 rows (two 16-row tiles) per pass
-#pragma unroll
-      for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int prow = ii * 16 + lg * 4 + r;  // C/D map: row = 4*(lane>>4) + reg, col = lane&15
-#pragma unroll
-          for (int j = 0; j < TN; ++j) patch[prow * PWP + j * 16 + (lane & 15)] = acc[i + ii][j][r];
-        }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      // The bias / residual loads above retire HERE, once, in a form the compiler's counter model sees.  Otherwise it
-      // cannot tell at the joins below whether they are still in flight, and because loads and stores share vmcnt it
-      // puts s_waitcnt vmcnt(0) in front of the first bias use of EVERY iteration -- i.e. each iteration waited for
-      // the previous iteration's stores to be acknowledged by memory (~1 k cycles each, 8 per workgroup).
-      if (i == 0) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    for (int i = 0; i < TM; i += 2) {  // 32 rows (two 16-row tiles) per pass: one GroupNorm row group
       // GroupNorm statistics of this 32-row group, per 8-channel unit, split at the image boundary
       // (a group touches at most two images when OH*OW >= 32): [sum, sumsq] of image A, then of image A+1
-      float gsum[4] = {0.f, 0.f, 0.f, 0.f};
+      float gsum[NP][4];
+#pragma unroll
+      for (int jp = 0; jp < NP; ++jp)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gsum[jp][e] = 0.f;
       const int m_grp = m0 + wm * (BM / WM) + i * 16;
       const int m_split = (fastdiv(m_grp < o.M ? m_grp : o.M - 1, o.mg_ohow, o.sh_ohow) + 1) * ohow;  // first row of the next image
 #pragma unroll
-      for (int k = 0; k < (32 * GROUPS) / 64; ++k) {
-        const int qq = lane + 64 * k;
-        const int prow = qq / GROUPS, g = qq - prow * GROUPS;
-        const int m = m0 + wm * (BM / WM) + i * 16 + prow;
-        const int n = n_lane;
-        const f32x4 c0 = *reinterpret_cast<const f32x4*>(&patch[prow * PWP + g * 8]);
-        const f32x4 c1 = *reinterpret_cast<const f32x4*>(&patch[prow * PWP + g * 8 + 4]);
-        if (m >= o.M || n >= p.Cout) continue;
-        float v[8];
+      for (int ii = 0; ii < 2; ++ii) {
+        const int m = m_grp + ii * 16 + px;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {   // + 0 when there is no bias (exact)
-          v[e] = c0[e] + bias0[e];
-          v[4 + e] = c1[e] + bias1[e];
-        }
-        if (q.gn_partial) {
-          float s1 = 0.f, s2 = 0.f;
+        for (int jp = 0; jp < NP; ++jp) {
+          f32x4 x = acc[i + ii][2 * jp], y = acc[i + ii][2 * jp + 1];
+          swap8(x, y);
+          const int n = n_wave + jp * 32 + nsub;
+          if (m >= o.M || n >= p.Cout) continue;
+          float v[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            s1 += v[e];
-            s2 += v[e] * v[e];
+          for (int e = 0; e < 4; ++e) {   // + 0 when there is no bias (exact)
+            v[e] = x[e] + bias0[jp][e];
+            v[4 + e] = y[e] + bias1[jp][e];
           }
-          const bool second = m >= m_split;
-          gsum[0] += second ? 0.f : s1;
-          gsum[1] += second ? 0.f : s2;
-          gsum[2] += second ? s1 : 0.f;
-          gsum[3] += second ? s2 : 0.f;
-        }
-        if constexpr (PREF) {
-          if (use_pre) epi_finish8(q, m, n, v, ohow, &rpre_h[(i / 2) * EK + k], &rpre_l[(i / 2) * EK + k]);
-          else epi_finish8(q, m, n, v, ohow);
-        } else {
-          epi_finish8(q, m, n, v, ohow);
+          if (q.gn_partial) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              s1 += v[e];
+              s2 += v[e] * v[e];
+            }
+            const bool second = m >= m_split;
+            gsum[jp][0] += second ? 0.f : s1;
+            gsum[jp][1] += second ? 0.f : s2;
+            gsum[jp][2] += second ? s1 : 0.f;
+            gsum[jp][3] += second ? s2 : 0.f;
+          }
+          if constexpr (PREF) {
+            if (use_pre) epi_finish8(q, m, n, v, ohow, &rpre_h[(i + ii) * NP + jp], &rpre_l[(i + ii) * NP + jp]);
+            else epi_finish8(q, m, n, v, ohow);
+          } else {
+            epi_finish8(q, m, n, v, ohow);
+          }
         }
       }
       if (q.gn_partial) {
-        // lanes with equal (lane % GROUPS) hold the same channel unit: fixed-order butterfly over the rows
+        // the 16 lanes of a row (equal lane >> 4) hold the same channel unit for 16 different pixels: fixed-order butterfly
 #pragma unroll
-        for (int o = GROUPS; o < 64; o <<= 1)
+        for (int jp = 0; jp < NP; ++jp) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) gsum[e] += __shfl_xor(gsum[e], o);
-        const int n = n0 + wn * (BN / WN) + lane * 8;
-        if (lane < GROUPS && n < p.Cout && m_grp < o.M) {
-          f32x4 o4 = {gsum[0], gsum[1], gsum[2], gsum[3]};
-          *reinterpret_cast<f32x4*>(q.gn_partial + ((long)(m_grp >> 5) * p.gn_units + (n >> 3)) * 4) = o4;
+          for (int ofs = 1; ofs < 16; ofs <<= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gsum[jp][e] += __shfl_xor(gsum[jp][e], ofs);
+          const int n = n_wave + jp * 32 + nsub;
+          if (px == 0 && n < p.Cout && m_grp < o.M) {
+            f32x4 o4 = {gsum[jp][0], gsum[jp][1], gsum[jp][2], gsum[jp][3]};
+            *reinterpret_cast<f32x4*>(q.gn_partial + ((long)(m_grp >> 5) * p.gn_units + (n >> 3)) * 4) = o4;
+          }
         }
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // patch reads done before the next pass rewrites it
     }
     return;
   }
-  // Scalar path (ragged Cout such as the 5-channel FCOS outputs, or unaligned fp32 strides)
+  // Scalar path (ragged Cout such as the 5-channel FCOS outputs, or unaligned fp32 strides): the raw (swapped) MFMA
+  // layout -- lane = pixel (lane & 15), registers = channels 16j + 4*(lane >> 4) + r
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * (BM / WM) + i * 16 + px;
+    if (m >= o.M) continue;
+    long rpix = 0;
+    if (p.res_mode == 1) {
+      rpix = (long)m;
+    } else if (p.res_mode == 2) {
+      const int img = m / ohow;
+      const int rem = m - img * ohow;
+      const int oh = rem / o.OW, ow = rem - oh * o.OW;
+      const int sh_ = (int)(((long)oh * p.res_h) / o.OH), sw_ = (int)(((long)ow * p.res_w) / o.OW);
+      rpix = ((long)img * p.res_h + sh_) * p.res_w + sw_;
+    }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = wm * (BM / WM) + i * 16 + lg * 4 + r;
-      const int m = m0 + row;
-      if (m >= o.M) continue;
-      long rpix = 0;
-      if (p.res_mode == 1) {
-        rpix = (long)m;
-      } else if (p.res_mode == 2) {
-        const int img = m / ohow;
-        const int rem = m - img * ohow;
-        const int oh = rem / o.OW, ow = rem - oh * o.OW;
-        const int sh_ = (int)(((long)oh * p.res_h) / o.OH), sw_ = (int)(((long)ow * p.res_w) / o.OW);
-        rpix = ((long)img * p.res_h + sh_) * p.res_w + sw_;
-      }
+    for (int j = 0; j < TN; ++j) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / WN) + j * 16 + (lane & 15);
+      for (int r = 0; r < 4; ++r) {
+        const int n = n_wave + j * 16 + lg * 4 + r;
         if (n >= p.Cout) continue;
         float v = acc[i][j][r];
         if (q.bias) v += q.bias[n];

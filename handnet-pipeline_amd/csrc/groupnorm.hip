@@ -130,7 +130,88 @@ __global__ __launch_bounds__(256) void gn_finalize_rows32_kernel(const float* __
   }
 }
 
+// The same finalize for all FPN levels of one tower layer in ONE launch (blockIdx.z = level): at small batch the three
+// per-level launches are 4.5 us each of pure launch latency (profiles/r03_b1_timeline.txt).
+struct GnLevelTable {
+  int count;
+  int hw[HN_FCOS_MAX_LEVELS];
+  const float* partial[HN_FCOS_MAX_LEVELS];
+  float* scale[HN_FCOS_MAX_LEVELS];
+  float* shift[HN_FCOS_MAX_LEVELS];
+};
+
+__global__ __launch_bounds__(256) void gn_finalize_rows32_levels_kernel(const GnLevelTable lt, const float* __restrict__ gamma,
+                                                                        const float* __restrict__ beta, int c, int groups,
+                                                                        float eps) {
+  const int lvl = blockIdx.z;
+  const int img = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (g >= groups) return;
+  // constant-index selects: a dynamic index into the by-value table would send it through scratch memory
+  int hw = lt.hw[0];
+  const float* partial = lt.partial[0];
+  float *scale = lt.scale[0], *shift = lt.shift[0];
+#pragma unroll
+  for (int l = 1; l < HN_FCOS_MAX_LEVELS; ++l)
+    if (l == lvl) {
+      hw = lt.hw[l];
+      partial = lt.partial[l];
+      scale = lt.scale[l];
+      shift = lt.shift[l];
+    }
+  const int cpg = c / groups, upg = cpg >> 3, units = c >> 3;
+  const long row0 = (long)img * hw, row1 = row0 + hw - 1;
+  const int rg0 = (int)(row0 >> 5), rg1 = (int)(row1 >> 5);
+  const int items = (rg1 - rg0 + 1) * upg;
+  double s = 0.0, ss = 0.0;
+  for (int k = lane; k < items; k += 64) {   // same lane assignment and order as gn_finalize_rows32_kernel: same bits
+    const int rg = rg0 + k / upg, u = g * upg + k % upg;
+    const int img_a = (int)(((long)rg << 5) / hw);
+    const float* pp = partial + ((long)rg * units + u) * 4 + (img_a == img ? 0 : 2);
+    s += (double)pp[0];
+    ss += (double)pp[1];
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o);
+    ss += __shfl_xor(ss, o);
+  }
+  const double cnt = (double)hw * cpg;
+  const double mean = s / cnt;
+  double var = ss / cnt - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  for (int e = lane; e < cpg; e += 64) {
+    const int ch = g * cpg + e;
+    const float sc = gamma[ch] * rstd;
+    scale[(long)img * c + ch] = sc;
+    shift[(long)img * c + ch] = beta[ch] - (float)mean * sc;
+  }
+}
+
 }  // namespace
+
+extern "C" int hn_groupnorm_finalize_rows32_levels(const hn_gn_levels* lv, const float* gamma, const float* beta, int n,
+                                                   int c, int groups, float eps, void* stream) {
+  HN_CHECK_ARG(lv && gamma && beta, "hn_groupnorm_finalize_rows32_levels: null pointer");
+  HN_CHECK_ARG(lv->count >= 1 && lv->count <= HN_FCOS_MAX_LEVELS, "level count must be 1..%d", HN_FCOS_MAX_LEVELS);
+  HN_CHECK_ARG(n > 0 && c > 0 && groups > 0 && c % groups == 0, "bad dims");
+  HN_CHECK_ARG((c / groups) % 8 == 0, "channels per group (%d) must be a multiple of 8", c / groups);
+  GnLevelTable lt;
+  lt.count = lv->count;
+  for (int l = 0; l < HN_FCOS_MAX_LEVELS; ++l) {
+    const bool on = l < lv->count;
+    if (on) HN_CHECK_ARG(lv->partial[l] && lv->scale[l] && lv->shift[l] && lv->hw[l] >= 32, "level %d: null pointer or hw < 32", l);
+    lt.hw[l] = on ? lv->hw[l] : 32;
+    lt.partial[l] = on ? lv->partial[l] : nullptr;
+    lt.scale[l] = on ? lv->scale[l] : nullptr;
+    lt.shift[l] = on ? lv->shift[l] : nullptr;
+  }
+  hipLaunchKernelGGL(gn_finalize_rows32_levels_kernel, dim3((groups + 3) / 4, n, lv->count), dim3(256), 0, (hipStream_t)stream,
+                     lt, gamma, beta, c, groups, eps);
+  HN_CHECK_LAUNCH("gn_finalize_rows32_levels_kernel");
+  return HN_OK;
+}
 
 extern "C" int64_t hn_groupnorm_rows32_scratch_floats(int64_t rows, int c) {
   if (rows <= 0 || c <= 0) return 0;

@@ -152,6 +152,84 @@ __global__ __launch_bounds__(256) void affine_split_pow2_kernel(const float* __r
   }
 }
 
+// All FPN levels of one tower layer in ONE launch (small batch: three launches are 4.5 us of launch latency each).
+// blockIdx.x walks the levels' block ranges one after the other; otherwise affine_split_pow2_kernel<true, 0, 2>.
+struct SplitLevelTable {
+  int count;
+  int hw[HN_FCOS_MAX_LEVELS];
+  int first_block[HN_FCOS_MAX_LEVELS + 1];
+  const float* x[HN_FCOS_MAX_LEVELS];
+  const float* scale[HN_FCOS_MAX_LEVELS];
+  const float* shift[HN_FCOS_MAX_LEVELS];
+  _Float16* y[HN_FCOS_MAX_LEVELS];
+};
+
+__global__ __launch_bounds__(256) void affine_split_pow2_levels_kernel(const SplitLevelTable lt, int relu, int c8_log2, int xs,
+                                                                       int as, int ys, int* range_flag) {
+  // constant-index selects (a dynamic index into the by-value table would go through scratch memory)
+  int lvl = 0;
+#pragma unroll
+  for (int l = 1; l < HN_FCOS_MAX_LEVELS; ++l)
+    if (l < lt.count && (int)blockIdx.x >= lt.first_block[l]) lvl = l;
+  int hw = lt.hw[0], b0 = lt.first_block[0], b1 = lt.first_block[1];
+  const float *x = lt.x[0], *scale = lt.scale[0], *shift = lt.shift[0];
+  _Float16* y = lt.y[0];
+#pragma unroll
+  for (int l = 1; l < HN_FCOS_MAX_LEVELS; ++l)
+    if (l == lvl) {
+      hw = lt.hw[l]; b0 = lt.first_block[l]; b1 = lt.first_block[l + 1];
+      x = lt.x[l]; scale = lt.scale[l]; shift = lt.shift[l]; y = lt.y[l];
+    }
+  const int c8 = 1 << c8_log2;
+  const int grp = threadIdx.x & (c8 - 1), ch = grp * 8;
+  const int ppb = 256 >> c8_log2;
+  const int img = blockIdx.y;
+  const long o = (long)img * as + ch;
+  const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale + o), s1 = *reinterpret_cast<const f32x4*>(scale + o + 4);
+  const f32x4 t0 = *reinterpret_cast<const f32x4*>(shift + o), t1 = *reinterpret_cast<const f32x4*>(shift + o + 4);
+  const float* xi = x + (long)img * hw * xs + ch;
+  _Float16* yi = y + (long)img * hw * ys + (ch >> 5) * 64 + (ch & 31);
+  const int step = (b1 - b0) * ppb;
+  auto one = [&](f32x4 a, f32x4 b, int pix) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      a[e] = a[e] * s0[e] + t0[e];
+      b[e] = b[e] * s1[e] + t1[e];
+    }
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a[e] = fmaxf(a[e], 0.f);
+        b[e] = fmaxf(b[e], 0.f);
+      }
+    }
+    if (range_flag) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        hn::range_note(range_flag, a[e]);
+        hn::range_note(range_flag, b[e]);
+      }
+    }
+    f16x8 hi, lo;
+    split8(a, b, hi, lo);
+    _Float16* dst = yi + (long)pix * ys;
+    *reinterpret_cast<f16x8*>(dst) = hi;
+    *reinterpret_cast<f16x8*>(dst + 32) = lo;
+  };
+  int pix = ((int)blockIdx.x - b0) * ppb + (threadIdx.x >> c8_log2);
+  for (; pix + step < hw; pix += 2 * step) {
+    const float *q0 = xi + (long)pix * xs, *q1 = xi + (long)(pix + step) * xs;
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(q0), b0v = *reinterpret_cast<const f32x4*>(q0 + 4);
+    const f32x4 a1 = *reinterpret_cast<const f32x4*>(q1), b1v = *reinterpret_cast<const f32x4*>(q1 + 4);
+    one(a0, b0v, pix);
+    one(a1, b1v, pix + step);
+  }
+  for (; pix < hw; pix += step) {
+    const float* q = xi + (long)pix * xs;
+    one(*reinterpret_cast<const f32x4*>(q), *reinterpret_cast<const f32x4*>(q + 4), pix);
+  }
+}
+
 __global__ __launch_bounds__(256) void unsplit_kernel(const _Float16* __restrict__ x, long npix, int c, int xs,
                                                       float* __restrict__ y, int ys) {
   const int c8 = c >> 3;
@@ -271,6 +349,55 @@ extern "C" int hn_affine_split_f32(const float* x, const float* scale, const flo
   hipLaunchKernelGGL(affine_split_kernel, dim3(grid_for(npix * (c / 8))), dim3(256), 0, (hipStream_t)stream, x, scale,
                      shift, relu, npix, hw, c, xs, as, (_Float16*)y16, ys, hn::range_flag_ptr());
   HN_CHECK_LAUNCH("affine_split_kernel");
+  return HN_OK;
+}
+
+extern "C" int hn_affine_split_f32_levels(const hn_split_levels* lv, int relu, int n, int c, int in_pix_stride,
+                                          int affine_stride, int out_pix_stride, void* stream) {
+  HN_CHECK_ARG(lv, "hn_affine_split_f32_levels: null pointer");
+  HN_CHECK_ARG(lv->count >= 1 && lv->count <= HN_FCOS_MAX_LEVELS, "level count must be 1..%d", HN_FCOS_MAX_LEVELS);
+  HN_CHECK_ARG(n > 0 && c > 0 && c % 32 == 0, "bad dims (c must be a multiple of 32)");
+  const int xs = in_pix_stride ? in_pix_stride : c;
+  const int as = affine_stride ? affine_stride : c;
+  const int ys = out_pix_stride ? out_pix_stride : 2 * c;
+  HN_CHECK_ARG(xs >= c && xs % 4 == 0 && as >= c && as % 4 == 0 && ys >= 2 * c && ys % 64 == 0, "bad strides");
+  const int c8 = c / 8;
+  bool merged = (c8 & (c8 - 1)) == 0 && c8 <= 256 && n <= 65535 && !hn::env_flags().split_generic;
+  for (int l = 0; l < lv->count; ++l) {
+    HN_CHECK_ARG(lv->x[l] && lv->y16[l] && lv->scale[l] && lv->shift[l] && lv->hw[l] > 0, "level %d: null pointer or hw <= 0", l);
+    // tensors no cache keeps take the streaming-store form of the per-level launch (see hn_affine_split_f32)
+    if ((int64_t)n * lv->hw[l] * c * 4 >= ((int64_t)128 << 20)) merged = false;
+  }
+  if (!merged) {
+    for (int l = 0; l < lv->count; ++l) {
+      const int rc = hn_affine_split_f32(lv->x[l], lv->scale[l], lv->shift[l], relu, n, lv->hw[l], c, in_pix_stride,
+                                         affine_stride, lv->y16[l], out_pix_stride, stream);
+      if (rc != HN_OK) return rc;
+    }
+    return HN_OK;
+  }
+  int lg = 0;
+  while ((1 << lg) < c8) ++lg;
+  const int ppb = 256 >> lg;
+  SplitLevelTable lt;
+  lt.count = lv->count;
+  lt.first_block[0] = 0;
+  const int cap = hn::cdiv(16384, n);
+  for (int l = 0; l < HN_FCOS_MAX_LEVELS; ++l) {
+    const bool on = l < lv->count;
+    int gx = on ? hn::cdiv(lv->hw[l], 2 * ppb) : 0;
+    gx = gx < cap ? gx : cap;
+    gx = on && gx < 1 ? 1 : gx;
+    lt.hw[l] = on ? lv->hw[l] : 0;
+    lt.first_block[l + 1] = lt.first_block[l] + gx;
+    lt.x[l] = on ? lv->x[l] : nullptr;
+    lt.scale[l] = on ? lv->scale[l] : nullptr;
+    lt.shift[l] = on ? lv->shift[l] : nullptr;
+    lt.y[l] = on ? (_Float16*)lv->y16[l] : nullptr;
+  }
+  hipLaunchKernelGGL(affine_split_pow2_levels_kernel, dim3(lt.first_block[lv->count], n), dim3(256), 0, (hipStream_t)stream, lt,
+                     relu, lg, xs, as, ys, hn::range_flag_ptr());
+  HN_CHECK_LAUNCH("affine_split_pow2_levels_kernel");
   return HN_OK;
 }
 

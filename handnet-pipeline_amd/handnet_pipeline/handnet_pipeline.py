@@ -22,6 +22,7 @@ import torch
 from a2j.a2j import A2JModel
 from fcos_utils.fcos import FCOS
 from a2j.a2j import A2JModelLightning
+from hn_amd import ops
 from hn_amd.pipeline import HandNetEngine
 from hn_amd.state import EngineOwner
 
@@ -103,6 +104,13 @@ class HandNet(EngineOwner):
         mask = out.has_hand.bool()
         final_results = out.keypoints.cpu()          # the reference returns keypoints on the CPU
         mask_cpu = mask.cpu()
+        # always-on safety net of the f16x3 range contract, at no device cost: the check runs on the 8 KB the reference's
+        # own .cpu() has just copied.  An activation beyond the fp16 range (|v| > 65504, e.g. BN-folded trained filters of
+        # extreme scale) shows up here as inf / NaN keypoints -- refuse to hand them to the caller.
+        if not bool(torch.isfinite(final_results).all()):
+            raise ops.RangeError("non-finite keypoints: an activation left the range of the f16x3 split format "
+                                 "(|v| > 65504) or the inputs were non-finite.  Run with HN_CHECK_RANGE=1 to locate the "
+                                 "producer, or build the engines with precision='f32'")
         if not bool(mask_cpu.any()):  # handnet_pipeline.py:107-108: the crops placeholder is a CPU float tensor
             return torch.zeros((n, 21, 3)), torch.zeros_like(depth_images), torch.zeros((n, 4))
         sel = out.crops_nhwc[mask]

@@ -12,7 +12,7 @@ from pathlib import Path
 
 from . import build as _build
 
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, TILE_256x128, TILE_64x128 = range(7)
 HN_FCOS_MAX_LEVELS = 5
@@ -53,6 +53,18 @@ class FcosLevels(C.Structure):
                 ("stride", C.c_int32 * HN_FCOS_MAX_LEVELS),
                 ("cls_lr", C.c_void_p * HN_FCOS_MAX_LEVELS),
                 ("reg_ctr", C.c_void_p * HN_FCOS_MAX_LEVELS)]
+
+
+class GnLevels(C.Structure):  # == struct hn_gn_levels
+    _fields_ = [("count", C.c_int32), ("hw", C.c_int32 * HN_FCOS_MAX_LEVELS),
+                ("partial", C.c_void_p * HN_FCOS_MAX_LEVELS), ("scale", C.c_void_p * HN_FCOS_MAX_LEVELS),
+                ("shift", C.c_void_p * HN_FCOS_MAX_LEVELS)]
+
+
+class SplitLevels(C.Structure):  # == struct hn_split_levels
+    _fields_ = [("count", C.c_int32), ("hw", C.c_int32 * HN_FCOS_MAX_LEVELS),
+                ("x", C.c_void_p * HN_FCOS_MAX_LEVELS), ("scale", C.c_void_p * HN_FCOS_MAX_LEVELS),
+                ("shift", C.c_void_p * HN_FCOS_MAX_LEVELS), ("y16", C.c_void_p * HN_FCOS_MAX_LEVELS)]
 
 
 # name -> (restype, argtypes); every symbol of include/handnet_hip.h is listed here and
@@ -112,6 +124,11 @@ SIGNATURES = {
     "hn_a2j_forward": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, VP, VP, VP]),
     "hn_handnet_forward": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP]),
     "hn_destroy": (C.c_int, [VP]),
+    "hn_groupnorm_finalize_rows32_levels": (C.c_int, [C.POINTER(GnLevels), VP, VP, C.c_int, C.c_int, C.c_int, C.c_float, VP]),
+    "hn_affine_split_f32_levels": (C.c_int, [C.POINTER(SplitLevels)] + [C.c_int] * 6 + [VP]),
+    "hn_pack_records": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP]),
+    "hn_unpack_records": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, VP]),
+    "hn_nonfinite_count_f32": (C.c_int, [VP, C.c_int64, VP, VP]),
     "hn_convert_joints_f32": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_float, C.c_float, c_f32p, VP, VP]),
 }
 

@@ -90,6 +90,7 @@ class A2JEngine:
 
     def trunk(self, x):
         """x [K,H,W,4] NHWC fp32 -> (x3 [K,H/16,W/16,1024], x4 [K,H/16,W/16,2048]) (S32 in f16x3 mode)."""
+        ops.PROFILE_STAGE = "a2j_trunk"
         x = self._conv(x, self.stem, algo_cin=4 if self.rgbd else 3)
         x = ops.maxpool3x3s2_nhwc(x)
         x3 = None
@@ -104,6 +105,7 @@ class A2JEngine:
         return x3, x
 
     def heads(self, x3, x4):
+        ops.PROFILE_STAGE = "a2j_heads"
         c = self._conv(x3, self.cls_convs[0])
         rd = self._conv(x4, self.regdep_conv1)
         # the fused tensor has 512 channels: 0..255 regression tower, 256..511 depth tower

@@ -82,13 +82,25 @@ def gather_results(keypoints: torch.Tensor, crop_box: torch.Tensor, has_hand: to
     j3 = j * three
     rec = _record_bytes(j3)
     send, recv = _buffers(per_rank, world, rec, dev)
+    grouped = world > 1 or dist.is_initialized()
+    if keypoints.is_cuda and three == 3:
+        # the GPU path: ONE pack launch (shard padding included), the collective, ONE unpack launch
+        from . import ops
+        with ops.on_device(dev):
+            ops.pack_records(keypoints.to(torch.float32).contiguous(), crop_box.to(torch.int64).contiguous(),
+                             has_hand.to(torch.int32).contiguous(), per_rank, rec, out=send)
+            if grouped:  # a single-rank group still runs the collective (RCCL rehearsal on one GPU)
+                dist.all_gather_into_tensor(recv, send, group=group)
+            kp, box, has, valid = ops.unpack_records(recv, j)
+        return kp, box, has, valid.bool()
+    # host tensors (gloo rehearsal, CPU tests): the same record layout with torch ops
     if b < per_rank:
         send[b:].zero_()
     send[:b, :32] = crop_box.to(torch.int64).contiguous().view(torch.uint8).reshape(b, 32)
     flags = torch.stack([has_hand.to(torch.int32), torch.ones_like(has_hand, dtype=torch.int32)], dim=1)
     send[:b, 32:_HEAD] = flags.contiguous().view(torch.uint8).reshape(b, 8)
     send[:b, _HEAD:_HEAD + 4 * j3] = keypoints.to(torch.float32).reshape(b, j3).contiguous().view(torch.uint8)
-    if world > 1 or dist.is_initialized():  # a single-rank group still runs the collective (RCCL rehearsal on one GPU)
+    if grouped:
         dist.all_gather_into_tensor(recv, send, group=group)
     rows = world * per_rank
     box = recv[:, :32].contiguous().view(torch.int64).reshape(rows, 4)

@@ -132,6 +132,7 @@ class FCOSEngine:
     def backbone(self, x):
         """x: preprocessed canvas -- fp32 [N,PH,PW,4], or the fp16 stem image [2,N,PH+6,PW+6,4] of
         ops.fcos_preprocess_split (f16x3 mode) -> [P3, P4, P5] (256 channels, strides 8/16/32; S32 in f16x3 mode)."""
+        ops.PROFILE_STAGE = "resnet34_body"
         if x.dtype == torch.float16:
             x = ops.conv_stem_split(x, self.stem16.w16, self.stem16.bias, 64, r=7, stride=2, relu=True)
         else:
@@ -145,6 +146,7 @@ class FCOSEngine:
             if blk["last"] and blk["layer"] >= 2:
                 feats.append(x)
         c3, c4, c5 = feats
+        ops.PROFILE_STAGE = "fpn"
         lat5 = self._conv(c5, self.inner[2])
         lat4 = self._conv(c4, self.inner[1], residual=lat5, res_upsample=True)
         lat3 = self._conv(c3, self.inner[0], residual=lat4, res_upsample=True)
@@ -189,6 +191,13 @@ class FCOSEngine:
         return ops.to_split(x, scale, shift, relu=True) if self.precision == "f16x3" else (x, scale, shift)
 
     def _out_conv(self, a, cw, **kw):
+        prev, ops.PROFILE_STAGE = ops.PROFILE_STAGE, "head_outputs"
+        try:
+            return self._out_conv_impl(a, cw, **kw)
+        finally:
+            ops.PROFILE_STAGE = prev
+
+    def _out_conv_impl(self, a, cw, **kw):
         if self.precision == "f16x3":
             return self._conv(a, cw, out_f32=True, **kw)
         return self._conv(a[0], cw, in_scale=a[1], in_shift=a[2], **kw)
@@ -256,17 +265,21 @@ class FCOSEngine:
         parts = [self._scratch(("lv", l), ops.gn_rows32_scratch_floats(n * hw[l], 512), dev) for l in range(L)]
         new_t = lambda: [torch.empty((n, h, w, 512), device=dev, dtype=torch.float32) for h, w in dims]  # noqa: E731
         t = new_t()
+        ops.PROFILE_STAGE = "towers"
         ops.conv2d_nhwc_grouped(feats, [self.tower0] * L, pad=1, outs=t, gn=[(parts[l], 0) for l in range(L)], gn_units=64)
-        aff = [ops.groupnorm_finalize_rows32(parts[l], self.gn0_gamma, self.gn0_beta, n, hw[l], 64) for l in range(L)]
+        # GroupNorm finalize and the affine + ReLU + split pass: ONE launch each over the levels (the library falls back
+        # to per-level launches of the apply pass for tensors beyond the caches, where streaming stores win)
+        aff = ops.groupnorm_finalize_rows32_levels(parts, self.gn0_gamma, self.gn0_beta, n, hw, 64)
         for cwc, cwr, (g2, b2) in zip(self.cls_tower, self.reg_tower, self.both_gn):
-            a = [self._act(t[l], *aff[l]) for l in range(L)]            # S32 [N,h,w,16,2,32]: cls blocks 0-7, reg 8-15
+            a = ops.to_split_levels(t, aff, relu=True)                  # S32 [N,h,w,16,2,32]: cls blocks 0-7, reg 8-15
             t = new_t()
             ops.conv2d_nhwc_grouped([x[:, :, :, :8] for x in a] + [x[:, :, :, 8:] for x in a], [cwc] * L + [cwr] * L,
                                     pad=1, outs=t + t, out_channel_offsets=[0] * L + [256] * L,
                                     gn=[(parts[l], 0) for l in range(L)] + [(parts[l], 32) for l in range(L)], gn_units=64)
-            aff = [ops.groupnorm_finalize_rows32(parts[l], g2, b2, n, hw[l], 64) for l in range(L)]
-        a = [self._act(t[l], *aff[l]) for l in range(L)]
+            aff = ops.groupnorm_finalize_rows32_levels(parts, g2, b2, n, hw, 64)
+        a = ops.to_split_levels(t, aff, relu=True)
         ac, ar = [x[:, :, :, :8] for x in a], [x[:, :, :, 8:] for x in a]
+        ops.PROFILE_STAGE = "head_outputs"
         cls_lr = ops.conv2d_nhwc_grouped(ac, [self.cls_out] * L, pad=1)
         ext = ops.conv2d_nhwc_grouped(ac, [self.ext_out] * L, pad=1, relu_cols=3) if self.ext else [None] * L
         reg_ctr = ops.conv2d_nhwc_grouped(ar, [self.reg_out] * L, pad=1, relu_cols=4)
@@ -276,6 +289,7 @@ class FCOSEngine:
         """All levels.  With head_streams > 1 the 2 x levels independent tower chains are spread over side
         streams so that the tail of one convolution's grid (e.g. 1700 workgroups on 512 slots at the
         stride-16 level) is filled by another chain's workgroups."""
+        ops.PROFILE_STAGE = "towers"
         if (self.head_streams <= 1 and self.group_towers and self.precision == "f16x3" and 2 * len(feats) <= 6
                 and all(f.shape[1] * f.shape[2] >= 32 for f in feats)):
             return self.heads_grouped(feats)

@@ -179,6 +179,9 @@ def from_split(xs16, out=None):
 # bench.py's roofline leg: when set to a list, every conv launch is bracketed by HIP events
 # on the launch stream and ((precision, tile id), algorithmic MACs, timer, shape) is appended.
 CONV_PROFILE = None
+# which stage of the hot path the engines are in (bench.py's roofline.stages): "resnet34_body", "fpn", "towers",
+# "head_outputs", "a2j_trunk", "a2j_heads"; recorded with every profiled conv launch
+PROFILE_STAGE = None
 TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x64", 4: "128x32", 5: "256x128", 6: "64x128", 7: "32x64", 8: "256x64", 9: "256x128w8", 10: "256x64w8"}
 TILE_RS = 0x100  # profile records: tile id | TILE_RS when the launch ran the row-shared-A instantiation of that tile
 
@@ -366,7 +369,7 @@ def conv2d_nhwc(x, w, bias=None, *, stride=1, pad=0, dil=1, relu=False, relu_col
             kind = ("f16x3", lib.hn_conv2d_f16x3_pick_tile(C.byref(d)) | (TILE_RS if lib.hn_conv2d_f16x3_uses_rs(C.byref(d)) else 0))
         else:
             kind = ("f32", lib.hn_conv2d_pick_tile(C.byref(d)))
-        prof.append((kind, macs, timer, (n, h, wd, cin, cout, r, stride, dil)))
+        prof.append((kind, macs, timer, (n, h, wd, cin, cout, r, stride, dil), PROFILE_STAGE))
     return out
 
 
@@ -451,7 +454,7 @@ def conv2d_nhwc_grouped(xs, ws, *, pad=0, relu=False, relu_cols=None, out_split=
         q = ConvDesc.from_buffer_copy(d)                           # geometry of the launch, picked tile, narrowest member
         q.tile, q.w = tile, min(ow for _, ow in sizes)
         prof.append((("f16x3", tile | (TILE_RS if lib.hn_conv2d_f16x3_uses_rs(C.byref(q)) else 0)), rows * cout * r * s * cin,
-                     timer, (1, rows, 1, cin, cout, r, 1, 1)))
+                     timer, (1, rows, 1, cin, cout, r, 1, 1), PROFILE_STAGE))
     return outs
 
 
@@ -510,6 +513,51 @@ def groupnorm_finalize_rows32(partial, gamma, beta, n, hw, groups=32, eps=1e-5, 
     check(lib.hn_groupnorm_finalize_rows32(ptr(partial), ptr(gamma), ptr(beta), n, hw, c, groups, eps, ptr(scale),
                                            ptr(shift), _stream()), "hn_groupnorm_finalize_rows32")
     return scale, shift
+
+
+def groupnorm_finalize_rows32_levels(partials, gamma, beta, n, hws, groups=32, eps=1e-5):
+    """groupnorm_finalize_rows32 for all FPN levels of one tower layer in ONE launch -> [(scale, shift)] per level."""
+    lib = _lib.load()
+    _req(gamma, name="gamma"); _req(beta, name="beta")
+    c = gamma.numel()
+    lv = _lib.GnLevels()
+    lv.count = len(partials)
+    tables = torch.empty((len(partials), 2, n, c), device=gamma.device, dtype=torch.float32)
+    for i, (part, hw) in enumerate(zip(partials, hws)):
+        _req(part, name="partial")
+        if part.numel() < lib.hn_groupnorm_rows32_scratch_floats(n * hw, c):
+            raise ValueError("partial buffer too small")
+        lv.hw[i], lv.partial[i] = hw, part.data_ptr()
+        lv.scale[i], lv.shift[i] = tables[i, 0].data_ptr(), tables[i, 1].data_ptr()
+    check(lib.hn_groupnorm_finalize_rows32_levels(C.byref(lv), ptr(gamma), ptr(beta), n, c, groups, eps, _stream()),
+          "hn_groupnorm_finalize_rows32_levels")
+    return [(tables[i, 0], tables[i, 1]) for i in range(len(partials))]
+
+
+def to_split_levels(xs, affines, relu=True):
+    """to_split(x, scale, shift, relu) for the FPN levels of one tower layer in ONE launch (per-level launches when a
+    level is too large for the caches, decided by the library).  xs: fp32 [N,h_l,w_l,C]; affines: [(scale, shift)]."""
+    lib = _lib.load()
+    n, _, _, c = xs[0].shape
+    xstride = _pixel_stride(xs[0], "x")
+    a_stride = affines[0][0].stride(0)
+    lv = _lib.SplitLevels()
+    lv.count = len(xs)
+    outs = []
+    for i, (x, (scale, shift)) in enumerate(zip(xs, affines)):
+        if x.shape[0] != n or x.shape[3] != c or _pixel_stride(x, "x") != xstride or is_split(x):
+            raise ValueError("levels must be fp32 NHWC tensors of one batch size, channel count and pixel stride")
+        for t in (scale, shift):
+            if (not t.is_cuda or t.dtype != torch.float32 or tuple(t.shape) != (n, c) or t.stride(1) != 1
+                    or t.stride(0) != a_stride):
+                raise ValueError("scale / shift must be fp32 GPU [N, C] tables with equal row stride")
+        out = torch.empty((n, x.shape[1], x.shape[2], c // 32, 2, 32), device=x.device, dtype=torch.float16)
+        lv.hw[i] = x.shape[1] * x.shape[2]
+        lv.x[i], lv.scale[i], lv.shift[i], lv.y16[i] = x.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.data_ptr()
+        outs.append(out)
+    check(lib.hn_affine_split_f32_levels(C.byref(lv), 1 if relu else 0, n, c, xstride, a_stride, 2 * c, _stream()),
+          "hn_affine_split_f32_levels")
+    return outs
 
 
 def fcos_preprocess(images, oh, ow, ph, pw, mean, std, out=None):
@@ -601,7 +649,8 @@ def conv_stem_split(x16, w16, bias, cout, r=7, stride=2, relu=True, out_split=Tr
     if prof is not None:
         timer.stop()
         tile = 4 if cout <= 32 else (2 if cout <= 64 else 1)  # HN_TILE_128x32 / 128x64 / 128x128
-        prof.append((("f16x3", tile), n * oh * ow * cout * r * r * algo_cin, timer, (n, ph, pw, 4, cout, r, stride, 1)))
+        prof.append((("f16x3", tile), n * oh * ow * cout * r * r * algo_cin, timer, (n, ph, pw, 4, cout, r, stride, 1),
+                     PROFILE_STAGE))
     return out
 
 
@@ -627,18 +676,31 @@ class Detections:
     count: torch.Tensor
 
 
+def _zero_fields(n, cap, device, widths):
+    """One zero-filled allocation carved into [n, cap(, w)] fields + an [n] counter (a torch.zeros per field was 14
+    fill launches per detector pass: 65 us of the 2.8 ms batch-1 step, profiles/r03_b1_timeline.txt).  Every field is
+    4 bytes wide; int fields are int32 views of the fp32 buffer."""
+    words = sum(widths) * n * cap + n
+    flat = torch.zeros((words,), device=device, dtype=torch.float32)
+    out, off = [], 0
+    for w in widths:
+        t = flat[off:off + n * cap * w]
+        out.append(t.view(n, cap, w) if w > 1 else t.view(n, cap))
+        off += n * cap * w
+    out.append(flat[off:off + n])
+    return out
+
+
 def alloc_candidates(n, cap, device) -> Candidates:
-    i32 = dict(device=device, dtype=torch.int32)
-    return Candidates(torch.zeros((n, cap, 4), device=device), torch.zeros((n, cap), device=device),
-                      torch.zeros((n, cap), **i32), torch.zeros((n, cap), **i32), torch.zeros((n, cap), **i32),
-                      torch.zeros((n,), **i32), torch.zeros((n, cap), **i32))
+    b, s, l, sd, lv, pt, cnt = _zero_fields(n, cap, device, [4, 1, 1, 1, 1, 1])
+    i32 = torch.int32
+    return Candidates(b, s, l.view(i32), sd.view(i32), lv.view(i32), cnt.view(i32), pt.view(i32))
 
 
 def alloc_detections(n, cap, device) -> Detections:
-    i32 = dict(device=device, dtype=torch.int32)
-    return Detections(torch.zeros((n, cap, 4), device=device), torch.zeros((n, cap), device=device),
-                      torch.zeros((n, cap), **i32), torch.zeros((n, cap), **i32), torch.zeros((n, cap), **i32),
-                      torch.zeros((n, cap), **i32), torch.zeros((n,), **i32))
+    b, s, l, sd, lv, kp, cnt = _zero_fields(n, cap, device, [4, 1, 1, 1, 1, 1])
+    i32 = torch.int32
+    return Detections(b, s, l.view(i32), sd.view(i32), lv.view(i32), kp.view(i32), cnt.view(i32))
 
 
 def fcos_candidates(cls_lr, reg_ctr, strides, num_classes, score_thresh=0.7, out: Candidates | None = None):
@@ -804,6 +866,41 @@ def convert_joints(kp, crop_box, valid=None, paras=None, crop=176, out=None):
     check(lib.hn_convert_joints_f32(ptr(kp), ptr(crop_box), ptr(valid), n, j, float(crop), float(crop), pp, ptr(out),
                                     _stream()), "hn_convert_joints_f32")
     return out
+
+
+def pack_records(kp, crop_box, has_hand, rows, rec_bytes, out=None):
+    """One step's per-frame results -> [rows, rec_bytes] uint8 records (rows >= frames: shard padding is zero rows)."""
+    _req(kp, name="keypoints"); _req(crop_box, torch.int64, "crop_box"); _req(has_hand, torch.int32, "has_hand")
+    n, j = kp.shape[0], kp.shape[1]
+    if out is None:
+        out = torch.empty((rows, rec_bytes), device=kp.device, dtype=torch.uint8)
+    check(_lib.load().hn_pack_records(ptr(kp), ptr(crop_box), ptr(has_hand), n, rows, j, rec_bytes, ptr(out), _stream()),
+          "hn_pack_records")
+    return out
+
+
+def unpack_records(rec, joints):
+    """[rows, rec_bytes] uint8 records -> (keypoints [rows,J,3], crop_box [rows,4] int64, has_hand [rows] int32,
+    valid [rows] int32)."""
+    _req(rec, torch.uint8, "records")
+    rows, rec_bytes = rec.shape
+    dev = rec.device
+    kp = torch.empty((rows, joints, 3), device=dev, dtype=torch.float32)
+    box = torch.empty((rows, 4), device=dev, dtype=torch.int64)
+    has = torch.empty((rows,), device=dev, dtype=torch.int32)
+    valid = torch.empty((rows,), device=dev, dtype=torch.int32)
+    check(_lib.load().hn_unpack_records(ptr(rec), rows, joints, rec_bytes, ptr(kp), ptr(box), ptr(has), ptr(valid), _stream()),
+          "hn_unpack_records")
+    return kp, box, has, valid
+
+
+def nonfinite_count(x, flag=None):
+    """Adds the number of non-finite values of x (fp32 GPU) to flag[0] (int32 GPU; fresh zero by default); no sync."""
+    _req(x, name="x")
+    if flag is None:
+        flag = torch.zeros((1,), device=x.device, dtype=torch.int32)
+    check(_lib.load().hn_nonfinite_count_f32(ptr(x), x.numel(), ptr(flag), _stream()), "hn_nonfinite_count_f32")
+    return flag
 
 
 def reread_env():

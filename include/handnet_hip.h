@@ -33,7 +33,7 @@ extern "C" {
 #define HN_ERR_HIP 2
 
 /* ABI version; bumped whenever a struct below changes. */
-#define HN_ABI_VERSION 24
+#define HN_ABI_VERSION 25
 int hn_abi_version(void);
 const char* hn_last_error(void);
 
@@ -211,6 +211,32 @@ int hn_groupnorm_finalize_rows32(const float* partial, const float* gamma, const
                                  int n, int hw, int c, int groups, float eps,
                                  float* scale, float* shift, void* stream);
 
+/* The GroupNorm finalize / apply passes of ONE tower layer for all FPN levels at once (the tower weights and the
+ * GroupNorm affine are shared across levels, fcos_utils/fcos.py:276-289,377-380; the levels differ in map size only).
+ * Same arithmetic and bits as hn_groupnorm_finalize_rows32 / hn_affine_split_f32 per level; one launch instead of
+ * `count` (at batch 1 every launch of this size is pure latency).  hn_affine_split_f32_levels falls back to the
+ * per-level launches when a level is too large for any cache (>= 128 MiB), where the streaming-store form wins. */
+#define HN_FCOS_MAX_LEVELS 5
+typedef struct hn_gn_levels {
+  int32_t count;
+  int32_t hw[HN_FCOS_MAX_LEVELS];            /* pixels per image of each level (>= 32)        */
+  const float* partial[HN_FCOS_MAX_LEVELS];  /* conv-epilogue partial sums of each level       */
+  float* scale[HN_FCOS_MAX_LEVELS];          /* out: [n][c] per level                          */
+  float* shift[HN_FCOS_MAX_LEVELS];
+} hn_gn_levels;
+int hn_groupnorm_finalize_rows32_levels(const hn_gn_levels* lv, const float* gamma, const float* beta,
+                                        int n, int c, int groups, float eps, void* stream);
+typedef struct hn_split_levels {
+  int32_t count;
+  int32_t hw[HN_FCOS_MAX_LEVELS];
+  const float* x[HN_FCOS_MAX_LEVELS];        /* fp32 [n][hw][c] (pixel stride in_pix_stride)   */
+  const float* scale[HN_FCOS_MAX_LEVELS];    /* [n][c] tables (row stride affine_stride)       */
+  const float* shift[HN_FCOS_MAX_LEVELS];
+  void* y16[HN_FCOS_MAX_LEVELS];             /* out: S32 [n][hw][c/32][2][32]                  */
+} hn_split_levels;
+int hn_affine_split_f32_levels(const hn_split_levels* lv, int relu, int n, int c, int in_pix_stride,
+                               int affine_stride, int out_pix_stride, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * FCOS pre-processing: normalize + bilinear resize (align_corners=False, scale =
  * in/out as with recompute_scale_factor=True) + zero pad, NCHW fp32 in -> NHWC(4) out.
@@ -257,7 +283,6 @@ int hn_conv_stem_f16x3(const void* x16, int n, int ph, int pw, int pad, int r, i
  *   otherwise; CPU-kernel rule: suppress iff (double)iou > iou_thresh), write kept
  *   detections in score order, boxes rescaled by (ratio_h, ratio_w).
  * ------------------------------------------------------------------------------------ */
-#define HN_FCOS_MAX_LEVELS 5
 typedef struct hn_fcos_levels {
   int32_t num_levels;
   int32_t h[HN_FCOS_MAX_LEVELS], w[HN_FCOS_MAX_LEVELS], stride[HN_FCOS_MAX_LEVELS];
@@ -341,6 +366,20 @@ int hn_a2j_aggregate_f32(const float* cls, const float* reg, const float* dep,
 int hn_convert_joints_f32(const float* kp, const int64_t* crop_box, const int32_t* valid,
                           int n, int joints, float crop_w, float crop_h,
                           const float* paras /* host, 4 floats, or NULL */, float* out, void* stream);
+
+/* Per-frame result records for the N > 1 all-gather (ONE collective of fixed-size records per step).
+ * Record layout (rec_bytes >= 40 + 12*joints, multiple of 8): bytes 0..31 crop box 4 x int64, 32..35 has_hand,
+ * 36..39 row-is-a-real-frame, 40.. keypoints joints*3 x fp32.  hn_pack_records writes rows [0, n) from the three
+ * result tensors and zero rows [n, rows) (shard padding); hn_unpack_records is the inverse over `rows` records
+ * (valid[r] = the row flag).  One launch each, so a step adds pack + collective + unpack to the engine's launches. */
+int hn_pack_records(const float* keypoints, const int64_t* crop_box, const int32_t* has_hand, int n, int rows,
+                    int joints, int rec_bytes, void* records, void* stream);
+int hn_unpack_records(const void* records, int rows, int joints, int rec_bytes, float* keypoints,
+                      int64_t* crop_box, int32_t* has_hand, int32_t* valid, void* stream);
+
+/* Always-on safety net of the f16x3 path (range contract): counts non-finite values of x[0..count) into
+ * *flag (device int32; the caller zeroes it and reads it with the copy of the results it makes anyway). */
+int hn_nonfinite_count_f32(const float* x, int64_t count, int32_t* flag, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Pose2Mesh lifter: Chebyshev graph convolution helpers.  Replaces

@@ -108,9 +108,11 @@ def body(x, sd, p="backbone.body."):
     return cs
 
 
-def backbone(x, sd):
-    """[N,3,PH,PW] -> OrderedDict('0','1','2','pool') of 256-channel maps (strides 8,16,32,64)."""
-    cs = body(x, sd)[1:]
+def fpn(cs, sd):
+    """torchvision-0.11.3 ops/feature_pyramid_network.py FeaturePyramidNetwork.forward on [C3, C4, C5] (extra block
+    unused here: the reference builds resnet_fpn_backbone(returned_layers=[2,3,4]) and reads levels '0','1','2'):
+    lateral 1x1, top-down `lat + interpolate(last, size=lat.shape[-2:], mode='nearest')` from the coarsest level,
+    3x3 output conv per level."""
     f = "backbone.fpn."
 
     def inner(i, t):
@@ -125,6 +127,12 @@ def backbone(x, sd):
         lat = inner(idx, cs[idx])
         last = lat + F.interpolate(last, size=lat.shape[-2:], mode="nearest")
         results.insert(0, layer(idx, last))
+    return results
+
+
+def backbone(x, sd):
+    """[N,3,PH,PW] -> OrderedDict('0','1','2','pool') of 256-channel maps (strides 8,16,32,64)."""
+    results = fpn(body(x, sd)[1:], sd)
     results.append(F.max_pool2d(results[-1], 1, 2, 0))
     return OrderedDict(zip(["0", "1", "2", "pool"], results))
 

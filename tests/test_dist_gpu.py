@@ -122,3 +122,44 @@ def test_bench_line_contract():
         assert k in cpu, k
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["parity"]["frames"] == 2
     assert cpu["parity"]["keypoints_within_tolerance"] is True
+
+
+def test_four_ranks_equal_single_process_batch(tmp_path, fcos_sd, a2j_sd):
+    """4 ranks x 8 frames == 1 x 32 frames through the real engine (crop boxes / has_hand bit-for-bit).  Four, not
+    eight: the GPU box's process guard allows six GPU-touching processes (this test process is one of them); the
+    8-rank rendezvous / sharding / record plumbing runs on gloo in tests/test_dist_cpu.py."""
+    from hn_amd import synth
+    from hn_amd.a2j_engine import A2JEngine
+    from hn_amd.fcos_engine import FCOSEngine
+    from hn_amd.pipeline import HandNetEngine
+    total, world = 32, 4
+    port = _free_port()
+    out_file = tmp_path / "gathered4.pt"
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(REPO / "tests" / "dist_worker.py"), str(total), "gloo",
+                                       str(out_file)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    kp, box, has, w = torch.load(out_file)
+    assert w == world and kp.shape == (total, 21, 3)
+    eng = HandNetEngine(FCOSEngine(fcos_sd, 3, device="cuda"), A2JEngine(a2j_sd, device="cuda"), 3)
+    ref = eng.forward_device(synth.make_rgb(total, seed=1000).cuda(), synth.make_depth(total, seed=2000).cuda())
+    assert torch.equal(box, ref.crop_box.cpu()) and torch.equal(has, ref.has_hand.cpu())
+    assert (kp - ref.keypoints.cpu()).abs().max().item() <= 1e-4
+
+
+def test_bench_four_rank_rehearsal():
+    """`bench.py --gpus 4 --share-gpu --dist-backend gloo --batch 8`: the self-launch path at a world size > 2 (global
+    batch 32 as 4 x 8), one JSON line from rank 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "4", "--share-gpu", "--dist-backend", "gloo",
+                        "--steps", "2", "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--no-roofline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 4 and line["config"]["global_batch"] == 32 and line["config"]["rccl_ranks"] == 4

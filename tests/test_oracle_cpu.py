@@ -231,3 +231,50 @@ def test_resnet34_body_matches_third_party_basic_block_resnet(fcos_sd):
         assert a.shape == b.shape, name
         scale = b.abs().max().item()
         assert (a - b).abs().max().item() <= 1e-5 * max(scale, 1.0), name
+
+
+@pytest.mark.parametrize("k,classes", [(64, 1), (300, 3), (1200, 3)])
+def test_nms_oracle_satisfies_the_definition_of_greedy_nms(k, classes):
+    """Row a8' anchor that needs neither torchvision nor the HIP kernel: on tie-free boxes the kept set of the C
+    restatement (both batched_nms paths: coordinate trick up to 1000 boxes, per-class above) is THE set the definition
+    of greedy NMS admits (tests/nms_property.py), IoUs recomputed in fp64 with a guard band around 0.3."""
+    import nms_property
+    boxes, scores, labels = nms_property.make_case(k, classes, seed=100 + k)
+    keep = fcos_ref.batched_nms(boxes, scores, labels.to(torch.int64), 0.3)
+    nms_property.check(boxes, scores, labels, keep.numpy(), 0.3)
+    if classes == 1:
+        keep1 = fcos_ref.nms(boxes, scores, 0.3)
+        assert torch.equal(keep1, keep)
+
+
+def test_fpn_top_down_matches_hand_written_fp64_loops(fcos_sd):
+    """Row a4 (FPN wiring, torchvision 0.11.3 ops/feature_pyramid_network.py, call site fcos.py:476): the oracle's
+    top-down pathway -- nearest-neighbour 2x upsampling of the coarser lateral, added to the finer lateral BEFORE the
+    3x3 output conv, coarsest level first -- against explicit fp64 loops written from the definition
+    (src index = floor(dst * in / out)), on odd map sizes where 'nearest' and 'size=' matter."""
+    g = torch.Generator().manual_seed(5)
+    cs = [torch.randn((1, 128, 13, 18), generator=g), torch.randn((1, 256, 7, 9), generator=g),
+          torch.randn((1, 512, 4, 5), generator=g)]
+    f = "backbone.fpn."
+    lat = [torch.nn.functional.conv2d(c.double(), fcos_sd[f"{f}inner_blocks.{i}.weight"].double(),
+                                      fcos_sd[f"{f}inner_blocks.{i}.bias"].double()) for i, c in enumerate(cs)]
+    merged = [None, None, lat[2]]
+    for lvl in (1, 0):
+        coarse, fine = merged[lvl + 1], lat[lvl]
+        _, ch, fh, fw = fine.shape
+        ih, iw = coarse.shape[-2:]
+        out = fine.clone()
+        for y in range(fh):
+            sy = min(int(np.floor(y * (ih / fh))), ih - 1)
+            for x in range(fw):
+                sx = min(int(np.floor(x * (iw / fw))), iw - 1)
+                out[0, :, y, x] += coarse[0, :, sy, sx]
+        merged[lvl] = out
+    want = [torch.nn.functional.conv2d(m, fcos_sd[f"{f}layer_blocks.{i}.weight"].double(),
+                                       fcos_sd[f"{f}layer_blocks.{i}.bias"].double(), padding=1) for i, m in enumerate(merged)]
+    # the oracle's FPN on the same C3..C5 (fcos_ref.backbone takes an image; its FPN half is restated here call by call)
+    import oracle.fcos_ref as R
+    got = R.fpn(cs, fcos_sd)
+    for i in range(3):
+        assert got[i].shape == want[i].shape
+        assert (got[i].double() - want[i]).abs().max().item() < 1e-4 * max(1.0, want[i].abs().max().item())

@@ -27,7 +27,7 @@ for _ in range(reps):
 torch.cuda.synchronize()
 recs, ops.CONV_PROFILE = ops.CONV_PROFILE, None
 tab = OrderedDict()
-for kind, macs, timer, shape in recs:
+for kind, macs, timer, shape, *_stage in recs:
     k = (kind, shape)
     t = tab.setdefault(k, [0, 0.0, 0.0])
     t[0] += 1

@@ -26,7 +26,7 @@ for _ in range(reps):
 torch.cuda.synchronize()
 recs, ops.CONV_PROFILE = ops.CONV_PROFILE, None
 tab = OrderedDict()
-for kind, macs, timer, shape in recs:
+for kind, macs, timer, shape, *_stage in recs:
     e = tab.setdefault((kind, shape), [0, 0.0, 0.0])
     e[0] += 1; e[1] += timer.elapsed_ms(); e[2] += 2.0 * macs
 tot = sum(v[1] for v in tab.values())

@@ -34,8 +34,11 @@ rep('  dma_tile(0);\n  drain_and_barrier();', '  STAMP(1);\n  dma_tile(0);\n  dr
 rep('  int cs = 0, ns = 1;\n  for (int t = 0; t < T; ++t) {', '  int cs = 0, ns = 1;\n  STAMP(3);\n  for (int t = 0; t < T; ++t) {')
 rep('  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant tail loads must land before LDS is reused / freed\n',
     '  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant tail loads must land before LDS is reused / freed\n  STAMP(4);\n')
-rep('      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // patch reads done before the next pass rewrites it\n    }\n    return;',
-    '      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // patch reads done before the next pass rewrites it\n    }\n    STAMP(5);\n    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n    STAMP(6);\n    return;')
+rep('    return;\n  }\n  // Scalar path',
+    '    STAMP(5);\n    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n    STAMP(6);\n    return;\n  }\n  // Scalar path')
+import os
+if os.environ.get("STAMPS_UNSWAPPED"):   # timing-only A/B: the round-2 operand order under the v8 epilogue (results are wrong)
+    rep('"v_mfma_f32_16x16x32_f16 %0, %2, %1, %0"', '"v_mfma_f32_16x16x32_f16 %0, %1, %2, %0"')
 Path("/tmp/hn_stamps.hip").write_text(src)
 cc = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", f"-I{R}/include"]
 subprocess.run(cc + ["-c", "/tmp/hn_stamps.hip", "-o", "/tmp/hn_stamps.o"], check=True)
