@@ -105,6 +105,10 @@ struct ConvParams16 {
   unsigned mg_w1, sh_w1, mg_h, sh_h;
   unsigned gmg_w1[HN_CONV_MAX_GROUP], gsh_w1[HN_CONV_MAX_GROUP], gmg_h[HN_CONV_MAX_GROUP], gsh_h[HN_CONV_MAX_GROUP];
   int rs_ok;          // host: the row-shared A kernel may be used (set by conv16_run, refined in launch16)
+  // fused 3x3 / stride-2 / pad-1 max pooling (POOL kernel, the FCOS stem): a workgroup computes a 15 x 17 patch of conv
+  // pixels = 7 x 8 pooled pixels; pool_ty x pool_tx patches per image, pooled map pool_oh x pool_ow
+  int pool_ty, pool_tx, pool_oh, pool_ow;
+  unsigned mg_pt, sh_pt, mg_ptx, sh_ptx;   // exact division of the patch index by pool_ty * pool_tx and by pool_tx
   unsigned a_records; // bytes covered by the A descriptor (< 2^31 so that bit 31 is out of range)
   unsigned b_records;
   unsigned ga_records[HN_CONV_MAX_GROUP];
@@ -282,10 +286,17 @@ struct HalfSched {
 // prologue / epilogue runs under the other's MFMAs.  The second launch bound makes the register allocator keep to the
 // 256 registers per lane that allows (the v8 epilogue once came out at 194 + 64 = 260 on the 128x128 tile: one workgroup
 // per CU, -40 % on every short-k layer of that tile).  The 4-wave 256x128 sweep variant needs 128 accumulators: one wave.
-template <int BM, int BN, int WM, int WN, int NBUF, bool BUF, bool RS = false>
+// POOL (the FCOS stem, conv -> ReLU -> 3x3 / stride-2 / pad-1 max pooling fused; 256x64 tile only): the 256 rows of a tile
+// are a 15 x 17 PATCH of conv pixels (row-major, row 255 unused) instead of 256 consecutive ones -- the conv pixels that 7 x 8
+// pooled pixels need, one halo row / column shared with the neighbouring patches (1.16x the convolution work of the
+// unfused form) -- and the epilogue pools the patch through LDS and stores only the pooled S32 tensor: the 64-channel
+// conv map at half resolution (1.8 GB at batch 32) is neither written nor read back.
+constexpr int kPoolRows = 15, kPoolCols = 17, kPoolPR = 7, kPoolPC = 8;
+template <int BM, int BN, int WM, int WN, int NBUF, bool BUF, bool RS = false, bool POOL = false>
 __global__ __launch_bounds__(WM* WN * 64, (BM * BN / (WM * WN) > 64 * 64 ? 1 : 2))
 void conv_igemm_f16x3_kernel(const ConvParams16 p) {
   static_assert(NBUF >= 2 && NBUF <= 6, "2..6 LDS stages");
+  static_assert(!POOL || (BUF && !RS && BM == 256 && BN == 64 && WN == 1), "the pooling epilogue is written for the 256x64 tile");
   static_assert(!RS || (BUF && NBUF == 2), "row-shared A needs the descriptor form and the 2-stage pipeline");
   // Grouped launch: workgroup z works on member z -- its own tensors and, for FPN levels, its own spatial size.
   // Only these fields differ per member; they live in a small local struct `o` (picked with constant-index
@@ -361,6 +372,16 @@ void conv_igemm_f16x3_kernel(const ConvParams16 p) {
   const int tile_m = lid / p.tiles_n, tile_n = lid - tile_m * p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // POOL: patch (image, patch row, patch column); conv pixel of tile row `row` = (oy0 + row / 17, ox0 + row % 17)
+  int pl_img = 0, pl_ty = 0, pl_tx = 0, pl_oy0 = 0, pl_ox0 = 0;
+  if constexpr (POOL) {
+    pl_img = fastdiv(lid, p.mg_pt, p.sh_pt);
+    const int rem = lid - pl_img * (p.pool_ty * p.pool_tx);
+    pl_ty = fastdiv(rem, p.mg_ptx, p.sh_ptx);
+    pl_tx = rem - pl_ty * p.pool_tx;
+    pl_oy0 = 2 * kPoolPR * pl_ty - 1;
+    pl_ox0 = 2 * kPoolPC * pl_tx - 1;
+  }
   const int wm = wave / WN, wn = wave - wm * WN;
   const int ohow = o.OH * o.OW;
 
@@ -397,6 +418,19 @@ void conv_igemm_f16x3_kernel(const ConvParams16 p) {
                          : 0u;
       // bit r: filter row r reads image row oh + r - 1
       a_inv[it] = !pix_ok ? 7u : (oh == 0 ? 1u : 0u) | (oh == o.H - 1 ? 4u : 0u);
+      continue;
+    }
+    if constexpr (POOL) {
+      // conv pixels outside the map (the pooling's own padding ring, patches past the bottom / right edge, row 255) read a
+      // clamped pixel: their results are zeroed in the epilogue (every pooling window holds a real pixel and ReLU >= 0)
+      const int pr = row / kPoolCols, pc = row - pr * kPoolCols;
+      int oy = pl_oy0 + pr, ox = pl_ox0 + pc;
+      oy = oy < 0 ? 0 : (oy < o.OH ? oy : o.OH - 1);
+      ox = ox < 0 ? 0 : (ox < o.OW ? ox : o.OW - 1);
+      const int chunk = dpos ^ swz(row);
+      a_off[it] = (((unsigned)(pl_img * o.H + oy * p.stride) * (unsigned)o.pitch + (unsigned)(ox * p.stride)) * (unsigned)p.xs +
+                   (unsigned)((chunk & 3) * 8) + (unsigned)(chunk >> 2) * (unsigned)p.lo_off) * 2u;
+      a_inv[it] = 0u;
       continue;
     }
     int m = m0 + row;
@@ -866,6 +900,73 @@ void conv_igemm_f16x3_kernel(const ConvParams16 p) {
       y[r] = __uint_as_float(s[1]);
     }
   };
+  if constexpr (POOL) {
+    // conv + bias + ReLU patch -> LDS (fp32 [256][64], pitch 68 floats), then 7 x 8 pooled pixels x 8 channel groups
+    constexpr int NP = TN / 2;
+    constexpr int PITCH = BN + 4;
+    static_assert(BM * PITCH * 4 <= NBUF * (A_BUF + B_BUF) * 2, "the pooling patch reuses the operand stages");
+    float* patch = reinterpret_cast<float*>(smem);
+    __syncthreads();  // every wave is done with the operand tiles in LDS
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row = wm * (BM / WM) + i * 16 + px;
+      const int pr = row / kPoolCols, pc = row - pr * kPoolCols;
+      const int oy = pl_oy0 + pr, ox = pl_ox0 + pc;
+      const bool ok = row < kPoolRows * kPoolCols && (unsigned)oy < (unsigned)o.OH && (unsigned)ox < (unsigned)o.OW;
+#pragma unroll
+      for (int jp = 0; jp < NP; ++jp) {
+        f32x4 x = acc[i][2 * jp], y = acc[i][2 * jp + 1];
+        swap8(x, y);
+        const int n = jp * 32 + nsub;
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(q.bias + n), b1 = *reinterpret_cast<const f32x4*>(q.bias + n + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          x[e] = ok ? fmaxf(x[e] + b0[e], 0.f) : 0.f;
+          y[e] = ok ? fmaxf(y[e] + b1[e], 0.f) : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(patch + row * PITCH + n) = x;
+        *reinterpret_cast<f32x4*>(patch + row * PITCH + n + 4) = y;
+      }
+    }
+    __syncthreads();
+    _Float16* y16p = reinterpret_cast<_Float16*>(q.y);
+    for (int item = tid; item < kPoolPR * kPoolPC * (BN / 8); item += NT) {
+      const int c8 = item & (BN / 8 - 1), pp = item / (BN / 8);
+      const int pr = pp / kPoolPC, pc = pp - pr * kPoolPC;
+      const int gy = kPoolPR * pl_ty + pr, gx = kPoolPC * pl_tx + pc;
+      if (gy >= p.pool_oh || gx >= p.pool_ow) continue;
+      f32x4 m0v = {0.f, 0.f, 0.f, 0.f}, m1v = m0v;   // ReLU output: 0 is the identity of max here
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const float* src = patch + ((2 * pr + dy) * kPoolCols + 2 * pc + dx) * PITCH + c8 * 8;
+          const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            m0v[e] = fmaxf(m0v[e], a[e]);
+            m1v[e] = fmaxf(m1v[e], b[e]);
+          }
+        }
+      f16x8 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (p.range_flag) {
+          hn::range_note(p.range_flag, m0v[e]);
+          hn::range_note(p.range_flag, m1v[e]);
+        }
+        const _Float16 h0 = (_Float16)m0v[e], h1 = (_Float16)m1v[e];
+        hi[e] = h0;
+        hi[4 + e] = h1;
+        lo[e] = (_Float16)(m0v[e] - (float)h0);
+        lo[4 + e] = (_Float16)(m1v[e] - (float)h1);
+      }
+      _Float16* dst = y16p + (((long)pl_img * p.pool_oh + gy) * p.pool_ow + gx) * p.ys + (c8 >> 2) * 64 + (c8 & 3) * 8;
+      *reinterpret_cast<f16x8*>(dst) = hi;
+      *reinterpret_cast<f16x8*>(dst + 32) = lo;
+    }
+    return;
+  }
   if (p.vec_epi) {
     constexpr int NP = TN / 2;        // column-tile pairs per wave
     f32x4 bias0[NP], bias1[NP];
@@ -1017,19 +1118,16 @@ void conv_igemm_f16x3_kernel(const ConvParams16 p) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, int NBUF, bool BUF>
-int launch16_impl(const ConvParams16& p0, hipStream_t st) {
-  ConvParams16 p = p0;
-  p.tiles_m = hn::cdiv(p.M, BM);
-  p.tiles_n = hn::cdiv(p.Cout, BN);
-  p.nblocks = p.tiles_m * p.tiles_n;
-  // Split-K for grids that leave most of the chip idle AND have a long serial k loop (~0.33 us per 32-deep
-  // tile): e.g. the 2048->512 3x3 A2J layer at batch 1 is 8 workgroups x 576 tiles = 190 us.  Up to 16
-  // workgroups then share an output tile, each keeping >= 16 tiles.  Shorter loops stay single-pass unless
-  // the caller says launches are free (desc.splitk = 1, graph replay): in eager mode the second launch
-  // costs more than it saves (measured in-pipeline, tools/probes/exp/splitk.sh).
+// ---- host-side launch planning, shared by the launcher and by hn_conv2d_f16x3_uses_rs (ONE definition of each decision) ----
+// Split-K for grids that leave most of the chip idle AND have a long serial k loop (~0.33 us per 32-deep
+// tile): e.g. the 2048->512 3x3 A2J layer at batch 1 is 8 workgroups x 576 tiles = 190 us.  Up to 16
+// workgroups then share an output tile, each keeping >= 16 tiles.  Shorter loops stay single-pass unless
+// the caller says launches are free (desc.splitk = 1, graph replay): in eager mode the second launch
+// costs more than it saves (measured in-pipeline, tools/probes/exp/splitk.sh).
+static void plan_splits(ConvParams16& p) {   // needs p.nblocks; sets p.splits / p.kt_per
   p.splits = 1;
   p.kt_per = p.ktiles;
+  if (p.groups > 1) return;  // grouped problems never split (the grid is already groups x larger)
   const int min_tiles = p.splitk_mode > 0 ? 8 : 128;  // hn_conv_desc.splitk
   const int min_per = p.splitk_mode > 0 ? 4 : 16;
   if (p.split_ws && p.splitk_mode >= 0 && p.vec_epi && !p.gn_partial && p.nblocks < 256 && p.ktiles >= min_tiles) {
@@ -1043,25 +1141,66 @@ int launch16_impl(const ConvParams16& p0, hipStream_t st) {
       p.splits = hn::cdiv(p.ktiles, p.kt_per);  // every split has at least one tile
     }
   }
+}
+
+// Row-shared A operand: 3x3 / stride 1 / pad 1 / dilation 1 on a dense-row tensor, single pass (no split-K), a tile form
+// whose two wide A stages fit beside the W stages with eight waves per CU, and every (member's) image row long enough
+// that the gap slots of a wide tile fit (a tile of BM + 1 pixels crosses at most BM / W + 1 row ends).
+static bool rs_tile_form(int bm, int bn, int waves, int nbuf, bool buf) {
+  const int lds = nbuf * (bm + waves * 8 + bn) * ROWH * 2;
+  return buf && nbuf == 2 && (waves == 4 || waves == 8) && lds <= (waves == 4 ? 80 : 160) * 1024 - 2048;
+}
+static bool rs_geometry(const ConvParams16& p) {
+  return p.R == 3 && p.S == 3 && p.stride == 1 && p.dil == 1 && p.pad == 1 && p.pitch == p.W && p.OH == p.H && p.OW == p.W &&
+         !hn::env_flags().no_rs;
+}
+static bool rs_will_run(const ConvParams16& p, int bm, int bn, int waves, int nbuf, bool buf) {   // needs p.splits
+  if (!(p.rs_ok && rs_geometry(p) && rs_tile_form(bm, bn, waves, nbuf, buf)) || p.splits != 1) return false;
+  const int spare = waves * 8 - 2;  // A_ROWS - BM - 2 gap slots
+  if ((bm + 1) / p.W + 1 > spare) return false;
+  for (int g = 0; p.groups > 1 && g < p.groups; ++g)
+    if ((bm + 1) / p.gW[g] + 1 > spare) return false;
+  return true;
+}
+
+template <int BM, int BN, int WM, int WN, int NBUF, bool BUF>
+int launch16_impl(const ConvParams16& p0, hipStream_t st) {
+  ConvParams16 p = p0;
+  p.tiles_m = hn::cdiv(p.M, BM);
+  p.tiles_n = hn::cdiv(p.Cout, BN);
+  p.nblocks = p.tiles_m * p.tiles_n;
+  plan_splits(p);
   int grid_x = p.nblocks;
-  if (p.groups > 1) {  // grouped problems never split (the grid is already groups x larger)
-    p.splits = 1;
-    p.kt_per = p.ktiles;
+  if (p.groups > 1) {
     grid_x = 0;
     for (int g = 0; g < p.groups; ++g) {
       p.gnblocks[g] = hn::cdiv(p.gM[g], BM) * p.tiles_n;
       grid_x = grid_x > p.gnblocks[g] ? grid_x : p.gnblocks[g];
     }
   }
+  if (p.pool_ty > 0) {  // fused conv + ReLU + max pooling (hn_conv_stem_pool_f16x3): one workgroup per 15 x 17 patch
+    if constexpr (BUF && BM == 256 && BN == 64 && WM == 4 && WN == 1 && NBUF == 2) {
+      p.tiles_n = 1;
+      p.nblocks = p.N * p.pool_ty * p.pool_tx;
+      p.tiles_m = p.nblocks;
+      p.splits = 1;
+      p.kt_per = p.ktiles;
+      hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, NBUF, true, false, true>), dim3(p.nblocks), dim3(WM * WN * 64),
+                         0, st, p);
+      HN_CHECK_LAUNCH("conv_igemm_f16x3_kernel<pool>");
+      return HN_OK;
+    } else {
+      return hn::fail(HN_ERR_ARG, "the pooling epilogue exists for the 256x64 tile only");
+    }
+  }
   // Row-shared A operand: 3x3 / stride 1 / pad 1 / dilation 1 on a dense-row tensor, no split-K, and every (member's) image
   // row long enough that the gap slots of a wide tile fit (a tile of BM + 1 pixels crosses at most BM / W + 1 row ends).
   bool rs = false;
   constexpr int RS_LDS_BYTES = NBUF * (BM + WM * WN * 8 + BN) * ROWH * 2;
-  // eight waves per CU must remain: two 4-wave workgroups or one 8-wave workgroup
+  // eight waves per CU must remain: two 4-wave workgroups or one 8-wave workgroup (rs_tile_form, evaluated at compile time
+  // here so that only the eligible tile forms instantiate the RS kernel)
   if constexpr (BUF && NBUF == 2 && (WM * WN == 4 || WM * WN == 8) && RS_LDS_BYTES <= (WM * WN == 4 ? 80 : 160) * 1024 - 2048) {
-    constexpr int SPARE = (WM * WN * 8) - 2;  // A_ROWS - BM - 2 gap slots
-    rs = p.rs_ok && p.splits == 1 && (BM + 1) / p.W + 1 <= SPARE;
-    for (int g = 0; rs && p.groups > 1 && g < p.groups; ++g) rs = (BM + 1) / p.gW[g] + 1 <= SPARE;
+    rs = rs_will_run(p, BM, BN, WM * WN, NBUF, BUF);
     if (rs) {
       constexpr int LDS_BYTES = RS_LDS_BYTES;
       static bool attr_set[64] = {};  // per device: the attribute belongs to the function's image on the current device
@@ -1111,6 +1250,8 @@ int launch16(const ConvParams16& p0, hipStream_t st) {
   magic_u31((unsigned)p.OW, p.mg_ow, p.sh_ow);
   magic_u31((unsigned)p.W + 1u, p.mg_w1, p.sh_w1);
   magic_u31((unsigned)p.H, p.mg_h, p.sh_h);
+  magic_u31(p.pool_ty > 0 ? (unsigned)(p.pool_ty * p.pool_tx) : 1u, p.mg_pt, p.sh_pt);
+  magic_u31(p.pool_ty > 0 ? (unsigned)p.pool_tx : 1u, p.mg_ptx, p.sh_ptx);
   for (int g = 0; g < HN_CONV_MAX_GROUP; ++g) {
     const bool on = p.groups > 1 && g < p.groups;
     magic_u31(on ? (unsigned)(p.gOH[g] * p.gOW[g]) : 1u, p.gmg_ohow[g], p.gsh_ohow[g]);
@@ -1120,8 +1261,7 @@ int launch16(const ConvParams16& p0, hipStream_t st) {
   }
   // (the padded index of the last slot stays far below 2^31: M < 2^31 / (1 + 1/W) is implied by the extent check below
   // for every xs >= 2)
-  p.rs_ok = p.rs_ok && p.R == 3 && p.S == 3 && p.stride == 1 && p.dil == 1 && p.pad == 1 && p.pitch == p.W && p.OH == p.H &&
-            p.OW == p.W && !hn::env_flags().no_rs;
+  p.rs_ok = p.rs_ok && rs_geometry(p);
   const int64_t lim = (int64_t)1 << 31;
   auto extent = [&](int h, int pitch) {
     // bytes the A descriptor covers: it starts pad rows + pad columns before x (kernel: a_shift) and ends at the last
@@ -1171,15 +1311,53 @@ extern "C" int hn_conv2d_f16x3_pick_tile(const hn_conv_desc* d) {
   return HN_TILE_64x64;
 }
 
-// mirrors the choice launch16 / launch16_impl make for a single-pass launch (split-K launches use the per-tap form)
+// The tile forms behind the HN_TILE_* ids: {BM, BN, waves, LDS stages}; conv16_run's switch instantiates exactly these.
+struct TileForm { int bm, bn, waves, nbuf; };
+static bool rs32_preferred(const hn_conv_desc* d) {
+  return d->r == 3 && d->s == 3 && d->stride == 1 && d->dil == 1 && d->pad == 1 && !hn::env_flags().no_rs && !hn::env_flags().no_rs32;
+}
+static TileForm tile_form(int tile, bool rs32) {
+  switch (tile) {
+    case HN_TILE_128x128: return {128, 128, 4, 2};
+    case HN_TILE_128x64: return {128, 64, 4, 2};
+    case HN_TILE_64x64: return {64, 64, 4, 3};
+    case HN_TILE_128x32: return {128, 32, 4, rs32 ? 2 : 3};   // 2 stages only when the row-shared form will run
+    case HN_TILE_64x128: return {64, 128, 4, 3};
+    case HN_TILE_256x128: return {256, 128, 4, 2};
+    case HN_TILE_32x64: return {32, 64, 2, 4};
+    case HN_TILE_256x64: return {256, 64, 4, 2};
+    case HN_TILE_256x128_W8: return {256, 128, 8, 2};
+    case HN_TILE_256x64_W8: return {256, 64, 8, 2};
+    default: return {0, 0, 0, 0};
+  }
+}
+
+// Does a launch of this descriptor run the row-shared-A kernel?  Evaluates the SAME functions as the launcher (tile pick,
+// plan_splits, rs_will_run) for a call through hn_conv2d_nhwc_f16x3_ws with the engines' 32 MiB workspace (d->splitk < 0:
+// no workspace), so a layer that goes split-K -- which uses the per-tap form -- answers 0.  For a grouped launch pass the
+// smallest member width in d->w, all members' rows as n * oh * ow and the picked tile in d->tile.
 extern "C" int hn_conv2d_f16x3_uses_rs(const hn_conv_desc* d) {
-  if (!d || hn::env_flags().no_rs) return 0;
-  if (!(d->r == 3 && d->s == 3 && d->stride == 1 && d->dil == 1 && d->pad == 1 && d->w > 0)) return 0;
+  if (!d || d->w <= 0 || d->cin <= 0) return 0;
   const int tile = hn_conv2d_f16x3_pick_tile(d);
-  if (tile == HN_TILE_256x64_W8 || tile == HN_TILE_256x128_W8) return (256 + 1) / d->w + 1 <= 62 ? 1 : 0;
-  if (tile != HN_TILE_128x128 && tile != HN_TILE_128x64 && tile != HN_TILE_128x32) return 0;
-  if (tile == HN_TILE_128x32 && hn::env_flags().no_rs32) return 0;
-  return (128 + 1) / d->w + 1 <= 30 ? 1 : 0;
+  ConvParams16 p;
+  p.R = d->r; p.S = d->s; p.stride = d->stride; p.dil = d->dil; p.pad = d->pad;
+  p.H = d->h; p.W = d->w; p.pitch = d->w; p.OH = d->oh; p.OW = d->ow;
+  p.Cout = d->cout;
+  p.M = d->n * d->oh * d->ow;
+  p.ktiles = d->r * d->s * d->cin / BK;
+  p.groups = 1;
+  p.rs_ok = 1;
+  p.gn_partial = nullptr;
+  p.vec_epi = d->cout % 8 == 0;
+  p.splitk_mode = d->splitk;
+  p.split_ws = d->splitk >= 0 ? reinterpret_cast<float*>(16) : nullptr;   // "a workspace is given" (never dereferenced here)
+  p.split_ws_bytes = (int64_t)32 << 20;
+  TileForm f = tile_form(tile, tile == HN_TILE_128x32 && rs32_preferred(d));
+  if (f.bm == 0) return 0;
+  p.nblocks = hn::cdiv(p.M, f.bm) * hn::cdiv(p.Cout, f.bn);
+  plan_splits(p);
+  if (tile == HN_TILE_128x32 && f.nbuf == 2 && !rs_will_run(p, f.bm, f.bn, f.waves, 2, true)) return 0;
+  return rs_will_run(p, f.bm, f.bn, f.waves, f.nbuf, true) ? 1 : 0;
 }
 
 static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, const float* bias, const void* residual,
@@ -1279,6 +1457,7 @@ static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, c
   p.splitk_mode = d->splitk;
   p.groups = 1;
   p.rs_ok = 1;
+  p.pool_ty = p.pool_tx = p.pool_oh = p.pool_ow = 0;
   p.gn_units = d->cout >> 3;
   hn_conv_desc tile_desc = *d;  // what the tile heuristic sees: for a group, all members' rows together
   if (group) {
@@ -1323,11 +1502,23 @@ static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, c
     // where they do not cost occupancy
     case HN_TILE_128x64: return launch16<128, 64, 2, 2, 2>(p, st);
     case HN_TILE_64x64: return launch16<64, 64, 2, 2, 3>(p, st);
-    case HN_TILE_128x32:
-      // few output columns: the A operand is nearly all of the traffic, so the row-shared form (2 stages) is tried first
-      if (d->r == 3 && d->s == 3 && d->stride == 1 && d->dil == 1 && d->pad == 1 && !hn::env_flags().no_rs && !hn::env_flags().no_rs32)
-        return launch16<128, 32, 4, 1, 2>(p, st);
+    case HN_TILE_128x32: {
+      // few output columns: the A operand is nearly all of the traffic, so the row-shared form (2 stages) is preferred --
+      // but only when it will really run (no split-K, rows long enough); otherwise the tuned 3-stage per-tap form
+      bool rs2 = rs32_preferred(d);
+      if (rs2) {
+        ConvParams16 q = p;
+        q.nblocks = hn::cdiv(q.M, 128) * hn::cdiv(q.Cout, 32);
+        if (group) {
+          q.nblocks = 0;
+          for (int g = 0; g < q.groups; ++g) q.nblocks += hn::cdiv(q.gM[g], 128) * hn::cdiv(q.Cout, 32);
+        }
+        plan_splits(q);
+        rs2 = rs_will_run(q, 128, 32, 4, 2, true);
+      }
+      if (rs2) return launch16<128, 32, 4, 1, 2>(p, st);
       return launch16<128, 32, 4, 1, 3>(p, st);
+    }
     case HN_TILE_64x128: return launch16<64, 128, 2, 2, 3>(p, st);
     case HN_TILE_256x128: return launch16<256, 128, 2, 2, 2>(p, st);
     case HN_TILE_32x64: return launch16<32, 64, 1, 2, 4>(p, st);
@@ -1340,13 +1531,8 @@ static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, c
   }
 }
 
-// Stem convolution (R x R, 4-channel pixels, R <= 8) on the f16x3 kernel.  The image is stored as two fp16
-// planes (hi, lo) of [n][ph + 2*pad][pw + 2*pad][4] with a physically zero border, so the R*4 <= 32
-// values one filter ROW touches are 64 contiguous bytes per plane: filter row ky is one 32-deep k tile
-// (k = kx*4 + c, zero weights for k >= R*4), the im2col row of output pixel (oy, ox) starts at bordered
-// pixel (oy*stride + ky, ox*stride), and no tap is ever out of bounds.  Same kernel, same DMA path.
-extern "C" int hn_conv_stem_f16x3(const void* x16, int n, int ph, int pw, int pad, int r, int stride, int cout,
-                                  const void* w16, const float* bias, int relu, void* y, int out_split, void* stream) {
+static int stem16_run(const void* x16, int n, int ph, int pw, int pad, int r, int stride, int cout, const void* w16,
+                      const float* bias, int relu, void* y, int out_split, bool pool, void* stream) {
   HN_CHECK_ARG(x16 && w16 && y, "hn_conv_stem_f16x3: null pointer");
   HN_CHECK_ARG(n > 0 && ph > 0 && pw > 0 && cout > 0 && stride > 0, "bad dims");
   HN_CHECK_ARG(r >= 1 && r <= 8 && pad == r / 2, "stem filter must be R x R with R <= 8 and pad = R/2");
@@ -1374,11 +1560,39 @@ extern "C" int hn_conv_stem_f16x3(const void* x16, int n, int ph, int pw, int pa
   p.vec_epi = (cout % 8 == 0) && ((uintptr_t)y % 16 == 0) && (bias == nullptr || (uintptr_t)bias % 16 == 0);
   p.tiles_m = p.tiles_n = p.nblocks = 0;
   p.rs_ok = 0;
+  p.pool_ty = p.pool_tx = p.pool_oh = p.pool_ow = 0;
   p.range_flag = hn::range_flag_ptr();
   hipStream_t st = (hipStream_t)stream;
+  if (pool) {
+    HN_CHECK_ARG(cout == 64 && relu && out_split && bias, "the fused stem + max-pool kernel needs cout = 64, bias, ReLU and an S32 output");
+    HN_CHECK_ARG((uintptr_t)y % 16 == 0 && (uintptr_t)bias % 16 == 0, "unaligned output / bias");
+    p.pool_oh = (oh + 2 - 3) / 2 + 1;
+    p.pool_ow = (ow + 2 - 3) / 2 + 1;
+    p.pool_ty = hn::cdiv(p.pool_oh, kPoolPR);
+    p.pool_tx = hn::cdiv(p.pool_ow, kPoolPC);
+    HN_CHECK_ARG((int64_t)n * p.pool_ty * p.pool_tx < (int64_t)1 << 31, "too many patches");
+    return launch16<256, 64, 4, 1, 2>(p, st);
+  }
   if (cout <= 32) return launch16<128, 32, 4, 1, 3>(p, st);
   // 128x64 measured against 256x64 (+2 %) and 64x64 / 3 stages (+21 %) on the 800x1088 canvas (tools/probes/exp/stem.py)
   if (cout <= 64) return launch16<128, 64, 2, 2, 2>(p, st);
   return launch16<128, 128, 2, 2, 2>(p, st);
 }
 
+// Stem convolution (R x R, 4-channel pixels, R <= 8) on the f16x3 kernel.  The image is stored as two fp16
+// planes (hi, lo) of [n][ph + 2*pad][pw + 2*pad][4] with a physically zero border, so the R*4 <= 32
+// values one filter ROW touches are 64 contiguous bytes per plane: filter row ky is one 32-deep k tile
+// (k = kx*4 + c, zero weights for k >= R*4), the im2col row of output pixel (oy, ox) starts at bordered
+// pixel (oy*stride + ky, ox*stride), and no tap is ever out of bounds.  Same kernel, same DMA path.
+extern "C" int hn_conv_stem_f16x3(const void* x16, int n, int ph, int pw, int pad, int r, int stride, int cout,
+                                  const void* w16, const float* bias, int relu, void* y, int out_split, void* stream) {
+  return stem16_run(x16, n, ph, pw, pad, r, stride, cout, w16, bias, relu, y, out_split, false, stream);
+}
+
+// The same stem with the 3x3 / stride-2 / pad-1 max pooling that follows it in a ResNet (conv1 -> bn1 -> relu -> maxpool,
+// torchvision resnet34 at fcos_utils/fcos.py:737) fused into the epilogue: y is the POOLED S32 map
+// [n][(oh+1)/2][(ow+1)/2][64]; bit-identical to hn_conv_stem_f16x3 + hn_maxpool3x3s2_s32.
+extern "C" int hn_conv_stem_pool_f16x3(const void* x16, int n, int ph, int pw, int pad, int r, int stride, int cout,
+                                       const void* w16, const float* bias, void* y, void* stream) {
+  return stem16_run(x16, n, ph, pw, pad, r, stride, cout, w16, bias, 1, y, 1, true, stream);
+}

@@ -83,6 +83,8 @@ struct hn_model {
   // ---- run-time state ----
   Arena arena;
   std::map<std::string, size_t> plan;  // arena bytes per (entry, n, h, w)
+  void* last_stream = nullptr;         // stream of the previous forward (the arena is per model, not per stream)
+  bool has_last_stream = false;
 };
 
 namespace {
@@ -234,7 +236,9 @@ int upload(hn_model* m, ConvW& cw) {
     HN_CHECK_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
     return HN_OK;
   };
-  if (!cw.hw.empty()) HN_TRY(put(cw.hw.data(), cw.hw.size() * 4, (void**)&cw.w));
+  // the fp32 bank is read by the f32 kernel only (the A2J stem, Cin = 4): convolutions with a split bank run on
+  // hn_conv2d_nhwc_f16x3* and never touch it -- uploading both doubled the weight memory
+  if (!cw.hw.empty() && cw.hw16.empty()) HN_TRY(put(cw.hw.data(), cw.hw.size() * 4, (void**)&cw.w));
   if (cw.has_bias) HN_TRY(put(cw.hb.data(), cw.hb.size() * 4, (void**)&cw.bias));
   if (!cw.hw16.empty()) HN_TRY(put(cw.hw16.data(), cw.hw16.size() * 2, (void**)&cw.w16));
   cw.hw.clear(); cw.hw.shrink_to_fit();
@@ -453,15 +457,10 @@ int fcos_graph(Ctx& cx, const float* rgb, int n, int h, int w, const FcosOut& ou
   if (!cx.dry) HN_TRY(hn_fcos_preprocess_split(rgb, img16, n, h, w, g.oh, g.ow, g.ph, g.pw, border, mean, stdv, cx.stream));
   int sh, sw;
   out_size(g.ph + 2 * border, g.pw + 2 * border, 7, 7, 2, 0, 1, sh, sw);
-  T x = alloc(cx, n, sh, sw, 64, true);
+  // conv1 + bn1 + relu + 3x3/2 max pooling as ONE kernel (like hn_amd/fcos_engine.py): the half-resolution map is never stored
+  T x = alloc(cx, n, (sh + 2 - 3) / 2 + 1, (sw + 2 - 3) / 2 + 1, 64, true);
   if (!cx.dry)
-    HN_TRY(hn_conv_stem_f16x3(img16, n, g.ph, g.pw, border, 7, 2, 64, m->f_stem16.w16, m->f_stem16.bias, 1, x.p, 1, cx.stream));
-  {
-    const int oh = (x.h + 2 - 3) / 2 + 1, ow = (x.w + 2 - 3) / 2 + 1;
-    T p = alloc(cx, n, oh, ow, 64, true);
-    if (!cx.dry) HN_TRY(hn_maxpool3x3s2_s32(x.p, p.p, n, x.h, x.w, 64, oh, ow, cx.stream));
-    x = p;
-  }
+    HN_TRY(hn_conv_stem_pool_f16x3(img16, n, g.ph, g.pw, border, 7, 2, 64, m->f_stem16.w16, m->f_stem16.bias, x.p, cx.stream));
   T feats_c[3];
   int nf = 0;
   for (auto& b : m->f_blocks) {
@@ -513,19 +512,22 @@ int fcos_graph(Ctx& cx, const float* rgb, int n, int h, int w, const FcosOut& ou
     scale[l] = (float*)alloc_bytes(cx, (size_t)n * 512 * 4);
     shift[l] = (float*)alloc_bytes(cx, (size_t)n * 512 * 4);
   }
-  auto finalize = [&](const float* gamma, const float* beta) -> int {
+  auto finalize = [&](const float* gamma, const float* beta) -> int {   // one launch over the levels
     if (cx.dry) return HN_OK;
-    for (int l = 0; l < L; ++l)
-      HN_TRY(hn_groupnorm_finalize_rows32(parts[l], gamma, beta, n, hw[l], 512, 64, 1e-5f, scale[l], shift[l], cx.stream));
-    return HN_OK;
+    hn_gn_levels lv;
+    lv.count = L;
+    for (int l = 0; l < L; ++l) { lv.hw[l] = hw[l]; lv.partial[l] = parts[l]; lv.scale[l] = scale[l]; lv.shift[l] = shift[l]; }
+    return hn_groupnorm_finalize_rows32_levels(&lv, gamma, beta, n, 512, 64, 1e-5f, cx.stream);
   };
   auto activate = [&](T* a) -> int {  // GroupNorm affine + ReLU + split: S32 [n][h][w][16][2][32], cls blocks 0-7, reg 8-15
+    hn_split_levels lv;
+    lv.count = L;
     for (int l = 0; l < L; ++l) {
       a[l] = alloc(cx, n, t[l].h, t[l].w, 512, true);
-      if (!cx.dry)
-        HN_TRY(hn_affine_split_f32((const float*)t[l].p, scale[l], shift[l], 1, n, hw[l], 512, 512, 512, a[l].p, 1024, cx.stream));
+      lv.hw[l] = hw[l]; lv.x[l] = (const float*)t[l].p; lv.scale[l] = scale[l]; lv.shift[l] = shift[l]; lv.y16[l] = a[l].p;
     }
-    return HN_OK;
+    if (cx.dry) return HN_OK;
+    return hn_affine_split_f32_levels(&lv, 1, n, 512, 512, 512, 1024, cx.stream);   // one launch unless a level is cache-sized
   };
   HN_TRY(finalize(m->f_gn0_gamma, m->f_gn0_beta));
   T a[3];
@@ -620,6 +622,11 @@ int run_planned(hn_model* m, const std::string& key, void* stream, F&& graph) {
     HN_CHECK_HIP(hipMalloc((void**)&m->arena.base, bytes));
     m->arena.cap = bytes;
   }
+  // the arena is shared by every forward of this model: calls on different streams would use the same buffers without
+  // ordering, so a change of stream waits for the work of the previous one (steady-state callers keep one stream)
+  if (m->has_last_stream && m->last_stream != stream) HN_CHECK_HIP(hipStreamSynchronize((hipStream_t)m->last_stream));
+  m->last_stream = stream;
+  m->has_last_stream = true;
   m->arena.dry = false;
   m->arena.off = 0;
   Ctx cx{m, stream, false, nullptr};
@@ -662,6 +669,12 @@ extern "C" int hn_load_weight(hn_model* m, const char* name, const float* data, 
 
 extern "C" int hn_finalize(hn_model* m) {
   HN_CHECK_ARG(m && !m->finalized, "hn_finalize: null or already finalized");
+  // a failed earlier attempt (missing weight, fp16-range error) may have left partial state: start clean, so that a
+  // second hn_finalize after the missing weight was loaded builds the graph once
+  m->a_blocks.clear();
+  m->f_blocks.clear();
+  for (void* q : m->owned) (void)hipFree(q);
+  m->owned.clear();
   if (m->cfg.parts & HN_MODEL_A2J) {
     const std::string p = "Backbone.model.";
     HN_TRY(pack_conv(m, p + "conv1.weight", "", p + "bn1", 2, 3, 1, !m->cfg.rgbd, m->a_stem));

@@ -105,6 +105,7 @@ SIGNATURES = {
     "hn_fcos_preprocess_split": (C.c_int, [VP, VP] + [C.c_int] * 8 + [c_f32p, c_f32p, VP]),
     "hn_fcos_preprocess_list": (C.c_int, [VP, VP, VP] + [C.c_int] * 5 + [c_f32p, c_f32p, VP]),
     "hn_conv_stem_f16x3": (C.c_int, [VP] + [C.c_int] * 7 + [VP, VP, C.c_int, VP, C.c_int, VP]),
+    "hn_conv_stem_pool_f16x3": (C.c_int, [VP] + [C.c_int] * 7 + [VP, VP, VP, VP]),
     "hn_fcos_candidates": (C.c_int, [C.POINTER(FcosLevels), C.c_int, C.c_int, C.c_float,
                                      VP, VP, VP, VP, VP, VP, VP, C.c_int, VP]),
     "hn_fcos_ext_gather": (C.c_int, [C.POINTER(FcosLevels), C.POINTER(VP), VP, VP, VP, C.c_int, C.c_int, VP, VP, VP]),

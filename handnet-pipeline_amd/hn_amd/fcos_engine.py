@@ -114,6 +114,7 @@ class FCOSEngine:
         self._side = None
         self.head_streams = int(os.environ.get("HN_HEAD_STREAMS", "1")) if head_streams is None else head_streams
         self.group_towers = os.environ.get("HN_GROUP_CONVS", "1") != "0"
+        self.fuse_stem_pool = os.environ.get("HN_FUSE_STEM_POOL", "1") != "0"   # A/B switch (results are bit-identical)
 
     # -----------------------------------------------------------------------------------
     def _conv(self, x, cw: ConvW, relu=False, out_f32=False, **kw):
@@ -133,11 +134,15 @@ class FCOSEngine:
         """x: preprocessed canvas -- fp32 [N,PH,PW,4], or the fp16 stem image [2,N,PH+6,PW+6,4] of
         ops.fcos_preprocess_split (f16x3 mode) -> [P3, P4, P5] (256 channels, strides 8/16/32; S32 in f16x3 mode)."""
         ops.PROFILE_STAGE = "resnet34_body"
-        if x.dtype == torch.float16:
-            x = ops.conv_stem_split(x, self.stem16.w16, self.stem16.bias, 64, r=7, stride=2, relu=True)
+        if x.dtype == torch.float16 and self.fuse_stem_pool:
+            # conv1 + bn1 + relu + maxpool as one kernel: the 64-channel half-resolution map never reaches HBM
+            x = ops.conv_stem_pool_split(x, self.stem16.w16, self.stem16.bias, 64, r=7, stride=2)
         else:
-            x = self._conv(x, self.stem, relu=True, algo_cin=3)
-        x = ops.maxpool3x3s2_nhwc(x)
+            if x.dtype == torch.float16:
+                x = ops.conv_stem_split(x, self.stem16.w16, self.stem16.bias, 64, r=7, stride=2, relu=True)
+            else:
+                x = self._conv(x, self.stem, relu=True, algo_cin=3)
+            x = ops.maxpool3x3s2_nhwc(x)
         feats = []
         for blk in self.blocks:
             o = self._conv(x, blk["c1"], relu=True)

@@ -654,6 +654,36 @@ def conv_stem_split(x16, w16, bias, cout, r=7, stride=2, relu=True, out_split=Tr
     return out
 
 
+def conv_stem_pool_split(x16, w16, bias, cout=64, r=7, stride=2, algo_cin=3, out=None):
+    """Stem conv + ReLU + 3x3/2 max pooling in ONE kernel (hn_conv_stem_pool_f16x3): stem image -> pooled S32 map
+    [N, (oh+1)//2, (ow+1)//2, cout/32, 2, 32]; bit-identical to conv_stem_split(...) followed by maxpool3x3s2_nhwc."""
+    lib = _lib.load()
+    pad = r // 2
+    if x16.dim() != 5 or x16.shape[0] != 2 or x16.shape[4] != 4 or x16.dtype != torch.float16 or not x16.is_cuda \
+            or not x16.is_contiguous():
+        raise ValueError("x16 must be the contiguous fp16 GPU stem image [2, N, H+2p, W+2p, 4]")
+    _check_device(x16, "x16")
+    n, hb, wb = x16.shape[1:4]
+    ph, pw = hb - 2 * pad, wb - 2 * pad
+    oh, ow = (hb - r) // stride + 1, (wb - r) // stride + 1
+    poh, pow_ = (oh + 2 - 3) // 2 + 1, (ow + 2 - 3) // 2 + 1
+    if tuple(w16.shape) != (cout, r, 2, 32) or w16.dtype != torch.float16 or not w16.is_cuda or not w16.is_contiguous():
+        raise ValueError("w16 must be the fp16 GPU tensor [cout, r, 2, 32] from weights.pack_stem_split")
+    if out is None:
+        out = torch.empty((n, poh, pow_, cout // 32, 2, 32), device=x16.device, dtype=torch.float16)
+    prof = CONV_PROFILE
+    if prof is not None:
+        timer = HipTimer()
+        timer.start()
+    check(lib.hn_conv_stem_pool_f16x3(ptr(x16), n, ph, pw, pad, r, stride, cout, ptr(w16), ptr(bias), ptr(out), _stream()),
+          "hn_conv_stem_pool_f16x3")
+    if prof is not None:
+        timer.stop()
+        # algorithmic work = the stem convolution as the reference executes it (the patch halo is overhead, not work)
+        prof.append((("f16x3", 8), n * oh * ow * cout * r * r * algo_cin, timer, (n, ph, pw, 4, cout, r, stride, 1), PROFILE_STAGE))
+    return out
+
+
 @dataclass
 class Candidates:
     boxes: torch.Tensor

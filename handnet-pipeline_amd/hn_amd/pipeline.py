@@ -41,6 +41,13 @@ class HandNetEngine:
         # f16x3 range contract as a debug switch: every split producer flags values outside the fp16 range and
         # forward_device raises instead of returning inf / NaN keypoints (costs one device -> host sync per call)
         self.check_range = os.environ.get("HN_CHECK_RANGE", "0") == "1"
+        # Sparse streams: A2J runs on all N frames with a validity mask (static launch sequence, capturable), which wastes
+        # its time on frames without a hand.  When the PREVIOUS step had a hand in fewer than half of its frames (read
+        # back asynchronously: no sync on the dense path), this step reads its own count (one sync) and runs A2J on the
+        # frames with a hand only.  Never under graph capture; HN_COMPACT_SPARSE=0 turns it off.
+        self.compact_sparse = os.environ.get("HN_COMPACT_SPARSE", "1") != "0"
+        self._hand_stat = None      # (event, pinned count tensor, frames) of the last eager step
+        self._sparse_hint = False
 
     @ops.device_guarded
     def forward_device(self, images, depth: torch.Tensor) -> HandNetOutput:
@@ -56,11 +63,49 @@ class HandNetEngine:
         det, cand = self.fcos.detect(images)
         crop_box, has_hand, crops = ops.crop_resize(det, self.num_classes - 1, depth.float().contiguous(), CROP, 4,
                                                     reorder_bgr=self.a2j.rgbd)
-        kp = self.a2j.forward_nhwc(crops, valid=has_hand)
+        kp = self._a2j_sparse(crops, has_hand) if self._use_compaction(len(images)) else None
+        if kp is None:
+            kp = self.a2j.forward_nhwc(crops, valid=has_hand)
+        self._note_hand_count(has_hand, len(images))
         if self.check_range and ops.range_check_fetch(reset=True):
             raise ops.RangeError("an activation left the fp16 range (|v| > 65504 or non-finite) on the f16x3 path: "
                                  "results would be inf/NaN.  Run the engines with precision='f32' for this model")
         return HandNetOutput(kp, crops, crop_box, has_hand, det, cand)
+
+    # -------------------------------------------------------------------------------
+    # sparse streams: A2J on the frames with a hand only
+    # -------------------------------------------------------------------------------
+    def _use_compaction(self, n: int) -> bool:
+        if not self.compact_sparse or n < 8 or torch.cuda.is_current_stream_capturing():
+            return False
+        st = self._hand_stat
+        if st is not None and st[0].query():          # the previous step's count has arrived: refresh the hint
+            self._sparse_hint = int(st[1].item()) * 2 < st[2]
+            self._hand_stat = None
+        return self._sparse_hint
+
+    def _note_hand_count(self, has_hand, n):
+        """Asynchronous read-back of this step's hand count (hint for the next step; no sync)."""
+        if not self.compact_sparse or n < 8 or torch.cuda.is_current_stream_capturing() or self._hand_stat is not None:
+            return
+        pinned = torch.empty((1,), dtype=torch.int64, pin_memory=True)
+        pinned.copy_(has_hand.sum(dtype=torch.int64).reshape(1), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._hand_stat = (ev, pinned, n)
+
+    def _a2j_sparse(self, crops, has_hand):
+        """A2J on the frames with a hand only (one device -> host sync for the count); None = not sparse after all."""
+        n = has_hand.shape[0]
+        idx = torch.nonzero(has_hand, as_tuple=False).flatten()      # synchronises
+        k = int(idx.numel())
+        if k * 2 >= n:
+            self._sparse_hint = False
+            return None
+        kp = torch.zeros((n, self.a2j.joints, 3), device=crops.device, dtype=torch.float32)
+        if k:
+            kp[idx] = self.a2j.forward_nhwc(crops[idx].contiguous())
+        return kp
 
     # -------------------------------------------------------------------------------
     # hipGraph replay for a fixed batch shape (launch-bound at small batch)

@@ -266,6 +266,12 @@ int hn_fcos_preprocess_list(const float* const* srcs, const int32_t* geom, void*
 int hn_conv_stem_f16x3(const void* x16, int n, int ph, int pw, int pad, int r, int stride, int cout,
                        const void* w16, const float* bias, int relu, void* y, int out_split,
                        void* stream);
+/* The stem with the ResNet's 3x3 / stride-2 / pad-1 max pooling fused into its epilogue (conv1 -> bn1 -> relu -> maxpool of
+ * torchvision resnet34, fcos_utils/fcos.py:737): cout = 64, ReLU on, y = the POOLED S32 map [n][(oh+1)/2][(ow+1)/2][64].
+ * Bit-identical to hn_conv_stem_f16x3 followed by hn_maxpool3x3s2_s32; the half-resolution conv map (1.8 GB at batch
+ * 32) never reaches HBM. */
+int hn_conv_stem_pool_f16x3(const void* x16, int n, int ph, int pw, int pad, int r, int stride, int cout,
+                            const void* w16, const float* bias, void* y, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * FCOS post-processing.  Replaces fcos_utils/fcos.py:572-659 (postprocess_detections),

@@ -50,3 +50,19 @@ def test_argument_errors_do_not_need_a_gpu():
     assert st == 1 and b"multiple of 4" in lib.hn_last_error()
     assert lib.hn_fcos_nms_scratch_bytes(2, 1000) > 2 * 1024 * 8
     assert lib.hn_groupnorm_scratch_floats(2, 13600, 256, 32) == 2 * 213 * 32 * 2
+
+
+def test_probes_compile():
+    """tools/probes/*.hip are measurement aids quoted in DESIGN.md / profiles/: keep them compiling for gfx950 (compile
+    only; they run on the GPU box by hand)."""
+    from concurrent.futures import ThreadPoolExecutor
+    probes = sorted((build.REPO_ROOT / "tools" / "probes").glob("*.hip"))
+    assert len(probes) >= 5
+
+    def compile_one(src):
+        r = subprocess.run([build._hipcc(), f"--offload-arch={build.ARCH}", "-O2", "-c", str(src), "-o", "/dev/null"],
+                           capture_output=True, text=True)
+        return src.name, r.returncode, r.stderr[-400:]
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        for name, rc, err in ex.map(compile_one, probes):
+            assert rc == 0, f"{name}: {err}"

@@ -430,3 +430,27 @@ def test_nms_kernel_satisfies_the_definition_of_greedy_nms(k, classes):
     nms_property.check(boxes, scores, labels, keep, 0.3)
     if classes == 1:
         assert torch.equal(ops.nms(boxes.cuda(), scores.cuda(), 0.3).cpu(), torch.from_numpy(keep))
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 480, 640), (1, 96, 128), (3, 100, 260)])
+def test_fused_stem_pool_equals_stem_then_pool(fcos_sd, n, h, w):
+    """hn_conv_stem_pool_f16x3 (conv1 + bn1 + relu + 3x3/2 max pooling in one kernel, 15 x 17 conv patches per workgroup)
+    is bit-identical to hn_conv_stem_f16x3 followed by hn_maxpool3x3s2_s32, including canvases whose pooled map is not a
+    multiple of the 7 x 8 patch (partial patches at the bottom / right edge) and odd conv maps."""
+    from hn_amd import ops, synth
+    from hn_amd.fcos_engine import FCOSEngine, IMAGE_MEAN, IMAGE_STD
+    eng = FCOSEngine(fcos_sd, 3, device="cuda")
+    rgb = synth.make_rgb(n, seed=77, h=h, w=w).cuda() if "h" in synth.make_rgb.__code__.co_varnames else \
+        torch.rand((n, 3, h, w), generator=torch.Generator().manual_seed(77)).cuda()
+    oh, ow, ph, pw = eng.geometry(h, w)
+    img16 = ops.fcos_preprocess_split(rgb, oh, ow, ph, pw, IMAGE_MEAN, IMAGE_STD)
+    ref = ops.maxpool3x3s2_nhwc(ops.conv_stem_split(img16, eng.stem16.w16, eng.stem16.bias, 64, r=7, stride=2, relu=True))
+    got = ops.conv_stem_pool_split(img16, eng.stem16.w16, eng.stem16.bias, 64, r=7, stride=2)
+    assert got.shape == ref.shape
+    assert torch.equal(got, ref)
+    # and through the engine switch: same features either way
+    a = eng.backbone(img16)
+    eng.fuse_stem_pool = False
+    b = eng.backbone(img16)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)

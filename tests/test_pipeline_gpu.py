@@ -388,3 +388,43 @@ def test_handnet_refuses_nonfinite_keypoints(fcos_sd, a2j_sd):
         assert not torch.isfinite(net.forward_device([rgb[0]], depth).keypoints).all()   # the engine itself returns them
         with pytest.raises(ops.RangeError):
             net([rgb[0]], depth_images=depth)
+
+
+def test_sparse_stream_compacts_a2j(fcos_sd, a2j_sd, monkeypatch):
+    """Sparse streams: once a step has had a hand in fewer than half of its frames, the next eager
+    step runs A2J on the frames with a hand only -- same keypoints on those frames, zero rows elsewhere; the dense path
+    never synchronises for it, and graph capture never takes it."""
+    from hn_amd import ops, pipeline, synth
+    from hn_amd.a2j_engine import A2JEngine
+    from hn_amd.fcos_engine import FCOSEngine
+    eng = pipeline.HandNetEngine(FCOSEngine(fcos_sd, 3, device="cuda"), A2JEngine(a2j_sd, device="cuda"), 3)
+    n = 16
+    rgb, depth = synth.make_rgb(n, seed=1000).cuda(), synth.make_depth(n, seed=2000).cuda()
+    dense = eng.forward_device(rgb, depth)
+    torch.cuda.synchronize()
+    assert int(dense.has_hand.sum()) == n and not eng._sparse_hint
+    keep = torch.zeros((n,), dtype=torch.int32, device="cuda")
+    keep[[1, 6, 11]] = 1
+    real_crop = ops.crop_resize
+    calls = []
+
+    def sparse_crop(*a, **k):          # frames 1, 6, 11 keep their hand, the others lose it (as an empty scene would)
+        box, has, crops = real_crop(*a, **k)
+        has = has * keep
+        return box * keep[:, None].to(box.dtype), has, crops * keep[:, None, None, None].to(crops.dtype)
+    monkeypatch.setattr(pipeline.ops, "crop_resize", sparse_crop)
+    real_fwd = eng.a2j.forward_nhwc
+
+    def spy(x, valid=None, **k):
+        calls.append(x.shape[0])
+        return real_fwd(x, valid=valid, **k)
+    monkeypatch.setattr(eng.a2j, "forward_nhwc", spy)
+    first = eng.forward_device(rgb, depth)        # still the masked full-batch form; its count arms the hint
+    torch.cuda.synchronize()
+    second = eng.forward_device(rgb, depth)       # compacted
+    assert calls == [n, 3], calls
+    assert torch.equal(second.has_hand, first.has_hand) and int(second.has_hand.sum()) == 3
+    assert torch.equal(second.keypoints[keep == 0], torch.zeros_like(second.keypoints[keep == 0]))
+    sel = keep.bool()
+    assert (second.keypoints[sel] - first.keypoints[sel]).abs().max().item() < 1e-4
+    assert (second.keypoints[sel] - dense.keypoints[sel]).abs().max().item() < 1e-4
