@@ -312,3 +312,50 @@ extern "C" int hn_nonfinite_count_f32(const float* x, int64_t count, int32_t* fl
   HN_CHECK_LAUNCH("nonfinite_count_kernel");
   return HN_OK;
 }
+
+// ---------------------------------------------------------------------------------------
+// fp32 NHWC(4) image -> the stem image of hn_conv_stem_f16x3 / hn_conv_stem_pool_f16x3: two fp16 planes (hi, lo) of
+// [n][h + 2b][w + 2b][4] with a zero border of b pixels (the A2J crops; the FCOS image is written in this form by the
+// preprocess kernel).  One thread per bordered pixel: 16 B read, 8 B + 8 B written.
+// ---------------------------------------------------------------------------------------
+namespace {
+typedef _Float16 f16x4s __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void stem_image_kernel(const float* __restrict__ x, _Float16* __restrict__ dst, int n, int h,
+                                                         int w, int b, int* range_flag) {
+  const int hb = h + 2 * b, wb = w + 2 * b;
+  const long total = (long)n * hb * wb;
+  _Float16* lo_plane = dst + total * 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int xx = (int)(i % wb);
+    const long t = i / wb;
+    const int yy = (int)(t % hb);
+    const int img = (int)(t / hb);
+    f16x4s hi = {(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0}, lo = hi;
+    const int sy = yy - b, sx = xx - b;
+    if ((unsigned)sy < (unsigned)h && (unsigned)sx < (unsigned)w) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((long)img * h + sy) * w + sx) * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (range_flag) hn::range_note(range_flag, v[e]);
+        const _Float16 hh = (_Float16)v[e];
+        hi[e] = hh;
+        lo[e] = (_Float16)(v[e] - (float)hh);
+      }
+    }
+    *reinterpret_cast<f16x4s*>(dst + i * 4) = hi;
+    *reinterpret_cast<f16x4s*>(lo_plane + i * 4) = lo;
+  }
+}
+}  // namespace
+
+extern "C" int hn_stem_image_nhwc4(const float* x, int n, int h, int w, int border, void* dst16, void* stream) {
+  HN_CHECK_ARG(x && dst16, "hn_stem_image_nhwc4: null pointer");
+  HN_CHECK_ARG(n > 0 && h > 0 && w > 0 && border >= 0 && border <= 4, "bad dims");
+  HN_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)dst16 % 8 == 0, "unaligned tensors");
+  const long total = (long)n * (h + 2 * border) * (w + 2 * border);
+  const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  hipLaunchKernelGGL(stem_image_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (_Float16*)dst16, n, h, w, border,
+                     hn::range_flag_ptr());
+  HN_CHECK_LAUNCH("stem_image_kernel");
+  return HN_OK;
+}

@@ -70,6 +70,7 @@ struct hn_model {
   std::vector<void*> owned;  // device allocations of the weights
   // ---- A2J ----
   ConvW a_stem;
+  ConvW a_stem16;  // w16 = [64][7][2][32] stem rows (depth-only model: the three identical input channels folded into one), bias
   struct Bneck { ConvW c1, c2, c3, ds; bool has_ds = false; int layer = 0; };
   std::vector<Bneck> a_blocks;
   ConvW a_cls[4], a_reg[3], a_dep[3], a_regdep1, a_cls_out, a_reg_out, a_dep_out;
@@ -209,7 +210,8 @@ int concat_cout(const ConvW& a, const ConvW& b, ConvW& out, const char* what) {
 }
 
 // R x R stem (cin <= 4) for hn_conv_stem_f16x3: each filter ROW is one 32-deep k tile, k = kx*4 + c
-int pack_stem_split(const hn_model* m, const std::string& wname, const std::string& bnname, ConvW& cw) {
+// sum_cin: collapse the input channels into one (the A2J stem sees the depth map replicated 3x, a2j/a2j.py:199)
+int pack_stem_split(const hn_model* m, const std::string& wname, const std::string& bnname, ConvW& cw, bool sum_cin = false) {
   const HostT* w;
   HN_TRY(need(m, wname, &w, 4));
   const int cout = (int)w->shape[0], cin = (int)w->shape[1], r = (int)w->shape[2], s = (int)w->shape[3];
@@ -220,8 +222,14 @@ int pack_stem_split(const hn_model* m, const std::string& wname, const std::stri
   for (int o = 0; o < cout; ++o)
     for (int ky = 0; ky < r; ++ky)
       for (int kx = 0; kx < r; ++kx)
-        for (int c = 0; c < cin; ++c)
-          rows[((size_t)o * r + ky) * 32 + kx * 4 + c] = (float)((double)w->v[(((size_t)o * cin + c) * r + ky) * s + kx] * scale[o]);
+        if (sum_cin) {
+          double acc = 0.0;
+          for (int c = 0; c < cin; ++c) acc += (double)w->v[(((size_t)o * cin + c) * r + ky) * s + kx];
+          rows[((size_t)o * r + ky) * 32 + kx * 4] = (float)(acc * scale[o]);
+        } else {
+          for (int c = 0; c < cin; ++c)
+            rows[((size_t)o * r + ky) * 32 + kx * 4 + c] = (float)((double)w->v[(((size_t)o * cin + c) * r + ky) * s + kx] * scale[o]);
+        }
   cw.cout = cout; cw.r = r; cw.s = r; cw.cin = 4; cw.stride = 2; cw.pad = r / 2; cw.dil = 1;
   cw.has_bias = true;
   cw.hb.resize(cout);
@@ -350,17 +358,15 @@ int conv_grouped(Ctx& cx, const GroupSpec& g, int relu_cols, bool out_split, int
 int a2j_graph(Ctx& cx, const T& crops /* fp32 [k][176][176][4] */, const int32_t* valid, float* keypoints) {
   hn_model* m = cx.m;
   const int k = crops.n;
-  // stem: exact f32-MFMA kernel (Cin 4), S32 output
-  hn_conv_desc d = make_desc(crops, m->a_stem, m->a_stem.cout);
-  d.out_split = 1;
-  T x = alloc(cx, k, d.oh, d.ow, 64, true);
-  if (!cx.dry) HN_TRY(hn_conv2d_nhwc_f32(&d, (const float*)crops.p, m->a_stem.w, m->a_stem.bias, nullptr, nullptr, nullptr, (float*)x.p, cx.stream));
-  {
-    const int oh = (x.h + 2 - 3) / 2 + 1, ow = (x.w + 2 - 3) / 2 + 1;
-    T p = alloc(cx, k, oh, ow, 64, true);
-    if (!cx.dry) HN_TRY(hn_maxpool3x3s2_s32(x.p, p.p, k, x.h, x.w, 64, oh, ow, cx.stream));
-    x = p;
-  }
+  // stem: conv1 + bn1 + relu + maxpool as ONE split-precision kernel on the crops' stem image (like hn_amd/a2j_engine.py)
+  const int border = 3;
+  char* img16 = alloc_bytes(cx, (size_t)2 * k * (crops.h + 2 * border) * (crops.w + 2 * border) * 4 * 2);
+  if (!cx.dry) HN_TRY(hn_stem_image_nhwc4((const float*)crops.p, k, crops.h, crops.w, border, img16, cx.stream));
+  int sh, sw;
+  out_size(crops.h + 2 * border, crops.w + 2 * border, 7, 7, 2, 0, 1, sh, sw);
+  T x = alloc(cx, k, (sh + 2 - 3) / 2 + 1, (sw + 2 - 3) / 2 + 1, 64, true);
+  if (!cx.dry)
+    HN_TRY(hn_conv_stem_pool_f16x3(img16, k, crops.h, crops.w, border, 7, 2, 64, m->a_stem16.w16, m->a_stem16.bias, x.p, cx.stream));
   T x3;
   for (size_t i = 0; i < m->a_blocks.size(); ++i) {
     auto& b = m->a_blocks[i];
@@ -678,6 +684,7 @@ extern "C" int hn_finalize(hn_model* m) {
   if (m->cfg.parts & HN_MODEL_A2J) {
     const std::string p = "Backbone.model.";
     HN_TRY(pack_conv(m, p + "conv1.weight", "", p + "bn1", 2, 3, 1, !m->cfg.rgbd, m->a_stem));
+    HN_TRY(pack_stem_split(m, p + "conv1.weight", p + "bn1", m->a_stem16, !m->cfg.rgbd));
     const int planes[4] = {64, 128, 256, 512}, blocks[4] = {3, 4, 6, 3}, strides[4] = {1, 2, 2, 1}, dils[4] = {1, 1, 1, 2};
     (void)planes;
     for (int li = 1; li <= 4; ++li)
@@ -708,6 +715,7 @@ extern "C" int hn_finalize(hn_model* m) {
     for (int i = 0; i < 3; ++i) { m->a_reg[i] = reg4[i + 1]; m->a_dep[i] = dep4[i + 1]; }
     HN_CHECK_ARG(m->a_cls_out.cout == 16 * m->cfg.num_joints, "checkpoint does not match num_joints");
     HN_TRY(upload(m, m->a_stem));
+    HN_TRY(upload(m, m->a_stem16));
     for (auto& k : m->a_blocks) {
       HN_TRY(upload(m, k.c1)); HN_TRY(upload(m, k.c2)); HN_TRY(upload(m, k.c3));
       if (k.has_ds) HN_TRY(upload(m, k.ds));

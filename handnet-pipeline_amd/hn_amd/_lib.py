@@ -114,6 +114,7 @@ SIGNATURES = {
     "hn_fcos_nms_ratios": (C.c_int, [VP] * 6 + [C.c_int, C.c_int, C.c_double, VP] + [VP] * 9),
     "hn_nms": (C.c_int, [VP, VP, C.c_int, C.c_double, VP, VP, VP, VP]),
     "hn_crop_resize": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, VP] + [C.c_int] * 7 + [VP, VP, VP, VP]),
+    "hn_stem_image_nhwc4": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP]),
     "hn_pack_depth_nhwc": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, VP]),
     "hn_a2j_aggregate_f32": (C.c_int, [VP, VP, VP, VP] + [C.c_int] * 5 + [VP, VP]),
     "hn_create": (C.c_int, [C.POINTER(ModelConfig), C.POINTER(VP)]),

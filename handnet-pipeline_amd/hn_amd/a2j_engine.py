@@ -14,7 +14,7 @@ import os
 import torch
 
 from . import ops
-from .weights import ConvW, bn_scale_shift, concat_cout, pack_conv, strip_prefix
+from .weights import ConvW, bn_scale_shift, concat_cout, pack_conv, pack_stem_split, strip_prefix
 
 # (planes, blocks, stride of first block, dilation of later blocks)  a2j/resnet.py:109-112
 _LAYERS = [(64, 3, 1, 1), (128, 4, 2, 1), (256, 6, 2, 1), (512, 3, 1, 2)]
@@ -42,6 +42,12 @@ class A2JEngine:
 
         # stem: depth replicated to 3 channels in the reference -> fold to one channel
         self.stem = cbn(p + "conv1", p + "bn1", stride=2, pad=3, sum_cin=not rgbd)
+        # f16x3 mode: conv1 + bn1 + relu + maxpool as ONE split-precision kernel (the FCOS stem's, hn_conv_stem_pool_f16x3)
+        # on the crops' stem image; the f32-MFMA stem + separate pooling pass was 5 % of the batch-64 step
+        w1 = sd[p + "conv1.weight"].double()
+        self.stem16 = pack_stem_split(w1 if rgbd else w1.sum(dim=1, keepdim=True), bn_scale_shift(sd, p + "bn1")).to(dev) \
+            if precision == "f16x3" else None
+        self.fuse_stem_pool = os.environ.get("HN_FUSE_STEM_POOL", "1") != "0"
         self.blocks = []
         for li, (planes, blocks, stride, dil) in enumerate(_LAYERS, start=1):
             for b in range(blocks):
@@ -91,8 +97,12 @@ class A2JEngine:
     def trunk(self, x):
         """x [K,H,W,4] NHWC fp32 -> (x3 [K,H/16,W/16,1024], x4 [K,H/16,W/16,2048]) (S32 in f16x3 mode)."""
         ops.PROFILE_STAGE = "a2j_trunk"
-        x = self._conv(x, self.stem, algo_cin=4 if self.rgbd else 3)
-        x = ops.maxpool3x3s2_nhwc(x)
+        if self.stem16 is not None and self.fuse_stem_pool:
+            x = ops.conv_stem_pool_split(ops.stem_image_nhwc4(x), self.stem16.w16, self.stem16.bias, 64, r=7, stride=2,
+                                         algo_cin=4 if self.rgbd else 3)
+        else:
+            x = self._conv(x, self.stem, algo_cin=4 if self.rgbd else 3)
+            x = ops.maxpool3x3s2_nhwc(x)
         x3 = None
         for i, blk in enumerate(self.blocks):
             o = self._conv(x, blk["c1"])

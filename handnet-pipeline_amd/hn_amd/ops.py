@@ -848,6 +848,18 @@ def crop_resize(det: Detections, hand_label, depth, out_size=176, cpad=4, crop_b
     return crop_box, has_hand, crops
 
 
+def stem_image_nhwc4(x, border=3, out=None):
+    """fp32 [N,H,W,4] -> stem image fp16 [2 (hi, lo), N, H+2b, W+2b, 4] with a zero border (input of conv_stem_*_split)."""
+    _req(x, name="x")
+    n, h, w, c = x.shape
+    if c != 4:
+        raise ValueError("x must be [N,H,W,4]")
+    if out is None:
+        out = torch.empty((2, n, h + 2 * border, w + 2 * border, 4), device=x.device, dtype=torch.float16)
+    check(_lib.load().hn_stem_image_nhwc4(ptr(x), n, h, w, border, ptr(out), _stream()), "hn_stem_image_nhwc4")
+    return out
+
+
 def pack_depth_nhwc(depth, cpad=4, out=None):
     """depth [N,1,H,W] -> [N,H,W,cpad] with depth in channel 0."""
     lib = _lib.load()

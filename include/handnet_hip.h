@@ -348,6 +348,11 @@ int hn_crop_resize(const float* det_boxes, const int32_t* det_labels, const int3
                    int h, int w, int out, int cpad, int64_t* crop_box, int32_t* has_hand, float* crops,
                    void* stream);
 
+/* fp32 NHWC(4) image [n][h][w][4] -> the stem image of hn_conv_stem_f16x3 / hn_conv_stem_pool_f16x3 (two fp16 planes hi, lo of
+ * [n][h + 2*border][w + 2*border][4], zero border): the A2J crops on their way to the split-precision stem
+ * (a2j/resnet.py:155-158 conv1 -> bn1 -> relu -> maxpool). */
+int hn_stem_image_nhwc4(const float* x, int n, int h, int w, int border, void* dst16, void* stream);
+
 /* Pack [n][1][h][w] depth crops into NHWC(cpad) for the A2J stem (A2J-only entry). */
 int hn_pack_depth_nhwc(const float* src, float* dst, int n, int hw, int cpad, void* stream);
 
