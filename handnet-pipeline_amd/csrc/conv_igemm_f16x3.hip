@@ -1566,6 +1566,9 @@ static int stem16_run(const void* x16, int n, int ph, int pw, int pad, int r, in
   if (pool) {
     HN_CHECK_ARG(cout == 64 && relu && out_split && bias, "the fused stem + max-pool kernel needs cout = 64, bias, ReLU and an S32 output");
     HN_CHECK_ARG((uintptr_t)y % 16 == 0 && (uintptr_t)bias % 16 == 0, "unaligned output / bias");
+    // the ResNet stem shape: direct convolution from an LDS-resident image patch (conv_stem_direct.hip); other filter sizes,
+    // and HN_STEM_POOL_GENERIC=1, take the implicit-GEMM form below (same results bit for bit)
+    if (r == 7 && stride == 2 && pad == 3 && !hn::env_flags().stem_generic) return hn::stem_pool_direct(x16, n, ph, pw, w16, bias, y, st);
     p.pool_oh = (oh + 2 - 3) / 2 + 1;
     p.pool_ow = (ow + 2 - 3) / 2 + 1;
     p.pool_ty = hn::cdiv(p.pool_oh, kPoolPR);
