@@ -143,6 +143,11 @@ struct LevelTable {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
+// One workgroup per image walks the points in anchor order, kU x 1024 at a time: the kU sub-blocks of an iteration are
+// evaluated first (their ~10 dependent-latency global loads per point in flight together) and compacted afterwards in
+// sub-block order, so the output order is the anchor order.  (kU = 1, the round-1/2 form, spent 63 us at batch 1 on 18
+// serial load -> ballot -> barrier rounds; kU = 4 needs 5.)
+constexpr int kCandUnroll = 4;
 __global__ __launch_bounds__(1024) void fcos_candidates_kernel(const LevelTable lt, int num_classes, float thresh,
                                                                float* __restrict__ cand_boxes,
                                                                float* __restrict__ cand_scores,
@@ -151,7 +156,8 @@ __global__ __launch_bounds__(1024) void fcos_candidates_kernel(const LevelTable 
                                                                int* __restrict__ cand_level,
                                                                int* __restrict__ cand_point,
                                                                int* __restrict__ cand_count, int cap) {
-  __shared__ int wave_counts[16];
+  constexpr int U = kCandUnroll;
+  __shared__ int wave_counts[U][16];
   __shared__ int base_s;
   const int img = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -159,72 +165,90 @@ __global__ __launch_bounds__(1024) void fcos_candidates_kernel(const LevelTable 
   const int cw = num_classes + 2;
   if (tid == 0) base_s = 0;
   __syncthreads();
-  for (int start = 0; start < P; start += blockDim.x) {
-    const int i = start + tid;
-    bool pass = false;
-    float score = 0.f, bx0 = 0.f, by0 = 0.f, bx1 = 0.f, by1 = 0.f;
-    int label = 0, side = 0, lvl = 0;
-    if (i < P) {
-      while (lvl + 1 < lt.num_levels && i >= lt.start[lvl + 1]) ++lvl;
-      const int q = i - lt.start[lvl];
-      const int hw = lt.h[lvl] * lt.w[lvl];
-      const float* pc = lt.cls_lr[lvl] + ((long)img * hw + q) * cw;
-      const float* pr = lt.reg_ctr[lvl] + ((long)img * hw + q) * 5;
-      const float sctr = sigmoidf_(pr[4]);
-      float best = -1.f;
-      for (int c = 0; c < num_classes; ++c) {
-        const float sc = sqrtf(sigmoidf_(pc[c]) * sctr);
-        if (sc > best) {  // ties keep the lowest class index (torch.max)
-          best = sc;
-          label = c;
+  for (int start = 0; start < P; start += U * (int)blockDim.x) {
+    bool pass[U];
+    float score[U], bx0[U], by0[U], bx1[U], by1[U];
+    int label[U], side[U], lvl[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = start + u * (int)blockDim.x + tid;
+      pass[u] = false;
+      score[u] = bx0[u] = by0[u] = bx1[u] = by1[u] = 0.f;
+      label[u] = side[u] = lvl[u] = 0;
+      if (i < P) {
+        int lv = 0;
+        while (lv + 1 < lt.num_levels && i >= lt.start[lv + 1]) ++lv;
+        lvl[u] = lv;
+        const int q = i - lt.start[lv];
+        const int hw = lt.h[lv] * lt.w[lv];
+        const float* pc = lt.cls_lr[lv] + ((long)img * hw + q) * cw;
+        const float* pr = lt.reg_ctr[lv] + ((long)img * hw + q) * 5;
+        const float sctr = sigmoidf_(pr[4]);
+        float best = -1.f;
+        int lab = 0;
+        for (int c = 0; c < num_classes; ++c) {
+          const float sc = sqrtf(sigmoidf_(pc[c]) * sctr);
+          if (sc > best) {  // ties keep the lowest class index (torch.max)
+            best = sc;
+            lab = c;
+          }
+        }
+        score[u] = best;
+        label[u] = lab;
+        pass[u] = best > thresh;
+        if (pass[u]) {
+          const float s0 = sigmoidf_(pc[num_classes]), s1 = sigmoidf_(pc[num_classes + 1]);
+          side[u] = s1 > s0 ? 1 : 0;
+          const int gy = q / lt.w[lv], gx = q - gy * lt.w[lv];
+          const float st = (float)lt.stride[lv];
+          const float half = rintf(st * 0.5f);  // base anchor [-s/2, -s/2, s/2, s/2].round()
+          const float ax0 = (float)(gx * lt.stride[lv]) - half, ay0 = (float)(gy * lt.stride[lv]) - half;
+          const float ax1 = (float)(gx * lt.stride[lv]) + half, ay1 = (float)(gy * lt.stride[lv]) + half;
+          const float cx = 0.5f * (ax0 + ax1), cy = 0.5f * (ay0 + ay1);
+          const float bw = ax1 - ax0, bh = ay1 - ay0;
+          bx0[u] = cx - pr[0] * bw;
+          by0[u] = cy - pr[1] * bh;
+          bx1[u] = cx + pr[2] * bw;
+          by1[u] = cy + pr[3] * bh;
         }
       }
-      score = best;
-      pass = score > thresh;
-      if (pass) {
-        const float s0 = sigmoidf_(pc[num_classes]), s1 = sigmoidf_(pc[num_classes + 1]);
-        side = s1 > s0 ? 1 : 0;
-        const int gy = q / lt.w[lvl], gx = q - gy * lt.w[lvl];
-        const float st = (float)lt.stride[lvl];
-        const float half = rintf(st * 0.5f);  // base anchor [-s/2, -s/2, s/2, s/2].round()
-        const float ax0 = (float)(gx * lt.stride[lvl]) - half, ay0 = (float)(gy * lt.stride[lvl]) - half;
-        const float ax1 = (float)(gx * lt.stride[lvl]) + half, ay1 = (float)(gy * lt.stride[lvl]) + half;
-        const float cx = 0.5f * (ax0 + ax1), cy = 0.5f * (ay0 + ay1);
-        const float bw = ax1 - ax0, bh = ay1 - ay0;
-        bx0 = cx - pr[0] * bw;
-        by0 = cy - pr[1] * bh;
-        bx1 = cx + pr[2] * bw;
-        by1 = cy + pr[3] * bh;
-      }
     }
-    const unsigned long long bal = __ballot(pass);
-    const int lane_prefix = __popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) wave_counts[wave] = __popcll(bal);
+    int lane_prefix[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned long long bal = __ballot(pass[u]);
+      lane_prefix[u] = __popcll(bal & ((1ull << lane) - 1ull));
+      if (lane == 0) wave_counts[u][wave] = __popcll(bal);
+    }
     __syncthreads();
-    int wave_off = 0, total = 0;
     const int nw = blockDim.x >> 6;
-    for (int k = 0; k < nw; ++k) {
-      if (k < wave) wave_off += wave_counts[k];
-      total += wave_counts[k];
-    }
-    const int base = base_s;
-    if (pass) {
-      const int pos = base + wave_off + lane_prefix;
-      if (pos < cap) {
-        const long o = (long)img * cap + pos;
-        cand_boxes[o * 4 + 0] = bx0;
-        cand_boxes[o * 4 + 1] = by0;
-        cand_boxes[o * 4 + 2] = bx1;
-        cand_boxes[o * 4 + 3] = by1;
-        cand_scores[o] = score;
-        cand_labels[o] = label;
-        cand_sides[o] = side;
-        cand_level[o] = lvl;
-        if (cand_point) cand_point[o] = i;
+    int base = base_s;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int wave_off = 0, total = 0;
+      for (int k = 0; k < nw; ++k) {
+        if (k < wave) wave_off += wave_counts[u][k];
+        total += wave_counts[u][k];
       }
+      if (pass[u]) {
+        const int pos = base + wave_off + lane_prefix[u];
+        if (pos < cap) {
+          const long o = (long)img * cap + pos;
+          cand_boxes[o * 4 + 0] = bx0[u];
+          cand_boxes[o * 4 + 1] = by0[u];
+          cand_boxes[o * 4 + 2] = bx1[u];
+          cand_boxes[o * 4 + 3] = by1[u];
+          cand_scores[o] = score[u];
+          cand_labels[o] = label[u];
+          cand_sides[o] = side[u];
+          cand_level[o] = lvl[u];
+          if (cand_point) cand_point[o] = start + u * (int)blockDim.x + tid;
+        }
+      }
+      base += total;
     }
     __syncthreads();
-    if (tid == 0) base_s = base + total;
+    if (tid == 0) base_s = base;
     __syncthreads();
   }
   if (tid == 0) cand_count[img] = min(base_s, cap);

@@ -22,22 +22,32 @@ def iou64(boxes: torch.Tensor) -> np.ndarray:
 
 
 def make_case(k, classes, seed, thr=0.3, band=1e-4, extent=600.0):
+    """k clustered boxes (plenty of overlaps on both sides of the threshold) with distinct scores; boxes taking part in a
+    same-class pair whose fp64 IoU lies within `band` of the threshold are dropped (the draw is 25 % larger to make up for
+    it), so that no decision hinges on the rounding of an IoU."""
     g = torch.Generator().manual_seed(seed)
-    while True:
-        # clustered boxes: plenty of overlaps on both sides of the threshold
-        centres = torch.rand((max(4, k // 8), 2), generator=g) * extent
-        c = centres[torch.randint(0, centres.shape[0], (k,), generator=g)] + torch.randn((k, 2), generator=g) * 12.0
-        wh = 20.0 + torch.rand((k, 2), generator=g) * 60.0
-        boxes = torch.cat([c - wh / 2, c + wh / 2], dim=1).float().contiguous()
-        scores = torch.rand((k,), generator=g).float()
-        if torch.unique(scores).numel() != k:
-            continue
-        labels = torch.randint(0, classes, (k,), generator=g, dtype=torch.int32)
-        iou = iou64(boxes)
-        same = labels[:, None].numpy() == labels[None, :].numpy()
-        np.fill_diagonal(same, False)
-        if not np.any(same & (np.abs(iou - thr) < band)):
-            return boxes, scores, labels
+    n = k + k // 4 + 8
+    centres = torch.rand((max(4, n // 8), 2), generator=g) * extent
+    c = centres[torch.randint(0, centres.shape[0], (n,), generator=g)] + torch.randn((n, 2), generator=g) * 12.0
+    wh = 20.0 + torch.rand((n, 2), generator=g) * 60.0
+    boxes = torch.cat([c - wh / 2, c + wh / 2], dim=1).float().contiguous()
+    scores = torch.rand((n,), generator=g).float()
+    labels = torch.randint(0, classes, (n,), generator=g, dtype=torch.int32)
+    iou = iou64(boxes)
+    same = labels[:, None].numpy() == labels[None, :].numpy()
+    np.fill_diagonal(same, False)
+    near = same & (np.abs(iou - thr) < band)
+    drop = np.zeros((n,), dtype=bool)
+    for a, b in np.argwhere(np.triu(near)):
+        if not drop[a] and not drop[b]:
+            drop[b] = True
+    # distinct scores: drop later duplicates
+    _, first = np.unique(scores.numpy(), return_index=True)
+    dup = np.ones((n,), dtype=bool)
+    dup[first] = False
+    keep = torch.from_numpy(np.where(~(drop | dup))[0][:k])
+    assert keep.numel() == k, (keep.numel(), k)
+    return boxes[keep].contiguous(), scores[keep].contiguous(), labels[keep].contiguous()
 
 
 def check(boxes, scores, labels, keep, thr=0.3):

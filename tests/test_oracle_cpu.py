@@ -233,7 +233,7 @@ def test_resnet34_body_matches_third_party_basic_block_resnet(fcos_sd):
         assert (a - b).abs().max().item() <= 1e-5 * max(scale, 1.0), name
 
 
-@pytest.mark.parametrize("k,classes", [(64, 1), (300, 3), (1200, 3)])
+@pytest.mark.parametrize("k,classes", [(64, 1), (300, 3), (1200, 3), (3000, 2)])
 def test_nms_oracle_satisfies_the_definition_of_greedy_nms(k, classes):
     """Row a8' anchor that needs neither torchvision nor the HIP kernel: on tie-free boxes the kept set of the C
     restatement (both batched_nms paths: coordinate trick up to 1000 boxes, per-class above) is THE set the definition
