@@ -1336,8 +1336,13 @@ static TileForm tile_form(int tile, bool rs32) {
 // plan_splits, rs_will_run) for a call through hn_conv2d_nhwc_f16x3_ws with the engines' 32 MiB workspace (d->splitk < 0:
 // no workspace), so a layer that goes split-K -- which uses the per-tap form -- answers 0.  For a grouped launch pass the
 // smallest member width in d->w, all members' rows as n * oh * ow and the picked tile in d->tile.
+extern "C" int hn_conv2d_f16x3_uses_halo(const hn_conv_desc* d, int has_residual) {
+  return d && hn::conv3x3_halo_applies(d, false, false, has_residual ? (const void*)d : nullptr) ? 1 : 0;
+}
+
 extern "C" int hn_conv2d_f16x3_uses_rs(const hn_conv_desc* d) {
   if (!d || d->w <= 0 || d->cin <= 0) return 0;
+  if (hn::conv3x3_halo_applies(d, false, false, d->res_mode ? (const void*)d : nullptr)) return 0;
   const int tile = hn_conv2d_f16x3_pick_tile(d);
   ConvParams16 p;
   p.R = d->r; p.S = d->s; p.stride = d->stride; p.dil = d->dil; p.pad = d->pad;
@@ -1430,6 +1435,10 @@ static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, c
   HN_CHECK_ARG(d->in_pix_stride == 0 || (d->in_pix_stride >= 2 * d->cin && d->in_pix_stride % 64 == 0), "bad in_pix_stride");
   HN_CHECK_ARG(d->out_pix_stride == 0 || d->out_pix_stride >= (d->out_split ? 2 : 1) * d->cout, "bad out_pix_stride");
   HN_CHECK_ARG((int64_t)d->n * d->oh * d->ow < (int64_t)1 << 31, "too many output pixels");
+  // 64-output-channel 3x3 / stride-1 layers with many tiles (ResNet-34 layer1): direct convolution from an LDS halo patch
+  // (conv3x3_halo.hip; same k order, bit-identical results; HN_CONV_NO_HALO=1 keeps them on this kernel)
+  if (hn::conv3x3_halo_applies(d, gn_partial != nullptr, group != nullptr, residual))
+    return hn::conv3x3_halo(d, x16, w16, bias, residual, y, (hipStream_t)stream);
 
   ConvParams16 p;
   p.x = (const _Float16*)x16; p.w = (const _Float16*)w16; p.bias = bias; p.res = residual; p.y = y;

@@ -51,6 +51,7 @@ static void read_env() {
   g_env.no_rs32 = getenv("HN_CONV_NO_RS32") != nullptr;
   g_env.split_generic = getenv("HN_SPLIT_GENERIC") != nullptr;
   g_env.stem_generic = getenv("HN_STEM_POOL_GENERIC") != nullptr;
+  g_env.no_halo = getenv("HN_CONV_NO_HALO") != nullptr;
   g_env_read = true;
 }
 const EnvFlags& env_flags() {

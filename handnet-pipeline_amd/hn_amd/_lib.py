@@ -90,6 +90,7 @@ SIGNATURES = {
     "hn_maxpool3x3s2_s32": (C.c_int, [VP, VP] + [C.c_int] * 6 + [VP]),
     "hn_conv2d_f16x3_pick_tile": (C.c_int, [C.POINTER(ConvDesc)]),
     "hn_conv2d_f16x3_uses_rs": (C.c_int, [C.POINTER(ConvDesc)]),
+    "hn_conv2d_f16x3_uses_halo": (C.c_int, [C.POINTER(ConvDesc), C.c_int]),
     "hn_maxpool3x3s2_nhwc_f32": (C.c_int, [VP, VP] + [C.c_int] * 6 + [VP]),
     "hn_groupnorm_scratch_floats": (C.c_int64, [C.c_int] * 4),
     "hn_groupnorm_affine_f32": (C.c_int, [VP, VP, VP] + [C.c_int] * 4 + [C.c_float, VP, VP, VP, VP]),

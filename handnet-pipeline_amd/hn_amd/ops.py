@@ -184,10 +184,13 @@ CONV_PROFILE = None
 PROFILE_STAGE = None
 TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x64", 4: "128x32", 5: "256x128", 6: "64x128", 7: "32x64", 8: "256x64", 9: "256x128w8", 10: "256x64w8"}
 TILE_RS = 0x100  # profile records: tile id | TILE_RS when the launch ran the row-shared-A instantiation of that tile
+TILE_HALO = 0x200  # ... | TILE_HALO when it was routed to the halo-patch kernel (conv3x3_halo_kernel)
 
 
 def tile_name(tile) -> str:
     """'128x128' / '128x128+rs' (the row-shared-A kernels are separate instantiations, i.e. separate profiler rows)."""
+    if isinstance(tile, int) and tile & TILE_HALO:
+        return "halo16x16"
     base = TILE_NAMES.get(tile & 0xFF, str(tile & 0xFF)) if isinstance(tile, int) else str(tile)
     return base + ("+rs" if isinstance(tile, int) and tile & TILE_RS else "")
 
@@ -366,7 +369,9 @@ def conv2d_nhwc(x, w, bias=None, *, stride=1, pad=0, dil=1, relu=False, relu_col
         timer.stop()
         macs = n * d.oh * d.ow * cout * r * s * (algo_cin or cin)
         if use16:
-            kind = ("f16x3", lib.hn_conv2d_f16x3_pick_tile(C.byref(d)) | (TILE_RS if lib.hn_conv2d_f16x3_uses_rs(C.byref(d)) else 0))
+            flags = TILE_HALO if lib.hn_conv2d_f16x3_uses_halo(C.byref(d), 1 if residual is not None else 0) else \
+                (TILE_RS if lib.hn_conv2d_f16x3_uses_rs(C.byref(d)) else 0)
+            kind = ("f16x3", lib.hn_conv2d_f16x3_pick_tile(C.byref(d)) | flags)
         else:
             kind = ("f32", lib.hn_conv2d_pick_tile(C.byref(d)))
         prof.append((kind, macs, timer, (n, h, wd, cin, cout, r, stride, dil), PROFILE_STAGE))

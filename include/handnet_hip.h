@@ -138,6 +138,11 @@ int hn_conv2d_f16x3_pick_tile(const hn_conv_desc* d);
  * profilers' kernel names differ (template argument RS), which is what bench.py asks this for.  For a grouped launch pass
  * the smallest member width in d->w and the picked tile in d->tile. */
 int hn_conv2d_f16x3_uses_rs(const hn_conv_desc* d);
+/* 1 when hn_conv2d_nhwc_f16x3(_ws) routes this descriptor to the halo-patch kernel (3x3 / stride 1 / pad 1, 64 output channels,
+ * S32 in and out, ReLU, optional S32 residual of the output's shape, at least 512 tiles of 16 x 16 pixels; HN_CONV_NO_HALO=1
+ * turns it off): a workgroup stages the 18 x 18 input patch of a 32-channel block once and reads all nine taps from it.
+ * Same k order as the implicit-GEMM kernel: bit-identical results (ResNet-34 layer1, fcos_utils/fcos.py:737). */
+int hn_conv2d_f16x3_uses_halo(const hn_conv_desc* d, int has_residual);
 
 /* ---- S32 split activation format: fp16 [N][H][W][C/32][2][32] (hi[32] | lo[32] per block) ----
  * hn_affine_split_f32: fp32 NHWC -> S32; with scale/shift [n][c] it first applies

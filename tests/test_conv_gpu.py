@@ -635,3 +635,40 @@ def test_affine_split_group_stationary_kernel_equals_generic(shape, monkeypatch)
     ref = torch.relu(x * sc[:, None, None, :] + sh[:, None, None, :]).cpu()
     got = ops.from_split(outs[0][1]).cpu()
     assert float((got - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("n,h,w,cin,res", [(3, 200, 272, 64, True), (3, 200, 272, 64, False), (60, 44, 44, 64, False),
+                                            (9, 100, 135, 128, True), (20, 67, 93, 32, False)])
+def test_halo_patch_kernel_is_bit_identical_to_the_implicit_gemm(n, h, w, cin, res):
+    """conv3x3_halo_kernel (3x3 / stride 1 / pad 1, 64 output channels, >= 512 tiles of 16 x 16 pixels: ResNet-34 layer1)
+    against the implicit-GEMM kernel it replaces for that shape (HN_CONV_NO_HALO=1): same k order, same bits -- on maps that
+    are not multiples of the tile (partial tiles right / bottom), 1-4 channel blocks, with and without the S32 residual --
+    and against an fp64 convolution."""
+    import os
+    from hn_amd import ops
+    from hn_amd.weights import split_f16x3
+    from oracle import ops_ref
+    x = _rand((n, h, w, cin), 51)
+    wt = _rand((64, 3, 3, cin), 52, scale=(2.0 / (cin * 9)) ** 0.5)
+    b = _rand((64,), 53, 0.1)
+    r = _rand((n, h, w, 64), 54) if res else None
+    xs, w16 = ops.to_split(x.cuda()), split_f16x3(wt).cuda()
+    rs = ops.to_split(r.cuda()) if res else None
+    d = ops.make_conv_desc(n, h, w, cin, 64, 3, 3, 1, 1, 1, 64, 1 if res else 0)
+    d.out_split, d.res_split = 1, 1 if res else 0
+    assert ops._lib.load().hn_conv2d_f16x3_uses_halo(d, 1 if res else 0) == 1
+    kw = dict(pad=1, relu=True, w16=w16, out_split=True, residual=rs)
+    y_halo = ops.conv2d_nhwc(xs, wt.cuda(), b.cuda(), **kw)
+    os.environ["HN_CONV_NO_HALO"] = "1"
+    ops.reread_env()
+    try:
+        assert ops._lib.load().hn_conv2d_f16x3_uses_halo(d, 1 if res else 0) == 0
+        y_gemm = ops.conv2d_nhwc(xs, wt.cuda(), b.cuda(), **kw)
+    finally:
+        del os.environ["HN_CONV_NO_HALO"]
+        ops.reread_env()
+    assert torch.equal(y_halo, y_gemm)
+    ref = ops_ref.conv2d_nhwc(x.double(), wt.double(), b.double(), 1, 1, 1, relu_cols=0)
+    ref = torch.relu(ref + (r.double() if res else 0.0)).float()
+    got = ops.from_split(y_halo).cpu()
+    assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
