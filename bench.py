@@ -67,8 +67,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None, help="frames (or crops) per GPU; default 32 (a2j: 64)")
     ap.add_argument("--workload", choices=["pipeline", "a2j", "fcos", "pose2mesh"], default="pipeline")
-    ap.add_argument("--precision", choices=["f16x3", "f32"], default="f16x3",
-                    help="f16x3: split-fp16 operands on the f16 MFMA (fp32-grade results); f32: exact f32 MFMA")
+    ap.add_argument("--precision", choices=["f16x3", "f32", "f16x1"], default="f16x3",
+                    help="f16x3: split-fp16 operands on the f16 MFMA (fp32-grade results; the headline); f32: exact f32 MFMA; "
+                         "f16x1: hi*hi term only = plain fp16 operands, 1 MFMA per MAC -- the THROUGHPUT mode SURVEY D6 plans "
+                         "beside the parity mode: misses the 1e-3 contract, reported with its error figures, never the headline")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
     ap.add_argument("--native", action="store_true",
                     help="drive the step through the model-level C ABI (C++ layer graphs, csrc/model.hip) instead of "
@@ -170,7 +172,7 @@ def build_workload(args, dev, rank):
     return step, info, (fcos_sd, a2j_sd)
 
 
-def roofline_leg(step, steps, ms_per_step, sample_clock=True):
+def roofline_leg(step, steps, ms_per_step, sample_clock=True, terms=3):
     """Bracket every conv launch with HIP events (on the launch stream) for `steps` steps; a one-wave sampler on a
     side stream reads the shader clock the chip holds meanwhile."""
     from hn_amd import ops
@@ -216,7 +218,7 @@ def roofline_leg(step, steps, ms_per_step, sample_clock=True):
     kernel = f"conv_igemm_{prec}_kernel<{ops.tile_name(tile)}>"
     gf_launch = round(g["flop"] / g["launches"] / 1e9, 3)
     traffic, traffic_source = measured_traffic(kernel, gf_launch, g["launches"] // steps)
-    issued = achieved * (3 if prec == "f16x3" else 1)
+    issued = achieved * (terms if prec == "f16x3" else 1)
     return {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
         "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
@@ -448,7 +450,8 @@ def main():
             raise SystemExit(f"all-gather returned {gathered['rows'].numel()} rows for {world} ranks x {batch} frames")
     roof = None
     if not args.no_roofline and not args.graph and not args.native:
-        roof = roofline_leg(step, max(1, min(args.steps, 3)), 1e3 * elapsed / args.steps, not args.no_clock_sample)
+        roof = roofline_leg(step, max(1, min(args.steps, 3)), 1e3 * elapsed / args.steps, not args.no_clock_sample,
+                            terms=1 if args.precision == "f16x1" else 3)
     dropin = None
     if (rank == 0 and world == 1 and args.workload == "pipeline" and not args.no_dropin and not args.native
             and not args.graph):
@@ -466,7 +469,10 @@ def main():
             "value": round(value, 2), "unit": info["unit"], "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "f32" else "f16x3 (fp32 values split into fp16 hi+lo, 3 MFMAs, fp32 accumulate; fp32 I/O)",
+            "dtype": {"f32": "f32",
+                      "f16x3": "f16x3 (fp32 values split into fp16 hi+lo, 3 MFMAs, fp32 accumulate; fp32 I/O)",
+                      "f16x1": "f16x1 (THROUGHPUT MODE, not parity-grade: fp16 hi parts only, 1 MFMA per MAC, fp32 accumulate; "
+                               "error figures in cpu_baseline.parity)"}[args.precision],
             "data": "synthetic (seeded uniform RGB in [0,1), depth 0.3-1.5 m; random-init weights of the "
                     "reference architectures, hn_amd.synth seed 0)",
             "config": {"workload": info["name"], "batch_per_gpu": batch, "global_batch": batch * world,

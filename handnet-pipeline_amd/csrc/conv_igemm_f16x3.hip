@@ -104,6 +104,7 @@ struct ConvParams16 {
   // row-shared A operand (RS kernels, 3x3 / stride 1 / pad 1): exact division by W + 1 and by H for the slot -> pixel map
   unsigned mg_w1, sh_w1, mg_h, sh_h;
   unsigned gmg_w1[HN_CONV_MAX_GROUP], gsh_w1[HN_CONV_MAX_GROUP], gmg_h[HN_CONV_MAX_GROUP], gsh_h[HN_CONV_MAX_GROUP];
+  int terms;          // host: 3 (default) or 1 (hn_conv_desc.terms: the hi*hi-only throughput mode)
   int rs_ok;          // host: the row-shared A kernel may be used (set by conv16_run, refined in launch16)
   // fused 3x3 / stride-2 / pad-1 max pooling (POOL kernel, the FCOS stem): a workgroup computes a 15 x 17 patch of conv
   // pixels = 7 x 8 pooled pixels; pool_ty x pool_tx patches per image, pooled map pool_oh x pool_ow
@@ -259,14 +260,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams16 p
   }
 }
 
-template <int TM, int TH, int DPT>
+// TERMS == 1 (f16x1): the lo fragments are never read -- NOT "read and ignored": an asynchronous LDS read into a register the
+// compiler considers dead lands in whatever that register holds by then (seen as nondeterministic garbage) -- so the list has
+// TH + TM reads; the MFMA slot space stays 3 * TM * TH with the slots of terms 0 / 1 empty.
+template <int TM, int TH, int DPT, int TERMS = 3>
 struct HalfSched {
   static constexpr int NM = 3 * TM * TH;
-  static constexpr int NMEM = DPT + 2 * TH + 2 * TM;
+  static constexpr int NB = (TERMS == 3 ? 2 : 1) * TH;    // W fragment reads of a column half
+  static constexpr int NAL = TERMS == 3 ? TM : 0;         // A lo fragment reads
+  static constexpr int NMEM = DPT + NB + NAL + TM;
   static constexpr int earliest(int q) {
-    return q < DPT + 2 * TH ? 0
-           : q < DPT + 2 * TH + TM ? (q - DPT - 2 * TH + 1) * TH
-                                   : 2 * TM * TH + (q - DPT - 2 * TH - TM + 1) * TH;
+    return q < DPT + NB ? 0
+           : q < DPT + NB + NAL ? (q - DPT - NB + 1) * TH
+                                : 2 * TM * TH + (q - DPT - NB - NAL + 1) * TH;
   }
   static constexpr int slot(int q) {
     const int spread = (q * NM) / NMEM;
@@ -292,9 +298,13 @@ struct HalfSched {
 // unfused form) -- and the epilogue pools the patch through LDS and stores only the pooled S32 tensor: the 64-channel
 // conv map at half resolution (1.8 GB at batch 32) is neither written nor read back.
 constexpr int kPoolRows = 15, kPoolCols = 17, kPoolPR = 7, kPoolPC = 8;
-template <int BM, int BN, int WM, int WN, int NBUF, bool BUF, bool RS = false, bool POOL = false>
+// TERMS = 3: the split-precision product (lo*hi + hi*lo + hi*hi, fp32-grade).  TERMS = 1 ("f16x1", the THROUGHPUT mode SURVEY D6
+// plans beside the parity mode; never the default): only hi*hi is issued -- one MFMA per MAC on plain fp16 operands, identical
+// data movement -- so that "what does the 1e-3 contract cost" has a measured answer (bench.py --precision f16x1).
+template <int BM, int BN, int WM, int WN, int NBUF, bool BUF, bool RS = false, bool POOL = false, int TERMS = 3>
 __global__ __launch_bounds__(WM* WN * 64, (BM * BN / (WM * WN) > 64 * 64 ? 1 : 2))
 void conv_igemm_f16x3_kernel(const ConvParams16 p) {
+  static_assert(TERMS == 3 || TERMS == 1, "three terms (fp32-grade) or the hi*hi term alone");
   static_assert(NBUF >= 2 && NBUF <= 6, "2..6 LDS stages");
   static_assert(!POOL || (BUF && !RS && BM == 256 && BN == 64 && WN == 1), "the pooling epilogue is written for the 256x64 tile");
   static_assert(!RS || (BUF && NBUF == 2), "row-shared A needs the descriptor form and the 2-stage pipeline");
@@ -652,7 +662,7 @@ void conv_igemm_f16x3_kernel(const ConvParams16 p) {
   BFrag b0, b1;
   AFrag af;  // ONE set of A fragments: the next tile's are read into each register after its last use
   constexpr int DPT = A_IT + B_IT;  // DMA instructions each wave issues per k tile
-  using S2 = HalfSched<TM, TH, DPT>;
+  using S2 = HalfSched<TM, TH, DPT, TERMS>;
   // all of this wave's DMA has landed and all of its LDS reads have returned; then rendezvous
   auto drain_and_barrier = [&]() {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -678,15 +688,19 @@ void conv_igemm_f16x3_kernel(const ConvParams16 p) {
     static_for<0, TH>([&](auto JJ) {
       constexpr int jj = decltype(JJ)::value;
       lds_read_pinned<(TH + jj) * TILE_OFF>(b1.h[jj], bcur_hi);
-      lds_read_pinned<(TH + jj) * TILE_OFF>(b1.l[jj], bcur_lo);
+      if constexpr (TERMS == 3) lds_read_pinned<(TH + jj) * TILE_OFF>(b1.l[jj], bcur_lo);
     });
     // outstanding reads, oldest first: b0 (2*TH), af.l (TM), af.h (TM) of this tile, then b1 (2*TH)
     static_for<0, S2::NM>([&](auto K) {
       constexpr int k = decltype(K)::value;
       constexpr int term = k / (TM * TH), i = (k / TH) % TM, jj = k % TH;
-      if constexpr (k == 0) lgkm_wait<TM + 2 * TH>();                             // all of af.l (and b0)
-      if constexpr (term == 1 && jj == 0) lgkm_wait<2 * TH + (TM - 1 - i)>();     // af.h[i]
-      mfma_pinned(acc[i][jj], term == 0 ? af.l[i] : af.h[i], term == 1 ? b0.l[jj] : b0.h[jj]);
+      if constexpr (TERMS == 3) {
+        if constexpr (k == 0) lgkm_wait<TM + 2 * TH>();                             // all of af.l (and b0)
+        if constexpr (term == 1 && jj == 0) lgkm_wait<2 * TH + (TM - 1 - i)>();     // af.h[i]
+      } else {
+        if constexpr (term == 2 && jj == 0) lgkm_wait<TH + (TM - 1 - i)>();         // b0 and af.h[i]; younger: af.h[i+1..], b1
+      }
+      if constexpr (TERMS == 3 || term == 2) mfma_pinned(acc[i][jj], term == 0 ? af.l[i] : af.h[i], term == 1 ? b0.l[jj] : b0.h[jj]);
     });
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NBUF - 2) * DPT) : "memory");
     __builtin_amdgcn_s_barrier();
@@ -708,24 +722,28 @@ void conv_igemm_f16x3_kernel(const ConvParams16 p) {
             dma_a_piece(q, Ad, dr, ds, uoff, sh);
           } else if constexpr (q < DPT) {
             dma_b_piece(q - A_IT, Bd, boff);
-          } else if constexpr (q < DPT + 2 * TH) {
-            constexpr int jj = (q - DPT) >> 1;
-            if constexpr ((q - DPT) & 1)
-              lds_read_pinned<jj * TILE_OFF>(b0.l[jj], bnx_lo);
-            else
-              lds_read_pinned<jj * TILE_OFF>(b0.h[jj], bnx_hi);
-          } else if constexpr (q < DPT + 2 * TH + TM) {
-            constexpr int i = q - DPT - 2 * TH;
+          } else if constexpr (q < DPT + S2::NB) {
+            if constexpr (TERMS == 3) {
+              constexpr int jj = (q - DPT) >> 1;
+              if constexpr ((q - DPT) & 1)
+                lds_read_pinned<jj * TILE_OFF>(b0.l[jj], bnx_lo);
+              else
+                lds_read_pinned<jj * TILE_OFF>(b0.h[jj], bnx_hi);
+            } else {
+              lds_read_pinned<(q - DPT) * TILE_OFF>(b0.h[q - DPT], bnx_hi);
+            }
+          } else if constexpr (q < DPT + S2::NB + S2::NAL) {
+            constexpr int i = q - DPT - S2::NB;
             lds_read_pinned<i * TILE_OFF>(af.l[i], anx_lo);
           } else {
-            constexpr int i = q - DPT - 2 * TH - TM;
+            constexpr int i = q - DPT - S2::NB - S2::NAL;
             lds_read_pinned<i * TILE_OFF>(af.h[i], anx_hi);
           }
         }
       });
       if constexpr (k < S2::NM) {
         constexpr int term = k / (TM * TH), i = (k / TH) % TM, jj = k % TH;
-        mfma_pinned(acc[i][TH + jj], term == 0 ? af.l[i] : af.h[i], term == 1 ? b1.l[jj] : b1.h[jj]);
+        if constexpr (TERMS == 3 || term == 2) mfma_pinned(acc[i][TH + jj], term == 0 ? af.l[i] : af.h[i], term == 1 ? b1.l[jj] : b1.h[jj]);
       }
     });
     advance_tile();
@@ -739,19 +757,23 @@ void conv_igemm_f16x3_kernel(const ConvParams16 p) {
     constexpr int NPH = (PH + 1) % 3;
     constexpr int A_CNT = PH == 2 ? A_IT : 0;
     constexpr int DPT_PH = A_CNT + B_IT;
-    using S3 = HalfSched<TM, TH, DPT_PH>;
+    using S3 = HalfSched<TM, TH, DPT_PH, TERMS>;
     const unsigned bcur_hi = b_rd_hi + cs * (B_BUF * 2), bcur_lo = b_rd_lo + cs * (B_BUF * 2);
     static_for<0, TH>([&](auto JJ) {
       constexpr int jj = decltype(JJ)::value;
       lds_read_pinned<(TH + jj) * TILE_OFF>(b1.h[jj], bcur_hi);
-      lds_read_pinned<(TH + jj) * TILE_OFF>(b1.l[jj], bcur_lo);
+      if constexpr (TERMS == 3) lds_read_pinned<(TH + jj) * TILE_OFF>(b1.l[jj], bcur_lo);
     });
     static_for<0, S3::NM>([&](auto K) {
       constexpr int k = decltype(K)::value;
       constexpr int term = k / (TM * TH), i = (k / TH) % TM, jj = k % TH;
-      if constexpr (k == 0) lgkm_wait<TM + 2 * TH>();
-      if constexpr (term == 1 && jj == 0) lgkm_wait<2 * TH + (TM - 1 - i)>();
-      mfma_pinned(acc[i][jj], term == 0 ? af.l[i] : af.h[i], term == 1 ? b0.l[jj] : b0.h[jj]);
+      if constexpr (TERMS == 3) {
+        if constexpr (k == 0) lgkm_wait<TM + 2 * TH>();
+        if constexpr (term == 1 && jj == 0) lgkm_wait<2 * TH + (TM - 1 - i)>();
+      } else {
+        if constexpr (term == 2 && jj == 0) lgkm_wait<TH + (TM - 1 - i)>();
+      }
+      if constexpr (TERMS == 3 || term == 2) mfma_pinned(acc[i][jj], term == 0 ? af.l[i] : af.h[i], term == 1 ? b0.l[jj] : b0.h[jj]);
     });
     // Phase 0 follows the step that put a wide A tile in flight as its YOUNGEST DMA instructions (W pieces first, A pieces
     // last, below): only the W tile of the next step has to be complete here, the A tile -- first read three steps from
@@ -781,24 +803,28 @@ void conv_igemm_f16x3_kernel(const ConvParams16 p) {
             dma_b_piece(q, Bd, boff);
           } else if constexpr (q < DPT_PH) {
             dma_a_piece(q - B_IT, Ad, 0, 0, uoff_a, sh_a);
-          } else if constexpr (q < DPT_PH + 2 * TH) {
-            constexpr int jj = (q - DPT_PH) >> 1;
-            if constexpr ((q - DPT_PH) & 1)
-              lds_read_pinned<jj * TILE_OFF>(b0.l[jj], bnx_lo);
-            else
-              lds_read_pinned<jj * TILE_OFF>(b0.h[jj], bnx_hi);
-          } else if constexpr (q < DPT_PH + 2 * TH + TM) {
-            constexpr int i = q - DPT_PH - 2 * TH;
+          } else if constexpr (q < DPT_PH + S3::NB) {
+            if constexpr (TERMS == 3) {
+              constexpr int jj = (q - DPT_PH) >> 1;
+              if constexpr ((q - DPT_PH) & 1)
+                lds_read_pinned<jj * TILE_OFF>(b0.l[jj], bnx_lo);
+              else
+                lds_read_pinned<jj * TILE_OFF>(b0.h[jj], bnx_hi);
+            } else {
+              lds_read_pinned<(q - DPT_PH) * TILE_OFF>(b0.h[q - DPT_PH], bnx_hi);
+            }
+          } else if constexpr (q < DPT_PH + S3::NB + S3::NAL) {
+            constexpr int i = q - DPT_PH - S3::NB;
             lds_read_pinned<0>(af.l[i], anx[i][1]);
           } else {
-            constexpr int i = q - DPT_PH - 2 * TH - TM;
+            constexpr int i = q - DPT_PH - S3::NB - S3::NAL;
             lds_read_pinned<0>(af.h[i], anx[i][0]);
           }
         }
       });
       if constexpr (k < S3::NM) {
         constexpr int term = k / (TM * TH), i = (k / TH) % TM, jj = k % TH;
-        mfma_pinned(acc[i][TH + jj], term == 0 ? af.l[i] : af.h[i], term == 1 ? b1.l[jj] : b1.h[jj]);
+        if constexpr (TERMS == 3 || term == 2) mfma_pinned(acc[i][TH + jj], term == 0 ? af.l[i] : af.h[i], term == 1 ? b1.l[jj] : b1.h[jj]);
       }
     });
     advance_tile();
@@ -814,9 +840,10 @@ void conv_igemm_f16x3_kernel(const ConvParams16 p) {
     static_for<0, TH>([&](auto JJ) {
       constexpr int jj = decltype(JJ)::value;
       lds_read_pinned<jj * TILE_OFF>(b0.h[jj], b_rd_hi);
-      lds_read_pinned<jj * TILE_OFF>(b0.l[jj], b_rd_lo);
+      if constexpr (TERMS == 3) lds_read_pinned<jj * TILE_OFF>(b0.l[jj], b_rd_lo);
     });
-    static_for<0, TM>([&](auto I) { lds_read_pinned<0>(af.l[decltype(I)::value], rs_addr(decltype(I)::value, -1, 1, 0)); });
+    if constexpr (TERMS == 3)
+      static_for<0, TM>([&](auto I) { lds_read_pinned<0>(af.l[decltype(I)::value], rs_addr(decltype(I)::value, -1, 1, 0)); });
     static_for<0, TM>([&](auto I) { lds_read_pinned<0>(af.h[decltype(I)::value], rs_addr(decltype(I)::value, -1, 0, 0)); });
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0), see below
     // one row tile (3 k steps) per iteration; the W stage parity flips from one row tile to the next
@@ -836,9 +863,10 @@ void conv_igemm_f16x3_kernel(const ConvParams16 p) {
   static_for<0, TH>([&](auto JJ) {  // same issue order as inside a step: b0, af.l, af.h
     constexpr int jj = decltype(JJ)::value;
     lds_read_pinned<jj * TILE_OFF>(b0.h[jj], b_rd_hi);
-    lds_read_pinned<jj * TILE_OFF>(b0.l[jj], b_rd_lo);
+    if constexpr (TERMS == 3) lds_read_pinned<jj * TILE_OFF>(b0.l[jj], b_rd_lo);
   });
-  static_for<0, TM>([&](auto I) { lds_read_pinned<decltype(I)::value * TILE_OFF>(af.l[decltype(I)::value], a_rd_lo); });
+  if constexpr (TERMS == 3)
+    static_for<0, TM>([&](auto I) { lds_read_pinned<decltype(I)::value * TILE_OFF>(af.l[decltype(I)::value], a_rd_lo); });
   static_for<0, TM>([&](auto I) { lds_read_pinned<decltype(I)::value * TILE_OFF>(af.h[decltype(I)::value], a_rd_hi); });
   // A wait the compiler's counter model can see (the asm ones it cannot): every kernel-argument load it still has
   // in flight retires HERE.  Otherwise the compiler may defer that wait to the first use inside the loop, where it
@@ -1163,7 +1191,7 @@ static bool rs_will_run(const ConvParams16& p, int bm, int bn, int waves, int nb
   return true;
 }
 
-template <int BM, int BN, int WM, int WN, int NBUF, bool BUF>
+template <int BM, int BN, int WM, int WN, int NBUF, bool BUF, int TERMS = 3>
 int launch16_impl(const ConvParams16& p0, hipStream_t st) {
   ConvParams16 p = p0;
   p.tiles_m = hn::cdiv(p.M, BM);
@@ -1185,8 +1213,8 @@ int launch16_impl(const ConvParams16& p0, hipStream_t st) {
       p.tiles_m = p.nblocks;
       p.splits = 1;
       p.kt_per = p.ktiles;
-      hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, NBUF, true, false, true>), dim3(p.nblocks), dim3(WM * WN * 64),
-                         0, st, p);
+      hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, NBUF, true, false, true, TERMS>), dim3(p.nblocks),
+                         dim3(WM * WN * 64), 0, st, p);
       HN_CHECK_LAUNCH("conv_igemm_f16x3_kernel<pool>");
       return HN_OK;
     } else {
@@ -1207,17 +1235,17 @@ int launch16_impl(const ConvParams16& p0, hipStream_t st) {
       int dev = 0;
       HN_CHECK_HIP(hipGetDevice(&dev));
       if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        HN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_igemm_f16x3_kernel<BM, BN, WM, WN, NBUF, true, true>,
+        HN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_igemm_f16x3_kernel<BM, BN, WM, WN, NBUF, true, true, false, TERMS>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
       }
-      hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, NBUF, true, true>),
+      hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, NBUF, true, true, false, TERMS>),
                          dim3(grid_x, 1, p.groups > 1 ? p.groups : 1), dim3(WM * WN * 64), LDS_BYTES, st, p);
     }
   }
   if (!rs)
-    hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, NBUF, BUF>), dim3(grid_x, p.splits, p.groups > 1 ? p.groups : 1),
-                       dim3(WM * WN * 64), 0, st, p);
+    hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, NBUF, BUF, false, false, TERMS>),
+                       dim3(grid_x, p.splits, p.groups > 1 ? p.groups : 1), dim3(WM * WN * 64), 0, st, p);
   HN_CHECK_LAUNCH("conv_igemm_f16x3_kernel");
   if (p.splits > 1) {
     const long total = (long)p.M * (p.Cout >> 3);
@@ -1243,7 +1271,7 @@ static void magic_u31(unsigned d, unsigned& mg, unsigned& sh) {
 // Operand extents for the buffer descriptors of the v6 addressing.  Falls back to the pointer-form kernel (one
 // instantiation, 128x128) when an operand spans 2 GB or more (bit 31 of an offset must stay out of range) or the
 // filter has more than 32 taps.
-template <int BM, int BN, int WM, int WN, int NBUF>
+template <int BM, int BN, int WM, int WN, int NBUF, bool ALLOW_F16X1 = true>
 int launch16(const ConvParams16& p0, hipStream_t st) {
   ConvParams16 p = p0;
   magic_u31((unsigned)(p.OH * p.OW), p.mg_ohow, p.sh_ohow);
@@ -1281,6 +1309,12 @@ int launch16(const ConvParams16& p0, hipStream_t st) {
       ok = ok && ea < lim;
       p.ga_records[g] = (unsigned)(ea < lim ? ea : 0);
     }
+  if (p.terms == 1) {   // throughput mode: descriptor-form kernels of the tiles the engines use
+    if constexpr (ALLOW_F16X1) {
+      if (ok) return launch16_impl<BM, BN, WM, WN, NBUF, true, 1>(p, st);
+    }
+    return hn::fail(HN_ERR_ARG, "the f16x1 mode exists for the descriptor-form kernels of the engine tiles only");
+  }
   if (ok) return launch16_impl<BM, BN, WM, WN, NBUF, true>(p, st);
   return launch16_impl<128, 128, 2, 2, 2, false>(p, st);
 }
@@ -1428,6 +1462,7 @@ static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, c
   const int ow = (d->w + 2 * d->pad - d->dil * (d->s - 1) - 1) / d->stride + 1;
   HN_CHECK_ARG(oh == d->oh && ow == d->ow, "output size mismatch: desc %dx%d, computed %dx%d", d->oh, d->ow, oh, ow);
   HN_CHECK_ARG(d->res_mode >= 0 && d->res_mode <= 2, "bad res_mode %d", d->res_mode);
+  HN_CHECK_ARG(d->terms == 0 || d->terms == 1 || d->terms == 3, "terms must be 0 / 3 (f16x3) or 1 (f16x1), got %d", d->terms);
   HN_CHECK_ARG(d->res_mode == 0 || residual, "res_mode set but residual is null");
   HN_CHECK_ARG(d->res_mode != 2 || (d->res_h > 0 && d->res_w > 0), "res_mode 2 needs res_h/res_w");
   HN_CHECK_ARG(!d->in_affine, "f16x3 conv takes pre-split input; apply GroupNorm with hn_affine_split_f32 first");
@@ -1437,7 +1472,7 @@ static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, c
   HN_CHECK_ARG((int64_t)d->n * d->oh * d->ow < (int64_t)1 << 31, "too many output pixels");
   // 64-output-channel 3x3 / stride-1 layers with many tiles (ResNet-34 layer1): direct convolution from an LDS halo patch
   // (conv3x3_halo.hip; same k order, bit-identical results; HN_CONV_NO_HALO=1 keeps them on this kernel)
-  if (hn::conv3x3_halo_applies(d, gn_partial != nullptr, group != nullptr, residual))
+  if (d->terms != 1 && hn::conv3x3_halo_applies(d, gn_partial != nullptr, group != nullptr, residual))
     return hn::conv3x3_halo(d, x16, w16, bias, residual, y, (hipStream_t)stream);
 
   ConvParams16 p;
@@ -1466,6 +1501,7 @@ static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, c
   p.splitk_mode = d->splitk;
   p.groups = 1;
   p.rs_ok = 1;
+  p.terms = d->terms == 1 ? 1 : 3;
   p.pool_ty = p.pool_tx = p.pool_oh = p.pool_ow = 0;
   p.gn_units = d->cout >> 3;
   hn_conv_desc tile_desc = *d;  // what the tile heuristic sees: for a group, all members' rows together
@@ -1529,19 +1565,19 @@ static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, c
       return launch16<128, 32, 4, 1, 3>(p, st);
     }
     case HN_TILE_64x128: return launch16<64, 128, 2, 2, 3>(p, st);
-    case HN_TILE_256x128: return launch16<256, 128, 2, 2, 2>(p, st);
+    case HN_TILE_256x128: return launch16<256, 128, 2, 2, 2, false>(p, st);
     case HN_TILE_32x64: return launch16<32, 64, 1, 2, 4>(p, st);
     // (the row-shared A form does not fit two 256-row workgroups on a CU, and 128x64 with it -- 442 us on ResNet-34 layer1 --
     // loses to 256x64 without: 421 us)
     case HN_TILE_256x64: return launch16<256, 64, 4, 1, 2>(p, st);
-    case HN_TILE_256x128_W8: return launch16<256, 128, 4, 2, 2>(p, st);
-    case HN_TILE_256x64_W8: return launch16<256, 64, 4, 2, 2>(p, st);
+    case HN_TILE_256x128_W8: return launch16<256, 128, 4, 2, 2, false>(p, st);
+    case HN_TILE_256x64_W8: return launch16<256, 64, 4, 2, 2, false>(p, st);
     default: return hn::fail(HN_ERR_ARG, "unknown tile id %d", d->tile);
   }
 }
 
 static int stem16_run(const void* x16, int n, int ph, int pw, int pad, int r, int stride, int cout, const void* w16,
-                      const float* bias, int relu, void* y, int out_split, bool pool, void* stream) {
+                      const float* bias, int relu, void* y, int out_split, bool pool, void* stream, int terms = 3) {
   HN_CHECK_ARG(x16 && w16 && y, "hn_conv_stem_f16x3: null pointer");
   HN_CHECK_ARG(n > 0 && ph > 0 && pw > 0 && cout > 0 && stride > 0, "bad dims");
   HN_CHECK_ARG(r >= 1 && r <= 8 && pad == r / 2, "stem filter must be R x R with R <= 8 and pad = R/2");
@@ -1569,6 +1605,7 @@ static int stem16_run(const void* x16, int n, int ph, int pw, int pad, int r, in
   p.vec_epi = (cout % 8 == 0) && ((uintptr_t)y % 16 == 0) && (bias == nullptr || (uintptr_t)bias % 16 == 0);
   p.tiles_m = p.tiles_n = p.nblocks = 0;
   p.rs_ok = 0;
+  p.terms = terms == 1 ? 1 : 3;
   p.pool_ty = p.pool_tx = p.pool_oh = p.pool_ow = 0;
   p.range_flag = hn::range_flag_ptr();
   hipStream_t st = (hipStream_t)stream;
@@ -1577,7 +1614,8 @@ static int stem16_run(const void* x16, int n, int ph, int pw, int pad, int r, in
     HN_CHECK_ARG((uintptr_t)y % 16 == 0 && (uintptr_t)bias % 16 == 0, "unaligned output / bias");
     // the ResNet stem shape: direct convolution from an LDS-resident image patch (conv_stem_direct.hip); other filter sizes,
     // and HN_STEM_POOL_GENERIC=1, take the implicit-GEMM form below (same results bit for bit)
-    if (r == 7 && stride == 2 && pad == 3 && !hn::env_flags().stem_generic) return hn::stem_pool_direct(x16, n, ph, pw, w16, bias, y, st);
+    if (r == 7 && stride == 2 && pad == 3 && !hn::env_flags().stem_generic && terms != 1)
+      return hn::stem_pool_direct(x16, n, ph, pw, w16, bias, y, st);
     p.pool_oh = (oh + 2 - 3) / 2 + 1;
     p.pool_ow = (ow + 2 - 3) / 2 + 1;
     p.pool_ty = hn::cdiv(p.pool_oh, kPoolPR);
@@ -1607,4 +1645,10 @@ extern "C" int hn_conv_stem_f16x3(const void* x16, int n, int ph, int pw, int pa
 extern "C" int hn_conv_stem_pool_f16x3(const void* x16, int n, int ph, int pw, int pad, int r, int stride, int cout,
                                        const void* w16, const float* bias, void* y, void* stream) {
   return stem16_run(x16, n, ph, pw, pad, r, stride, cout, w16, bias, 1, y, 1, true, stream);
+}
+
+extern "C" int hn_conv_stem_pool_f16x3_terms(const void* x16, int n, int ph, int pw, int pad, int r, int stride, int cout,
+                                             const void* w16, const float* bias, void* y, int terms, void* stream) {
+  HN_CHECK_ARG(terms == 0 || terms == 1 || terms == 3, "terms must be 0 / 3 or 1");
+  return stem16_run(x16, n, ph, pw, pad, r, stride, cout, w16, bias, 1, y, 1, true, stream, terms);
 }

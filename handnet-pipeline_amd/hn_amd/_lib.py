@@ -12,7 +12,7 @@ from pathlib import Path
 
 from . import build as _build
 
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, TILE_256x128, TILE_64x128 = range(7)
 HN_FCOS_MAX_LEVELS = 5
@@ -26,7 +26,7 @@ class ConvDesc(C.Structure):
     _fields_ = [(k, C.c_int32) for k in (
         "n", "h", "w", "cin", "cout", "r", "s", "stride", "pad", "dil", "oh", "ow",
         "relu_cols", "res_mode", "res_h", "res_w", "in_affine", "tile", "out_split", "res_split",
-        "res_pix_stride", "in_pix_stride", "out_pix_stride", "in_affine_stride", "splitk")]
+        "res_pix_stride", "in_pix_stride", "out_pix_stride", "in_affine_stride", "splitk", "terms")]
 
 
 CONV_MAX_GROUP = 6
@@ -107,6 +107,7 @@ SIGNATURES = {
     "hn_fcos_preprocess_list": (C.c_int, [VP, VP, VP] + [C.c_int] * 5 + [c_f32p, c_f32p, VP]),
     "hn_conv_stem_f16x3": (C.c_int, [VP] + [C.c_int] * 7 + [VP, VP, C.c_int, VP, C.c_int, VP]),
     "hn_conv_stem_pool_f16x3": (C.c_int, [VP] + [C.c_int] * 7 + [VP, VP, VP, VP]),
+    "hn_conv_stem_pool_f16x3_terms": (C.c_int, [VP] + [C.c_int] * 7 + [VP, VP, VP, C.c_int, VP]),
     "hn_fcos_candidates": (C.c_int, [C.POINTER(FcosLevels), C.c_int, C.c_int, C.c_float,
                                      VP, VP, VP, VP, VP, VP, VP, C.c_int, VP]),
     "hn_fcos_ext_gather": (C.c_int, [C.POINTER(FcosLevels), C.POINTER(VP), VP, VP, VP, C.c_int, C.c_int, VP, VP, VP]),

@@ -25,8 +25,12 @@ class A2JEngine:
     def __init__(self, state_dict, num_joints: int = 21, rgbd: bool = False, device="cuda", precision="f16x3"):
         """precision: "f16x3" (split-fp16 operands on the f16 MFMA, fp32-grade results; default)
         or "f32" (exact f32 MFMA).  Layers with Cin % 32 != 0 (the stem) always run in f32."""
-        if precision not in ("f32", "f16x3"):
-            raise ValueError("precision must be 'f32' or 'f16x3'")
+        if precision not in ("f32", "f16x3", "f16x1"):
+            raise ValueError("precision must be 'f32', 'f16x3' or 'f16x1'")
+        # "f16x1": the f16x3 engine with the hi*hi term alone (plain fp16 operands, one MFMA per MAC): the throughput mode
+        # SURVEY D6 plans BESIDE the parity mode -- misses the 1e-3 keypoint contract, never a default
+        self.terms = 1 if precision == "f16x1" else 3
+        precision = "f16x3" if precision == "f16x1" else precision
         self.precision = precision
         sd = strip_prefix(state_dict, "a2j.")
         ops.clear_plan_caches()   # plans are keyed by weight addresses; a rebuilt engine starts clean
@@ -147,8 +151,9 @@ class A2JEngine:
 
     @ops.device_guarded
     def forward_nhwc(self, x, valid=None, return_heads=False):
-        x3, x4 = self.trunk(x)
-        cls, reg, dep = self.heads(x3, x4)
+        with ops.f16_terms(self.terms):
+            x3, x4 = self.trunk(x)
+            cls, reg, dep = self.heads(x3, x4)
         out = ops.a2j_aggregate(cls, reg, dep, joints=self.joints, stride=16, valid=valid)
         if return_heads:
             if ops.is_split(x3):

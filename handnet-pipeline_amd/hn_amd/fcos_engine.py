@@ -46,8 +46,12 @@ class FCOSEngine:
     def __init__(self, state_dict, num_classes: int, device="cuda", min_size=800, max_size=1333,
                  precision="f16x3", ext=False, head_streams=None):
         """precision: "f16x3" (split-fp16 operands, fp32-grade; default) or "f32" (exact f32 MFMA)."""
-        if precision not in ("f32", "f16x3"):
-            raise ValueError("precision must be 'f32' or 'f16x3'")
+        if precision not in ("f32", "f16x3", "f16x1"):
+            raise ValueError("precision must be 'f32', 'f16x3' or 'f16x1'")
+        # "f16x1": the f16x3 engine with the hi*hi term alone (plain fp16 operands, one MFMA per MAC): the throughput mode
+        # SURVEY D6 plans BESIDE the parity mode -- misses the 1e-3 keypoint contract, never a default
+        self.terms = 1 if precision == "f16x1" else 3
+        precision = "f16x3" if precision == "f16x1" else precision
         self.precision = precision
         sd = state_dict
         ops.clear_plan_caches()   # plans are keyed by weight addresses; a rebuilt engine starts clean
@@ -343,6 +347,10 @@ class FCOSEngine:
 
     @ops.device_guarded
     def forward_heads(self, images):
+        with ops.f16_terms(self.terms):
+            return self._forward_heads(images)
+
+    def _forward_heads(self, images):
         """images [N,3,H,W] fp32 0..1 on the GPU (or a list of [3,h_i,w_i] images of different sizes)
         -> per-level head tensors + geometry."""
         if not torch.is_tensor(images):

@@ -195,6 +195,26 @@ def tile_name(tile) -> str:
     return base + ("+rs" if isinstance(tile, int) and tile & TILE_RS else "")
 
 
+# Term count of the f16x3 kernels for the launches issued from now on: 3 = the split-precision product (default),
+# 1 = hi*hi only (the engines' precision="f16x1" throughput mode, reported beside the headline by bench.py).
+F16_TERMS = 3
+
+
+class f16_terms:
+    """`with ops.f16_terms(1):` -- launches inside the block carry hn_conv_desc.terms = 1."""
+
+    def __init__(self, terms):
+        self.terms = terms
+
+    def __enter__(self):
+        global F16_TERMS
+        self._old, F16_TERMS = F16_TERMS, self.terms
+
+    def __exit__(self, *a):
+        global F16_TERMS
+        F16_TERMS = self._old
+
+
 def clear_plan_caches():
     """Drop the cached conv descriptors / launch plans (they are keyed by weight addresses: engines call this when
     they are rebuilt, so that a recycled address can never meet a stale plan and the caches stay bounded)."""
@@ -258,7 +278,7 @@ def conv2d_nhwc(x, w, bias=None, *, stride=1, pad=0, dil=1, relu=False, relu_col
         _check_device(x, "x")
         plan_key = (x.device.index, x.shape, x.stride(), w.data_ptr(), tuple(w.shape), w16.data_ptr(),
                     None if bias is None else bias.data_ptr(),
-                    stride, pad, dil, relu, relu_cols, tile, out_split, res_upsample, splitk, SPLITK, SPLITK_EAGER,
+                    stride, pad, dil, relu, relu_cols, tile, out_split, res_upsample, splitk, SPLITK, SPLITK_EAGER, F16_TERMS,
                     None if residual is None else (residual.shape, residual.stride(), residual.dtype))
         plan = _CONV_PLANS.get(plan_key)
         if plan is not None:
@@ -314,6 +334,7 @@ def conv2d_nhwc(x, w, bias=None, *, stride=1, pad=0, dil=1, relu=False, relu_col
     ys = _pixel_stride(out, "out")
     d.out_split = 1 if is_split(out) else 0
     d.out_pix_stride = 0 if ys == (2 * cout if d.out_split else cout) else ys
+    d.terms = 1 if (use16 and F16_TERMS == 1) else 0
     if residual is not None:
         rs = _pixel_stride(residual, "residual")
         d.res_split = 1 if is_split(residual) else 0
@@ -411,6 +432,7 @@ def conv2d_nhwc_grouped(xs, ws, *, pad=0, relu=False, relu_cols=None, out_split=
     d = make_conv_desc(n, h0, w0, cin, cout, r, s, 1, pad, 1, rc, 0, 0, 0, 0, tile,
                        in_pix_stride=0 if xstride == 2 * cin else xstride)
     d.splitk = -1
+    d.terms = 1 if F16_TERMS == 1 else 0
     if gn_partials is not None:
         if gn is not None or len(gn_partials) != k:
             raise ValueError("give gn_partials (one per member) or gn, not both")
@@ -680,8 +702,8 @@ def conv_stem_pool_split(x16, w16, bias, cout=64, r=7, stride=2, algo_cin=3, out
     if prof is not None:
         timer = HipTimer()
         timer.start()
-    check(lib.hn_conv_stem_pool_f16x3(ptr(x16), n, ph, pw, pad, r, stride, cout, ptr(w16), ptr(bias), ptr(out), _stream()),
-          "hn_conv_stem_pool_f16x3")
+    check(lib.hn_conv_stem_pool_f16x3_terms(ptr(x16), n, ph, pw, pad, r, stride, cout, ptr(w16), ptr(bias), ptr(out),
+                                            1 if F16_TERMS == 1 else 3, _stream()), "hn_conv_stem_pool_f16x3_terms")
     if prof is not None:
         timer.stop()
         # algorithmic work = the stem convolution as the reference executes it (the patch halo is overhead, not work)

@@ -33,7 +33,7 @@ extern "C" {
 #define HN_ERR_HIP 2
 
 /* ABI version; bumped whenever a struct below changes. */
-#define HN_ABI_VERSION 25
+#define HN_ABI_VERSION 26
 int hn_abi_version(void);
 const char* hn_last_error(void);
 
@@ -97,6 +97,10 @@ typedef struct hn_conv_desc {
   int32_t splitk;            /* f16x3 + workspace: 0 = split-K only for long k loops (an extra launch
                               * per conv costs eager callers more than it saves), 1 = also for short
                               * ones (launch cost hidden, e.g. under hipGraph replay), -1 = never */
+  int32_t terms;             /* f16x3 kernels: 0 / 3 = the three-term split product (fp32-grade, the default);
+                              * 1 = hi*hi only ("f16x1": plain fp16 operands, ONE MFMA per MAC, same data movement) --
+                              * the throughput mode SURVEY D6 plans beside the parity mode; misses the 1e-3 keypoint
+                              * contract by two orders and is reported beside the headline, never as it */
 } hn_conv_desc;
 
 #define HN_TILE_AUTO 0
@@ -277,6 +281,9 @@ int hn_conv_stem_f16x3(const void* x16, int n, int ph, int pw, int pad, int r, i
  * 32) never reaches HBM. */
 int hn_conv_stem_pool_f16x3(const void* x16, int n, int ph, int pw, int pad, int r, int stride, int cout,
                             const void* w16, const float* bias, void* y, void* stream);
+/* hn_conv_stem_pool_f16x3 with the term count of hn_conv_desc.terms (1 = the f16x1 throughput mode). */
+int hn_conv_stem_pool_f16x3_terms(const void* x16, int n, int ph, int pw, int pad, int r, int stride, int cout,
+                                  const void* w16, const float* bias, void* y, int terms, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * FCOS post-processing.  Replaces fcos_utils/fcos.py:572-659 (postprocess_detections),

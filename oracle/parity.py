@@ -90,9 +90,10 @@ def pipeline_parity(engine, rgb, depth, fcos_sd, a2j_sd, num_classes=3, chunk=8,
         flips.append(rec)
     eq = same & o_has
     kp_diff = float((g_kp[eq] - o_kp[eq]).abs().max()) if bool(eq.any()) else 0.0
+    kp_mean = float((g_kp[eq] - o_kp[eq]).abs().mean()) if bool(eq.any()) else 0.0
     stats = {"frames": n, "frames_with_hand": int(o_has.sum()), "crop_box_equal_frames": int(same.sum()),
              "crop_box_equality_rate": round(float(same.float().mean()), 6),
              "crop_boxes_identical": bool(same.all()),
-             "max_abs_keypoint_diff": kp_diff, "tolerance": tolerance,
+             "max_abs_keypoint_diff": kp_diff, "mean_abs_keypoint_diff": kp_mean, "tolerance": tolerance,
              "keypoints_within_tolerance": bool(kp_diff < tolerance), "flips": flips}
     return stats, oracle_s, (g_kp, g_box, g_has, o_kp, o_box, o_has)

@@ -672,3 +672,26 @@ def test_halo_patch_kernel_is_bit_identical_to_the_implicit_gemm(n, h, w, cin, r
     ref = torch.relu(ref + (r.double() if res else 0.0)).float()
     got = ops.from_split(y_halo).cpu()
     assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_f16x1_throughput_mode_is_plain_fp16_arithmetic():
+    """hn_conv_desc.terms = 1 (engines: precision="f16x1"; SURVEY D6's throughput mode, reported BESIDE the headline): only
+    the hi*hi term is issued, i.e. the result is that of fp16-rounded operands with fp32 accumulation -- checked against
+    exactly that reference -- and it is two to three orders less accurate than the default three-term mode."""
+    from hn_amd import ops
+    from hn_amd.weights import split_f16x3
+    from oracle import ops_ref
+    for (n, h, w, cin, cout, r) in [(2, 44, 44, 256, 256, 3), (1, 100, 136, 128, 128, 3), (2, 22, 22, 512, 128, 1)]:
+        x = _rand((n, h, w, cin), 61)
+        wt = _rand((cout, r, r, cin), 62, scale=(2.0 / (cin * r * r)) ** 0.5)
+        b = _rand((cout,), 63, 0.1)
+        exact = ops_ref.conv2d_nhwc(x.double(), wt.double(), b.double(), 1, r // 2, 1, relu_cols=cout).float()
+        half = ops_ref.conv2d_nhwc(x.half().double(), wt.half().double(), b.double(), 1, r // 2, 1, relu_cols=cout).float()
+        kw = dict(pad=r // 2, relu=True, w16=split_f16x3(wt).cuda())
+        y3 = ops.conv2d_nhwc(x.cuda(), wt.cuda(), b.cuda(), **kw).cpu()
+        with ops.f16_terms(1):
+            y1 = ops.conv2d_nhwc(x.cuda(), wt.cuda(), b.cuda(), **kw).cpu()
+        scale = max(1.0, float(exact.abs().max()))
+        assert float((y1 - half).abs().max()) <= 2e-5 * scale          # it IS the fp16-operand convolution
+        e3, e1 = float((y3 - exact).abs().max()), float((y1 - exact).abs().max())
+        assert e3 <= 2e-5 * scale and e1 > 30 * e3, (e3, e1)           # and far from fp32 grade
