@@ -104,7 +104,7 @@ def test_bench_line_contract():
     assert len(lines) == 1
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "dropin", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["vs_baseline"] is None
     assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
@@ -116,7 +116,11 @@ def test_bench_line_contract():
     assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == 2500.0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
     assert 400.0 < roof["clock_mhz"] < 2600.0                       # s_memtime / s_memrealtime under load
-    assert roof["traffic"] is None and "launches/step" in roof["traffic_source"]   # batch 2 != the profiled batch 32
+    # batch 2 != the profiled batch 32 (or, between collections, a PMC file of an older kernel revision): never paired
+    assert roof["traffic"] is None and ("launches/step" in roof["traffic_source"] or "another revision" in roof["traffic_source"])
+    assert set(roof["stages"]) >= {"resnet34_body", "fpn", "towers", "head_outputs", "a2j_trunk", "a2j_heads"}
+    dr = d["dropin"]
+    assert dr["batch1"]["frames_per_s"] > 0 and dr["batch2"]["frames_per_s"] > 0 and "HandNet.forward" in dr["call"]
     cpu = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample", "parity"):
         assert k in cpu, k
