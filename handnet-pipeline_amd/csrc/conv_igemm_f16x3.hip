@@ -1380,9 +1380,13 @@ extern "C" int hn_conv2d_f16x3_uses_rs(const hn_conv_desc* d) {
   const int tile = hn_conv2d_f16x3_pick_tile(d);
   ConvParams16 p;
   p.R = d->r; p.S = d->s; p.stride = d->stride; p.dil = d->dil; p.pad = d->pad;
-  p.H = d->h; p.W = d->w; p.pitch = d->w; p.OH = d->oh; p.OW = d->ow;
+  // output size from the geometry (for a grouped launch the caller passes the narrowest member's width in d->w: its
+  // d->oh / d->ow still describe the first member)
+  p.H = d->h; p.W = d->w; p.pitch = d->w;
+  p.OH = (d->h + 2 * d->pad - d->dil * (d->r - 1) - 1) / d->stride + 1;
+  p.OW = (d->w + 2 * d->pad - d->dil * (d->s - 1) - 1) / d->stride + 1;
   p.Cout = d->cout;
-  p.M = d->n * d->oh * d->ow;
+  p.M = d->n * d->oh * d->ow;   // rows of the launch (grouped: all members' rows, as the tile heuristic sees them)
   p.ktiles = d->r * d->s * d->cin / BK;
   p.groups = 1;
   p.rs_ok = 1;

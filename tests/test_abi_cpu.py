@@ -66,3 +66,29 @@ def test_probes_compile():
     with ThreadPoolExecutor(max_workers=4) as ex:
         for name, rc, err in ex.map(compile_one, probes):
             assert rc == 0, f"{name}: {err}"
+
+
+def test_kernel_form_queries_follow_the_launcher():
+    """hn_conv2d_f16x3_uses_rs / _uses_halo / _pick_tile are host-only and evaluate the launcher's own planning functions:
+    the dominant tower launch (grouped: narrowest member width in d.w, picked tile in d.tile) runs the row-shared-A
+    kernel; a small-grid layer that the launcher sends through split-K does not; ResNet-34 layer1 goes to the halo kernel."""
+    import ctypes as C
+    lib = _lib.load()
+
+    def desc(**kw):
+        base = dict(n=32, h=100, w=136, cin=256, cout=256, r=3, s=3, stride=1, pad=1, dil=1, oh=100, ow=136, relu_cols=0)
+        base.update(kw)
+        return _lib.ConvDesc(**base)
+    assert lib.hn_conv2d_f16x3_uses_rs(C.byref(desc())) == 1                                    # plain tower-shaped layer
+    # grouped launch as ops.conv2d_nhwc_grouped describes it: first member's geometry, narrowest width, picked tile, no split-K
+    assert lib.hn_conv2d_f16x3_uses_rs(C.byref(desc(w=34, tile=1, splitk=-1))) == 1
+    assert lib.hn_conv2d_f16x3_uses_rs(C.byref(desc(r=1, s=1, pad=0))) == 0                       # 1x1: per-tap form
+    assert lib.hn_conv2d_f16x3_uses_rs(C.byref(desc(stride=2, oh=50, ow=68))) == 0
+    small = desc(n=1, h=11, w=11, oh=11, ow=11, splitk=1)                                         # batch-1 A2J layer: split-K
+    assert lib.hn_conv2d_f16x3_uses_rs(C.byref(small)) == 0
+    small.splitk = -1                                                                             # ... unless the caller forbids it
+    assert lib.hn_conv2d_f16x3_uses_rs(C.byref(small)) == (1 if lib.hn_conv2d_f16x3_pick_tile(C.byref(small)) in (1, 2, 4) else 0)
+    l1 = desc(h=200, w=272, oh=200, ow=272, cin=64, cout=64, relu_cols=64, out_split=1)
+    assert lib.hn_conv2d_f16x3_uses_halo(C.byref(l1), 0) == 1 and lib.hn_conv2d_f16x3_uses_rs(C.byref(l1)) == 0
+    l1.n = 1
+    assert lib.hn_conv2d_f16x3_uses_halo(C.byref(l1), 0) == 0                                     # too few tiles: implicit GEMM
