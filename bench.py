@@ -270,12 +270,17 @@ def measured_traffic(kernel, gflop_per_launch, launches_per_step):
                       f"{gflop_per_launch}")
     want = stamp["kernel"].replace("conv_igemm_", "").split("_kernel<")
     prec, tile = want[0], want[1].rstrip(">")
-    rs = tile.endswith("+rs")                      # the row-shared-A instantiation: last template argument true
+    rs = tile.endswith("+rs")                      # the row-shared-A instantiation
     bm, bn = tile.replace("+rs", "").split("x")
     needle = f"conv_igemm_{prec}_kernel<{bm}, {bn},"
     for name, k in rec["kernels"].items():
-        if needle in name and (prec != "f16x3" or name.split(">")[0].rstrip().endswith("true" if rs else "false")):
-            return k["hbm_bytes_per_launch"], f"profiles/{rec.get('tag')}_traffic.json (commit {rec.get('commit')})"
+        if needle not in name:
+            continue
+        # template arguments <BM, BN, WM, WN, NBUF, BUF, RS, POOL, TERMS> (f16x3) / <BM, BN, SMALLC> (f32)
+        targs = [a.strip() for a in name.split("<", 1)[1].split(">", 1)[0].split(",")]
+        if prec == "f16x3" and (len(targs) < 9 or (targs[6] == "true") != rs or targs[7] != "false" or targs[8] != "3"):
+            continue
+        return k["hbm_bytes_per_launch"], f"profiles/{rec.get('tag')}_traffic.json (commit {rec.get('commit')})"
     return None, f"{rec.get('tag')}: no {needle} record"
 
 

@@ -48,16 +48,39 @@ struct T {  // device activation: dense NHWC fp32, or S32 split ([n][h][w][c/32]
   char* p = nullptr;
   int n = 0, h = 0, w = 0, c = 0, ps = 0;
   bool split = false;
+  size_t bytes = 0;   // size of the arena block this tensor OWNS (0 for channel slices / borrowed tensors)
 };
 
+// Activation arena with liveness: a tensor's block is handed back (give) once its last consumer has been
+// ENQUEUED -- launches of a forward are ordered on one stream, so the next producer may overwrite it -- and take() reuses
+// the smallest free block that fits before it bumps the high-water mark.  The dry pass replays exactly the same take / give
+// sequence, so the layout it sizes is the layout the real pass gets.  (Bump-only, the FCOS graph at batch 32 needed ~20 GB.)
 struct Arena {
   char* base = nullptr;
   size_t cap = 0, off = 0;
   bool dry = false;
+  struct Block { size_t off, bytes; };
+  std::vector<Block> free_blocks;
+  char* origin() const { return dry ? (char*)0x1000 : base; }
+  void reset() { off = 0; free_blocks.clear(); }
   char* take(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    int best = -1;
+    for (size_t i = 0; i < free_blocks.size(); ++i)
+      if (free_blocks[i].bytes >= bytes && (best < 0 || free_blocks[i].bytes < free_blocks[best].bytes)) best = (int)i;
+    if (best >= 0) {
+      const Block b = free_blocks[best];
+      if (b.bytes > bytes) free_blocks[best] = Block{b.off + bytes, b.bytes - bytes};
+      else free_blocks.erase(free_blocks.begin() + best);
+      return origin() + b.off;
+    }
     const size_t a = (off + 255) & ~(size_t)255;
     off = a + bytes;
-    return (dry ? (char*)0x1000 : base) + a;
+    return origin() + a;
+  }
+  void give(char* p, size_t bytes) {
+    if (!p || !bytes) return;
+    free_blocks.push_back(Block{(size_t)(p - origin()), (bytes + 255) & ~(size_t)255});
   }
 };
 
@@ -275,8 +298,15 @@ T alloc(Ctx& cx, int n, int h, int w, int c, bool split) {
   T t;
   t.n = n; t.h = h; t.w = w; t.c = c; t.split = split;
   t.ps = split ? 2 * c : c;
-  t.p = cx.m->arena.take((size_t)n * h * w * c * 4);  // S32 has the same bytes as fp32
+  t.bytes = (size_t)n * h * w * c * 4;  // S32 has the same bytes as fp32
+  t.p = cx.m->arena.take(t.bytes);
   return t;
+}
+
+// the last consumer of `t` has been enqueued: its block may be reused (no-op for slices / borrowed tensors)
+void release(Ctx& cx, T& t) {
+  cx.m->arena.give(t.p, t.bytes);
+  t.bytes = 0;
 }
 
 char* alloc_bytes(Ctx& cx, size_t bytes) { return cx.m->arena.take(bytes); }
@@ -321,6 +351,7 @@ T slice_blocks(const T& x, int b0, int b1) {
   T s = x;
   s.p = x.p + (size_t)b0 * 64 * 2;
   s.c = (b1 - b0) * 32;
+  s.bytes = 0;
   return s;
 }
 
@@ -376,6 +407,10 @@ int a2j_graph(Ctx& cx, const T& crops /* fp32 [k][176][176][4] */, const int32_t
     if (b.has_ds) HN_TRY(conv16(cx, x, b.ds, false, true, nullptr, false, idn));
     else idn = x;
     HN_TRY(conv16(cx, o2, b.c3, true, true, &idn, false, y));
+    release(cx, o);
+    release(cx, o2);
+    if (b.has_ds) release(cx, idn);
+    if (x.p != x3.p) release(cx, x);   // the block input is dead (x3 is read again by the classification head)
     x = y;
     const bool last_of_layer = i + 1 == m->a_blocks.size() || m->a_blocks[i + 1].layer != b.layer;
     if (b.layer == 3 && last_of_layer) x3 = x;
@@ -475,6 +510,11 @@ int fcos_graph(Ctx& cx, const float* rgb, int n, int h, int w, const FcosOut& ou
     if (b.has_ds) HN_TRY(conv16(cx, x, b.ds, false, true, nullptr, false, idn));
     else idn = x;
     HN_TRY(conv16(cx, o, b.c2, true, true, &idn, false, y));
+    release(cx, o);
+    if (b.has_ds) release(cx, idn);
+    bool saved = false;   // C3 / C4 / C5 are read again by the FPN laterals
+    for (int f = 0; f < nf; ++f) saved = saved || feats_c[f].p == x.p;
+    if (!saved) release(cx, x);
     x = y;
     if (b.last && b.layer >= 2) feats_c[nf++] = x;
   }
@@ -532,8 +572,9 @@ int fcos_graph(Ctx& cx, const float* rgb, int n, int h, int w, const FcosOut& ou
       a[l] = alloc(cx, n, t[l].h, t[l].w, 512, true);
       lv.hw[l] = hw[l]; lv.x[l] = (const float*)t[l].p; lv.scale[l] = scale[l]; lv.shift[l] = shift[l]; lv.y16[l] = a[l].p;
     }
-    if (cx.dry) return HN_OK;
-    return hn_affine_split_f32_levels(&lv, 1, n, 512, 512, 512, 1024, cx.stream);   // one launch unless a level is cache-sized
+    const int rc = cx.dry ? HN_OK : hn_affine_split_f32_levels(&lv, 1, n, 512, 512, 512, 1024, cx.stream);   // one launch unless a level is cache-sized
+    for (int l = 0; l < L; ++l) release(cx, t[l]);   // the raw tower output has been consumed
+    return rc;
   };
   HN_TRY(finalize(m->f_gn0_gamma, m->f_gn0_beta));
   T a[3];
@@ -548,6 +589,7 @@ int fcos_graph(Ctx& cx, const float* rgb, int n, int h, int w, const FcosOut& ou
       gs.gn[L + l] = (float*)((char*)parts[l] + 16 * 32);
     }
     HN_TRY(conv_grouped(cx, gs, 0, false, 512, 64));
+    for (int l = 0; l < L; ++l) release(cx, a[l]);   // the activated input of this tower layer
     HN_TRY(finalize(m->f_gn_gamma[layer], m->f_gn_beta[layer]));
   }
   HN_TRY(activate(a));
@@ -612,7 +654,7 @@ int run_planned(hn_model* m, const std::string& key, void* stream, F&& graph) {
   if (it == m->plan.end()) {
     Ctx dry{m, stream, true, nullptr};
     m->arena.dry = true;
-    m->arena.off = 0;
+    m->arena.reset();
     (void)m->arena.take(kConvWorkspaceBytes);
     HN_TRY(graph(dry));
     bytes = m->arena.off + 256;
@@ -634,7 +676,7 @@ int run_planned(hn_model* m, const std::string& key, void* stream, F&& graph) {
   m->last_stream = stream;
   m->has_last_stream = true;
   m->arena.dry = false;
-  m->arena.off = 0;
+  m->arena.reset();
   Ctx cx{m, stream, false, nullptr};
   cx.ws = m->arena.take(kConvWorkspaceBytes);
   return graph(cx);
