@@ -52,6 +52,9 @@ static void read_env() {
   g_env.split_generic = getenv("HN_SPLIT_GENERIC") != nullptr;
   g_env.stem_generic = getenv("HN_STEM_POOL_GENERIC") != nullptr;
   g_env.no_halo = getenv("HN_CONV_NO_HALO") != nullptr;
+  g_env.no_thin = getenv("HN_THIN_OUTPUTS") != nullptr && getenv("HN_THIN_OUTPUTS")[0] == '0';   // model.hip: grouped implicit GEMM
+  g_env.thin_tap = getenv("HN_THIN_FORM") != nullptr && getenv("HN_THIN_FORM")[0] == 't';          // thin kernel: never the P form
+  g_env.thin_flat = getenv("HN_THIN_FORM") != nullptr && getenv("HN_THIN_FORM")[0] == 'f';         // ... the P form at any size
   g_env_read = true;
 }
 const EnvFlags& env_flags() {

@@ -383,6 +383,22 @@ int conv_grouped(Ctx& cx, const GroupSpec& g, int relu_cols, bool out_split, int
   return hn_conv2d_nhwc_f16x3_grouped(&d, &grp, cx.stream);
 }
 
+// ops.conv3x3_thin_levels: one <= 16-channel 3x3 filter bank on every level (the FCOS head outputs), dense fp32 outputs
+int conv_thin_levels(Ctx& cx, const GroupSpec& g, int relu_cols) {
+  const ConvW& c0 = *g.w[0];
+  if (hn::env_flags().no_thin || c0.cout > 16 || g.count > HN_FCOS_MAX_LEVELS) return conv_grouped(cx, g, relu_cols, false, c0.cout, 0);
+  hn_thin_levels lv;
+  memset(&lv, 0, sizeof(lv));
+  lv.count = g.count;
+  for (int i = 0; i < g.count; ++i) {
+    lv.x16[i] = g.x[i].p; lv.y[i] = (float*)g.y[i]; lv.h[i] = g.x[i].h; lv.w[i] = g.x[i].w;
+  }
+  if (cx.dry) return HN_OK;
+  const int dense = 2 * g.x[0].c;
+  return hn_conv3x3_thin_f16x3_levels(&lv, g.x[0].n, g.x[0].c, c0.cout, c0.w16, c0.bias, relu_cols, g.x[0].ps == dense ? 0 : g.x[0].ps,
+                                      cx.stream);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // A2J (hn_amd/a2j_engine.py)
 // ------------------------------------------------------------------------------------------------------------------
@@ -609,7 +625,7 @@ int fcos_graph(Ctx& cx, const float* rgb, int n, int h, int w, const FcosOut& ou
       lv.h[l] = a[l].h; lv.w[l] = a[l].w; lv.stride[l] = g.ph / a[l].h;
       lv.cls_lr[l] = (const float*)cls_lr[l].p; lv.reg_ctr[l] = (const float*)reg_ctr[l].p;
     }
-    HN_TRY(conv_grouped(cx, gc, 0, false, ccls, 0));
+    HN_TRY(conv_thin_levels(cx, gc, 0));
     if (out.contacts) {  // ext heads: relu(hand_dydx_layer)[3] | hand_contact_state_layer[5] from the cls tower (fcos.py:255-264)
       GroupSpec ge;
       ge.count = L;
@@ -617,9 +633,9 @@ int fcos_graph(Ctx& cx, const float* rgb, int n, int h, int w, const FcosOut& ou
         ext_lv[l] = alloc(cx, n, a[l].h, a[l].w, 8, false);
         ge.x[l] = slice_blocks(a[l], 0, 8); ge.w[l] = &m->f_ext_out; ge.y[l] = ext_lv[l].p; ge.gn[l] = nullptr;
       }
-      HN_TRY(conv_grouped(cx, ge, 3, false, 8, 0));
+      HN_TRY(conv_thin_levels(cx, ge, 3));
     }
-    HN_TRY(conv_grouped(cx, gr, 4, false, 5, 0));
+    HN_TRY(conv_thin_levels(cx, gr, 4));
   }
   const int cap = hw[0] + hw[1] + hw[2];
   if (out.cap != cap) return hn::fail(HN_ERR_ARG, "internal: %d anchor points but capacity %d", cap, out.cap);

@@ -67,6 +67,11 @@ class SplitLevels(C.Structure):  # == struct hn_split_levels
                 ("shift", C.c_void_p * HN_FCOS_MAX_LEVELS), ("y16", C.c_void_p * HN_FCOS_MAX_LEVELS)]
 
 
+class ThinLevels(C.Structure):  # == struct hn_thin_levels
+    _fields_ = [("count", C.c_int32), ("x16", C.c_void_p * HN_FCOS_MAX_LEVELS), ("y", C.c_void_p * HN_FCOS_MAX_LEVELS),
+                ("h", C.c_int32 * HN_FCOS_MAX_LEVELS), ("w", C.c_int32 * HN_FCOS_MAX_LEVELS)]
+
+
 # name -> (restype, argtypes); every symbol of include/handnet_hip.h is listed here and
 # tests/test_abi.py checks the two stay in sync.
 VP = C.c_void_p
@@ -133,6 +138,8 @@ SIGNATURES = {
     "hn_pack_records": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP]),
     "hn_unpack_records": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, VP]),
     "hn_nonfinite_count_f32": (C.c_int, [VP, C.c_int64, VP, VP]),
+    "hn_conv3x3_thin_f16x3_levels": (C.c_int, [C.POINTER(ThinLevels), C.c_int, C.c_int, C.c_int, VP, VP, C.c_int, C.c_int, VP]),
+    "hn_conv3x3_thin_uses_flat": (C.c_int, [C.POINTER(ThinLevels), C.c_int, C.c_int, C.c_int]),
     "hn_convert_joints_f32": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_float, C.c_float, c_f32p, VP, VP]),
 }
 

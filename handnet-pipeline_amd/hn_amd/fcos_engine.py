@@ -119,6 +119,7 @@ class FCOSEngine:
         self.head_streams = int(os.environ.get("HN_HEAD_STREAMS", "1")) if head_streams is None else head_streams
         self.group_towers = os.environ.get("HN_GROUP_CONVS", "1") != "0"
         self.fuse_stem_pool = os.environ.get("HN_FUSE_STEM_POOL", "1") != "0"   # A/B switch (results are bit-identical)
+        self.thin_outputs = os.environ.get("HN_THIN_OUTPUTS", "1") != "0" and self.cls_out.cout <= 16   # A/B switch, bit-identical
 
     # -----------------------------------------------------------------------------------
     def _conv(self, x, cw: ConvW, relu=False, out_f32=False, **kw):
@@ -289,9 +290,14 @@ class FCOSEngine:
         a = ops.to_split_levels(t, aff, relu=True)
         ac, ar = [x[:, :, :, :8] for x in a], [x[:, :, :, 8:] for x in a]
         ops.PROFILE_STAGE = "head_outputs"
-        cls_lr = ops.conv2d_nhwc_grouped(ac, [self.cls_out] * L, pad=1)
-        ext = ops.conv2d_nhwc_grouped(ac, [self.ext_out] * L, pad=1, relu_cols=3) if self.ext else [None] * L
-        reg_ctr = ops.conv2d_nhwc_grouped(ar, [self.reg_out] * L, pad=1, relu_cols=4)
+        if self.thin_outputs and self.terms == 3:   # <= 8 output channels: the thin-N kernel (every input pixel staged once per channel block)
+            cls_lr = ops.conv3x3_thin_levels(ac, self.cls_out)
+            ext = ops.conv3x3_thin_levels(ac, self.ext_out, relu_cols=3) if self.ext else [None] * L
+            reg_ctr = ops.conv3x3_thin_levels(ar, self.reg_out, relu_cols=4)
+        else:
+            cls_lr = ops.conv2d_nhwc_grouped(ac, [self.cls_out] * L, pad=1)
+            ext = ops.conv2d_nhwc_grouped(ac, [self.ext_out] * L, pad=1, relu_cols=3) if self.ext else [None] * L
+            reg_ctr = ops.conv2d_nhwc_grouped(ar, [self.reg_out] * L, pad=1, relu_cols=4)
         return list(zip(cls_lr, reg_ctr, ext))
 
     def heads(self, feats):

@@ -485,6 +485,50 @@ def conv2d_nhwc_grouped(xs, ws, *, pad=0, relu=False, relu_cols=None, out_split=
     return outs
 
 
+def conv3x3_thin_levels(xs, cw, relu_cols=0):
+    """3x3 / pad 1 convolution with <= 16 output channels on several maps at once (the FCOS head outputs on all FPN levels,
+    hn_conv3x3_thin_f16x3_levels): xs = S32 inputs [N,h_l,w_l,Cin/32,2,32] (channel slices allowed), cw = ConvW-like with
+    .w [Cout,3,3,Cin], .w16, .bias -> list of fp32 [N,h_l,w_l,Cout].  Cout <= 5: the P-form kernel (equal to
+    conv2d_nhwc_grouped(xs, [cw]*L, pad=1) to fp32 rounding); else the tap kernel (bit-identical to it)."""
+    lib = _lib.load()
+    cout, r, s, cin = cw.w.shape
+    if (r, s) != (3, 3) or cout > 16 or cw.w16 is None or len(xs) > _lib.HN_FCOS_MAX_LEVELS:
+        raise ValueError("conv3x3_thin_levels needs a 3x3 filter bank with <= 16 output channels and a split bank")
+    n = xs[0].shape[0]
+    xstride = _pixel_stride(xs[0], "x")
+    lv = _lib.ThinLevels()
+    lv.count = len(xs)
+    outs = []
+    for i, x in enumerate(xs):
+        if not is_split(x) or x.shape[0] != n or channels(x) != cin or _pixel_stride(x, "x") != xstride:
+            raise ValueError("levels must be S32 tensors of one batch size, channel count and pixel stride")
+        y = torch.empty((n, x.shape[1], x.shape[2], cout), device=x.device, dtype=torch.float32)
+        lv.x16[i], lv.y[i], lv.h[i], lv.w[i] = x.data_ptr(), y.data_ptr(), x.shape[1], x.shape[2]
+        outs.append(y)
+    prof = CONV_PROFILE
+    if prof is not None:
+        timer = HipTimer()
+        timer.start()
+    check(lib.hn_conv3x3_thin_f16x3_levels(C.byref(lv), n, cin, cout, ptr(cw.w16), ptr(cw.bias), int(relu_cols),
+                                           0 if xstride == 2 * cin else xstride, _stream()), "hn_conv3x3_thin_f16x3_levels")
+    if prof is not None:
+        timer.stop()
+        rows = sum(n * x.shape[1] * x.shape[2] for x in xs)
+        form = "thin-P" if lib.hn_conv3x3_thin_uses_flat(C.byref(lv), n, cin, cout) else "thin16x16"
+        prof.append((("f16x3", form), rows * cout * 9 * cin, timer, (1, rows, 1, cin, cout, 3, 1, 1), PROFILE_STAGE))
+    return outs
+
+
+def thin_uses_flat(xs, cw) -> bool:
+    """Would conv3x3_thin_levels(xs, cw) run the P-form kernel (True) or the tap kernel (False)?"""
+    lv = _lib.ThinLevels()
+    lv.count = len(xs)
+    for i, x in enumerate(xs):
+        lv.h[i], lv.w[i] = x.shape[1], x.shape[2]
+    cout, _, _, cin = cw.w.shape
+    return bool(_lib.load().hn_conv3x3_thin_uses_flat(C.byref(lv), xs[0].shape[0], cin, cout))
+
+
 def maxpool3x3s2_nhwc(x, out=None):
     lib = _lib.load()
     if is_split(x):

@@ -246,6 +246,25 @@ typedef struct hn_split_levels {
 int hn_affine_split_f32_levels(const hn_split_levels* lv, int relu, int n, int c, int in_pix_stride,
                                int affine_stride, int out_pix_stride, void* stream);
 
+/* The FCOS head OUTPUT convolutions (cls_logits + hand_lr, bbox_reg + bbox_ctrness, the ext heads: fcos_utils/fcos.py:
+ * 247-264,299-320,362-363): 3x3 / stride 1 / pad 1, cin % 32 == 0, 1 <= cout <= 16, the same filter on every FPN level,
+ * all levels in ONE launch.  x16[l] = S32 input of level l (a channel slice of a wider tensor: in_pix_stride in halfs,
+ * 0 = dense), y[l] = fp32 [n][h_l][w_l][cout] dense, ReLU on channels [0, relu_cols).  Two kernels (csrc/conv3x3_thin.hip):
+ *   - cout <= 5, cin % 128 == 0, level width <= ~170, >= 65536 pixels in all (hn_conv3x3_thin_uses_flat() == 1): the P form -- one GEMM
+ *     P[(tap, oc)][pixel] over the flat pixel list, every input pixel read from HBM once, then nine shifted adds per output
+ *     from an LDS ring.  Same products as the implicit GEMM, summed per tap first: equal to fp32 rounding, not bit for bit;
+ *   - otherwise the tap kernel: 16 x 16 pixel tiles, the implicit GEMM's k / term order, bit-identical to
+ *     hn_conv2d_nhwc_f16x3_grouped on the same operands. */
+typedef struct hn_thin_levels {
+  int32_t count;
+  const void* x16[HN_FCOS_MAX_LEVELS];
+  float* y[HN_FCOS_MAX_LEVELS];
+  int32_t h[HN_FCOS_MAX_LEVELS], w[HN_FCOS_MAX_LEVELS];
+} hn_thin_levels;
+int hn_conv3x3_thin_f16x3_levels(const hn_thin_levels* lv, int n, int cin, int cout, const void* w16, const float* bias,
+                                 int relu_cols, int in_pix_stride, void* stream);
+int hn_conv3x3_thin_uses_flat(const hn_thin_levels* lv, int n, int cin, int cout);   /* only count and w[] are read */
+
 /* ------------------------------------------------------------------------------------
  * FCOS pre-processing: normalize + bilinear resize (align_corners=False, scale =
  * in/out as with recompute_scale_factor=True) + zero pad, NCHW fp32 in -> NHWC(4) out.

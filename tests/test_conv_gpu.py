@@ -695,3 +695,63 @@ def test_f16x1_throughput_mode_is_plain_fp16_arithmetic():
         assert float((y1 - half).abs().max()) <= 2e-5 * scale          # it IS the fp16-operand convolution
         e3, e1 = float((y3 - exact).abs().max()), float((y1 - exact).abs().max())
         assert e3 <= 2e-5 * scale and e1 > 30 * e3, (e3, e1)           # and far from fp32 grade
+
+
+@pytest.mark.parametrize("n,cout,relu_cols,sizes", [
+    (2, 5, 0, [(100, 136), (50, 68), (25, 34), (13, 17), (7, 9)]),     # the FCOS pyramid of an 800x1088 frame
+    (1, 5, 4, [(100, 136), (50, 68), (25, 34), (13, 17), (7, 9)]),
+    (3, 8, 3, [(33, 47), (16, 16), (1, 1)]),
+    (1, 16, 16, [(17, 15)]),
+    (2, 1, 0, [(5, 40), (40, 5)]),
+    (8, 5, 4, [(100, 136), (50, 68), (25, 34), (13, 17), (7, 9)]),    # > 256 flat-pixel ranges: unit_len above one step
+    (1, 5, 0, [(3, 167)]),                                               # the widest level the LDS ring takes
+    (1, 4, 2, [(1, 2), (1, 300), (300, 1), (2, 2)]),                     # 300 wide: falls back to the tap kernel
+])
+@pytest.mark.parametrize("form", ["auto", "flat"])
+def test_thin_output_conv_matches_the_grouped_kernel(n, cout, relu_cols, sizes, form, monkeypatch):
+    """hn_conv3x3_thin_f16x3_levels (csrc/conv3x3_thin.hip), the FCOS head outputs (fcos_utils/fcos.py:247-264,299-320).
+    Its tap kernel keeps the k and term order of the implicit GEMM: bit-identical.  Its P-form kernel (Cout <= 5, >= 64 k
+    pixels -- or any size under HN_THIN_FORM=flat, the second run) adds the same fp32 products in another order (per tap
+    over all channels, then the nine taps): equal to fp32 rounding of a 2304-term sum, and as close to the fp64 convolution
+    as the implicit GEMM is.  Inputs are channel slices of a 512-channel stack, as heads_grouped hands them over."""
+    from hn_amd import ops
+    from hn_amd.weights import ConvW
+    if form == "flat":
+        monkeypatch.setenv("HN_THIN_FORM", "flat")
+    ops.reread_env()
+    try:
+        g = torch.Generator().manual_seed(1234 + n + cout)
+        cin = 256
+        w = (torch.randn(cout, 3, 3, cin, generator=g) * 0.05).cuda()
+        b = torch.randn(cout, generator=g).cuda()
+        cw = ConvW(w.cpu(), b.cpu(), 1, 1, 1).to("cuda")
+        stacks = [ops.to_split(torch.randn(n, h, wd, 2 * cin, generator=g).cuda()) for h, wd in sizes]
+        flat = ops.thin_uses_flat([s[:, :, :, :8] for s in stacks], cw)
+        pixels = n * sum(h * wd for h, wd in sizes)
+        assert flat == (cout <= 5 and max(wd for _, wd in sizes) <= 167 and (form == "flat" or pixels >= 65536))
+        for half in (0, 1):
+            xs = [s[:, :, :, 8 * half:8 * half + 8] for s in stacks]
+            want = [ops.conv2d_nhwc(x, cw.w, cw.bias, pad=1, relu_cols=relu_cols, w16=cw.w16, splitk=False) for x in xs]
+            if len(xs) > 1:   # (a single member would fall through to the split-K plan of conv2d_nhwc: another summation order)
+                for a, e in zip(ops.conv2d_nhwc_grouped(xs, [cw] * len(xs), pad=1, relu_cols=relu_cols), want):
+                    assert torch.equal(a, e)
+            got = ops.conv3x3_thin_levels(xs, cw, relu_cols=relu_cols)
+            for a, e, x in zip(got, want, xs):
+                assert a.shape == e.shape
+                if not flat:
+                    assert torch.equal(a, e)
+                    continue
+                x64 = ops.from_split(x).double().permute(0, 3, 1, 2)
+                ref = torch.nn.functional.conv2d(x64, w.double().permute(0, 3, 1, 2), b.double(), padding=1).permute(0, 2, 3, 1)
+                ref = torch.cat([ref[..., :relu_cols].clamp_min(0), ref[..., relu_cols:]], dim=-1)
+                scale = ref.abs().max().item()
+                err_thin, err_gemm = (a.double() - ref).abs().max().item(), (e.double() - ref).abs().max().item()
+                assert err_thin <= 4e-6 * scale and err_thin <= 2 * err_gemm + 1e-7 * scale, (err_thin, err_gemm, scale)
+                assert (a - e).abs().max().item() <= 4e-6 * scale
+        dense = [s[:, :, :, :8].contiguous() for s in stacks]
+        for a, g2 in zip(ops.conv3x3_thin_levels(dense, cw, relu_cols=relu_cols),
+                         ops.conv3x3_thin_levels([s[:, :, :, :8] for s in stacks], cw, relu_cols=relu_cols)):
+            assert torch.equal(a, g2)     # dense and sliced inputs: the same kernel, the same bits
+    finally:
+        monkeypatch.delenv("HN_THIN_FORM", raising=False)
+        ops.reread_env()
