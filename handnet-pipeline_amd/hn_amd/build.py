@@ -23,6 +23,34 @@ ARCH = "gfx950"
 # (no FMA contraction), so that file is built with contraction off.
 EXTRA_FLAGS = {"fcos_post.hip": ["-ffp-contract=off"]}
 
+# Kernels that request operands with `asm volatile` loads / LDS-DMA and retire them with hand-counted s_waitcnt: the
+# compiler cannot see that such a register is still in flight, so a SPILL of it stores garbage (profiles/NOTEBOOK.md, round
+# 3).  The build records every kernel's resource usage (csrc/build/<file>.resources.txt) and refuses a spill in these.
+NO_SPILL_KERNELS = ("conv_igemm_f16x3_kernel", "conv3x3_halo_kernel", "conv_stem_pool_direct_kernel", "conv3x3_thin")
+
+
+def _check_resources(src: Path, remarks: str, objdir: Path) -> None:
+    name, rows = None, []
+    for line in remarks.splitlines():
+        if "remark:" not in line:
+            continue
+        body = line.split("remark:", 1)[1].split("[-Rpass", 1)[0].strip()
+        if body.startswith("Function Name:"):
+            name = body.split(":", 1)[1].strip()
+            rows.append([name, {}])
+        elif name and ":" in body:
+            k, v = body.rsplit(":", 1)
+            rows[-1][1][k.strip()] = v.strip()
+    out = []
+    for name, res in rows:
+        out.append(f"{name}: VGPRs {res.get('VGPRs')} AGPRs {res.get('AGPRs')} SGPRs {res.get('TotalSGPRs')} "
+                   f"scratch {res.get('ScratchSize [bytes/lane]')} occupancy {res.get('Occupancy [waves/SIMD]')} "
+                   f"vgpr_spill {res.get('VGPRs Spill')} sgpr_spill {res.get('SGPRs Spill')}")
+        if any(k in name for k in NO_SPILL_KERNELS) and (res.get("VGPRs Spill", "0") != "0" or res.get("SGPRs Spill", "0") != "0"):
+            raise RuntimeError(f"{src.name}: {name} spills registers ({res.get('VGPRs Spill')} VGPR, {res.get('SGPRs Spill')} SGPR): "
+                               "its asm loads / counted waits are only correct without spills")
+    (objdir / (src.stem + ".resources.txt")).write_text("\n".join(out) + "\n")
+
 
 def _hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
@@ -49,15 +77,20 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
 
     def compile_one(src: Path) -> Path:
         obj = objdir / (src.stem + ".o")
-        if force or _newer([src] + headers, obj):
-            cmd = base + EXTRA_FLAGS.get(src.name, []) + ["-c", str(src), "-o", str(obj)]
+        if force or _newer([src] + headers, obj) or not (objdir / (src.stem + ".resources.txt")).exists():
+            cmd = base + EXTRA_FLAGS.get(src.name, []) + ["-Rpass-analysis=kernel-resource-usage", "-c", str(src), "-o", str(obj)]
             if verbose:
                 print(" ".join(cmd), flush=True)
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError(f"hipcc failed on {src.name}:\n{r.stdout}\n{r.stderr}")
+            try:
+                _check_resources(src, r.stderr, objdir)
+            except RuntimeError:
+                obj.unlink(missing_ok=True)   # do not leave an object behind that a later incremental build would link
+                raise
             if verbose and r.stderr.strip():
-                print(r.stderr, file=sys.stderr)
+                print("\n".join(l for l in r.stderr.splitlines() if "kernel-resource-usage" not in l), file=sys.stderr)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(6, len(sources) or 1)) as ex:

@@ -107,3 +107,22 @@ def test_probe_scripts_parse():
     for f in sh:
         r = subprocess.run(["bash", "-n", str(f)], capture_output=True, text=True)
         assert r.returncode == 0, f"{f}: {r.stderr}"
+
+
+def test_hand_scheduled_kernels_do_not_spill():
+    """The kernels that retire `asm` loads / LDS-DMA with hand-counted s_waitcnt are only correct while the register
+    allocator spills nothing (a spilled in-flight register is stored before its data has arrived): the build records every
+    kernel's resource usage and refuses such a spill; check the record it left."""
+    from hn_amd import build
+    build.build_library()
+    seen = 0
+    for f in sorted((build.CSRC / "build").glob("*.resources.txt")):
+        for line in f.read_text().splitlines():
+            if ": VGPRs" not in line:
+                continue
+            name, rest = line.split(":", 1)
+            if any(k in name for k in build.NO_SPILL_KERNELS):
+                seen += 1
+                assert " vgpr_spill 0 " in rest + " " and rest.strip().endswith("sgpr_spill 0"), line
+                assert " scratch 0 " in rest, line
+    assert seen >= 30    # 31 instantiations of the implicit GEMM + halo + stem + the two thin-N kernels
