@@ -316,9 +316,14 @@ inline void out_size(int h, int w, int r, int s, int stride, int pad, int dil, i
   ow = (w + 2 * pad - dil * (s - 1) - 1) / stride + 1;
 }
 
+// hn_model_config.f16_terms of the model whose forward is being enqueued on this thread (set by run_planned): every
+// descriptor of the graph carries it (0 = f16x3; 1 = the f16x1 throughput mode)
+thread_local int t_terms = 0;
+
 hn_conv_desc make_desc(const T& x, const ConvW& cw, int relu_cols) {
   hn_conv_desc d;
   memset(&d, 0, sizeof(d));
+  d.terms = t_terms;
   d.n = x.n; d.h = x.h; d.w = x.w; d.cin = cw.cin; d.cout = cw.cout; d.r = cw.r; d.s = cw.s;
   d.stride = cw.stride; d.pad = cw.pad; d.dil = cw.dil;
   int oh, ow;
@@ -386,7 +391,7 @@ int conv_grouped(Ctx& cx, const GroupSpec& g, int relu_cols, bool out_split, int
 // ops.conv3x3_thin_levels: one <= 16-channel 3x3 filter bank on every level (the FCOS head outputs), dense fp32 outputs
 int conv_thin_levels(Ctx& cx, const GroupSpec& g, int relu_cols) {
   const ConvW& c0 = *g.w[0];
-  if (hn::env_flags().no_thin || c0.cout > 16 || g.count > HN_FCOS_MAX_LEVELS) return conv_grouped(cx, g, relu_cols, false, c0.cout, 0);
+  if (hn::env_flags().no_thin || t_terms == 1 || c0.cout > 16 || g.count > HN_FCOS_MAX_LEVELS) return conv_grouped(cx, g, relu_cols, false, c0.cout, 0);
   hn_thin_levels lv;
   memset(&lv, 0, sizeof(lv));
   lv.count = g.count;
@@ -413,7 +418,8 @@ int a2j_graph(Ctx& cx, const T& crops /* fp32 [k][176][176][4] */, const int32_t
   out_size(crops.h + 2 * border, crops.w + 2 * border, 7, 7, 2, 0, 1, sh, sw);
   T x = alloc(cx, k, (sh + 2 - 3) / 2 + 1, (sw + 2 - 3) / 2 + 1, 64, true);
   if (!cx.dry)
-    HN_TRY(hn_conv_stem_pool_f16x3(img16, k, crops.h, crops.w, border, 7, 2, 64, m->a_stem16.w16, m->a_stem16.bias, x.p, cx.stream));
+    HN_TRY(hn_conv_stem_pool_f16x3_terms(img16, k, crops.h, crops.w, border, 7, 2, 64, m->a_stem16.w16, m->a_stem16.bias, x.p, t_terms,
+                                         cx.stream));
   T x3;
   for (size_t i = 0; i < m->a_blocks.size(); ++i) {
     auto& b = m->a_blocks[i];
@@ -517,7 +523,8 @@ int fcos_graph(Ctx& cx, const float* rgb, int n, int h, int w, const FcosOut& ou
   // conv1 + bn1 + relu + 3x3/2 max pooling as ONE kernel (like hn_amd/fcos_engine.py): the half-resolution map is never stored
   T x = alloc(cx, n, (sh + 2 - 3) / 2 + 1, (sw + 2 - 3) / 2 + 1, 64, true);
   if (!cx.dry)
-    HN_TRY(hn_conv_stem_pool_f16x3(img16, n, g.ph, g.pw, border, 7, 2, 64, m->f_stem16.w16, m->f_stem16.bias, x.p, cx.stream));
+    HN_TRY(hn_conv_stem_pool_f16x3_terms(img16, n, g.ph, g.pw, border, 7, 2, 64, m->f_stem16.w16, m->f_stem16.bias, x.p, t_terms,
+                                         cx.stream));
   T feats_c[3];
   int nf = 0;
   for (auto& b : m->f_blocks) {
@@ -665,6 +672,7 @@ int fcos_graph(Ctx& cx, const float* rgb, int n, int h, int w, const FcosOut& ou
 template <class F>
 int run_planned(hn_model* m, const std::string& key, void* stream, F&& graph) {
   HN_CHECK_ARG(m && m->finalized, "model is not finalized (hn_finalize)");
+  t_terms = m->cfg.f16_terms == 1 ? 1 : 0;
   auto it = m->plan.find(key);
   size_t bytes;
   if (it == m->plan.end()) {
@@ -705,6 +713,7 @@ extern "C" int hn_create(const hn_model_config* cfg, hn_model** out) {
   HN_CHECK_ARG(cfg && out, "hn_create: null pointer");
   HN_CHECK_ARG(cfg->parts & (HN_MODEL_FCOS | HN_MODEL_A2J), "hn_create: parts must name HN_MODEL_FCOS and / or HN_MODEL_A2J");
   HN_CHECK_ARG(cfg->num_classes >= 1 && cfg->num_classes <= 64 && cfg->num_joints >= 1, "bad class / joint count");
+  HN_CHECK_ARG(cfg->f16_terms == 0 || cfg->f16_terms == 1 || cfg->f16_terms == 3, "f16_terms must be 0, 1 or 3");
   hn_model* m = new hn_model();
   m->cfg = *cfg;
   if (m->cfg.min_size <= 0) m->cfg.min_size = 800;     // fcos.py:460-461

@@ -12,7 +12,7 @@ from pathlib import Path
 
 from . import build as _build
 
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, TILE_256x128, TILE_64x128 = range(7)
 HN_FCOS_MAX_LEVELS = 5
@@ -40,7 +40,7 @@ class ConvGroup(C.Structure):  # == struct hn_conv_group
 
 
 class ModelConfig(C.Structure):  # == struct hn_model_config
-    _fields_ = [(k, C.c_int32) for k in ("parts", "num_classes", "num_joints", "rgbd", "min_size", "max_size", "ext")]
+    _fields_ = [(k, C.c_int32) for k in ("parts", "num_classes", "num_joints", "rgbd", "min_size", "max_size", "ext", "f16_terms")]
 
 
 MODEL_FCOS, MODEL_A2J = 1, 2

@@ -18,7 +18,7 @@ from .ops import _stream, on_device
 
 class NativeModel:
     def __init__(self, fcos_sd=None, a2j_sd=None, num_classes=3, num_joints=21, rgbd=False, device="cuda",
-                 min_size=0, max_size=0, ext=False):
+                 min_size=0, max_size=0, ext=False, precision="f16x3"):
         if fcos_sd is None and a2j_sd is None:
             raise ValueError("give a FCOS and / or an A2J state_dict (reference layouts, SURVEY A.6)")
         self.device = torch.device(device)
@@ -28,7 +28,8 @@ class NativeModel:
         self.num_classes, self.num_joints, self.rgbd = num_classes, num_joints, rgbd
         parts = (_lib.MODEL_FCOS if fcos_sd is not None else 0) | (_lib.MODEL_A2J if a2j_sd is not None else 0)
         cfg = _lib.ModelConfig(parts=parts, num_classes=num_classes, num_joints=num_joints, rgbd=1 if rgbd else 0,
-                               min_size=min_size, max_size=max_size, ext=1 if ext else 0)
+                               min_size=min_size, max_size=max_size, ext=1 if ext else 0,
+                               f16_terms={"f16x3": 3, "f16x1": 1}[precision])
         h = C.c_void_p()
         check(self.lib.hn_create(C.byref(cfg), C.byref(h)), "hn_create")
         self._h = h

@@ -33,7 +33,7 @@ extern "C" {
 #define HN_ERR_HIP 2
 
 /* ABI version; bumped whenever a struct below changes. */
-#define HN_ABI_VERSION 26
+#define HN_ABI_VERSION 27
 int hn_abi_version(void);
 const char* hn_last_error(void);
 
@@ -480,6 +480,9 @@ typedef struct hn_model_config {
   int32_t min_size, max_size; /* GeneralizedRCNNTransform sizes; 0 = 800 / 1333 (fcos.py:460-461) */
   int32_t ext;          /* 1: also load the ext=True heads (hand_dydx_layer, hand_contact_state_layer; the FCOS class
                            default, fcos.py:255-264) for hn_fcos_forward_ext */
+  int32_t f16_terms;    /* 0 or 3: f16x3, the parity-grade default.  1: the f16x1 THROUGHPUT mode -- every convolution of
+                           the layer graphs issues the hi*hi term only (hn_conv_desc.terms = 1): 1.4x faster, keypoints
+                           ~0.08 px from the reference, outside the 1e-3 contract */
 } hn_model_config;
 typedef struct hn_model hn_model;
 

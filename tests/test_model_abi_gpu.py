@@ -130,3 +130,33 @@ def test_model_abi_errors_are_loud(a2j_sd):
     big["regressionModel.conv2.weight"] = a2j_sd["regressionModel.conv2.weight"] * 1e6   # leaves the fp16 range once folded
     with pytest.raises(RuntimeError, match="fp16 range"):
         NativeModel(None, big)
+
+
+def test_f16x1_mode_through_the_model_abi(native, fcos_sd, a2j_sd):
+    """hn_model_config.f16_terms = 1: the throughput mode (hi*hi term only) through the C++ layer graphs -- the same
+    launches as the Python engines built with precision="f16x1" (bit-identical), and measurably NOT the default mode."""
+    from hn_amd import synth
+    from hn_amd.a2j_engine import A2JEngine
+    from hn_amd.fcos_engine import FCOSEngine
+    from hn_amd.native_model import NativeModel
+    from hn_amd.pipeline import HandNetEngine
+    eng = HandNetEngine(FCOSEngine(fcos_sd, 3, device="cuda", precision="f16x1"),
+                        A2JEngine(a2j_sd, device="cuda", precision="f16x1"), 3)
+    m = NativeModel(fcos_sd, a2j_sd, num_classes=3, precision="f16x1")
+    try:
+        rgb, depth = synth.make_rgb(3, seed=1000).cuda(), synth.make_depth(3, seed=2000).cuda()
+        ref = eng.forward_device(rgb, depth)
+        kp, box, has = m.handnet(rgb, depth)
+        assert torch.equal(box, ref.crop_box) and torch.equal(has, ref.has_hand) and torch.equal(kp, ref.keypoints)
+        kp3, box3, has3 = native.handnet(rgb, depth)
+        assert torch.equal(has3, has)
+        same = (box3 == box).all(dim=1)
+        d = (kp3 - kp)[same].abs().max().item()
+        assert 1e-4 < d < 1.0, d                       # fp16-grade, not fp32-grade: ~0.01-0.1 px on equal crop boxes
+    finally:
+        m.close()
+    with pytest.raises(RuntimeError, match="f16_terms"):
+        from hn_amd import _lib
+        cfg = _lib.ModelConfig(parts=_lib.MODEL_A2J, num_classes=3, num_joints=21, f16_terms=2)
+        h = C.c_void_p()
+        _lib.check(_lib.load().hn_create(C.byref(cfg), C.byref(h)), "hn_create")
