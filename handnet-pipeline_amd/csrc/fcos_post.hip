@@ -87,6 +87,9 @@ __global__ __launch_bounds__(256) void fcos_preprocess_kernel(const float* __res
 // [n][ph + 2b][pw + 2b][4] with a zero border of b pixels (hn_conv_stem_f16x3).
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
+// IDX = unsigned for fewer than 2^31 canvas pixels (three 32-bit divisions per pixel instead of three 64-bit ones: the
+// kernel is bound by its index arithmetic and the twelve IEEE divisions of the normalisation, not by its 20 bytes per pixel)
+template <typename IDX>
 __global__ __launch_bounds__(256) void fcos_preprocess_split_kernel(const float* __restrict__ src,
                                                                     _Float16* __restrict__ dst, int n, int h, int w,
                                                                     int oh, int ow, int ph, int pw, int b,
@@ -94,11 +97,12 @@ __global__ __launch_bounds__(256) void fcos_preprocess_split_kernel(const float*
                                                                     int* range_flag, ImageGeom g) {
   const int hb = ph + 2 * b, wb = pw + 2 * b;
   const long total = (long)n * hb * wb;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int ox = (int)(i % wb) - b;
-    const long t = i / wb;
-    const int oy = (int)(t % hb) - b;
-    const int img = (int)(t / hb);
+  for (IDX i = (IDX)blockIdx.x * blockDim.x + threadIdx.x; i < (IDX)total; i += (IDX)gridDim.x * blockDim.x) {
+    const IDX t = i / (IDX)wb;
+    const int ox = (int)(i - t * (IDX)wb) - b;
+    const IDX img_ = t / (IDX)hb;
+    const int oy = (int)(t - img_ * (IDX)hb) - b;
+    const int img = (int)img_;
     const float* base = image_geometry(g, src, img, h, w, oh, ow, scale_h, scale_w);
     float o[3] = {0.f, 0.f, 0.f};
     if ((unsigned)oy < (unsigned)oh && (unsigned)ox < (unsigned)ow) {
@@ -125,8 +129,8 @@ __global__ __launch_bounds__(256) void fcos_preprocess_split_kernel(const float*
       lo[c] = (_Float16)(o[c] - (float)hi[c]);
     }
     hi[3] = lo[3] = (_Float16)0.f;
-    *reinterpret_cast<f16x4*>(dst + i * 4) = hi;
-    *reinterpret_cast<f16x4*>(dst + (total + i) * 4) = lo;
+    *reinterpret_cast<f16x4*>(dst + (long)i * 4) = hi;
+    *reinterpret_cast<f16x4*>(dst + (total + (long)i) * 4) = lo;
   }
 }
 
@@ -625,8 +629,12 @@ static int preprocess_run(const float* src, const float* const* srcs, const int3
   const float scale_h = geom ? 1.f : (float)h / (float)oh, scale_w = geom ? 1.f : (float)w / (float)ow;
   if (split) {
     const long total = (long)n * (ph + 2 * border) * (pw + 2 * border);
-    hipLaunchKernelGGL(fcos_preprocess_split_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, src,
-                       (_Float16*)dst, n, h, w, oh, ow, ph, pw, border, scale_h, scale_w, nm, hn::range_flag_ptr(), g);
+    if (total < ((long)1 << 31))
+      hipLaunchKernelGGL(fcos_preprocess_split_kernel<unsigned>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                         (_Float16*)dst, n, h, w, oh, ow, ph, pw, border, scale_h, scale_w, nm, hn::range_flag_ptr(), g);
+    else
+      hipLaunchKernelGGL(fcos_preprocess_split_kernel<long>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                         (_Float16*)dst, n, h, w, oh, ow, ph, pw, border, scale_h, scale_w, nm, hn::range_flag_ptr(), g);
     HN_CHECK_LAUNCH("fcos_preprocess_split_kernel");
   } else {
     const long total = (long)n * ph * pw;
