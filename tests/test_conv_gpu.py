@@ -706,6 +706,8 @@ def test_f16x1_throughput_mode_is_plain_fp16_arithmetic():
     (8, 5, 4, [(100, 136), (50, 68), (25, 34), (13, 17), (7, 9)]),    # > 256 flat-pixel ranges: unit_len above one step
     (1, 5, 0, [(3, 167)]),                                               # the widest level the LDS ring takes
     (1, 4, 2, [(1, 2), (1, 300), (300, 1), (2, 2)]),                     # 300 wide: falls back to the tap kernel
+    (3, 5, 4, [(1, 2), (2, 1), (2, 3), (7, 9), (13, 17)]),              # levels smaller than one step / than the lead-in
+    (1, 3, 1, [(1, 167), (167, 1)]),                                     # one-row and one-column maps
 ])
 @pytest.mark.parametrize("form", ["auto", "flat"])
 def test_thin_output_conv_matches_the_grouped_kernel(n, cout, relu_cols, sizes, form, monkeypatch):
