@@ -757,3 +757,30 @@ def test_thin_output_conv_matches_the_grouped_kernel(n, cout, relu_cols, sizes, 
     finally:
         monkeypatch.delenv("HN_THIN_FORM", raising=False)
         ops.reread_env()
+
+
+def test_thin_output_conv_is_deterministic_at_full_size():
+    """The P-form kernel hands P columns from 16 waves to the output threads through an LDS ring that it overwrites every
+    step; a missing barrier would show as run-to-run differences.  Batch-32 pyramid (580 k pixels, 254 workgroup ranges
+    sweeping ~10 steps each), 20 launches, all bit-identical; and the result equals the tap kernel's to fp32 rounding."""
+    from hn_amd import ops
+    from hn_amd.weights import ConvW
+    g = torch.Generator().manual_seed(77)
+    cw = ConvW(torch.randn(5, 3, 3, 256, generator=g) * 0.05, torch.randn(5, generator=g), 1, 1, 1).to("cuda")
+    xs = [ops.to_split(torch.randn(32, h, w, 256, generator=g).cuda()) for h, w in ((100, 136), (50, 68), (25, 34), (13, 17), (7, 9))]
+    assert ops.thin_uses_flat(xs, cw)
+    first = ops.conv3x3_thin_levels(xs, cw, relu_cols=4)
+    for _ in range(19):
+        again = ops.conv3x3_thin_levels(xs, cw, relu_cols=4)
+        assert all(torch.equal(a, b) for a, b in zip(first, again))
+    import os
+    os.environ["HN_THIN_FORM"] = "tap"
+    ops.reread_env()
+    try:
+        assert not ops.thin_uses_flat(xs, cw)
+        tap = ops.conv3x3_thin_levels(xs, cw, relu_cols=4)
+    finally:
+        del os.environ["HN_THIN_FORM"]
+        ops.reread_env()
+    for a, b in zip(first, tap):
+        assert (a - b).abs().max().item() <= 4e-6 * b.abs().max().item()
