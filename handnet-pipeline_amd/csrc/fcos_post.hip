@@ -147,6 +147,56 @@ struct LevelTable {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
+// One anchor point: score = sqrt(sigmoid(cls) * sigmoid(ctr)), max / argmax over the classes (ties keep the lowest class
+// index, torch.max), threshold, and -- for a passing point only -- the hand side and the decoded box
+// (fcos.py:591-628, det_utils.py:266-294, anchor_utils.py:82-132).  Shared by the one-workgroup-per-image kernel and the
+// chunked pair below: one source, one arithmetic.
+struct CandPoint {
+  float score, x0, y0, x1, y1;
+  int label, side, lvl;
+};
+__device__ __forceinline__ bool eval_point(const LevelTable& lt, int img, int i, int num_classes, int cw, float thresh,
+                                           CandPoint& o) {
+  int lv = 0;
+  while (lv + 1 < lt.num_levels && i >= lt.start[lv + 1]) ++lv;
+  o.lvl = lv;
+  const int q = i - lt.start[lv];
+  const int hw = lt.h[lv] * lt.w[lv];
+  const float* pc = lt.cls_lr[lv] + ((long)img * hw + q) * cw;
+  const float* pr = lt.reg_ctr[lv] + ((long)img * hw + q) * 5;
+  const float sctr = sigmoidf_(pr[4]);
+  float best = -1.f;
+  int lab = 0;
+  for (int c = 0; c < num_classes; ++c) {
+    const float sc = sqrtf(sigmoidf_(pc[c]) * sctr);
+    if (sc > best) {  // ties keep the lowest class index (torch.max)
+      best = sc;
+      lab = c;
+    }
+  }
+  o.score = best;
+  o.label = lab;
+  o.side = 0;
+  o.x0 = o.y0 = o.x1 = o.y1 = 0.f;
+  const bool pass = best > thresh;
+  if (pass) {
+    const float s0 = sigmoidf_(pc[num_classes]), s1 = sigmoidf_(pc[num_classes + 1]);
+    o.side = s1 > s0 ? 1 : 0;
+    const int gy = q / lt.w[lv], gx = q - gy * lt.w[lv];
+    const float st = (float)lt.stride[lv];
+    const float half = rintf(st * 0.5f);  // base anchor [-s/2, -s/2, s/2, s/2].round()
+    const float ax0 = (float)(gx * lt.stride[lv]) - half, ay0 = (float)(gy * lt.stride[lv]) - half;
+    const float ax1 = (float)(gx * lt.stride[lv]) + half, ay1 = (float)(gy * lt.stride[lv]) + half;
+    const float cx = 0.5f * (ax0 + ax1), cy = 0.5f * (ay0 + ay1);
+    const float bw = ax1 - ax0, bh = ay1 - ay0;
+    o.x0 = cx - pr[0] * bw;
+    o.y0 = cy - pr[1] * bh;
+    o.x1 = cx + pr[2] * bw;
+    o.y1 = cy + pr[3] * bh;
+  }
+  return pass;
+}
+
 // One workgroup per image walks the points in anchor order, kU x 1024 at a time: the kU sub-blocks of an iteration are
 // evaluated first (their ~10 dependent-latency global loads per point in flight together) and compacted afterwards in
 // sub-block order, so the output order is the anchor order.  (kU = 1, the round-1/2 form, spent 63 us at batch 1 on 18
@@ -180,41 +230,10 @@ __global__ __launch_bounds__(1024) void fcos_candidates_kernel(const LevelTable 
       score[u] = bx0[u] = by0[u] = bx1[u] = by1[u] = 0.f;
       label[u] = side[u] = lvl[u] = 0;
       if (i < P) {
-        int lv = 0;
-        while (lv + 1 < lt.num_levels && i >= lt.start[lv + 1]) ++lv;
-        lvl[u] = lv;
-        const int q = i - lt.start[lv];
-        const int hw = lt.h[lv] * lt.w[lv];
-        const float* pc = lt.cls_lr[lv] + ((long)img * hw + q) * cw;
-        const float* pr = lt.reg_ctr[lv] + ((long)img * hw + q) * 5;
-        const float sctr = sigmoidf_(pr[4]);
-        float best = -1.f;
-        int lab = 0;
-        for (int c = 0; c < num_classes; ++c) {
-          const float sc = sqrtf(sigmoidf_(pc[c]) * sctr);
-          if (sc > best) {  // ties keep the lowest class index (torch.max)
-            best = sc;
-            lab = c;
-          }
-        }
-        score[u] = best;
-        label[u] = lab;
-        pass[u] = best > thresh;
-        if (pass[u]) {
-          const float s0 = sigmoidf_(pc[num_classes]), s1 = sigmoidf_(pc[num_classes + 1]);
-          side[u] = s1 > s0 ? 1 : 0;
-          const int gy = q / lt.w[lv], gx = q - gy * lt.w[lv];
-          const float st = (float)lt.stride[lv];
-          const float half = rintf(st * 0.5f);  // base anchor [-s/2, -s/2, s/2, s/2].round()
-          const float ax0 = (float)(gx * lt.stride[lv]) - half, ay0 = (float)(gy * lt.stride[lv]) - half;
-          const float ax1 = (float)(gx * lt.stride[lv]) + half, ay1 = (float)(gy * lt.stride[lv]) + half;
-          const float cx = 0.5f * (ax0 + ax1), cy = 0.5f * (ay0 + ay1);
-          const float bw = ax1 - ax0, bh = ay1 - ay0;
-          bx0[u] = cx - pr[0] * bw;
-          by0[u] = cy - pr[1] * bh;
-          bx1[u] = cx + pr[2] * bw;
-          by1[u] = cy + pr[3] * bh;
-        }
+        CandPoint cp;
+        pass[u] = eval_point(lt, img, i, num_classes, cw, thresh, cp);
+        score[u] = cp.score; label[u] = cp.label; side[u] = cp.side; lvl[u] = cp.lvl;
+        bx0[u] = cp.x0; by0[u] = cp.y0; bx1[u] = cp.x1; by1[u] = cp.y1;
       }
     }
     int lane_prefix[U];
@@ -256,6 +275,81 @@ __global__ __launch_bounds__(1024) void fcos_candidates_kernel(const LevelTable 
     __syncthreads();
   }
   if (tid == 0) cand_count[img] = min(base_s, cap);
+}
+
+// The same compaction with the points of an image spread over ceil(P / 1024) workgroups (hn_fcos_candidates_ws): the single
+// workgroup above is five serial rounds of load -> ballot -> barrier per image, 60 us at batch 1 whatever the number of
+// candidates, on one CU.  Kernel 1 counts the passing points of each 1024-point chunk into the workspace; kernel 2
+// evaluates the chunk again (the head outputs are L2-resident), adds the counts of the chunks before it and writes its
+// candidates at their final, anchor-ordered positions.  Two launches, no inter-workgroup waiting, identical output.
+__global__ __launch_bounds__(1024) void fcos_candidates_count_kernel(const LevelTable lt, int num_classes, float thresh,
+                                                                     int* __restrict__ chunk_counts) {
+  __shared__ int wave_counts[16];
+  const int img = blockIdx.y, chunk = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int P = lt.start[lt.num_levels];
+  const int i = chunk * 1024 + tid;
+  CandPoint cp;
+  const bool pass = i < P && eval_point(lt, img, i, num_classes, num_classes + 2, thresh, cp);
+  const unsigned long long bal = __ballot(pass);
+  if (lane == 0) wave_counts[wave] = __popcll(bal);
+  __syncthreads();
+  if (tid == 0) {
+    int total = 0;
+    for (int k = 0; k < 16; ++k) total += wave_counts[k];
+    chunk_counts[img * gridDim.x + chunk] = total;
+  }
+}
+
+__global__ __launch_bounds__(1024) void fcos_candidates_scatter_kernel(const LevelTable lt, int num_classes, float thresh,
+                                                                       const int* __restrict__ chunk_counts,
+                                                                       float* __restrict__ cand_boxes,
+                                                                       float* __restrict__ cand_scores,
+                                                                       int* __restrict__ cand_labels,
+                                                                       int* __restrict__ cand_sides,
+                                                                       int* __restrict__ cand_level,
+                                                                       int* __restrict__ cand_point,
+                                                                       int* __restrict__ cand_count, int cap) {
+  __shared__ int wave_counts[16];
+  __shared__ int base_s;
+  const int img = blockIdx.y, chunk = blockIdx.x, chunks = gridDim.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int P = lt.start[lt.num_levels];
+  const int i = chunk * 1024 + tid;
+  CandPoint cp;
+  const bool pass = i < P && eval_point(lt, img, i, num_classes, num_classes + 2, thresh, cp);
+  const unsigned long long bal = __ballot(pass);
+  const int lane_prefix = __popcll(bal & ((1ull << lane) - 1ull));
+  if (lane == 0) wave_counts[wave] = __popcll(bal);
+  if (wave == 0) {   // candidates of the chunks before this one
+    int s = 0;
+    for (int c = lane; c < chunk; c += 64) s += chunk_counts[img * chunks + c];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) base_s = s;
+  }
+  __syncthreads();
+  int wave_off = 0, total = 0;
+  for (int k = 0; k < 16; ++k) {
+    if (k < wave) wave_off += wave_counts[k];
+    total += wave_counts[k];
+  }
+  const int base = base_s;
+  if (pass) {
+    const int pos = base + wave_off + lane_prefix;
+    if (pos < cap) {
+      const long o = (long)img * cap + pos;
+      cand_boxes[o * 4 + 0] = cp.x0;
+      cand_boxes[o * 4 + 1] = cp.y0;
+      cand_boxes[o * 4 + 2] = cp.x1;
+      cand_boxes[o * 4 + 3] = cp.y1;
+      cand_scores[o] = cp.score;
+      cand_labels[o] = cp.label;
+      cand_sides[o] = cp.side;
+      cand_level[o] = cp.lvl;
+      if (cand_point) cand_point[o] = i;
+    }
+  }
+  if (chunk == chunks - 1 && tid == 0) cand_count[img] = min(base + total, cap);
 }
 
 // ext=True outputs of the kept detections (fcos.py:299-320 head maths, :605-607,631-647 gather):
@@ -669,10 +763,36 @@ extern "C" int hn_fcos_preprocess_list(const float* const* srcs, const int32_t* 
   return preprocess_run(nullptr, srcs, geom, dst, split, n, 1, 1, 1, 1, ph, pw, split ? border : 0, mean, stdv, stream);
 }
 
+extern "C" int64_t hn_fcos_candidates_ws_bytes(int n, int total_points) {
+  return n > 0 && total_points > 0 ? (int64_t)n * ((total_points + 1023) / 1024) * 4 : 0;
+}
+
+static int candidates_run(const hn_fcos_levels* lv, int n, int num_classes, float score_thresh, float* cand_boxes,
+                          float* cand_scores, int32_t* cand_labels, int32_t* cand_sides, int32_t* cand_level,
+                          int32_t* cand_point, int32_t* cand_count, int cap, void* workspace, int64_t workspace_bytes,
+                          void* stream);
+
 extern "C" int hn_fcos_candidates(const hn_fcos_levels* lv, int n, int num_classes, float score_thresh,
                                   float* cand_boxes, float* cand_scores, int32_t* cand_labels, int32_t* cand_sides,
                                   int32_t* cand_level, int32_t* cand_point, int32_t* cand_count, int cap,
                                   void* stream) {
+  return candidates_run(lv, n, num_classes, score_thresh, cand_boxes, cand_scores, cand_labels, cand_sides, cand_level,
+                        cand_point, cand_count, cap, nullptr, 0, stream);
+}
+
+extern "C" int hn_fcos_candidates_ws(const hn_fcos_levels* lv, int n, int num_classes, float score_thresh,
+                                     float* cand_boxes, float* cand_scores, int32_t* cand_labels, int32_t* cand_sides,
+                                     int32_t* cand_level, int32_t* cand_point, int32_t* cand_count, int cap,
+                                     void* workspace, int64_t workspace_bytes, void* stream) {
+  HN_CHECK_ARG(workspace && (uintptr_t)workspace % 4 == 0, "hn_fcos_candidates_ws: null / unaligned workspace");
+  return candidates_run(lv, n, num_classes, score_thresh, cand_boxes, cand_scores, cand_labels, cand_sides, cand_level,
+                        cand_point, cand_count, cap, workspace, workspace_bytes, stream);
+}
+
+static int candidates_run(const hn_fcos_levels* lv, int n, int num_classes, float score_thresh, float* cand_boxes,
+                          float* cand_scores, int32_t* cand_labels, int32_t* cand_sides, int32_t* cand_level,
+                          int32_t* cand_point, int32_t* cand_count, int cap, void* workspace, int64_t workspace_bytes,
+                          void* stream) {
   HN_CHECK_ARG(lv && cand_boxes && cand_scores && cand_labels && cand_sides && cand_level && cand_count,
                "hn_fcos_candidates: null pointer");
   HN_CHECK_ARG(lv->num_levels > 0 && lv->num_levels <= HN_FCOS_MAX_LEVELS, "bad level count");
@@ -693,6 +813,20 @@ extern "C" int hn_fcos_candidates(const hn_fcos_levels* lv, int n, int num_class
     lt.h[l] = lt.w[l] = lt.stride[l] = 0;
     lt.cls_lr[l] = lt.reg_ctr[l] = nullptr;
     lt.start[l + 1] = lt.start[lv->num_levels];
+  }
+  if (workspace) {
+    const int P = lt.start[lv->num_levels], chunks = (P + 1023) / 1024;
+    HN_CHECK_ARG(workspace_bytes >= hn_fcos_candidates_ws_bytes(n, P), "workspace too small: %lld < %lld bytes",
+                 (long long)workspace_bytes, (long long)hn_fcos_candidates_ws_bytes(n, P));
+    HN_CHECK_ARG(n <= 65535, "more than 65535 images");
+    hipLaunchKernelGGL(fcos_candidates_count_kernel, dim3(chunks, n), dim3(1024), 0, (hipStream_t)stream, lt, num_classes,
+                       score_thresh, (int*)workspace);
+    HN_CHECK_LAUNCH("fcos_candidates_count_kernel");
+    hipLaunchKernelGGL(fcos_candidates_scatter_kernel, dim3(chunks, n), dim3(1024), 0, (hipStream_t)stream, lt, num_classes,
+                       score_thresh, (const int*)workspace, cand_boxes, cand_scores, cand_labels, cand_sides, cand_level,
+                       cand_point, cand_count, cap);
+    HN_CHECK_LAUNCH("fcos_candidates_scatter_kernel");
+    return HN_OK;
   }
   hipLaunchKernelGGL(fcos_candidates_kernel, dim3(n), dim3(1024), 0, (hipStream_t)stream, lt, num_classes,
                      score_thresh, cand_boxes, cand_scores, cand_labels, cand_sides, cand_level, cand_point, cand_count,

@@ -655,8 +655,11 @@ int fcos_graph(Ctx& cx, const float* rgb, int n, int h, int w, const FcosOut& ou
   int32_t* keep = (int32_t*)alloc_bytes(cx, (size_t)n * cap * 4);
   int32_t* point = out.contacts ? (int32_t*)alloc_bytes(cx, (size_t)n * cap * 4) : nullptr;
   char* scratch = alloc_bytes(cx, (size_t)hn_fcos_nms_scratch_bytes(n, cap));
+  const int64_t cand_ws_bytes = hn_fcos_candidates_ws_bytes(n, cap);
+  char* cand_ws = alloc_bytes(cx, (size_t)cand_ws_bytes);
   if (cx.dry) return HN_OK;
-  HN_TRY(hn_fcos_candidates(&lv, n, m->cfg.num_classes, 0.7f /* fcos.py:600 */, cb, cs, cl, cd, cv, point, cc, cap, cx.stream));
+  HN_TRY(hn_fcos_candidates_ws(&lv, n, m->cfg.num_classes, 0.7f /* fcos.py:600 */, cb, cs, cl, cd, cv, point, cc, cap, cand_ws,
+                               cand_ws_bytes, cx.stream));
   // resize_boxes (fcos.py:770-783): fp32 / fp32
   const float ratio_h = (float)h / (float)g.oh, ratio_w = (float)w / (float)g.ow;
   HN_TRY(hn_fcos_nms(cb, cs, cl, cd, cv, cc, n, cap, 0.3 /* fcos.py:635 */, ratio_h, ratio_w, scratch, out.boxes, out.scores,

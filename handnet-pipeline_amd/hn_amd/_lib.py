@@ -12,7 +12,7 @@ from pathlib import Path
 
 from . import build as _build
 
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, TILE_256x128, TILE_64x128 = range(7)
 HN_FCOS_MAX_LEVELS = 5
@@ -115,6 +115,9 @@ SIGNATURES = {
     "hn_conv_stem_pool_f16x3_terms": (C.c_int, [VP] + [C.c_int] * 7 + [VP, VP, VP, C.c_int, VP]),
     "hn_fcos_candidates": (C.c_int, [C.POINTER(FcosLevels), C.c_int, C.c_int, C.c_float,
                                      VP, VP, VP, VP, VP, VP, VP, C.c_int, VP]),
+    "hn_fcos_candidates_ws_bytes": (C.c_int64, [C.c_int, C.c_int]),
+    "hn_fcos_candidates_ws": (C.c_int, [C.POINTER(FcosLevels), C.c_int, C.c_int, C.c_float,
+                                     VP, VP, VP, VP, VP, VP, VP, C.c_int, VP, C.c_int64, VP]),
     "hn_fcos_ext_gather": (C.c_int, [C.POINTER(FcosLevels), C.POINTER(VP), VP, VP, VP, C.c_int, C.c_int, VP, VP, VP]),
     "hn_fcos_nms_scratch_bytes": (C.c_int64, [C.c_int, C.c_int]),
     "hn_fcos_nms": (C.c_int, [VP] * 6 + [C.c_int, C.c_int, C.c_double, C.c_float, C.c_float] + [VP] * 9),

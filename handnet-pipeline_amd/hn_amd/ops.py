@@ -804,8 +804,12 @@ def alloc_detections(n, cap, device) -> Detections:
     return Detections(b, s, l.view(i32), sd.view(i32), lv.view(i32), kp.view(i32), cnt.view(i32))
 
 
+CANDIDATES_CHUNKED = os.environ.get("HN_CANDIDATES_CHUNKED", "1") != "0"   # A/B: hn_fcos_candidates_ws vs one workgroup per image
+
+
 def fcos_candidates(cls_lr, reg_ctr, strides, num_classes, score_thresh=0.7, out: Candidates | None = None):
-    """cls_lr[l] [N,h,w,C+2], reg_ctr[l] [N,h,w,5] per level -> ordered candidates."""
+    """cls_lr[l] [N,h,w,C+2], reg_ctr[l] [N,h,w,5] per level -> ordered candidates (hn_fcos_candidates_ws: the points of
+    an image spread over 1024-point workgroups; identical output to the one-workgroup form)."""
     lib = _lib.load()
     lv = FcosLevels()
     lv.num_levels = len(cls_lr)
@@ -820,7 +824,15 @@ def fcos_candidates(cls_lr, reg_ctr, strides, num_classes, score_thresh=0.7, out
         cap += a.shape[1] * a.shape[2]
     if out is None:
         out = alloc_candidates(n, cap, cls_lr[0].device)
-    cap = out.scores.shape[1]
+    points, cap = cap, out.scores.shape[1]
+    if CANDIDATES_CHUNKED:
+        nbytes = lib.hn_fcos_candidates_ws_bytes(n, points)
+        ws = torch.empty((nbytes // 4,), device=cls_lr[0].device, dtype=torch.int32)
+        check(lib.hn_fcos_candidates_ws(C.byref(lv), n, num_classes, score_thresh, ptr(out.boxes), ptr(out.scores),
+                                        ptr(out.labels), ptr(out.sides), ptr(out.level),
+                                        ptr(out.point) if out.point is not None else None, ptr(out.count), cap,
+                                        ptr(ws), nbytes, _stream()), "hn_fcos_candidates_ws")
+        return out
     check(lib.hn_fcos_candidates(C.byref(lv), n, num_classes, score_thresh, ptr(out.boxes), ptr(out.scores),
                                  ptr(out.labels), ptr(out.sides), ptr(out.level),
                                  ptr(out.point) if out.point is not None else None, ptr(out.count), cap, _stream()),

@@ -33,7 +33,7 @@ extern "C" {
 #define HN_ERR_HIP 2
 
 /* ABI version; bumped whenever a struct below changes. */
-#define HN_ABI_VERSION 27
+#define HN_ABI_VERSION 28
 int hn_abi_version(void);
 const char* hn_last_error(void);
 
@@ -332,6 +332,14 @@ int hn_fcos_candidates(const hn_fcos_levels* lv, int n, int num_classes, float s
                        int32_t* cand_labels, int32_t* cand_sides, int32_t* cand_level /* [n][cap] */,
                        int32_t* cand_point /* [n][cap] anchor-point index, may be NULL */,
                        int32_t* cand_count /* [n] */, int cap, void* stream);
+/* The same result from ceil(points / 1024) workgroups per image instead of one (two short launches; the single workgroup
+ * costs 60 us per call at batch 1 whatever the number of candidates): workspace = hn_fcos_candidates_ws_bytes(n, total
+ * points) bytes of device memory, contents irrelevant before and after. */
+int64_t hn_fcos_candidates_ws_bytes(int n, int total_points);
+int hn_fcos_candidates_ws(const hn_fcos_levels* lv, int n, int num_classes, float score_thresh, float* cand_boxes,
+                          float* cand_scores, int32_t* cand_labels, int32_t* cand_sides, int32_t* cand_level,
+                          int32_t* cand_point, int32_t* cand_count, int cap, void* workspace, int64_t workspace_bytes,
+                          void* stream);
 
 /* ext=True detector outputs (fcos_utils/fcos.py:255-264 layers, :299-320 head maths, :605-607 argmax,
  * :631-647 gather) for the detections hn_fcos_nms kept.  ext[l] is the raw NHWC conv output

@@ -454,3 +454,38 @@ def test_fused_stem_pool_equals_stem_then_pool(fcos_sd, n, h, w):
     b = eng.backbone(img16)
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("n,sizes,thresh", [
+    (1, [(100, 136), (50, 68), (25, 34), (13, 17), (7, 9)], 0.7),
+    (3, [(100, 136), (50, 68), (25, 34), (13, 17), (7, 9)], 0.5),      # ~half of the 17 850 points pass
+    (2, [(9, 7), (3, 3)], 0.3),                                          # fewer points than one chunk
+    (2, [(40, 26), (5, 5)], -1.0),                                       # every point passes: 1065 > one chunk, full capacity
+])
+def test_chunked_candidates_equal_the_single_workgroup_form(n, sizes, thresh):
+    """hn_fcos_candidates_ws (count kernel + scatter kernel over 1024-point chunks) against hn_fcos_candidates (one
+    workgroup per image): the same arithmetic from one shared device function and the same anchor order, so every output
+    array and the counts must be identical (fcos.py:591-628)."""
+    import ctypes as C
+    from hn_amd import _lib, ops
+    g = torch.Generator().manual_seed(99 + n)
+    nc = 3
+    cls = [torch.randn(n, h, w, nc + 2, generator=g).cuda() * 2 for h, w in sizes]
+    reg = [torch.cat([torch.rand(n, h, w, 4, generator=g) * 3, torch.randn(n, h, w, 1, generator=g) * 2], -1).cuda() for h, w in sizes]
+    strides = [8 * 2 ** i for i in range(len(sizes))]
+    assert ops.CANDIDATES_CHUNKED
+    a = ops.fcos_candidates(cls, reg, strides, nc, thresh)
+    ops.CANDIDATES_CHUNKED = False
+    try:
+        b = ops.fcos_candidates(cls, reg, strides, nc, thresh)
+    finally:
+        ops.CANDIDATES_CHUNKED = True
+    assert torch.equal(a.count, b.count) and int(a.count.min()) >= 0
+    if thresh < 0:
+        assert int(a.count.min()) == sum(h * w for h, w in sizes)
+    for i in range(n):
+        k = int(a.count[i])
+        for f in ("boxes", "scores", "labels", "sides", "level", "point"):
+            assert torch.equal(getattr(a, f)[i, :k], getattr(b, f)[i, :k]), f
+    lib = _lib.load()
+    assert lib.hn_fcos_candidates_ws_bytes(2, 17850) == 2 * 18 * 4 and lib.hn_fcos_candidates_ws_bytes(0, 5) == 0
