@@ -49,28 +49,35 @@ __global__ __launch_bounds__(256) void pack_depth_kernel(const float* __restrict
   }
 }
 
-// One workgroup per crop.  Thread (g, c): c = a*J + j owns one (anchor-in-cell, joint) channel, so every cell
-// read is one contiguous A*J-float run; the G = blockDim/(A*J) thread groups take the cells p = g, g+G, ...
-// (a single group walked all fh*fw cells with two dependent loads each: 60 us of pure latency per launch).
+// kJointSplit workgroups per crop, each owning a contiguous range of joints (the joints are independent; one workgroup
+// per crop was 28 us of the batch-1 frame on one CU).  Thread (g, a, jl): anchor-in-cell a, joint j = j0 + jl; the G
+// thread groups take the cells p = g, g+G, ... (a single group walked all fh*fw cells with two dependent loads each: 60 us
+// of pure latency per launch).
 // Pass 1: per-joint max of the logits (exact, order independent).
 // Pass 2: e = exp(x - max); partial sums of e, e*(anchor+offset), e*depth per (group, anchor, joint), then
-// combined through LDS in a fixed order (group-major, then anchor): bitwise reproducible.
+// combined through LDS in a fixed order (group-major, then anchor): bitwise reproducible, and independent of the joint split.
 constexpr int kAnchorsPerCell = 16;
 constexpr int kMaxGroups = 3;
+constexpr int kJointSplit = 3;
 
 __global__ __launch_bounds__(1024) void a2j_aggregate_kernel(const float* __restrict__ cls,
                                                              const float* __restrict__ reg,
                                                              const float* __restrict__ dep,
                                                              const int* __restrict__ valid, int fh, int fw,
-                                                             int J, int stride, int G, float* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // [G][4][A*J]
+                                                             int J, int Jw, int stride, int G, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [G][4][A*Jw]
   const int k = blockIdx.x;
-  const int AJ = kAnchorsPerCell * J;
-  const int g = threadIdx.x / AJ, c = threadIdx.x - g * AJ;
-  const bool active = g < G;
-  const int a = c / J, j = c - a * J;
+  const int j0 = blockIdx.y * Jw;
+  const int jn = min(Jw, J - j0);      // joints of this workgroup (the last one may have fewer, or none)
+  if (jn <= 0) return;
+  const int AJ = kAnchorsPerCell * J;   // channels per cell in memory
+  const int AW = kAnchorsPerCell * Jw;  // thread slots per cell group
+  const int g = threadIdx.x / AW, cl = threadIdx.x - g * AW;
+  const int a = cl / Jw, jl = cl - a * Jw;
+  const bool active = g < G && jl < jn;
+  const int c = a * J + j0 + jl;        // channel in memory
   if (valid && valid[k] == 0) {  // uniform per workgroup
-    if ((int)threadIdx.x < J * 3) out[(long)k * J * 3 + threadIdx.x] = 0.f;
+    if ((int)threadIdx.x < jn * 3) out[((long)k * J + j0) * 3 + threadIdx.x] = 0.f;
     return;
   }
   const int cells = fh * fw;
@@ -78,50 +85,77 @@ __global__ __launch_bounds__(1024) void a2j_aggregate_kernel(const float* __rest
   const float* depk = dep + (long)k * cells * AJ;
   const float* regk = reg + (long)k * cells * AJ * 2;
 
+  // Both cell loops fetch kBatch cells' operands before they use any (same operations in the same order): written as
+  // load -> use per cell, each of the 2 x 41 iterations waited for its own L2 round trip -- 27 us per launch.
+  constexpr int kBatch = 8;
   float mx = -FLT_MAX;
   if (active)
-    for (int p = g; p < cells; p += G) mx = fmaxf(mx, clsk[(long)p * AJ + c]);
-  if (active) lds[g * AJ + c] = mx;
+    for (int pb = g; pb < cells; pb += kBatch * G) {
+      float v[kBatch];
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        const int p = pb + u * G;
+        v[u] = p < cells ? clsk[(long)p * AJ + c] : -FLT_MAX;
+      }
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) mx = fmaxf(mx, v[u]);
+    }
+  if (g < G) lds[g * AW + cl] = mx;
   __syncthreads();
   float mj = -FLT_MAX;
   if (active)
     for (int gg = 0; gg < G; ++gg)
-      for (int aa = 0; aa < kAnchorsPerCell; ++aa) mj = fmaxf(mj, lds[gg * AJ + aa * J + j]);
+      for (int aa = 0; aa < kAnchorsPerCell; ++aa) mj = fmaxf(mj, lds[gg * AW + aa * Jw + jl]);
   __syncthreads();
 
   if (active) {
     float s = 0.f, s0 = 0.f, s1 = 0.f, sd = 0.f;
     const float p0 = 2.f + 4.f * (float)(a >> 2), p1 = 2.f + 4.f * (float)(a & 3);
-    for (int p = g; p < cells; p += G) {
-      const int hh = p / fw, ww = p - hh * fw;
-      const float e = expf(clsk[(long)p * AJ + c] - mj);
-      const float2 r = *reinterpret_cast<const float2*>(regk + ((long)p * AJ + c) * 2);
-      const float a0 = (float)(hh * stride) + p0, a1 = (float)(ww * stride) + p1;
-      s += e;
-      s0 += e * (a0 + r.x);
-      s1 += e * (a1 + r.y);
-      sd += e * depk[(long)p * AJ + c];
+    for (int pb = g; pb < cells; pb += kBatch * G) {
+      float vc[kBatch], vd[kBatch];
+      float2 vr[kBatch];
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        const int p = pb + u * G;
+        const long q = (long)(p < cells ? p : g) * AJ + c;   // (clamped: the tail batch's extra cells are not used)
+        vc[u] = clsk[q];
+        vr[u] = *reinterpret_cast<const float2*>(regk + q * 2);
+        vd[u] = depk[q];
+      }
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        const int p = pb + u * G;
+        if (p < cells) {
+          const int hh = p / fw, ww = p - hh * fw;
+          const float e = expf(vc[u] - mj);
+          const float a0 = (float)(hh * stride) + p0, a1 = (float)(ww * stride) + p1;
+          s += e;
+          s0 += e * (a0 + vr[u].x);
+          s1 += e * (a1 + vr[u].y);
+          sd += e * vd[u];
+        }
+      }
     }
-    float* o = lds + (long)g * 4 * AJ;
-    o[c] = s;
-    o[AJ + c] = s0;
-    o[2 * AJ + c] = s1;
-    o[3 * AJ + c] = sd;
+    float* o = lds + (long)g * 4 * AW;
+    o[cl] = s;
+    o[AW + cl] = s0;
+    o[2 * AW + cl] = s1;
+    o[3 * AW + cl] = sd;
   }
   __syncthreads();
-  if ((int)threadIdx.x < J) {
+  if ((int)threadIdx.x < jn) {
     const int jj = threadIdx.x;
     float t = 0.f, t0 = 0.f, t1 = 0.f, td = 0.f;
     for (int gg = 0; gg < G; ++gg) {
-      const float* o = lds + (long)gg * 4 * AJ;
+      const float* o = lds + (long)gg * 4 * AW;
       for (int aa = 0; aa < kAnchorsPerCell; ++aa) {
-        t += o[aa * J + jj];
-        t0 += o[AJ + aa * J + jj];
-        t1 += o[2 * AJ + aa * J + jj];
-        td += o[3 * AJ + aa * J + jj];
+        t += o[aa * Jw + jj];
+        t0 += o[AW + aa * Jw + jj];
+        t1 += o[2 * AW + aa * Jw + jj];
+        td += o[3 * AW + aa * Jw + jj];
       }
     }
-    float* o = out + ((long)k * J + jj) * 3;
+    float* o = out + ((long)k * J + j0 + jj) * 3;
     o[0] = t0 / t;
     o[1] = t1 / t;
     o[2] = td / t;
@@ -203,12 +237,16 @@ extern "C" int hn_a2j_aggregate_f32(const float* cls, const float* reg, const fl
   HN_CHECK_ARG(k >= 0 && fh > 0 && fw > 0 && stride > 0, "bad dims");
   HN_CHECK_ARG(joints > 0 && joints * kAnchorsPerCell <= 1024, "joints must be in [1, 64]");
   if (k == 0) return HN_OK;
+  // the cell-group count stays what it was with one workgroup per crop (it fixes the summation order): min(3, 1024 / (16 J))
   const int aj = kAnchorsPerCell * joints;
   int groups = 1024 / aj;
   groups = groups > kMaxGroups ? kMaxGroups : groups;
-  const int threads = ((groups * aj + 63) / 64) * 64;
-  hipLaunchKernelGGL(a2j_aggregate_kernel, dim3(k), dim3(threads), groups * 4 * aj * sizeof(float),
-                     (hipStream_t)stream, cls, reg, dep, valid, fh, fw, joints, stride, groups, out);
+  const int split = joints >= 2 * kJointSplit ? kJointSplit : 1;
+  const int jw = (joints + split - 1) / split;
+  const int aw = kAnchorsPerCell * jw;
+  const int threads = ((groups * aw + 63) / 64) * 64;
+  hipLaunchKernelGGL(a2j_aggregate_kernel, dim3(k, split), dim3(threads), groups * 4 * aw * sizeof(float),
+                     (hipStream_t)stream, cls, reg, dep, valid, fh, fw, joints, jw, stride, groups, out);
   HN_CHECK_LAUNCH("a2j_aggregate_kernel");
   return HN_OK;
 }
