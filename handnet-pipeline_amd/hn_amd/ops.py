@@ -777,12 +777,12 @@ class Detections:
     count: torch.Tensor
 
 
-def _zero_fields(n, cap, device, widths):
+def _zero_fields(n, cap, device, widths, zero=True):
     """One zero-filled allocation carved into [n, cap(, w)] fields + an [n] counter (a torch.zeros per field was 14
     fill launches per detector pass: 65 us of the 2.8 ms batch-1 step, profiles/r03_b1_timeline.txt).  Every field is
     4 bytes wide; int fields are int32 views of the fp32 buffer."""
     words = sum(widths) * n * cap + n
-    flat = torch.zeros((words,), device=device, dtype=torch.float32)
+    flat = (torch.zeros if zero else torch.empty)((words,), device=device, dtype=torch.float32)
     out, off = [], 0
     for w in widths:
         t = flat[off:off + n * cap * w]
@@ -793,7 +793,8 @@ def _zero_fields(n, cap, device, widths):
 
 
 def alloc_candidates(n, cap, device) -> Candidates:
-    b, s, l, sd, lv, pt, cnt = _zero_fields(n, cap, device, [4, 1, 1, 1, 1, 1])
+    # internal to the detector (rows beyond count[i] are never read; hn_fcos_candidates* writes every count): no fill launch
+    b, s, l, sd, lv, pt, cnt = _zero_fields(n, cap, device, [4, 1, 1, 1, 1, 1], zero=False)
     i32 = torch.int32
     return Candidates(b, s, l.view(i32), sd.view(i32), lv.view(i32), cnt.view(i32), pt.view(i32))
 
