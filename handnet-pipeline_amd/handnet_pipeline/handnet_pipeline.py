@@ -74,18 +74,41 @@ class HandNet(EngineOwner):
             self._engine = HandNetEngine(fcos, a2j, self.num_classes)
         return self._engine
 
-    def enable_graph(self, on: bool = True):
-        """Opt in to hipGraph replay: the first call with a given input shape captures the whole step, later
-        calls copy the inputs into the captured buffers and replay (no per-launch host cost; the launch
-        sequence is static by construction).  Results of forward_device() then alias the captured output
-        buffers and are overwritten by the next call; forward() returns fresh tensors either way."""
-        self.use_graph = bool(on)
+    # forward() switches ITSELF to hipGraph replay for a small batch once the same input shapes have come in a few times in a
+    # row -- the live caller's case (ros_demo.py:270-273: one 640x480 frame per call, ~200 dependent launches whose host cost
+    # is 8 % of the call).  forward() hands out fresh tensors (keypoints on the CPU, indexed copies of the crops), so replaying
+    # into captured buffers is invisible to the caller; enable_graph(False) turns it off, enable_graph(True) forces it from the
+    # first call and also for forward_device().
+    AUTO_GRAPH_CALLS = 3        # same-shape calls in a row before forward() captures
+    AUTO_GRAPH_MAX_BATCH = 7    # larger batches are GPU-bound (and use the sparse-stream compaction, which is not capturable)
+    AUTO_GRAPH_MAX_SHAPES = 4   # distinct input shapes captured automatically (each holds its own static buffers)
+
+    def enable_graph(self, on=True):
+        """hipGraph replay: the first call with a given input shape captures the whole step, later calls copy the inputs
+        into the captured buffers and replay (no per-launch host cost; the launch sequence is static by construction).
+        on=True: always (results of forward_device() then alias the captured output buffers and are overwritten by the next
+        call; forward() returns fresh tensors either way); on=False: never; on=None: the default -- forward() decides by
+        itself (see AUTO_GRAPH_*), forward_device() stays eager."""
+        self.use_graph = None if on is None else bool(on)
         return self
 
-    def forward_device(self, images, depth_images):
+    def _auto_graph(self, batch, depth) -> bool:
+        eng = self.engine()
+        if eng.check_range or batch.shape[0] > self.AUTO_GRAPH_MAX_BATCH or not (batch.is_cuda and depth.is_cuda):
+            return False
+        key = (tuple(batch.shape), tuple(depth.shape))
+        if key in eng._graphs:
+            return True
+        if key == getattr(self, "_streak_key", None):
+            self._streak += 1
+        else:
+            self._streak_key, self._streak = key, 1
+        return self._streak > self.AUTO_GRAPH_CALLS and len(eng._graphs) < self.AUTO_GRAPH_MAX_SHAPES
+
+    def forward_device(self, images, depth_images, _graph=None):
         """Sync-free variant: returns hn_amd.pipeline.HandNetOutput with everything on the GPU."""
         batch = images if torch.is_tensor(images) else torch.stack([i.float() for i in images])
-        if getattr(self, "use_graph", False):
+        if getattr(self, "use_graph", None) if _graph is None else _graph:
             batch, depth = batch.float().contiguous(), depth_images.float().contiguous()
             run, s_img, s_dep, out = self.engine().graphed(batch, depth)
             s_img.copy_(batch)
@@ -100,10 +123,17 @@ class HandNet(EngineOwner):
         if depth_images is None:
             raise ValueError("depth_images is required for the ensemble inference branch")
         n = len(images)
-        out = self.forward_device(images, depth_images)
-        mask = out.has_hand.bool()
-        final_results = out.keypoints.cpu()          # the reference returns keypoints on the CPU
-        mask_cpu = mask.cpu()
+        mode = getattr(self, "use_graph", None)
+        if mode is None and torch.is_tensor(depth_images):
+            batch = images if torch.is_tensor(images) else torch.stack([i.float() for i in images])
+            out = self.forward_device(batch, depth_images, _graph=self._auto_graph(batch, depth_images))
+        else:
+            out = self.forward_device(images, depth_images)
+        # ONE device -> host copy (and sync) per call: the keypoints with the has-hand flags as a last column
+        kp = out.keypoints
+        flat = torch.cat([kp.reshape(n, -1), out.has_hand.reshape(n, 1).to(kp.dtype)], dim=1).cpu()
+        final_results = flat[:, :-1].reshape(kp.shape).contiguous()     # the reference returns keypoints on the CPU
+        mask_cpu = flat[:, -1] != 0
         # always-on safety net of the f16x3 range contract, at no device cost: the check runs on the 8 KB the reference's
         # own .cpu() has just copied.  An activation beyond the fp16 range (|v| > 65504, e.g. BN-folded trained filters of
         # extreme scale) shows up here as inf / NaN keypoints -- refuse to hand them to the caller.
@@ -113,9 +143,13 @@ class HandNet(EngineOwner):
                                  "producer, or build the engines with precision='f32'")
         if not bool(mask_cpu.any()):  # handnet_pipeline.py:107-108: the crops placeholder is a CPU float tensor
             return torch.zeros((n, 21, 3)), torch.zeros_like(depth_images), torch.zeros((n, 4))
-        sel = out.crops_nhwc[mask]
+        if bool(mask_cpu.all()):      # the usual case: no gather (a boolean-mask index would synchronise once more)
+            sel, crops = out.crops_nhwc, out.crop_box.clone()
+        else:
+            idx = mask_cpu.nonzero().flatten().to(out.crop_box.device)
+            sel, crops = out.crops_nhwc.index_select(0, idx), out.crop_box.index_select(0, idx)
+        # (.contiguous() of the permuted / sliced view is a copy: the caller never holds a view of a captured buffer)
         depth_batch = (sel.permute(0, 3, 1, 2) if self.RGBD else sel[..., 0].unsqueeze(1)).contiguous()
-        crops = out.crop_box[mask]
         return final_results, depth_batch, crops
 
 

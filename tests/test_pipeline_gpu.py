@@ -428,3 +428,37 @@ def test_sparse_stream_compacts_a2j(fcos_sd, a2j_sd, monkeypatch):
     sel = keep.bool()
     assert (second.keypoints[sel] - first.keypoints[sel]).abs().max().item() < 1e-4
     assert (second.keypoints[sel] - dense.keypoints[sel]).abs().max().item() < 1e-4
+
+
+def test_dropin_forward_switches_itself_to_graph_replay(fcos_sd, a2j_sd):
+    """handnet_pipeline.HandNet.forward as ros_demo.py:270-273 calls it, one frame per call: after AUTO_GRAPH_CALLS same-shape
+    calls it captures the step and replays it -- same kernels, so the results stay bit-identical to the eager calls, they are
+    fresh tensors (not views of the captured buffers), a new input shape falls back to eager, and enable_graph(False) keeps
+    the whole thing off."""
+    import types
+    from handnet_pipeline.handnet_pipeline import HandNet
+    from hn_amd import synth
+    net = HandNet(types.SimpleNamespace(pretrained_fcos="-", pretrained_a2j="-"), num_classes=3)
+    net.detector.load_state_dict(fcos_sd, strict=False)
+    net.a2j.load_state_dict(a2j_sd, strict=False)
+    net = net.cuda().eval()
+    frames = [(synth.make_rgb(1, seed=1000 + i).cuda(), synth.make_depth(1, seed=2000 + i).cuda()) for i in range(3)]
+    with torch.inference_mode():
+        eager = [net([rgb[0]], depth_images=dep) for rgb, dep in frames]            # calls 1-3: eager
+        assert len(net.engine()._graphs) == 0
+        held = net([frames[0][0][0]], depth_images=frames[0][1])                     # call 4: still eager (streak == 3)
+        again = [net([rgb[0]], depth_images=dep) for rgb, dep in frames]            # calls 5-7: captured, then replayed
+        assert len(net.engine()._graphs) == 1
+        for (kp, db, box), (kp2, db2, box2) in zip(eager, again):
+            assert kp2.device.type == "cpu" and torch.equal(kp, kp2) and torch.equal(db, db2) and torch.equal(box, box2)
+        assert torch.equal(held[0], eager[0][0]) and torch.equal(held[1], eager[0][1])   # earlier results are not overwritten
+        first = again[0][1].clone()
+        net([frames[1][0][0]], depth_images=frames[1][1])
+        assert torch.equal(again[0][1], first)                                         # ... nor are results of replayed calls
+        wide = synth.make_rgb(1, seed=5).cuda()[:, :, :400, :]
+        kp_w, _, _ = net([wide[0]], depth_images=frames[0][1][:, :, :400, :].contiguous())   # another shape: eager again
+        assert len(net.engine()._graphs) == 1 and tuple(kp_w.shape) == (1, 21, 3)
+        net.enable_graph(False)
+        for rgb, dep in frames * 2:
+            net([rgb[0]], depth_images=dep)
+        assert len(net.engine()._graphs) == 1
