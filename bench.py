@@ -416,6 +416,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if world > 1:   # N ranks build their engines at once on one host: share the cores instead of oversubscribing them N-fold
+        torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
 
     step, info, sds = build_workload(args, dev, rank)
     batch = info["batch_per_gpu"]

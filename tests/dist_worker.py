@@ -29,6 +29,9 @@ def main():
     if backend == "gloo":
         os.environ["LOCAL_RANK"] = "0"
     rank, local, world = hdist.init_from_env(backend, force=True)
+    # N ranks build their engines at the same time on one host: without a cap every rank's CPU ops (seeded weights, BN
+    # folding, fp16 splitting) spawn a thread per core and the four-rank rehearsal took 400 s instead of 70
+    torch.set_num_threads(max(1, (os.cpu_count() or 4) // (2 * world)))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     eng = HandNetEngine(FCOSEngine(synth.make_fcos_state_dict(0, 3), 3, device=dev),
