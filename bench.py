@@ -307,8 +307,8 @@ def dropin_leg(args, sds, dev, batch):
     net = net.to(dev).eval()
     out = {"call": "handnet_pipeline.HandNet.forward(list of [3,H,W], depth_images=[N,1,H,W]) -> (keypoints on the CPU, "
                    "depth_batch, crops), ros_demo.py:270-273", "precision": args.precision,
-           "host": "eager Python at the bench batch; at batch 1 forward() has switched itself to hipGraph replay (its default "
-                   "for batches below 8 once the input shapes repeat; results are fresh tensors either way)"}
+           "host": "forward() has switched itself to hipGraph replay (its default once the input shapes repeat on a dense "
+                   "stream; results are fresh tensors either way)"}
     for b, steps in ((batch, args.steps), (1, max(50, args.steps))):
         rgb = synth.make_rgb(b, seed=1000).to(dev)
         depth = synth.make_depth(b, seed=2000).to(dev)

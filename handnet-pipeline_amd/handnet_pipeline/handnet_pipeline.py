@@ -74,14 +74,15 @@ class HandNet(EngineOwner):
             self._engine = HandNetEngine(fcos, a2j, self.num_classes)
         return self._engine
 
-    # forward() switches ITSELF to hipGraph replay for a small batch once the same input shapes have come in a few times in a
-    # row -- the live caller's case (ros_demo.py:270-273: one 640x480 frame per call, ~200 dependent launches whose host cost
-    # is 8 % of the call).  forward() hands out fresh tensors (keypoints on the CPU, indexed copies of the crops), so replaying
+    # forward() switches ITSELF to hipGraph replay once the same input shapes have come in a few times in a row -- the live
+    # caller's case (ros_demo.py:270-273: one 640x480 frame per call, ~200 dependent launches whose host cost is 8 % of the
+    # call; at batch 32 the replay saves the ~0.3 ms the GPU idles while Python issues the first launches after the sync).  forward() hands out fresh tensors (keypoints on the CPU, indexed copies of the crops), so replaying
     # into captured buffers is invisible to the caller; enable_graph(False) turns it off, enable_graph(True) forces it from the
     # first call and also for forward_device().
     AUTO_GRAPH_CALLS = 3        # same-shape calls in a row before forward() captures
-    AUTO_GRAPH_MAX_BATCH = 7    # larger batches are GPU-bound (and use the sparse-stream compaction, which is not capturable)
     AUTO_GRAPH_MAX_SHAPES = 4   # distinct input shapes captured automatically (each holds its own static buffers)
+    # A SPARSE stream (a hand in fewer than half of the frames of a batch of >= 8: forward() sees the flags on the CPU anyway)
+    # stays eager, because the engine then runs A2J on the frames with a hand only and that path is data dependent.
 
     def enable_graph(self, on=True):
         """hipGraph replay: the first call with a given input shape captures the whole step, later calls copy the inputs
@@ -94,7 +95,7 @@ class HandNet(EngineOwner):
 
     def _auto_graph(self, batch, depth) -> bool:
         eng = self.engine()
-        if eng.check_range or batch.shape[0] > self.AUTO_GRAPH_MAX_BATCH or not (batch.is_cuda and depth.is_cuda):
+        if eng.check_range or getattr(self, "_last_sparse", False) or not (batch.is_cuda and depth.is_cuda):
             return False
         key = (tuple(batch.shape), tuple(depth.shape))
         if key in eng._graphs:
@@ -134,6 +135,7 @@ class HandNet(EngineOwner):
         flat = torch.cat([kp.reshape(n, -1), out.has_hand.reshape(n, 1).to(kp.dtype)], dim=1).cpu()
         final_results = flat[:, :-1].reshape(kp.shape).contiguous()     # the reference returns keypoints on the CPU
         mask_cpu = flat[:, -1] != 0
+        self._last_sparse = n >= 8 and int(mask_cpu.sum()) * 2 < n      # (the engine's own threshold for compaction)
         # always-on safety net of the f16x3 range contract, at no device cost: the check runs on the 8 KB the reference's
         # own .cpu() has just copied.  An activation beyond the fp16 range (|v| > 65504, e.g. BN-folded trained filters of
         # extreme scale) shows up here as inf / NaN keypoints -- refuse to hand them to the caller.
