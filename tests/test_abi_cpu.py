@@ -126,3 +126,29 @@ def test_hand_scheduled_kernels_do_not_spill():
                 assert " vgpr_spill 0 " in rest + " " and rest.strip().endswith("sgpr_spill 0"), line
                 assert " scratch 0 " in rest, line
     assert seen >= 30    # 31 instantiations of the implicit GEMM + halo + stem + the two thin-N kernels
+
+
+def test_documents_cite_files_that_exist():
+    """DESIGN.md / INTEGRATION.md / README.md quote measurements by file name (`profiles/r03e_*.json`, `tools/...`, `csrc/...`):
+    every back-quoted path with a known prefix or a profile-file suffix must exist, so a renamed collection cannot leave the
+    documents pointing at nothing."""
+    import re
+    root = build.REPO_ROOT
+    prof = {p.name for p in (root / "profiles").iterdir()}
+    missing = []
+    for doc in ("DESIGN.md", "INTEGRATION.md", "README.md"):
+        text = (root / doc).read_text()
+        for tok in re.findall(r"`([^`\s]+)`", text):
+            tok = tok.rstrip(".,;:)")
+            if "*" in tok or "<" in tok or "(" in tok:
+                continue
+            if tok.startswith(("profiles/", "tools/", "tests/", "oracle/", "include/", "examples/")):
+                if not (root / tok.split("::")[0].split(":")[0]).exists():
+                    missing.append((doc, tok))
+            elif re.fullmatch(r"r0\d[a-z]?_[\w.]+\.(json|txt|csv)", tok):
+                if tok not in prof:
+                    missing.append((doc, tok))
+            elif tok.startswith("csrc/") or tok.startswith("hn_amd/"):
+                if not (root / "handnet-pipeline_amd" / tok.split(":")[0]).exists():
+                    missing.append((doc, tok))
+    assert not missing, missing
