@@ -290,7 +290,7 @@ class FCOSEngine:
         a = ops.to_split_levels(t, aff, relu=True)
         ac, ar = [x[:, :, :, :8] for x in a], [x[:, :, :, 8:] for x in a]
         ops.PROFILE_STAGE = "head_outputs"
-        if self.thin_outputs and self.terms == 3:   # <= 8 output channels: the thin-N kernel (every input pixel staged once per channel block)
+        if self.thin_outputs and self.terms == 3:   # <= 16 output channels: the thin-N kernels (csrc/conv3x3_thin.hip)
             cls_lr = ops.conv3x3_thin_levels(ac, self.cls_out)
             ext = ops.conv3x3_thin_levels(ac, self.ext_out, relu_cols=3) if self.ext else [None] * L
             reg_ctr = ops.conv3x3_thin_levels(ar, self.reg_out, relu_cols=4)
