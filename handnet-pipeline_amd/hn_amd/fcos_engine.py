@@ -119,7 +119,7 @@ class FCOSEngine:
         self.head_streams = int(os.environ.get("HN_HEAD_STREAMS", "1")) if head_streams is None else head_streams
         self.group_towers = os.environ.get("HN_GROUP_CONVS", "1") != "0"
         self.fuse_stem_pool = os.environ.get("HN_FUSE_STEM_POOL", "1") != "0"   # A/B switch (results are bit-identical)
-        self.thin_outputs = os.environ.get("HN_THIN_OUTPUTS", "1") != "0" and self.cls_out.cout <= 16   # A/B switch, bit-identical
+        self.thin_outputs = os.environ.get("HN_THIN_OUTPUTS", "1") != "0" and self.cls_out.cout <= 16   # A/B switch (tap form bit-identical, P form to fp32 rounding)
 
     # -----------------------------------------------------------------------------------
     def _conv(self, x, cw: ConvW, relu=False, out_f32=False, **kw):
