@@ -176,19 +176,31 @@ __global__ __launch_bounds__(kNT, 2) void conv3x3_thin_kernel(const ThinParams p
 constexpr int kStepPx = 256, kMT = 3, kDepth = 4, kFlatMaxC = 5;
 
 struct FlatLevel {
-  const _Float16* x;
+  const _Float16* x;    // S32 input (plain form)
+  const float* xf;      // AFFINE form: raw fp32 [pixel][xs] conv output, already at the head's first channel
+  const float* scale;   // AFFINE form: GroupNorm scale / shift tables [image][as], already at the head's first channel
+  const float* shift;
   float* y;
   int h, w, total, first_unit, unit_len;
 };
 struct FlatParams {
   FlatLevel lv[HN_FCOS_MAX_LEVELS];
-  int levels, cbs, cout, xs, relu_cols, ring;
+  int levels, cbs, cout, xs, relu_cols, ring, as;
   const _Float16* wt;
   const float* bias;
+  int* range_flag;
 };
+constexpr int kAffImages = 8;   // AFFINE: images whose scale / shift rows a workgroup keeps in LDS (its pixel range spans no more)
 
 __device__ __forceinline__ void wg_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// AFFINE: the input is the RAW fp32 output of the last tower layer and the GroupNorm apply pass (y = relu(x * scale +
+// shift), split into fp16 hi + lo: hn_affine_split_f32's arithmetic, expression for expression) happens on the fragments in
+// registers -- the kernel streams at the HBM / L1 rate with its VALU idle, and the separate pass moved 2.4 GB per step
+// (0.4 ms at batch 32) only to hand this kernel the same bytes again.  The scale / shift rows of the (at most kAffImages)
+// images a workgroup's pixel range touches sit in LDS: vmcnt retires in order, so a table load from memory at the point
+// of use would wait for every older fragment prefetch and drain the stream.
+template <bool AFFINE>
 __global__ __launch_bounds__(kNT, 1) void conv3x3_thin_flat_kernel(const FlatParams p) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, px = lane & 15;
@@ -208,6 +220,17 @@ __global__ __launch_bounds__(kNT, 1) void conv3x3_thin_flat_kernel(const FlatPar
   const int cbs = p.cbs, cout = p.cout, ring = p.ring, rows = 9 * cout;
   char* wbank = smem;                                              // [cb][mt][hi|lo][lane] x 16 B
   float* ringp = reinterpret_cast<float*>(smem + cbs * (kMT * 2 * 1024));   // [rows][ring]
+  float* afftab = ringp + ((rows * ring + 3) & ~3);                // AFFINE: [image - img0][scale | shift][cbs * 32]
+  const int hw = L.h * L.w;
+  const int img0 = p0 / hw;
+  if constexpr (AFFINE) {
+    const int cin = cbs * 32, nimg = (p1 - 1) / hw - img0 + 1;     // <= kAffImages (the host sizes the ranges for that)
+    for (int e = tid; e < nimg * 2 * (cin / 4); e += kNT) {
+      const int c4 = e % (cin / 4), q = e / (cin / 4), which = q & 1, j = q >> 1;
+      const float* src = (which ? L.shift : L.scale) + (size_t)(img0 + j) * p.as + c4 * 4;
+      *reinterpret_cast<f32x4*>(afftab + (j * 2 + which) * cin + c4 * 4) = *reinterpret_cast<const f32x4*>(src);
+    }
+  }
 
   for (int e = tid; e < cbs * kMT * 2 * 64; e += kNT) {
     const int ln = e & 63, hl = (e >> 6) & 1, q = e >> 7;
@@ -225,13 +248,20 @@ __global__ __launch_bounds__(kNT, 1) void conv3x3_thin_flat_kernel(const FlatPar
   // end of the level hold a duplicate that no output ever reads)
   const int col0 = (wave * 2) * 16 + px;
   const _Float16* xl = L.x + lg * 8;
+  const float* xfl = L.xf + lg * 8;
   auto issue = [&](int step, int cb, f16x8 (&dst)[2][2]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int g = min(p0 + step * kStepPx + col0 + i * 16, L.total - 1);
-      const _Float16* src = xl + (size_t)g * p.xs + cb * 64;
-      dst[i][0] = *reinterpret_cast<const f16x8*>(src);
-      dst[i][1] = *reinterpret_cast<const f16x8*>(src + 32);
+      if constexpr (AFFINE) {   // eight raw fp32 channels: the same 32 bytes per lane as hi + lo
+        const float* src = xfl + (size_t)g * p.xs + cb * 32;
+        dst[i][0] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(src));
+        dst[i][1] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(src + 4));
+      } else {
+        const _Float16* src = xl + (size_t)g * p.xs + cb * 64;
+        dst[i][0] = *reinterpret_cast<const f16x8*>(src);
+        dst[i][1] = *reinterpret_cast<const f16x8*>(src + 32);
+      }
     }
   };
   float bv[kFlatMaxC];   // read before the stream starts: a global load in the output phase would drain the prefetch queue
@@ -251,6 +281,14 @@ __global__ __launch_bounds__(kNT, 1) void conv3x3_thin_flat_kernel(const FlatPar
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int m = 0; m < kMT; ++m) acc[i][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* aff[2];   // AFFINE: this lane's rows of the LDS table (the image of each of its two pixels, its 8 channels)
+    if constexpr (AFFINE) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int g = min(min(p0 + step * kStepPx + col0 + i * 16, p1 - 1), L.total - 1);   // (columns past p1 are never used)
+        aff[i] = afftab + (g / hw - img0) * 2 * (cbs * 32) + lg * 8;
+      }
+    }
 #pragma unroll 1
     for (int cb0 = 0; cb0 < cbs; cb0 += kDepth) {
 #pragma unroll
@@ -259,6 +297,35 @@ __global__ __launch_bounds__(kNT, 1) void conv3x3_thin_flat_kernel(const FlatPar
         f16x8 xv[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) { xv[i][0] = xr[k][i][0]; xv[i][1] = xr[k][i][1]; }
+        if constexpr (AFFINE) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            f32x4 a = __builtin_bit_cast(f32x4, xv[i][0]), b = __builtin_bit_cast(f32x4, xv[i][1]);
+            const float* sp = aff[i] + cb * 32;
+            const float* tp = sp + cbs * 32;
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(tp), t1 = *reinterpret_cast<const f32x4*>(tp + 4);
+            f16x8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {   // hn_affine_split_f32 with relu = 1, expression for expression
+              a[e] = a[e] * s0[e] + t0[e];
+              b[e] = b[e] * s1[e] + t1[e];
+              a[e] = fmaxf(a[e], 0.f);
+              b[e] = fmaxf(b[e], 0.f);
+              if (p.range_flag) {
+                hn::range_note(p.range_flag, a[e]);
+                hn::range_note(p.range_flag, b[e]);
+              }
+              const _Float16 h0 = (_Float16)a[e], h1 = (_Float16)b[e];
+              hi[e] = h0;
+              hi[4 + e] = h1;
+              lo[e] = (_Float16)(a[e] - (float)h0);
+              lo[4 + e] = (_Float16)(b[e] - (float)h1);
+            }
+            xv[i][0] = hi;
+            xv[i][1] = lo;
+          }
+        }
         const bool wrap = cb0 + kDepth >= cbs;   // the block kDepth ahead belongs to the next step
         issue(wrap ? step + 1 : step, wrap ? k : cb + kDepth, xr[k]);
         __builtin_amdgcn_sched_barrier(0);   // keep the loads HERE: sunk to the end of the loop body they are one unit deep
@@ -358,11 +425,14 @@ extern "C" int hn_conv3x3_thin_uses_flat(const hn_thin_levels* lv, int n, int ci
   return lds <= 160 * 1024 ? 1 : 0;
 }
 
-static int thin_flat_run(const hn_thin_levels* lv, int n, int cin, int cout, const void* w16, const float* bias, int relu_cols,
-                         int xs, hipStream_t st) {
+// aff != nullptr: the AFFINE form (x = raw fp32, GroupNorm apply fused); lv->x16 is then ignored
+static int thin_flat_run(const hn_thin_levels* lv, const hn_thin_affine* aff, int n, int cin, int cout, const void* w16,
+                         const float* bias, int relu_cols, int xs, hipStream_t st) {
   FlatParams p;
   p.levels = lv->count; p.cbs = cin / 32; p.cout = cout; p.xs = xs; p.relu_cols = relu_cols;
   p.wt = (const _Float16*)w16; p.bias = bias;
+  p.as = aff ? aff->affine_stride : 0;
+  p.range_flag = aff ? hn::range_flag_ptr() : nullptr;
   int wmax = 1;
   int64_t all = 0;
   for (int l = 0; l < lv->count; ++l) {
@@ -372,7 +442,7 @@ static int thin_flat_run(const hn_thin_levels* lv, int n, int cin, int cout, con
     wmax = lv->w[l] > wmax ? lv->w[l] : wmax;
   }
   p.ring = flat_ring_words(wmax);
-  const int lds = p.cbs * (kMT * 2 * 1024) + 9 * cout * p.ring * 4;
+  const int lds = p.cbs * (kMT * 2 * 1024) + ((9 * cout * p.ring + 3) & ~3) * 4 + (aff ? kAffImages * 2 * cin * 4 : 0);
   static int cus[64] = {};
   int dev = 0;
   HN_CHECK_HIP(hipGetDevice(&dev));
@@ -380,7 +450,8 @@ static int thin_flat_run(const hn_thin_levels* lv, int n, int cin, int cout, con
   if (!cus[dev]) {
     int c = 0;
     HN_CHECK_HIP(hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev));
-    HN_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_thin_flat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HN_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_thin_flat_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HN_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_thin_flat_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     cus[dev] = c > 0 ? c : 256;
   }
   // one range of flat pixels per workgroup, one workgroup per CU (the LDS allows no more): the shortest range length
@@ -397,17 +468,58 @@ static int thin_flat_run(const hn_thin_levels* lv, int n, int cin, int cout, con
   for (int l = 0; l < HN_FCOS_MAX_LEVELS; ++l) {
     FlatLevel& t = p.lv[l];
     if (l < lv->count) {
-      t.x = (const _Float16*)lv->x16[l]; t.y = lv->y[l]; t.h = lv->h[l]; t.w = lv->w[l];
+      t.x = aff ? nullptr : (const _Float16*)lv->x16[l];
+      t.xf = aff ? aff->x[l] : nullptr; t.scale = aff ? aff->scale[l] : nullptr; t.shift = aff ? aff->shift[l] : nullptr;
+      t.y = lv->y[l]; t.h = lv->h[l]; t.w = lv->w[l];
       t.total = n * t.h * t.w;
-      t.first_unit = units; t.unit_len = (int)unit_len;
-      units += (int)((t.total + unit_len - 1) / unit_len);
+      int64_t ul = unit_len;
+      if (aff) {   // a range of R pixels touches at most (R - 2) / HW + 2 images: keep that within the LDS table
+        const int64_t cap = (int64_t)(kAffImages - 2) * t.h * t.w + 2 - 2 * (t.w + 1);
+        ul = ul < cap ? ul : cap / 64 * 64;
+        HN_CHECK_ARG(ul >= 64, "level %d: map too small for the fused GroupNorm apply (hn_conv3x3_thin_affine_applies)", l);
+      }
+      t.first_unit = units; t.unit_len = (int)ul;
+      units += (int)((t.total + ul - 1) / ul);
     } else {
-      t.x = nullptr; t.y = nullptr; t.h = t.w = t.total = 1; t.first_unit = 0x7fffffff; t.unit_len = 1;
+      t.x = nullptr; t.xf = t.scale = t.shift = nullptr; t.y = nullptr; t.h = t.w = t.total = 1; t.first_unit = 0x7fffffff; t.unit_len = 1;
     }
   }
-  hipLaunchKernelGGL(conv3x3_thin_flat_kernel, dim3(units), dim3(kNT), lds, st, p);
+  if (aff) hipLaunchKernelGGL(conv3x3_thin_flat_kernel<true>, dim3(units), dim3(kNT), lds, st, p);
+  else hipLaunchKernelGGL(conv3x3_thin_flat_kernel<false>, dim3(units), dim3(kNT), lds, st, p);
   HN_CHECK_LAUNCH("conv3x3_thin_flat_kernel");
   return HN_OK;
+}
+
+// Does the fused form take this problem?  The plain P form must (hn_conv3x3_thin_uses_flat), the table must fit beside
+// the filter bank and the ring, and every map must be large enough that a 64-pixel range stays within kAffImages images.
+extern "C" int hn_conv3x3_thin_affine_applies(const hn_thin_levels* lv, int n, int cin, int cout) {
+  if (!hn_conv3x3_thin_uses_flat(lv, n, cin, cout)) return 0;
+  int wmax = 1;
+  for (int l = 0; l < lv->count; ++l) {
+    wmax = lv->w[l] > wmax ? lv->w[l] : wmax;
+    if ((int64_t)(kAffImages - 2) * lv->h[l] * lv->w[l] + 2 - 2 * (lv->w[l] + 1) < 64) return 0;
+  }
+  const int64_t lds = (int64_t)(cin / 32) * (kMT * 2 * 1024) + (int64_t)((9 * cout * flat_ring_words(wmax) + 3) & ~3) * 4 +
+                      (int64_t)kAffImages * 2 * cin * 4;
+  return lds <= 160 * 1024 ? 1 : 0;
+}
+
+extern "C" int hn_conv3x3_thin_affine_f16x3_levels(const hn_thin_levels* lv, const hn_thin_affine* aff, int n, int cin, int cout,
+                                                   const void* w16, const float* bias, int relu_cols, void* stream) {
+  HN_CHECK_ARG(lv && aff && w16, "hn_conv3x3_thin_affine_f16x3_levels: null pointer");
+  HN_CHECK_ARG(lv->count >= 1 && lv->count <= HN_FCOS_MAX_LEVELS, "level count must be 1..%d", HN_FCOS_MAX_LEVELS);
+  HN_CHECK_ARG(n > 0 && cin > 0 && cout >= 1 && relu_cols >= 0 && relu_cols <= cout, "bad dims");
+  HN_CHECK_ARG(hn_conv3x3_thin_affine_applies(lv, n, cin, cout), "the fused form does not take this problem "
+               "(hn_conv3x3_thin_affine_applies): run hn_affine_split_f32_levels + hn_conv3x3_thin_f16x3_levels");
+  HN_CHECK_ARG(aff->in_pix_stride >= cin && aff->in_pix_stride % 4 == 0 && aff->affine_stride >= cin && aff->affine_stride % 4 == 0 &&
+                   (uintptr_t)w16 % 16 == 0, "bad strides / unaligned filter bank");
+  for (int l = 0; l < lv->count; ++l) {
+    HN_CHECK_ARG(aff->x[l] && aff->scale[l] && aff->shift[l] && lv->y[l] && lv->h[l] > 0 && lv->w[l] > 0,
+                 "level %d: null pointer or empty map", l);
+    HN_CHECK_ARG((uintptr_t)aff->x[l] % 16 == 0 && (uintptr_t)aff->scale[l] % 16 == 0 && (uintptr_t)aff->shift[l] % 16 == 0,
+                 "level %d: unaligned tensor", l);
+  }
+  return thin_flat_run(lv, aff, n, cin, cout, w16, bias, relu_cols, aff->in_pix_stride, (hipStream_t)stream);
 }
 
 extern "C" int hn_conv3x3_thin_f16x3_levels(const hn_thin_levels* lv, int n, int cin, int cout, const void* w16, const float* bias,
@@ -430,7 +542,7 @@ extern "C" int hn_conv3x3_thin_f16x3_levels(const hn_thin_levels* lv, int n, int
     HN_CHECK_ARG((uintptr_t)lv->x16[l] % 16 == 0, "level %d: unaligned input", l);
   }
   if (hn_conv3x3_thin_uses_flat(lv, n, cin, cout))
-    return thin_flat_run(lv, n, cin, cout, w16, bias, relu_cols, p.xs, (hipStream_t)stream);
+    return thin_flat_run(lv, nullptr, n, cin, cout, w16, bias, relu_cols, p.xs, (hipStream_t)stream);
   int blocks = 0;
   for (int l = 0; l < HN_FCOS_MAX_LEVELS; ++l) {
     ThinLevel& t = p.lv[l];

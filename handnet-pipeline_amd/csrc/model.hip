@@ -615,12 +615,40 @@ int fcos_graph(Ctx& cx, const float* rgb, int n, int h, int w, const FcosOut& ou
     for (int l = 0; l < L; ++l) release(cx, a[l]);   // the activated input of this tower layer
     HN_TRY(finalize(m->f_gn_gamma[layer], m->f_gn_beta[layer]));
   }
-  HN_TRY(activate(a));
+  // the last GroupNorm apply pass rides on the head-output kernels' fragments where the fused P form takes the problem
+  // (fcos_engine.heads_grouped; HN_FUSE_LAST_GN=0: A/B)
+  hn_thin_levels tl;
+  memset(&tl, 0, sizeof(tl));
+  tl.count = L;
+  for (int l = 0; l < L; ++l) { tl.h[l] = t[l].h; tl.w[l] = t[l].w; }
+  const bool fuse_gn = !hn::env_flags().no_thin && !hn::env_flags().no_fuse_last_gn && t_terms != 1 && !out.contacts &&
+                       hn_conv3x3_thin_affine_applies(&tl, n, 256, m->f_cls_out.cout) &&
+                       hn_conv3x3_thin_affine_applies(&tl, n, 256, m->f_reg_out.cout);
   hn_fcos_levels lv;
   memset(&lv, 0, sizeof(lv));
   lv.num_levels = L;
   T cls_lr[3], reg_ctr[3], ext_lv[3];
-  {
+  if (fuse_gn) {
+    hn_thin_affine ac, ar;
+    hn_thin_levels yc = tl, yr = tl;
+    ac.in_pix_stride = ar.in_pix_stride = 512;
+    ac.affine_stride = ar.affine_stride = 512;
+    for (int l = 0; l < L; ++l) {
+      cls_lr[l] = alloc(cx, n, t[l].h, t[l].w, m->f_cls_out.cout, false);
+      reg_ctr[l] = alloc(cx, n, t[l].h, t[l].w, 5, false);
+      ac.x[l] = (const float*)t[l].p; ac.scale[l] = scale[l]; ac.shift[l] = shift[l];
+      ar.x[l] = (const float*)t[l].p + 256; ar.scale[l] = scale[l] + 256; ar.shift[l] = shift[l] + 256;
+      yc.y[l] = (float*)cls_lr[l].p; yr.y[l] = (float*)reg_ctr[l].p;
+      lv.h[l] = t[l].h; lv.w[l] = t[l].w; lv.stride[l] = g.ph / t[l].h;
+      lv.cls_lr[l] = (const float*)cls_lr[l].p; lv.reg_ctr[l] = (const float*)reg_ctr[l].p;
+    }
+    if (!cx.dry) {
+      HN_TRY(hn_conv3x3_thin_affine_f16x3_levels(&yc, &ac, n, 256, m->f_cls_out.cout, m->f_cls_out.w16, m->f_cls_out.bias, 0, cx.stream));
+      HN_TRY(hn_conv3x3_thin_affine_f16x3_levels(&yr, &ar, n, 256, 5, m->f_reg_out.w16, m->f_reg_out.bias, 4, cx.stream));
+    }
+    for (int l = 0; l < L; ++l) release(cx, t[l]);
+  } else {
+    HN_TRY(activate(a));
     GroupSpec gc, gr;
     gc.count = gr.count = L;
     const int ccls = m->f_cls_out.cout;

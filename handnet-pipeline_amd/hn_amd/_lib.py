@@ -12,7 +12,7 @@ from pathlib import Path
 
 from . import build as _build
 
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, TILE_256x128, TILE_64x128 = range(7)
 HN_FCOS_MAX_LEVELS = 5
@@ -70,6 +70,11 @@ class SplitLevels(C.Structure):  # == struct hn_split_levels
 class ThinLevels(C.Structure):  # == struct hn_thin_levels
     _fields_ = [("count", C.c_int32), ("x16", C.c_void_p * HN_FCOS_MAX_LEVELS), ("y", C.c_void_p * HN_FCOS_MAX_LEVELS),
                 ("h", C.c_int32 * HN_FCOS_MAX_LEVELS), ("w", C.c_int32 * HN_FCOS_MAX_LEVELS)]
+
+
+class ThinAffine(C.Structure):  # == struct hn_thin_affine
+    _fields_ = [("x", C.c_void_p * HN_FCOS_MAX_LEVELS), ("scale", C.c_void_p * HN_FCOS_MAX_LEVELS),
+                ("shift", C.c_void_p * HN_FCOS_MAX_LEVELS), ("in_pix_stride", C.c_int32), ("affine_stride", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol of include/handnet_hip.h is listed here and
@@ -142,6 +147,9 @@ SIGNATURES = {
     "hn_unpack_records": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, VP]),
     "hn_nonfinite_count_f32": (C.c_int, [VP, C.c_int64, VP, VP]),
     "hn_conv3x3_thin_f16x3_levels": (C.c_int, [C.POINTER(ThinLevels), C.c_int, C.c_int, C.c_int, VP, VP, C.c_int, C.c_int, VP]),
+    "hn_conv3x3_thin_affine_applies": (C.c_int, [C.POINTER(ThinLevels), C.c_int, C.c_int, C.c_int]),
+    "hn_conv3x3_thin_affine_f16x3_levels": (C.c_int, [C.POINTER(ThinLevels), C.POINTER(ThinAffine), C.c_int, C.c_int, C.c_int,
+                                                      VP, VP, C.c_int, VP]),
     "hn_conv3x3_thin_uses_flat": (C.c_int, [C.POINTER(ThinLevels), C.c_int, C.c_int, C.c_int]),
     "hn_convert_joints_f32": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_float, C.c_float, c_f32p, VP, VP]),
 }

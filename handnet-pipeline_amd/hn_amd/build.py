@@ -46,7 +46,10 @@ def _check_resources(src: Path, remarks: str, objdir: Path) -> None:
         out.append(f"{name}: VGPRs {res.get('VGPRs')} AGPRs {res.get('AGPRs')} SGPRs {res.get('TotalSGPRs')} "
                    f"scratch {res.get('ScratchSize [bytes/lane]')} occupancy {res.get('Occupancy [waves/SIMD]')} "
                    f"vgpr_spill {res.get('VGPRs Spill')} sgpr_spill {res.get('SGPRs Spill')}")
-        if any(k in name for k in NO_SPILL_KERNELS) and (res.get("VGPRs Spill", "0") != "0" or res.get("SGPRs Spill", "0") != "0"):
+        # (SGPR spills go to VGPR lanes, not to memory: harmless where no asm load is in flight -- the P-form kernel uses
+        # plain loads only -- but they are refused in the hand-counted kernels all the same)
+        sgpr_ok = res.get("SGPRs Spill", "0") == "0" or "thin_flat" in name
+        if any(k in name for k in NO_SPILL_KERNELS) and (res.get("VGPRs Spill", "0") != "0" or not sgpr_ok):
             raise RuntimeError(f"{src.name}: {name} spills registers ({res.get('VGPRs Spill')} VGPR, {res.get('SGPRs Spill')} SGPR): "
                                "its asm loads / counted waits are only correct without spills")
     (objdir / (src.stem + ".resources.txt")).write_text("\n".join(out) + "\n")

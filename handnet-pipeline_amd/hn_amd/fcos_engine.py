@@ -119,6 +119,7 @@ class FCOSEngine:
         self.head_streams = int(os.environ.get("HN_HEAD_STREAMS", "1")) if head_streams is None else head_streams
         self.group_towers = os.environ.get("HN_GROUP_CONVS", "1") != "0"
         self.fuse_stem_pool = os.environ.get("HN_FUSE_STEM_POOL", "1") != "0"   # A/B switch (results are bit-identical)
+        self.fuse_last_gn = os.environ.get("HN_FUSE_LAST_GN", "1") != "0"   # A/B switch, bit-identical
         self.thin_outputs = os.environ.get("HN_THIN_OUTPUTS", "1") != "0" and self.cls_out.cout <= 16   # A/B switch (tap form bit-identical, P form to fp32 rounding)
 
     # -----------------------------------------------------------------------------------
@@ -287,6 +288,14 @@ class FCOSEngine:
                                     pad=1, outs=t + t, out_channel_offsets=[0] * L + [256] * L,
                                     gn=[(parts[l], 0) for l in range(L)] + [(parts[l], 32) for l in range(L)], gn_units=64)
             aff = ops.groupnorm_finalize_rows32_levels(parts, g2, b2, n, hw, 64)
+        ops.PROFILE_STAGE = "head_outputs"
+        if (self.thin_outputs and self.fuse_last_gn and self.terms == 3 and not self.ext
+                and ops.thin_affine_applies(t, self.cls_out) and ops.thin_affine_applies(t, self.reg_out)):
+            # the last GroupNorm apply pass happens on the head-output kernels' fragments (no 8 bytes per element round trip)
+            cls_lr = ops.conv3x3_thin_affine_levels(t, aff, 0, self.cls_out)
+            reg_ctr = ops.conv3x3_thin_affine_levels(t, aff, 256, self.reg_out, relu_cols=4)
+            return list(zip(cls_lr, reg_ctr, [None] * L))
+        ops.PROFILE_STAGE = "towers"
         a = ops.to_split_levels(t, aff, relu=True)
         ac, ar = [x[:, :, :, :8] for x in a], [x[:, :, :, 8:] for x in a]
         ops.PROFILE_STAGE = "head_outputs"

@@ -519,6 +519,59 @@ def conv3x3_thin_levels(xs, cw, relu_cols=0):
     return outs
 
 
+def _thin_levels_of(shapes):
+    lv = _lib.ThinLevels()
+    lv.count = len(shapes)
+    for i, (h, w) in enumerate(shapes):
+        lv.h[i], lv.w[i] = h, w
+    return lv
+
+
+def thin_affine_applies(ts, cw) -> bool:
+    """Would conv3x3_thin_affine_levels take these raw tower outputs ts (fp32 [N,h_l,w_l,C]) with filter bank cw?"""
+    cout, _, _, cin = cw.w.shape
+    lv = _thin_levels_of([t.shape[1:3] for t in ts])
+    return len(ts) <= _lib.HN_FCOS_MAX_LEVELS and bool(_lib.load().hn_conv3x3_thin_affine_applies(C.byref(lv), ts[0].shape[0], cin, cout))
+
+
+def conv3x3_thin_affine_levels(ts, affines, ch0, cw, relu_cols=0):
+    """The head-output convolution on the RAW outputs of the last tower layer with that layer's GroupNorm apply pass fused
+    in (hn_conv3x3_thin_affine_f16x3_levels): ts[l] fp32 [N,h_l,w_l,C] raw conv outputs, affines[l] = (scale, shift) fp32
+    [N,C] from groupnorm_finalize_rows32_levels, ch0 = first channel of this head's cw.cin channels inside C.  Equals
+    conv3x3_thin_levels(to_split_levels(ts, affines)[..., ch0 // 32 : (ch0 + cin) // 32], cw) bit for bit, without the pass."""
+    lib = _lib.load()
+    cout, r, s, cin = cw.w.shape
+    n, c = ts[0].shape[0], ts[0].shape[3]
+    if (r, s) != (3, 3) or cw.w16 is None or ch0 % 32 or ch0 + cin > c:
+        raise ValueError("conv3x3_thin_affine_levels needs a split 3x3 filter bank and a 32-aligned channel range")
+    xstride = _pixel_stride(ts[0], "x")
+    a_stride = affines[0][0].stride(0)
+    lv, aff = _thin_levels_of([t.shape[1:3] for t in ts]), _lib.ThinAffine()
+    aff.in_pix_stride, aff.affine_stride = xstride, a_stride
+    outs = []
+    for i, (t, (scale, shift)) in enumerate(zip(ts, affines)):
+        if t.dtype != torch.float32 or is_split(t) or t.shape[0] != n or t.shape[3] != c or _pixel_stride(t, "x") != xstride:
+            raise ValueError("levels must be fp32 NHWC tensors of one batch size, channel count and pixel stride")
+        for q in (scale, shift):
+            if not q.is_cuda or q.dtype != torch.float32 or tuple(q.shape) != (n, c) or q.stride(1) != 1 or q.stride(0) != a_stride:
+                raise ValueError("scale / shift must be fp32 GPU [N, C] tables with equal row stride")
+        y = torch.empty((n, t.shape[1], t.shape[2], cout), device=t.device, dtype=torch.float32)
+        aff.x[i], aff.scale[i], aff.shift[i] = t.data_ptr() + 4 * ch0, scale.data_ptr() + 4 * ch0, shift.data_ptr() + 4 * ch0
+        lv.y[i] = y.data_ptr()
+        outs.append(y)
+    prof = CONV_PROFILE
+    if prof is not None:
+        timer = HipTimer()
+        timer.start()
+    check(lib.hn_conv3x3_thin_affine_f16x3_levels(C.byref(lv), C.byref(aff), n, cin, cout, ptr(cw.w16), ptr(cw.bias),
+                                                  int(relu_cols), _stream()), "hn_conv3x3_thin_affine_f16x3_levels")
+    if prof is not None:
+        timer.stop()
+        rows = sum(n * t.shape[1] * t.shape[2] for t in ts)
+        prof.append((("f16x3", "thin-P+gn"), rows * cout * 9 * cin, timer, (1, rows, 1, cin, cout, 3, 1, 1), PROFILE_STAGE))
+    return outs
+
+
 def thin_uses_flat(xs, cw) -> bool:
     """Would conv3x3_thin_levels(xs, cw) run the P-form kernel (True) or the tap kernel (False)?"""
     lv = _lib.ThinLevels()

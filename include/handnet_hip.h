@@ -33,7 +33,7 @@ extern "C" {
 #define HN_ERR_HIP 2
 
 /* ABI version; bumped whenever a struct below changes. */
-#define HN_ABI_VERSION 28
+#define HN_ABI_VERSION 29
 int hn_abi_version(void);
 const char* hn_last_error(void);
 
@@ -263,7 +263,24 @@ typedef struct hn_thin_levels {
 } hn_thin_levels;
 int hn_conv3x3_thin_f16x3_levels(const hn_thin_levels* lv, int n, int cin, int cout, const void* w16, const float* bias,
                                  int relu_cols, int in_pix_stride, void* stream);
-int hn_conv3x3_thin_uses_flat(const hn_thin_levels* lv, int n, int cin, int cout);   /* only count and w[] are read */
+int hn_conv3x3_thin_uses_flat(const hn_thin_levels* lv, int n, int cin, int cout);   /* only count, h[] and w[] are read */
+
+/* The P form with the LAST GroupNorm apply pass of the towers fused in (fcos.py:232-239 conv -> GroupNorm -> ReLU, then the
+ * output conv): x[l] = RAW fp32 conv output [n][h_l][w_l][in_pix_stride] at the head's first channel, scale[l] / shift[l] =
+ * the tables of hn_groupnorm_finalize_rows32 [n][affine_stride] at the same channel; the kernel computes relu(x * scale +
+ * shift), splits it into fp16 hi + lo in registers (hn_affine_split_f32's arithmetic) and convolves: bit-identical to
+ * hn_affine_split_f32_levels + hn_conv3x3_thin_f16x3_levels, without the 8 bytes per element the separate pass moves.
+ * lv->x16 is ignored; lv->y / h / w as above.  Only where hn_conv3x3_thin_affine_applies() == 1. */
+typedef struct hn_thin_affine {
+  const float* x[HN_FCOS_MAX_LEVELS];
+  const float* scale[HN_FCOS_MAX_LEVELS];
+  const float* shift[HN_FCOS_MAX_LEVELS];
+  int32_t in_pix_stride;   /* floats per pixel of x */
+  int32_t affine_stride;   /* floats per image row of scale / shift */
+} hn_thin_affine;
+int hn_conv3x3_thin_affine_applies(const hn_thin_levels* lv, int n, int cin, int cout);
+int hn_conv3x3_thin_affine_f16x3_levels(const hn_thin_levels* lv, const hn_thin_affine* aff, int n, int cin, int cout,
+                                        const void* w16, const float* bias, int relu_cols, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * FCOS pre-processing: normalize + bilinear resize (align_corners=False, scale =

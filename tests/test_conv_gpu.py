@@ -784,3 +784,30 @@ def test_thin_output_conv_is_deterministic_at_full_size():
         ops.reread_env()
     for a, b in zip(first, tap):
         assert (a - b).abs().max().item() <= 4e-6 * b.abs().max().item()
+
+
+@pytest.mark.parametrize("n,sizes", [
+    (8, [(100, 136), (50, 68), (25, 34), (13, 17), (7, 9)]),      # the FCOS pyramid, 145 k pixels
+    (300, [(13, 17), (7, 9)]),                                     # small maps only: every pixel range spans several images
+    (33, [(25, 34), (50, 68)]),
+])
+def test_fused_groupnorm_apply_in_the_head_output_kernel_is_bit_identical(n, sizes):
+    """hn_conv3x3_thin_affine_f16x3_levels: relu(x * scale + shift) and the fp16 hi / lo split happen on the P-form kernel's
+    fragments (scale / shift rows of the images a workgroup touches in LDS).  Same arithmetic as hn_affine_split_f32_levels
+    followed by hn_conv3x3_thin_f16x3_levels, expression for expression: torch.equal, for both channel halves of the
+    512-channel tower output (fcos.py:232-239,247-264)."""
+    from hn_amd import ops
+    from hn_amd.weights import ConvW
+    g = torch.Generator().manual_seed(4321 + n)
+    cw = ConvW(torch.randn(5, 3, 3, 256, generator=g) * 0.05, torch.randn(5, generator=g), 1, 1, 1).to("cuda")
+    ts = [(torch.randn(n, h, w, 512, generator=g) * 3).cuda() for h, w in sizes]
+    aff = [((torch.rand(n, 512, generator=g) + 0.5).cuda(), torch.randn(n, 512, generator=g).cuda()) for _ in sizes]
+    assert ops.thin_affine_applies(ts, cw)
+    a = ops.to_split_levels(ts, aff, relu=True)
+    for ch0, rc in ((0, 0), (256, 4)):
+        want = ops.conv3x3_thin_levels([x[:, :, :, ch0 // 32:ch0 // 32 + 8] for x in a], cw, relu_cols=rc)
+        got = ops.conv3x3_thin_affine_levels(ts, aff, ch0, cw, relu_cols=rc)
+        for u, v in zip(got, want):
+            assert u.shape == v.shape and torch.equal(u, v)
+    # too small a problem (the tap kernel's territory) or maps too small for the table: the query says no
+    assert not ops.thin_affine_applies([t[:1] for t in ts], cw)
