@@ -17,7 +17,10 @@ raw = torch.randn((n, h, w, 512), generator=g).cuda()
 sc = (torch.rand((n, 512), generator=g) + 0.5).cuda(); sh = torch.randn((n, 512), generator=g).cuda() * 0.1
 y = torch.empty((n, h, w, 512), device="cuda")
 act = torch.empty((n, h, w, 16, 2, 32), device="cuda", dtype=torch.float16)
-sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+# argv[1] = priority of the apply stream (0 = default, -1 = high: does the dispatcher then interleave its workgroups with the
+# conv's instead of waiting for the conv's queue to drain?)
+prio = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+sa, sb = torch.cuda.Stream(), torch.cuda.Stream(priority=prio)
 def conv(): ops.conv2d_nhwc(x, wt, None, pad=1, w16=w16, out=y)
 def apply(): ops.to_split(raw, sc, sh, relu=True, out=act)
 def run(fa, fb, iters=200):
@@ -39,4 +42,5 @@ def run(fa, fb, iters=200):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
 tc, ta, tb = run(conv, None), run(None, apply), run(conv, apply)
+print(f"apply stream priority {prio}: ", end="")
 print(f"conv alone {tc*1e3:.0f} us   apply alone {ta*1e3:.0f} us   both concurrently {tb*1e3:.0f} us per pair   (serial sum {1e3*(tc+ta):.0f} us)")
