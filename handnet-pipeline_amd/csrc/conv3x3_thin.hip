@@ -190,14 +190,16 @@ struct FlatParams {
   const float* bias;
   int* range_flag;
 };
-constexpr int kAffImages = 8;   // AFFINE: images whose scale / shift rows a workgroup keeps in LDS (its pixel range spans no more)
+// AFFINE: images whose scale / shift rows a workgroup keeps in LDS (its pixel range spans no more): as many as fit beside the
+// filter bank and the ring, at most 8, at least 3
+constexpr int kAffImagesMax = 8, kAffImagesMin = 3;
 
 __device__ __forceinline__ void wg_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // AFFINE: the input is the RAW fp32 output of the last tower layer and the GroupNorm apply pass (y = relu(x * scale +
 // shift), split into fp16 hi + lo: hn_affine_split_f32's arithmetic, expression for expression) happens on the fragments in
 // registers -- the kernel streams at the HBM / L1 rate with its VALU idle, and the separate pass moved 2.4 GB per step
-// (0.4 ms at batch 32) only to hand this kernel the same bytes again.  The scale / shift rows of the (at most kAffImages)
+// (0.4 ms at batch 32) only to hand this kernel the same bytes again.  The scale / shift rows of the (at most eight)
 // images a workgroup's pixel range touches sit in LDS: vmcnt retires in order, so a table load from memory at the point
 // of use would wait for every older fragment prefetch and drain the stream.
 template <bool AFFINE>
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(kNT, 1) void conv3x3_thin_flat_kernel(const FlatPar
   const int hw = L.h * L.w;
   const int img0 = p0 / hw;
   if constexpr (AFFINE) {
-    const int cin = cbs * 32, nimg = (p1 - 1) / hw - img0 + 1;     // <= kAffImages (the host sizes the ranges for that)
+    const int cin = cbs * 32, nimg = (p1 - 1) / hw - img0 + 1;     // <= the table's capacity (the host sizes the ranges for that)
     for (int e = tid; e < nimg * 2 * (cin / 4); e += kNT) {
       const int c4 = e % (cin / 4), q = e / (cin / 4), which = q & 1, j = q >> 1;
       const float* src = (which ? L.shift : L.scale) + (size_t)(img0 + j) * p.as + c4 * 4;
@@ -425,6 +427,13 @@ extern "C" int hn_conv3x3_thin_uses_flat(const hn_thin_levels* lv, int n, int ci
   return lds <= 160 * 1024 ? 1 : 0;
 }
 
+// images the scale / shift table can hold for this problem (0: no room)
+static int aff_table_images(int cin, int cout, int wmax) {
+  const int64_t fixed = (int64_t)(cin / 32) * (kMT * 2 * 1024) + (int64_t)((9 * cout * flat_ring_words(wmax) + 3) & ~3) * 4;
+  const int64_t k = (160 * 1024 - fixed) / ((int64_t)2 * cin * 4);
+  return k < kAffImagesMin ? 0 : (int)(k > kAffImagesMax ? kAffImagesMax : k);
+}
+
 // aff != nullptr: the AFFINE form (x = raw fp32, GroupNorm apply fused); lv->x16 is then ignored
 static int thin_flat_run(const hn_thin_levels* lv, const hn_thin_affine* aff, int n, int cin, int cout, const void* w16,
                          const float* bias, int relu_cols, int xs, hipStream_t st) {
@@ -442,7 +451,8 @@ static int thin_flat_run(const hn_thin_levels* lv, const hn_thin_affine* aff, in
     wmax = lv->w[l] > wmax ? lv->w[l] : wmax;
   }
   p.ring = flat_ring_words(wmax);
-  const int lds = p.cbs * (kMT * 2 * 1024) + ((9 * cout * p.ring + 3) & ~3) * 4 + (aff ? kAffImages * 2 * cin * 4 : 0);
+  const int aff_images = aff ? aff_table_images(cin, cout, wmax) : 0;
+  const int lds = p.cbs * (kMT * 2 * 1024) + ((9 * cout * p.ring + 3) & ~3) * 4 + aff_images * 2 * cin * 4;
   static int cus[64] = {};
   int dev = 0;
   HN_CHECK_HIP(hipGetDevice(&dev));
@@ -474,7 +484,7 @@ static int thin_flat_run(const hn_thin_levels* lv, const hn_thin_affine* aff, in
       t.total = n * t.h * t.w;
       int64_t ul = unit_len;
       if (aff) {   // a range of R pixels touches at most (R - 2) / HW + 2 images: keep that within the LDS table
-        const int64_t cap = (int64_t)(kAffImages - 2) * t.h * t.w + 2 - 2 * (t.w + 1);
+        const int64_t cap = (int64_t)(aff_images - 2) * t.h * t.w + 2 - 2 * (t.w + 1);
         ul = ul < cap ? ul : cap / 64 * 64;
         HN_CHECK_ARG(ul >= 64, "level %d: map too small for the fused GroupNorm apply (hn_conv3x3_thin_affine_applies)", l);
       }
@@ -491,17 +501,16 @@ static int thin_flat_run(const hn_thin_levels* lv, const hn_thin_affine* aff, in
 }
 
 // Does the fused form take this problem?  The plain P form must (hn_conv3x3_thin_uses_flat), the table must fit beside
-// the filter bank and the ring, and every map must be large enough that a 64-pixel range stays within kAffImages images.
+// the filter bank and the ring, and every map must be large enough that a 64-pixel range stays within the table's images.
 extern "C" int hn_conv3x3_thin_affine_applies(const hn_thin_levels* lv, int n, int cin, int cout) {
   if (!hn_conv3x3_thin_uses_flat(lv, n, cin, cout)) return 0;
   int wmax = 1;
-  for (int l = 0; l < lv->count; ++l) {
-    wmax = lv->w[l] > wmax ? lv->w[l] : wmax;
-    if ((int64_t)(kAffImages - 2) * lv->h[l] * lv->w[l] + 2 - 2 * (lv->w[l] + 1) < 64) return 0;
-  }
-  const int64_t lds = (int64_t)(cin / 32) * (kMT * 2 * 1024) + (int64_t)((9 * cout * flat_ring_words(wmax) + 3) & ~3) * 4 +
-                      (int64_t)kAffImages * 2 * cin * 4;
-  return lds <= 160 * 1024 ? 1 : 0;
+  for (int l = 0; l < lv->count; ++l) wmax = lv->w[l] > wmax ? lv->w[l] : wmax;
+  const int k = aff_table_images(cin, cout, wmax);
+  if (!k) return 0;
+  for (int l = 0; l < lv->count; ++l)
+    if ((int64_t)(k - 2) * lv->h[l] * lv->w[l] + 2 - 2 * (lv->w[l] + 1) < 64) return 0;
+  return 1;
 }
 
 extern "C" int hn_conv3x3_thin_affine_f16x3_levels(const hn_thin_levels* lv, const hn_thin_affine* aff, int n, int cin, int cout,

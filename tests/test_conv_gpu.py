@@ -811,3 +811,21 @@ def test_fused_groupnorm_apply_in_the_head_output_kernel_is_bit_identical(n, siz
             assert u.shape == v.shape and torch.equal(u, v)
     # too small a problem (the tap kernel's territory) or maps too small for the table: the query says no
     assert not ops.thin_affine_applies([t[:1] for t in ts], cw)
+
+
+def test_fused_groupnorm_apply_on_a_wide_frame_pyramid():
+    """A 1280 x 720 frame resizes to 1344 x 768 (levels 96 x 168, 48 x 84, 24 x 42): the P-form ring for 168-wide rows leaves
+    room for fewer scale / shift rows in LDS (the table holds what fits, three images at least); still bit-identical."""
+    from hn_amd import ops
+    from hn_amd.weights import ConvW
+    g = torch.Generator().manual_seed(99)
+    cw = ConvW(torch.randn(5, 3, 3, 256, generator=g) * 0.05, torch.randn(5, generator=g), 1, 1, 1).to("cuda")
+    n, sizes = 6, [(96, 160), (48, 80), (24, 40)]
+    ts = [(torch.randn(n, h, w, 512, generator=g) * 3).cuda() for h, w in sizes]
+    aff = [((torch.rand(n, 512, generator=g) + 0.5).cuda(), torch.randn(n, 512, generator=g).cuda()) for _ in sizes]
+    assert ops.thin_affine_applies(ts, cw)
+    a = ops.to_split_levels(ts, aff, relu=True)
+    want = ops.conv3x3_thin_levels([x[:, :, :, 8:] for x in a], cw, relu_cols=4)
+    got = ops.conv3x3_thin_affine_levels(ts, aff, 256, cw, relu_cols=4)
+    for u, v in zip(got, want):
+        assert torch.equal(u, v)
