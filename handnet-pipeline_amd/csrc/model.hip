@@ -508,16 +508,59 @@ struct FcosOut {
   float* dxdymags = nullptr;
 };
 
-int fcos_graph(Ctx& cx, const float* rgb, int n, int h, int w, const FcosOut& out) {
+// a batch of differently sized images (torchvision batch_images, fcos.py:702-709): host tables of the device image
+// pointers and sizes; every image is resized on its own into the common canvas, the boxes are rescaled per image
+struct ImageList {
+  const float* const* images;   // HOST array of n DEVICE pointers to [3][h_i][w_i]
+  const int32_t *hs, *ws;       // HOST
+};
+
+Geometry list_canvas(const hn_model_config& c, const ImageList& ls, int n) {
+  Geometry g{0, 0, 0, 0};
+  for (int i = 0; i < n; ++i) {
+    const Geometry gi = geometry(c, ls.hs[i], ls.ws[i]);
+    g.oh = gi.oh > g.oh ? gi.oh : g.oh;
+    g.ow = gi.ow > g.ow ? gi.ow : g.ow;
+  }
+  g.ph = (g.oh + 31) / 32 * 32;
+  g.pw = (g.ow + 31) / 32 * 32;
+  return g;
+}
+
+int fcos_graph(Ctx& cx, const float* rgb, int n, int h, int w, const FcosOut& out, const ImageList* ls = nullptr) {
   hn_model* m = cx.m;
-  const Geometry g = geometry(m->cfg, h, w);
-  if (out.cap != (int)hn_fcos_capacity(m, h, w))
-    return hn::fail(HN_ERR_ARG, "detection arrays must have hn_fcos_capacity(m, %d, %d) = %d rows per image (got %d)", h, w,
-                    (int)hn_fcos_capacity(m, h, w), out.cap);
+  const Geometry g = ls ? list_canvas(m->cfg, *ls, n) : geometry(m->cfg, h, w);
+  const int want_cap = (g.ph / 8) * (g.pw / 8) + (g.ph / 16) * (g.pw / 16) + (g.ph / 32) * (g.pw / 32);
+  if (out.cap != want_cap)
+    return hn::fail(HN_ERR_ARG, "detection arrays must have hn_fcos_capacity%s = %d rows per image (got %d)", ls ? "_list" : "",
+                    want_cap, out.cap);
   const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
   const int border = 3;
   char* img16 = alloc_bytes(cx, (size_t)2 * n * (g.ph + 2 * border) * (g.pw + 2 * border) * 4 * 2);
-  if (!cx.dry) HN_TRY(hn_fcos_preprocess_split(rgb, img16, n, h, w, g.oh, g.ow, g.ph, g.pw, border, mean, stdv, cx.stream));
+  float* ratios_dev = nullptr;
+  if (ls) {   // device tables: image pointers, (h, w, oh, ow) rows, (ratio_h, ratio_w) rows; uploaded from pageable host memory,
+              // which hipMemcpyAsync stages before it returns
+    const float** ptrs_dev = (const float**)alloc_bytes(cx, (size_t)n * 8);
+    int32_t* geom_dev = (int32_t*)alloc_bytes(cx, (size_t)n * 16);
+    ratios_dev = (float*)alloc_bytes(cx, (size_t)n * 8);
+    if (!cx.dry) {
+      std::vector<int32_t> geom(4 * (size_t)n);
+      std::vector<float> ratios(2 * (size_t)n);
+      for (int i = 0; i < n; ++i) {
+        const Geometry gi = geometry(m->cfg, ls->hs[i], ls->ws[i]);
+        geom[4 * i] = ls->hs[i]; geom[4 * i + 1] = ls->ws[i]; geom[4 * i + 2] = gi.oh; geom[4 * i + 3] = gi.ow;
+        ratios[2 * i] = (float)ls->hs[i] / (float)gi.oh;       // resize_boxes (fcos.py:770-783): fp32 / fp32
+        ratios[2 * i + 1] = (float)ls->ws[i] / (float)gi.ow;
+      }
+      hipStream_t st = (hipStream_t)cx.stream;
+      HN_CHECK_HIP(hipMemcpyAsync((void*)ptrs_dev, ls->images, (size_t)n * 8, hipMemcpyHostToDevice, st));
+      HN_CHECK_HIP(hipMemcpyAsync(geom_dev, geom.data(), (size_t)n * 16, hipMemcpyHostToDevice, st));
+      HN_CHECK_HIP(hipMemcpyAsync(ratios_dev, ratios.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+      HN_TRY(hn_fcos_preprocess_list(ptrs_dev, geom_dev, img16, 1, n, g.ph, g.pw, border, mean, stdv, cx.stream));
+    }
+  } else if (!cx.dry) {
+    HN_TRY(hn_fcos_preprocess_split(rgb, img16, n, h, w, g.oh, g.ow, g.ph, g.pw, border, mean, stdv, cx.stream));
+  }
   int sh, sw;
   out_size(g.ph + 2 * border, g.pw + 2 * border, 7, 7, 2, 0, 1, sh, sw);
   // conv1 + bn1 + relu + 3x3/2 max pooling as ONE kernel (like hn_amd/fcos_engine.py): the half-resolution map is never stored
@@ -689,9 +732,14 @@ int fcos_graph(Ctx& cx, const float* rgb, int n, int h, int w, const FcosOut& ou
   HN_TRY(hn_fcos_candidates_ws(&lv, n, m->cfg.num_classes, 0.7f /* fcos.py:600 */, cb, cs, cl, cd, cv, point, cc, cap, cand_ws,
                                cand_ws_bytes, cx.stream));
   // resize_boxes (fcos.py:770-783): fp32 / fp32
-  const float ratio_h = (float)h / (float)g.oh, ratio_w = (float)w / (float)g.ow;
-  HN_TRY(hn_fcos_nms(cb, cs, cl, cd, cv, cc, n, cap, 0.3 /* fcos.py:635 */, ratio_h, ratio_w, scratch, out.boxes, out.scores,
-                     out.labels, out.sides, out.level, keep, out.count, cx.stream));
+  if (ls) {
+    HN_TRY(hn_fcos_nms_ratios(cb, cs, cl, cd, cv, cc, n, cap, 0.3 /* fcos.py:635 */, ratios_dev, scratch, out.boxes, out.scores,
+                              out.labels, out.sides, out.level, keep, out.count, cx.stream));
+  } else {
+    const float ratio_h = (float)h / (float)g.oh, ratio_w = (float)w / (float)g.ow;
+    HN_TRY(hn_fcos_nms(cb, cs, cl, cd, cv, cc, n, cap, 0.3 /* fcos.py:635 */, ratio_h, ratio_w, scratch, out.boxes, out.scores,
+                       out.labels, out.sides, out.level, keep, out.count, cx.stream));
+  }
   if (out.contacts) {
     const float* ext_ptrs[HN_FCOS_MAX_LEVELS] = {(const float*)ext_lv[0].p, (const float*)ext_lv[1].p, (const float*)ext_lv[2].p, nullptr, nullptr};
     HN_TRY(hn_fcos_ext_gather(&lv, ext_ptrs, keep, point, out.count, n, cap, out.contacts, out.dxdymags, cx.stream));
@@ -906,6 +954,30 @@ extern "C" int64_t hn_fcos_capacity(const hn_model* m, int h, int w) {
   if (!m || h <= 0 || w <= 0) return 0;
   const Geometry g = geometry(m->cfg, h, w);
   return (int64_t)(g.ph / 8) * (g.pw / 8) + (int64_t)(g.ph / 16) * (g.pw / 16) + (int64_t)(g.ph / 32) * (g.pw / 32);
+}
+
+extern "C" int64_t hn_fcos_capacity_list(const hn_model* m, const int32_t* hs, const int32_t* ws, int n) {
+  if (!m || !hs || !ws || n <= 0) return 0;
+  for (int i = 0; i < n; ++i)
+    if (hs[i] <= 0 || ws[i] <= 0) return 0;
+  const ImageList ls{nullptr, hs, ws};
+  const Geometry g = list_canvas(m->cfg, ls, n);
+  return (int64_t)(g.ph / 8) * (g.pw / 8) + (int64_t)(g.ph / 16) * (g.pw / 16) + (int64_t)(g.ph / 32) * (g.pw / 32);
+}
+
+extern "C" int hn_fcos_forward_list(hn_model* m, const float* const* images, const int32_t* hs, const int32_t* ws, int n,
+                                    float* det_boxes, float* det_scores, int32_t* det_labels, int32_t* det_sides,
+                                    int32_t* det_level, int32_t* det_count, int cap, void* stream) {
+  HN_CHECK_ARG(m && images && hs && ws && det_boxes && det_scores && det_labels && det_sides && det_level && det_count,
+               "hn_fcos_forward_list: null pointer");
+  HN_CHECK_ARG(m->cfg.parts & HN_MODEL_FCOS, "model was created without HN_MODEL_FCOS");
+  HN_CHECK_ARG(n > 0, "empty image list");
+  for (int i = 0; i < n; ++i) HN_CHECK_ARG(images[i] && hs[i] > 0 && ws[i] > 0, "image %d: null pointer or empty", i);
+  const ImageList ls{images, hs, ws};
+  const Geometry g = list_canvas(m->cfg, ls, n);
+  const std::string key = "fcosl:" + std::to_string(n) + "x" + std::to_string(g.ph) + "x" + std::to_string(g.pw);
+  FcosOut out{det_boxes, det_scores, det_labels, det_sides, det_level, det_count, cap};
+  return run_planned(m, key, stream, [&](Ctx& cx) -> int { return fcos_graph(cx, nullptr, n, 0, 0, out, &ls); });
 }
 
 extern "C" int hn_a2j_forward(hn_model* m, const float* crops, int k, int h, int w, const int32_t* valid, float* keypoints,

@@ -12,7 +12,7 @@ from pathlib import Path
 
 from . import build as _build
 
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, TILE_256x128, TILE_64x128 = range(7)
 HN_FCOS_MAX_LEVELS = 5
@@ -138,6 +138,9 @@ SIGNATURES = {
     "hn_fcos_capacity": (C.c_int64, [VP, C.c_int, C.c_int]),
     "hn_fcos_forward": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int] + [VP] * 6 + [C.c_int, VP]),
     "hn_fcos_forward_ext": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int] + [VP] * 8 + [C.c_int, VP]),
+    "hn_fcos_capacity_list": (C.c_int64, [VP, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int]),
+    "hn_fcos_forward_list": (C.c_int, [VP, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int,
+                                       VP, VP, VP, VP, VP, VP, C.c_int, VP]),
     "hn_a2j_forward": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, VP, VP, VP]),
     "hn_handnet_forward": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP]),
     "hn_destroy": (C.c_int, [VP]),

@@ -76,6 +76,25 @@ class NativeModel:
                   "hn_fcos_forward")
         return out
 
+    def fcos_list(self, images):
+        """A list of fp32 GPU [3,h_i,w_i] images of different sizes (torchvision batch_images, fcos.py:702-709) -> the
+        same tuple as fcos(), boxes rescaled per image (hn_fcos_forward_list)."""
+        imgs = [i.float().contiguous() for i in images]
+        k = len(imgs)
+        hs = (C.c_int32 * k)(*[int(i.shape[1]) for i in imgs])
+        ws = (C.c_int32 * k)(*[int(i.shape[2]) for i in imgs])
+        ptrs = (C.c_void_p * k)(*[i.data_ptr() for i in imgs])
+        cap = int(self.lib.hn_fcos_capacity_list(self._h, hs, ws, k))
+        with on_device(self.device):
+            i32 = dict(device=self.device, dtype=torch.int32)
+            out = (torch.zeros((k, cap, 4), device=self.device), torch.zeros((k, cap), device=self.device),
+                   torch.zeros((k, cap), **i32), torch.zeros((k, cap), **i32), torch.zeros((k, cap), **i32),
+                   torch.zeros((k,), **i32))
+            check(self.lib.hn_fcos_forward_list(self._h, ptrs, hs, ws, k, *[ptr(t) for t in out], cap, _stream()),
+                  "hn_fcos_forward_list")
+            torch.cuda.current_stream().synchronize()   # the graph reads `imgs` asynchronously: keep them alive until it has
+        return out
+
     def fcos_ext(self, rgb):
         """ext=True detector: fcos() outputs + (contacts [N,cap] int32, dxdymags [N,cap,3])"""
         rgb = rgb.float().contiguous()

@@ -33,7 +33,7 @@ extern "C" {
 #define HN_ERR_HIP 2
 
 /* ABI version; bumped whenever a struct below changes. */
-#define HN_ABI_VERSION 29
+#define HN_ABI_VERSION 30
 int hn_abi_version(void);
 const char* hn_last_error(void);
 
@@ -518,6 +518,13 @@ int64_t hn_fcos_capacity(const hn_model* m, int h, int w);
 int hn_fcos_forward(hn_model* m, const float* rgb, int n, int h, int w, float* det_boxes, float* det_scores,
                     int32_t* det_labels, int32_t* det_sides, int32_t* det_level, int32_t* det_count, int cap,
                     void* stream);
+/* A list of differently sized images (torchvision batch_images, fcos.py:702-709, as FCOS.forward takes it): images = HOST
+ * array of n DEVICE pointers to fp32 [3][hs[i]][ws[i]], hs / ws HOST arrays.  Each image is resized on its own into the
+ * common canvas and its boxes are rescaled by its own ratios; cap = hn_fcos_capacity_list(m, hs, ws, n). */
+int64_t hn_fcos_capacity_list(const hn_model* m, const int32_t* hs, const int32_t* ws, int n);
+int hn_fcos_forward_list(hn_model* m, const float* const* images, const int32_t* hs, const int32_t* ws, int n,
+                         float* det_boxes, float* det_scores, int32_t* det_labels, int32_t* det_sides, int32_t* det_level,
+                         int32_t* det_count, int cap, void* stream);
 /* ext=True detections (fcos.py:637-647): additionally det_contacts [n][cap] (argmax of the contact state) and
  * det_dxdymags [n][cap][3] (magnitude, 0.1 * unit dx, 0.1 * unit dy) per kept detection. */
 int hn_fcos_forward_ext(hn_model* m, const float* rgb, int n, int h, int w, float* det_boxes, float* det_scores,

@@ -160,3 +160,33 @@ def test_f16x1_mode_through_the_model_abi(native, fcos_sd, a2j_sd):
         cfg = _lib.ModelConfig(parts=_lib.MODEL_A2J, num_classes=3, num_joints=21, f16_terms=2)
         h = C.c_void_p()
         _lib.check(_lib.load().hn_create(C.byref(cfg), C.byref(h)), "hn_create")
+
+
+def test_fcos_forward_list_equals_python_engine(native, fcos_sd):
+    """hn_fcos_forward_list: differently sized images through the C++ layer graph (torchvision batch_images semantics,
+    fcos.py:702-709: each image resized on its own into the common canvas, boxes rescaled per image) == FCOSEngine.detect
+    on the same list, bit for bit; and a list of equal sizes == the batched entry point."""
+    from hn_amd import synth
+    from hn_amd.fcos_engine import FCOSEngine
+    eng = FCOSEngine(fcos_sd, 3, device="cuda")
+    full = synth.make_rgb(3, seed=1200).cuda()
+    images = [full[0], full[1][:, :400, :560].contiguous(), full[2][:, :300, :].contiguous()]
+    det, _ = eng.detect(images)
+    boxes, scores, labels, sides, level, count = native.fcos_list(images)
+    assert boxes.shape[1] == det.scores.shape[1] and torch.equal(count, det.count)
+    for i, k in enumerate(count.tolist()):
+        assert torch.equal(boxes[i, :k], det.boxes[i, :k]) and torch.equal(scores[i, :k], det.scores[i, :k])
+        assert torch.equal(labels[i, :k], det.labels[i, :k]) and torch.equal(level[i, :k], det.level[i, :k])
+    assert int(count.max()) > 0
+    same = [full[0], full[1], full[2]]
+    a, b = native.fcos_list(same), native.fcos(full)
+    assert torch.equal(a[5], b[5])
+    for i, k in enumerate(a[5].tolist()):
+        assert torch.equal(a[0][i, :k], b[0][i, :k]) and torch.equal(a[1][i, :k], b[1][i, :k])
+    with pytest.raises(RuntimeError, match="hn_fcos_forward_list"):
+        i32 = dict(device="cuda", dtype=torch.int32)
+        hs, ws, ptrs = (C.c_int32 * 1)(480), (C.c_int32 * 1)(640), (C.c_void_p * 1)(full[0].data_ptr())
+        bad = torch.zeros((1, 7, 4), device="cuda")
+        from hn_amd._lib import check
+        check(native.lib.hn_fcos_forward_list(native._h, ptrs, hs, ws, 1, bad.data_ptr(), bad.data_ptr(), bad.data_ptr(),
+                                              bad.data_ptr(), bad.data_ptr(), bad.data_ptr(), 7, None), "hn_fcos_forward_list")
