@@ -462,3 +462,23 @@ def test_dropin_forward_switches_itself_to_graph_replay(fcos_sd, a2j_sd):
         for rgb, dep in frames * 2:
             net([rgb[0]], depth_images=dep)
         assert len(net.engine()._graphs) == 1
+
+
+def test_pipeline_is_deterministic_over_many_steps(fcos_sd, a2j_sd):
+    """A race in any of the hand-synchronised kernels (LDS rings, counted waits, chunked compaction, fused GroupNorm apply)
+    would show as run-to-run differences: 60 steps of the full batch-32 pipeline and 200 of the single-frame pipeline on
+    fixed inputs, every output bit-identical to the first step's."""
+    from hn_amd import synth
+    from hn_amd.a2j_engine import A2JEngine
+    from hn_amd.fcos_engine import FCOSEngine
+    from hn_amd.pipeline import HandNetEngine
+    eng = HandNetEngine(FCOSEngine(fcos_sd, 3, device="cuda"), A2JEngine(a2j_sd, device="cuda"), 3)
+    for n, steps in ((32, 60), (1, 200)):
+        rgb, depth = synth.make_rgb(n, seed=1000).cuda(), synth.make_depth(n, seed=2000).cuda()
+        ref = eng.forward_device(rgb, depth)
+        kp0, box0, has0 = ref.keypoints.clone(), ref.crop_box.clone(), ref.has_hand.clone()
+        bad = torch.zeros((), device="cuda", dtype=torch.int64)
+        for _ in range(steps):
+            out = eng.forward_device(rgb, depth)
+            bad += (out.keypoints != kp0).sum() + (out.crop_box != box0).sum() + (out.has_hand != has0).sum()
+        assert int(bad) == 0
