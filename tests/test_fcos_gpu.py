@@ -489,3 +489,26 @@ def test_chunked_candidates_equal_the_single_workgroup_form(n, sizes, thresh):
             assert torch.equal(getattr(a, f)[i, :k], getattr(b, f)[i, :k]), f
     lib = _lib.load()
     assert lib.hn_fcos_candidates_ws_bytes(2, 17850) == 2 * 18 * 4 and lib.hn_fcos_candidates_ws_bytes(0, 5) == 0
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 480, 640), (1, 720, 1280), (3, 300, 333), (1, 1200, 1600)])
+def test_tiled_preprocess_is_bit_identical_to_the_per_pixel_kernel(n, h, w, monkeypatch):
+    """fcos_preprocess_split_tiled_kernel normalises the source rectangle of an 8 x 128 output tile once into LDS and
+    interpolates from there: the same divisions on the same values and the same interpolation expressions as the per-pixel
+    kernel (tv GeneralizedRCNNTransform: normalize, then bilinear resize, fcos.py:702-709) -> torch.equal on the stem image,
+    for up- and down-scaling frames (the 1200 x 1600 frame is DOWNscaled: its tiles need more source rows than the patch
+    holds only beyond scale 1.85, so it still takes the tiled kernel)."""
+    from hn_amd import ops, synth
+    from hn_amd.fcos_engine import FCOSEngine, IMAGE_MEAN, IMAGE_STD, resized_size
+    x = synth.make_rgb(n, h, w, seed=7).cuda()
+    oh, ow = resized_size(h, w, 800, 1333)
+    ph, pw = (oh + 31) // 32 * 32, (ow + 31) // 32 * 32
+    a = ops.fcos_preprocess_split(x, oh, ow, ph, pw, IMAGE_MEAN, IMAGE_STD)
+    monkeypatch.setenv("HN_PREPROCESS_GENERIC", "1")
+    ops.reread_env()
+    try:
+        b = ops.fcos_preprocess_split(x, oh, ow, ph, pw, IMAGE_MEAN, IMAGE_STD)
+    finally:
+        monkeypatch.delenv("HN_PREPROCESS_GENERIC")
+        ops.reread_env()
+    assert a.shape == b.shape and torch.equal(a, b)
