@@ -76,8 +76,10 @@ __global__ __launch_bounds__(1024) void a2j_aggregate_kernel(const float* __rest
   const int a = cl / Jw, jl = cl - a * Jw;
   const bool active = g < G && jl < jn;
   const int c = a * J + j0 + jl;        // channel in memory
-  if (valid && valid[k] == 0) {  // uniform per workgroup
-    if ((int)threadIdx.x < jn * 3) out[((long)k * J + j0) * 3 + threadIdx.x] = 0.f;
+  if (valid && valid[k] != 1) {  // uniform per workgroup: 0 = no crop (zero row), 2 = non-finite crop (NaN row, as the
+    // reference's network returns for it: every cell of the 11 x 11 maps sees every pixel of the crop)
+    if ((int)threadIdx.x < jn * 3)
+      out[((long)k * J + j0) * 3 + threadIdx.x] = valid[k] == 0 ? 0.f : __builtin_nanf("");
     return;
   }
   const int cells = fh * fw;
@@ -359,7 +361,7 @@ extern "C" int hn_nonfinite_count_f32(const float* x, int64_t count, int32_t* fl
 namespace {
 typedef _Float16 f16x4s __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void stem_image_kernel(const float* __restrict__ x, _Float16* __restrict__ dst, int n, int h,
-                                                         int w, int b, int* range_flag) {
+                                                         int w, int b, int* range_flag, int* __restrict__ valid) {
   const int hb = h + 2 * b, wb = w + 2 * b;
   const long total = (long)n * hb * wb;
   _Float16* lo_plane = dst + total * 4;
@@ -374,7 +376,9 @@ __global__ __launch_bounds__(256) void stem_image_kernel(const float* __restrict
       const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((long)img * h + sy) * w + sx) * 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        if (range_flag) hn::range_note(range_flag, v[e]);
+        if (range_flag) hn::range_note_input(range_flag, v[e]);
+        // a non-finite pixel: mark the image (every writer stores the same value; images with valid == 0 stay 0)
+        if (valid && !(fabsf(v[e]) <= 3.402823466e38f) && valid[img] == 1) valid[img] = 2;
         const _Float16 hh = (_Float16)v[e];
         hi[e] = hh;
         lo[e] = (_Float16)(v[e] - (float)hh);
@@ -387,13 +391,18 @@ __global__ __launch_bounds__(256) void stem_image_kernel(const float* __restrict
 }  // namespace
 
 extern "C" int hn_stem_image_nhwc4(const float* x, int n, int h, int w, int border, void* dst16, void* stream) {
+  return hn_stem_image_nhwc4_valid(x, n, h, w, border, dst16, nullptr, stream);
+}
+
+extern "C" int hn_stem_image_nhwc4_valid(const float* x, int n, int h, int w, int border, void* dst16, int32_t* valid,
+                                         void* stream) {
   HN_CHECK_ARG(x && dst16, "hn_stem_image_nhwc4: null pointer");
   HN_CHECK_ARG(n > 0 && h > 0 && w > 0 && border >= 0 && border <= 4, "bad dims");
   HN_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)dst16 % 8 == 0, "unaligned tensors");
   const long total = (long)n * (h + 2 * border) * (w + 2 * border);
   const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
   hipLaunchKernelGGL(stem_image_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (_Float16*)dst16, n, h, w, border,
-                     hn::range_flag_ptr());
+                     hn::range_flag_ptr(), valid);
   HN_CHECK_LAUNCH("stem_image_kernel");
   return HN_OK;
 }

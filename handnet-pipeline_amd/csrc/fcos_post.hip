@@ -34,6 +34,18 @@ __device__ __forceinline__ void src_index(float scale, int dst, int in_size, int
   l0 = 1.f - l1;
 }
 
+// The interpolation itself, in the operation order of ATen's CPU kernel (UpSampleKernel.cpp: horizontal pairs first, each
+// `w0 * a + w1 * b` contracted by its build into fma(a, w0, b * w1)): with this order and the fused source index above the
+// canvas is BIT-IDENTICAL to F.interpolate(..., mode="bilinear", align_corners=False) of the torch build in this image
+// (tests/test_fcos_gpu.py::test_preprocess_matches_transform), so a constant image stays constant and the score ties of
+// such a frame are the oracle's ties.  (This file is built with -ffp-contract=off: only the explicit fmaf fuse.)
+__device__ __forceinline__ float bilerp(float v00, float v01, float v10, float v11, float wx0, float wx1, float wy0,
+                                        float wy1) {
+  const float r0 = fmaf(v00, wx0, v01 * wx1);
+  const float r1 = fmaf(v10, wx0, v11 * wx1);
+  return fmaf(r0, wy0, r1 * wy1);
+}
+
 // Batches of differently sized images (torchvision batch_images, fcos_utils/fcos.py:702-709): image `img` is
 // its own [3][h][w] buffer srcs[img] with geometry geom[img] = {h, w, oh, ow}; every image is resized on its own
 // and lands in the top-left corner of the common zero-padded canvas.  Null tables = one dense [n][3][h][w] batch.
@@ -74,9 +86,7 @@ __global__ __launch_bounds__(256) void fcos_preprocess_kernel(const float* __res
         const float m = nm.mean[c], s = nm.stdv[c];
         const float v00 = (pl[(long)y0 * w + x0] - m) / s, v01 = (pl[(long)y0 * w + x1] - m) / s;
         const float v10 = (pl[(long)y1 * w + x0] - m) / s, v11 = (pl[(long)y1 * w + x1] - m) / s;
-        const float r0 = v00 * wx0 + v01 * wx1;
-        const float r1 = v10 * wx0 + v11 * wx1;
-        o[c] = r0 * wy0 + r1 * wy1;
+        o[c] = bilerp(v00, v01, v10, v11, wx0, wx1, wy0, wy1);
       }
     }
     *reinterpret_cast<f32x4*>(dst + i * 4) = o;
@@ -116,15 +126,13 @@ __global__ __launch_bounds__(256) void fcos_preprocess_split_kernel(const float*
         const float m = nm.mean[c], s = nm.stdv[c];
         const float v00 = (pl[(long)y0 * w + x0] - m) / s, v01 = (pl[(long)y0 * w + x1] - m) / s;
         const float v10 = (pl[(long)y1 * w + x0] - m) / s, v11 = (pl[(long)y1 * w + x1] - m) / s;
-        const float r0 = v00 * wx0 + v01 * wx1;
-        const float r1 = v10 * wx0 + v11 * wx1;
-        o[c] = r0 * wy0 + r1 * wy1;
+        o[c] = bilerp(v00, v01, v10, v11, wx0, wx1, wy0, wy1);
       }
     }
     f16x4 hi, lo;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      if (range_flag) hn::range_note(range_flag, o[c]);
+      if (range_flag) hn::range_note_input(range_flag, o[c]);
       hi[c] = (_Float16)o[c];
       lo[c] = (_Float16)(o[c] - (float)hi[c]);
     }
@@ -201,14 +209,12 @@ __global__ __launch_bounds__(256) void fcos_preprocess_split_tiled_kernel(const 
         for (int c = 0; c < 3; ++c) {
           const float v00 = tile[c][y0 - ys0][x0[j] - xs0], v01 = tile[c][y0 - ys0][x1[j] - xs0];
           const float v10 = tile[c][y1 - ys0][x0[j] - xs0], v11 = tile[c][y1 - ys0][x1[j] - xs0];
-          const float r0 = v00 * wx0[j] + v01 * wx1[j];
-          const float r1 = v10 * wx0[j] + v11 * wx1[j];
-          o[c] = r0 * wy0 + r1 * wy1;
+          o[c] = bilerp(v00, v01, v10, v11, wx0[j], wx1[j], wy0, wy1);
         }
       }
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        if (range_flag) hn::range_note(range_flag, o[c]);
+        if (range_flag) hn::range_note_input(range_flag, o[c]);
         const _Float16 hh = (_Float16)o[c];
         hi[j * 4 + c] = hh;
         lo[j * 4 + c] = (_Float16)(o[c] - (float)hh);

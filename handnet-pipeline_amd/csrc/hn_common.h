@@ -54,5 +54,11 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 __device__ __forceinline__ void range_note(int* flag, float v) {
   if (!(fabsf(v) <= 65504.f)) *flag = 1;
 }
+// the same for a value that comes straight from the caller's INPUT (preprocessed RGB, depth crops): word 1 of the flag
+// block for a finite value beyond the fp16 range, word 2 for a non-finite one (NaN / inf pixels of a depth camera, which
+// the reference passes through: ros_demo.py:227-231).  `flag` = range_flag_ptr().
+__device__ __forceinline__ void range_note_input(int* flag, float v) {
+  if (!(fabsf(v) <= 65504.f)) flag[fabsf(v) <= 3.402823466e38f ? 1 : 2] = 1;
+}
 
 }  // namespace hn

@@ -6,15 +6,21 @@
 
 #include <string.h>
 
-// Sticky per-device flag of the f16x3 range contract (hn_range_check_enable): set by any producer of split
-// (hi + lo fp16) data that meets a value outside the fp16 range or a non-finite one.
-__device__ int g_range_flag;
+// Sticky per-device flags of the f16x3 range contract (hn_range_check_enable): set by any producer of split
+// (hi + lo fp16) data that meets a value outside the fp16 range or a non-finite one.  Word 0: an ACTIVATION (conv epilogue,
+// GroupNorm apply); word 1: a finite INPUT value beyond +-65504 (preprocessed RGB, depth crop); word 2: a non-finite input
+// value (a depth camera's NaN / inf pixels); word 3 unused.
+__device__ int g_range_flag[4];
 static int g_range_check_on = 0;
+// hn_range_check_bind: the caller's own flag block (4 device words) instead of the library's, so that two engines of one
+// process never see each other's flags; read at LAUNCH time on the host, like the switch itself
+static int* g_range_bound = nullptr;
 
 namespace hn {
 
 int* range_flag_ptr() {
   if (!g_range_check_on) return nullptr;
+  if (g_range_bound) return g_range_bound;
   static int* ptrs[64] = {nullptr};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
@@ -111,22 +117,50 @@ extern "C" int hn_event_elapsed_ms(void* start, void* stop, float* ms) {
   return HN_OK;
 }
 
-// ---- f16x3 range contract (debug switch) ----
+// ---- f16x3 range contract ----
 extern "C" int hn_range_check_enable(int on) {
   g_range_check_on = on ? 1 : 0;
+  return HN_OK;
+}
+
+extern "C" int hn_range_check_enabled(void) { return g_range_check_on; }
+
+extern "C" int hn_range_check_bind(int32_t* block) {
+  g_range_bound = block;
   return HN_OK;
 }
 
 extern "C" int hn_range_check_fetch(int* flag, int reset, void* stream) {
   HN_CHECK_ARG(flag, "hn_range_check_fetch: null");
   void* p = nullptr;
+  int words[4] = {0, 0, 0, 0};
   HN_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(g_range_flag)));
-  HN_CHECK_HIP(hipMemcpyAsync(flag, p, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HN_CHECK_HIP(hipMemcpyAsync(words, p, sizeof(words), hipMemcpyDeviceToHost, (hipStream_t)stream));
   HN_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  *flag = (words[0] ? HN_RANGE_ACTIVATION : 0) | (words[1] ? HN_RANGE_INPUT : 0) | (words[2] ? HN_RANGE_INPUT_NONFINITE : 0);
   if (reset) {
-    HN_CHECK_HIP(hipMemsetAsync(p, 0, sizeof(int), (hipStream_t)stream));
+    HN_CHECK_HIP(hipMemsetAsync(p, 0, sizeof(words), (hipStream_t)stream));
     HN_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
   }
+  return HN_OK;
+}
+
+namespace {
+__global__ void range_collect_kernel(int* __restrict__ flags, int* __restrict__ dst) {
+  const int t = threadIdx.x;
+  if (t < 4) {
+    dst[t] = flags[t];
+    flags[t] = 0;
+  }
+}
+}  // namespace
+
+extern "C" int hn_range_check_collect(int32_t* block, int32_t* dst, void* stream) {
+  HN_CHECK_ARG(dst, "hn_range_check_collect: null");
+  void* p = block;
+  if (!p) HN_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(g_range_flag)));
+  hipLaunchKernelGGL(range_collect_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (int*)p, dst);
+  HN_CHECK_LAUNCH("range_collect_kernel");
   return HN_OK;
 }
 

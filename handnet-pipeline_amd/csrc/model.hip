@@ -59,10 +59,11 @@ struct Arena {
   char* base = nullptr;
   size_t cap = 0, off = 0;
   bool dry = false;
+  bool overflow = false;   // a real pass asked for more than the planned bytes (run_planned fails the call)
   struct Block { size_t off, bytes; };
   std::vector<Block> free_blocks;
   char* origin() const { return dry ? (char*)0x1000 : base; }
-  void reset() { off = 0; free_blocks.clear(); }
+  void reset() { off = 0; overflow = false; free_blocks.clear(); }
   char* take(size_t bytes) {
     bytes = (bytes + 255) & ~(size_t)255;
     int best = -1;
@@ -75,6 +76,10 @@ struct Arena {
       return origin() + b.off;
     }
     const size_t a = (off + 255) & ~(size_t)255;
+    if (!dry && a + bytes > cap) {   // never hand out memory beyond the arena: alias its start and report
+      overflow = true;
+      return base;
+    }
     off = a + bytes;
     return origin() + a;
   }
@@ -109,6 +114,7 @@ struct hn_model {
   std::map<std::string, size_t> plan;  // arena bytes per (entry, n, h, w)
   void* last_stream = nullptr;         // stream of the previous forward (the arena is per model, not per stream)
   bool has_last_stream = false;
+  hipEvent_t done = nullptr;           // recorded at the end of every forward: a forward on ANOTHER stream waits for it
 };
 
 namespace {
@@ -407,13 +413,16 @@ int conv_thin_levels(Ctx& cx, const GroupSpec& g, int relu_cols) {
 // ------------------------------------------------------------------------------------------------------------------
 // A2J (hn_amd/a2j_engine.py)
 // ------------------------------------------------------------------------------------------------------------------
-int a2j_graph(Ctx& cx, const T& crops /* fp32 [k][176][176][4] */, const int32_t* valid, float* keypoints) {
+// valid_rw: the per-crop flags when they are the model's own to update (hn_handnet_forward's has_hand: a crop with non-finite
+// pixels becomes 2 = NaN keypoints, like the Python engine); null for a caller's read-only flags
+int a2j_graph(Ctx& cx, const T& crops /* fp32 [k][176][176][4] */, const int32_t* valid, float* keypoints,
+              int32_t* valid_rw = nullptr) {
   hn_model* m = cx.m;
   const int k = crops.n;
   // stem: conv1 + bn1 + relu + maxpool as ONE split-precision kernel on the crops' stem image (like hn_amd/a2j_engine.py)
   const int border = 3;
   char* img16 = alloc_bytes(cx, (size_t)2 * k * (crops.h + 2 * border) * (crops.w + 2 * border) * 4 * 2);
-  if (!cx.dry) HN_TRY(hn_stem_image_nhwc4((const float*)crops.p, k, crops.h, crops.w, border, img16, cx.stream));
+  if (!cx.dry) HN_TRY(hn_stem_image_nhwc4_valid((const float*)crops.p, k, crops.h, crops.w, border, img16, valid_rw, cx.stream));
   int sh, sw;
   out_size(crops.h + 2 * border, crops.w + 2 * border, 7, 7, 2, 0, 1, sh, sw);
   T x = alloc(cx, k, (sh + 2 - 3) / 2 + 1, (sw + 2 - 3) / 2 + 1, 64, true);
@@ -749,9 +758,14 @@ int fcos_graph(Ctx& cx, const float* rgb, int n, int h, int w, const FcosOut& ou
 
 // dry pass (sizes the arena) + real pass
 template <class F>
-int run_planned(hn_model* m, const std::string& key, void* stream, F&& graph) {
+int run_planned(hn_model* m, const std::string& key0, void* stream, F&& graph) {
   HN_CHECK_ARG(m && m->finalized, "model is not finalized (hn_finalize)");
   t_terms = m->cfg.f16_terms == 1 ? 1 : 0;
+  // the take / give sequence of a graph depends on the library's A/B switches (hn_reread_env): a plan is only valid for
+  // the switch state it was sized under
+  const hn::EnvFlags& ef = hn::env_flags();
+  const int sw = (ef.no_thin ? 1 : 0) | (ef.thin_tap ? 2 : 0) | (ef.thin_flat ? 4 : 0) | (ef.no_fuse_last_gn ? 8 : 0);
+  const std::string key = key0 + "/" + std::to_string(sw);
   auto it = m->plan.find(key);
   size_t bytes;
   if (it == m->plan.end()) {
@@ -773,16 +787,33 @@ int run_planned(hn_model* m, const std::string& key, void* stream, F&& graph) {
     HN_CHECK_HIP(hipMalloc((void**)&m->arena.base, bytes));
     m->arena.cap = bytes;
   }
-  // the arena is shared by every forward of this model: calls on different streams would use the same buffers without
-  // ordering, so a change of stream waits for the work of the previous one (steady-state callers keep one stream)
-  if (m->has_last_stream && m->last_stream != stream) HN_CHECK_HIP(hipStreamSynchronize((hipStream_t)m->last_stream));
-  m->last_stream = stream;
-  m->has_last_stream = true;
+  // The arena is shared by every forward of this model: calls on different streams would use the same buffers without
+  // ordering, so a forward on another stream than the previous one first waits (on the device) for the event the previous
+  // forward recorded at its end.  Steady-state callers keep one stream and pay nothing; no raw stream handle of an earlier
+  // call is ever touched again, and nothing here synchronises the host (legal under stream capture as well, where the
+  // event bookkeeping is skipped: a captured step is replayed on one stream by construction).
+  hipStreamCaptureStatus cap_st = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing((hipStream_t)stream, &cap_st);
+  const bool capturing = cap_st != hipStreamCaptureStatusNone;
+  if (!capturing) {
+    if (!m->done) HN_CHECK_HIP(hipEventCreateWithFlags(&m->done, hipEventDisableTiming));
+    if (m->has_last_stream && m->last_stream != stream) HN_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, m->done, 0));
+  }
   m->arena.dry = false;
   m->arena.reset();
   Ctx cx{m, stream, false, nullptr};
   cx.ws = m->arena.take(kConvWorkspaceBytes);
-  return graph(cx);
+  const int st = graph(cx);
+  if (!capturing) {
+    // (recorded also after a failed graph: whatever it enqueued still uses the arena)
+    HN_CHECK_HIP(hipEventRecord(m->done, (hipStream_t)stream));
+    m->last_stream = stream;
+    m->has_last_stream = true;
+  }
+  if (st == HN_OK && m->arena.overflow)
+    return hn::fail(HN_ERR_ARG, "model arena overflow: the graph asked for more than the %zu bytes planned for '%s' (results of this "
+                    "call are invalid)", m->arena.cap, key.c_str());
+  return st;
 }
 
 }  // namespace
@@ -1044,7 +1075,7 @@ extern "C" int hn_handnet_forward(hn_model* m, const float* rgb, const float* de
     if (!cx.dry)
       HN_TRY(hn_crop_resize(out.boxes, out.labels, out.count, cap, m->cfg.num_classes - 1, depth, n, m->cfg.rgbd ? 4 : 1,
                             m->cfg.rgbd ? 1 : 0, h, w, kCrop, 4, crop_box, has_hand, (float*)crops.p, cx.stream));
-    return a2j_graph(cx, crops, has_hand, keypoints);
+    return a2j_graph(cx, crops, has_hand, keypoints, has_hand);
   });
 }
 
@@ -1052,6 +1083,7 @@ extern "C" int hn_destroy(hn_model* m) {
   if (!m) return HN_OK;
   for (void* p : m->owned) (void)hipFree(p);
   if (m->arena.base) (void)hipFree(m->arena.base);
+  if (m->done) (void)hipEventDestroy(m->done);
   delete m;
   return HN_OK;
 }

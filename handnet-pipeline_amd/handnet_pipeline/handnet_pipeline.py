@@ -17,6 +17,8 @@ the previous frame's crop (:100-105); here such frames simply count as "no hand"
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from a2j.a2j import A2JModel
@@ -64,6 +66,7 @@ class HandNet(EngineOwner):
         # the reference keeps the caller's flag (handnet_pipeline.py:55); a Lightning checkpoint knows its own stem
         self.RGBD = bool(self.a2j.rgbd) if isinstance(self.a2j, A2JModelLightning) else bool(RGBD)
         self.num_classes = num_classes
+        self._auto_graph_allowed = os.environ.get("HN_AUTO_GRAPH", "1") != "0"
 
     def engine(self) -> HandNetEngine:
         self._require_gpu()
@@ -81,6 +84,9 @@ class HandNet(EngineOwner):
     # first call and also for forward_device().
     AUTO_GRAPH_CALLS = 3        # same-shape calls in a row before forward() captures
     AUTO_GRAPH_MAX_SHAPES = 4   # distinct input shapes captured automatically (each holds its own static buffers)
+    # HN_AUTO_GRAPH=0 in the environment keeps forward() eager; a capture that FAILS (no memory for the static pool, a
+    # capture-unsafe call from another thread of the host) is not an error of the call: forward() runs that call eagerly and
+    # never tries again (self._auto_graph_allowed = False), see _forward_auto.
     # A SPARSE stream (a hand in fewer than half of the frames of a batch of >= 8: forward() sees the flags on the CPU anyway)
     # stays eager, because the engine then runs A2J on the frames with a hand only and that path is data dependent.
 
@@ -91,20 +97,24 @@ class HandNet(EngineOwner):
         call; forward() returns fresh tensors either way); on=False: never; on=None: the default -- forward() decides by
         itself (see AUTO_GRAPH_*), forward_device() stays eager."""
         self.use_graph = None if on is None else bool(on)
+        if on:
+            self._auto_graph_allowed = True
         return self
 
     def _auto_graph(self, batch, depth) -> bool:
+        """Whether this call of forward() should run as a graph replay (capturing first if need be)."""
         eng = self.engine()
-        if eng.check_range or getattr(self, "_last_sparse", False) or not (batch.is_cuda and depth.is_cuda):
+        if (not self._auto_graph_allowed or eng.check_range or getattr(self, "_last_sparse", False)
+                or not (batch.is_cuda and depth.is_cuda)):
             return False
-        key = (tuple(batch.shape), tuple(depth.shape))
-        if key in eng._graphs:
+        if eng.has_graph(batch.shape, depth.shape):
             return True
+        key = (tuple(batch.shape), tuple(depth.shape))
         if key == getattr(self, "_streak_key", None):
             self._streak += 1
         else:
             self._streak_key, self._streak = key, 1
-        return self._streak > self.AUTO_GRAPH_CALLS and len(eng._graphs) < self.AUTO_GRAPH_MAX_SHAPES
+        return self._streak > self.AUTO_GRAPH_CALLS and eng.graph_count() < self.AUTO_GRAPH_MAX_SHAPES
 
     def forward_device(self, images, depth_images, _graph=None):
         """Sync-free variant: returns hn_amd.pipeline.HandNetOutput with everything on the GPU."""
@@ -118,6 +128,53 @@ class HandNet(EngineOwner):
             return out
         return self.engine().forward_device(batch, depth_images)
 
+    def _forward_auto(self, images, depth_images, n):
+        """forward() in its default mode: replay when a captured step fits, capture when the shapes have repeated, else eager."""
+        eng = self.engine()
+        if (self._auto_graph_allowed and not torch.is_tensor(images) and n and depth_images.is_cuda
+                and depth_images.dtype == torch.float32 and all(i.dtype == torch.float32 and i.is_cuda for i in images)
+                and not eng.check_range and not getattr(self, "_last_sparse", False)):
+            out = eng.replay_frames(images, depth_images)
+            if out is not None:
+                return out
+        batch = images if torch.is_tensor(images) else torch.stack([i.float() for i in images])
+        if self._auto_graph(batch, depth_images):
+            try:
+                return self.forward_device(batch, depth_images, _graph=True)
+            except ops.RangeError:
+                raise
+            except Exception as e:  # noqa: BLE001 -- whatever made the capture fail, this call would succeed eagerly
+                import warnings
+                self._auto_graph_allowed = False
+                torch.cuda.synchronize()
+                warnings.warn(f"HandNet: automatic hipGraph capture failed ({type(e).__name__}: {e}); "
+                              "staying eager from now on (enable_graph(True) forces a new attempt)")
+        return self.forward_device(batch, depth_images, _graph=False)
+
+    def _check_range_contract(self, keypoints_cpu, words, depth_images):
+        """The f16x3 range contract, decided on values the call has copied to the host anyway (hn_amd.pipeline.range_message).
+        Non-finite INPUTS are the reference's business -- ROS 32FC1 depth marks invalid pixels with NaN and ros_demo.py:
+        227-231 passes them on; its network then returns NaN keypoints for the frames whose crop holds one, and so does
+        this one -- so they never raise.  A finite input beyond +-65504 or an activation that overflows with in-range
+        inputs WOULD give inf / NaN or (ReLU maps NaN to 0) silently wrong keypoints: those raise."""
+        from hn_amd._lib import RANGE_INPUT_NONFINITE
+        from hn_amd.pipeline import range_message
+        if words is not None:
+            bits = ops.range_bits(words)
+            if bits & RANGE_INPUT_NONFINITE:
+                return
+            if bits:
+                raise ops.RangeError(range_message(bits))
+            if not bool(torch.isfinite(keypoints_cpu).all()):    # (e.g. a non-finite bias of an output convolution)
+                raise ops.RangeError("non-finite keypoints from finite, in-range inputs: the checkpoint holds non-finite or "
+                                     "extreme values; build the engines with precision='f32' to compare")
+            return
+        # noting is off (HN_CHECK_RANGE=0): only the symptom is left -- non-finite keypoints from finite inputs
+        if not bool(torch.isfinite(keypoints_cpu).all()) and bool(torch.isfinite(depth_images).all()):
+            raise ops.RangeError("non-finite keypoints from finite inputs: a value left the range of the f16x3 split format "
+                                 "(|v| > 65504).  Unset HN_CHECK_RANGE=0 to locate the kind, or build the engines with "
+                                 "precision='f32'")
+
     def forward(self, images, depth_images=None, is_3D: bool = False, is_detect: bool = False):
         if is_detect or is_3D:
             return None
@@ -127,36 +184,23 @@ class HandNet(EngineOwner):
         mode = getattr(self, "use_graph", None)
         out = None
         if mode is None and torch.is_tensor(depth_images):
-            eng = self.engine()
-            if (not torch.is_tensor(images) and n and all(i.dtype == torch.float32 and i.is_cuda for i in images)
-                    and depth_images.dtype == torch.float32 and depth_images.is_cuda and not eng.check_range
-                    and not getattr(self, "_last_sparse", False)):
-                # steady state of the live caller: a captured step for these shapes exists -> stack the frames straight into
-                # its input buffer (one kernel instead of stack + copy) and replay
-                hit = eng._graphs.get(((n,) + tuple(images[0].shape), tuple(depth_images.shape)))
-                if hit is not None and all(i.shape == images[0].shape for i in images):
-                    g, s_img, s_dep, out = hit
-                    torch.stack(list(images), out=s_img)
-                    s_dep.copy_(depth_images)
-                    g.replay()
-            if out is None:
-                batch = images if torch.is_tensor(images) else torch.stack([i.float() for i in images])
-                out = self.forward_device(batch, depth_images, _graph=self._auto_graph(batch, depth_images))
+            out = self._forward_auto(images, depth_images, n)
         else:
             out = self.forward_device(images, depth_images)
-        # ONE device -> host copy (and sync) per call: the keypoints with the has-hand flags as a last column
+        # ONE device -> host copy (and sync) per call: the keypoints with the has-hand flags and the step's range-contract
+        # words as extra columns
         kp = out.keypoints
-        flat = torch.cat([kp.reshape(n, -1), out.has_hand.reshape(n, 1).to(kp.dtype)], dim=1).cpu()
-        final_results = flat[:, :-1].reshape(kp.shape).contiguous()     # the reference returns keypoints on the CPU
-        mask_cpu = flat[:, -1] != 0
+        j3 = kp.shape[1] * kp.shape[2]
+        # (as int32 words: the flags need no conversion kernels, the keypoints are reinterpreted back on the host)
+        cols = [kp.contiguous().reshape(n, j3).view(torch.int32), out.has_hand.reshape(n, 1)]
+        if out.range_flags is not None:
+            cols.append(out.range_flags[:3].reshape(1, 3).expand(n, 3))
+        flat = torch.cat(cols, dim=1).cpu()
+        final_results = flat[:, :j3].contiguous().view(torch.float32).reshape(kp.shape)   # the reference returns keypoints on the CPU
+        mask_cpu = flat[:, j3] != 0
         self._last_sparse = n >= 8 and int(mask_cpu.sum()) * 2 < n      # (the engine's own threshold for compaction)
-        # always-on safety net of the f16x3 range contract, at no device cost: the check runs on the 8 KB the reference's
-        # own .cpu() has just copied.  An activation beyond the fp16 range (|v| > 65504, e.g. BN-folded trained filters of
-        # extreme scale) shows up here as inf / NaN keypoints -- refuse to hand them to the caller.
-        if not bool(torch.isfinite(final_results).all()):
-            raise ops.RangeError("non-finite keypoints: an activation left the range of the f16x3 split format "
-                                 "(|v| > 65504) or the inputs were non-finite.  Run with HN_CHECK_RANGE=1 to locate the "
-                                 "producer, or build the engines with precision='f32'")
+        self._check_range_contract(final_results, flat[0, j3 + 1:].tolist() if out.range_flags is not None else None,
+                                   depth_images)
         if not bool(mask_cpu.any()):  # handnet_pipeline.py:107-108: the crops placeholder is a CPU float tensor
             return torch.zeros((n, 21, 3)), torch.zeros_like(depth_images), torch.zeros((n, 4))
         if bool(mask_cpu.all()):      # the usual case: no gather (a boolean-mask index would synchronise once more)

@@ -12,7 +12,7 @@ from pathlib import Path
 
 from . import build as _build
 
-ABI_VERSION = 30
+ABI_VERSION = 31
 
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, TILE_256x128, TILE_64x128 = range(7)
 HN_FCOS_MAX_LEVELS = 5
@@ -44,6 +44,7 @@ class ModelConfig(C.Structure):  # == struct hn_model_config
 
 
 MODEL_FCOS, MODEL_A2J = 1, 2
+RANGE_ACTIVATION, RANGE_INPUT, RANGE_INPUT_NONFINITE = 1, 2, 4
 
 
 class FcosLevels(C.Structure):
@@ -91,6 +92,9 @@ SIGNATURES = {
     "hn_clock_sample": (C.c_int, [C.c_int, VP, VP]),
     "hn_range_check_enable": (C.c_int, [C.c_int]),
     "hn_range_check_fetch": (C.c_int, [c_i32p, C.c_int, VP]),
+    "hn_range_check_enabled": (C.c_int, []),
+    "hn_range_check_bind": (C.c_int, [VP]),
+    "hn_range_check_collect": (C.c_int, [VP, VP, VP]),
     "hn_reread_env": (C.c_int, []),
     "hn_conv2d_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), VP, VP, VP, VP, VP, VP, VP, VP]),
     "hn_conv2d_pick_tile": (C.c_int, [C.POINTER(ConvDesc)]),
@@ -130,6 +134,7 @@ SIGNATURES = {
     "hn_nms": (C.c_int, [VP, VP, C.c_int, C.c_double, VP, VP, VP, VP]),
     "hn_crop_resize": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, VP] + [C.c_int] * 7 + [VP, VP, VP, VP]),
     "hn_stem_image_nhwc4": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP]),
+    "hn_stem_image_nhwc4_valid": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, VP]),
     "hn_pack_depth_nhwc": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, VP]),
     "hn_a2j_aggregate_f32": (C.c_int, [VP, VP, VP, VP] + [C.c_int] * 5 + [VP, VP]),
     "hn_create": (C.c_int, [C.POINTER(ModelConfig), C.POINTER(VP)]),

@@ -98,11 +98,12 @@ class A2JEngine:
                                residual=residual, tile=tile, algo_cin=algo_cin,
                                w16=cw.w16 if s16 else None, out_split=s16 and not out_f32)
 
-    def trunk(self, x):
-        """x [K,H,W,4] NHWC fp32 -> (x3 [K,H/16,W/16,1024], x4 [K,H/16,W/16,2048]) (S32 in f16x3 mode)."""
+    def trunk(self, x, valid=None):
+        """x [K,H,W,4] NHWC fp32 -> (x3 [K,H/16,W/16,1024], x4 [K,H/16,W/16,2048]) (S32 in f16x3 mode).  valid: the
+        aggregation's per-crop flags; a crop with non-finite pixels is marked 2 in them (NaN keypoints, like the reference)."""
         ops.PROFILE_STAGE = "a2j_trunk"
         if self.stem16 is not None and self.fuse_stem_pool:
-            x = ops.conv_stem_pool_split(ops.stem_image_nhwc4(x), self.stem16.w16, self.stem16.bias, 64, r=7, stride=2,
+            x = ops.conv_stem_pool_split(ops.stem_image_nhwc4(x, valid=valid), self.stem16.w16, self.stem16.bias, 64, r=7, stride=2,
                                          algo_cin=4 if self.rgbd else 3)
         else:
             x = self._conv(x, self.stem, algo_cin=4 if self.rgbd else 3)
@@ -152,7 +153,7 @@ class A2JEngine:
     @ops.device_guarded
     def forward_nhwc(self, x, valid=None, return_heads=False):
         with ops.f16_terms(self.terms):
-            x3, x4 = self.trunk(x)
+            x3, x4 = self.trunk(x, valid)
             cls, reg, dep = self.heads(x3, x4)
         out = ops.a2j_aggregate(cls, reg, dep, joints=self.joints, stride=16, valid=valid)
         if return_heads:
@@ -173,6 +174,10 @@ class A2JEngine:
             x = depth[:, :4].permute(0, 2, 3, 1).contiguous()
         else:
             x = ops.pack_depth_nhwc(depth[:, 0:1].contiguous(), cpad=4)
+        if valid is None and self.stem16 is not None:
+            # (the A2J-only entry: flags of its own, so that a crop with NaN / inf pixels gives NaN keypoints like
+            # a2j/a2j.py:243-250 does)
+            valid = torch.ones((depth.shape[0],), device=depth.device, dtype=torch.int32)
         return self.forward_nhwc(x, valid)
 
     # -----------------------------------------------------------------------------------

@@ -985,15 +985,20 @@ def crop_resize(det: Detections, hand_label, depth, out_size=176, cpad=4, crop_b
     return crop_box, has_hand, crops
 
 
-def stem_image_nhwc4(x, border=3, out=None):
-    """fp32 [N,H,W,4] -> stem image fp16 [2 (hi, lo), N, H+2b, W+2b, 4] with a zero border (input of conv_stem_*_split)."""
+def stem_image_nhwc4(x, border=3, out=None, valid=None):
+    """fp32 [N,H,W,4] -> stem image fp16 [2 (hi, lo), N, H+2b, W+2b, 4] with a zero border (input of conv_stem_*_split).
+    valid [N] int32 (optional): images with valid == 1 that hold a non-finite pixel get valid = 2 (a2j_aggregate then writes
+    NaN rows for them, as the reference's network does)."""
     _req(x, name="x")
     n, h, w, c = x.shape
     if c != 4:
         raise ValueError("x must be [N,H,W,4]")
     if out is None:
         out = torch.empty((2, n, h + 2 * border, w + 2 * border, 4), device=x.device, dtype=torch.float16)
-    check(_lib.load().hn_stem_image_nhwc4(ptr(x), n, h, w, border, ptr(out), _stream()), "hn_stem_image_nhwc4")
+    if valid is not None:
+        _req(valid, torch.int32, "valid")
+    check(_lib.load().hn_stem_image_nhwc4_valid(ptr(x), n, h, w, border, ptr(out), ptr(valid) if valid is not None else None,
+                                                _stream()), "hn_stem_image_nhwc4_valid")
     return out
 
 
@@ -1093,15 +1098,39 @@ def range_check_enable(on=True):
     check(_lib.load().hn_range_check_enable(1 if on else 0), "hn_range_check_enable")
 
 
-def range_check_fetch(reset=True) -> bool:
-    """True if a split producer met an out-of-range / non-finite value since the last reset (synchronises)."""
+def range_check_fetch(reset=True) -> int:
+    """OR of the _lib.RANGE_* bits a split producer has set in the LIBRARY's flag block since the last reset (non-zero: a
+    value was out of range / non-finite; synchronises)."""
     flag = C.c_int32(0)
     check(_lib.load().hn_range_check_fetch(C.byref(flag), 1 if reset else 0, _stream()), "hn_range_check_fetch")
-    return bool(flag.value)
+    return int(flag.value)
+
+
+def range_check_bind(block=None):
+    """Split producers launched from now on note into `block` (4 zeroed int32 on the GPU) instead of the library's own
+    flag words; None unbinds.  Host-side state, read at launch time."""
+    check(_lib.load().hn_range_check_bind(ptr(block) if block is not None else None), "hn_range_check_bind")
+
+
+def range_check_collect(block=None, out=None):
+    """One tiny launch: the flag words of `block` (None: the library's) -> out [4] int32 (activation, input out of range,
+    input non-finite, 0), and cleared.  No synchronisation."""
+    if out is None:
+        dev = block.device if block is not None else torch.device("cuda", torch.cuda.current_device())
+        out = torch.empty((4,), device=dev, dtype=torch.int32)
+    check(_lib.load().hn_range_check_collect(ptr(block) if block is not None else None, ptr(out), _stream()),
+          "hn_range_check_collect")
+    return out
+
+
+def range_bits(words) -> int:
+    """host list of the four collected words -> OR of the _lib.RANGE_* bits"""
+    return ((_lib.RANGE_ACTIVATION if words[0] else 0) | (_lib.RANGE_INPUT if words[1] else 0)
+            | (_lib.RANGE_INPUT_NONFINITE if words[2] else 0))
 
 
 class RangeError(RuntimeError):
-    """An activation left the dynamic range the f16x3 split format supports."""
+    """A value left the dynamic range the f16x3 split format supports."""
 
 
 def clock_sample(micros, out=None, stream=None):

@@ -26,9 +26,25 @@ class HandNetOutput:
     keypoints: torch.Tensor   # [N,21,3] fp32 device; zero rows where has_hand == 0
     crops_nhwc: torch.Tensor  # [N,176,176,4] fp32 device; channel 0 = cropped depth
     crop_box: torch.Tensor    # [N,4] int64 device (x1,y1,x2,y2 after padding)
-    has_hand: torch.Tensor    # [N] int32 device
+    has_hand: torch.Tensor    # [N] int32 device: 0 no hand, 1 hand, 2 hand whose depth crop holds non-finite pixels (NaN row)
     detections: ops.Detections
-    candidates: ops.Candidates
+    candidates: ops.Candidates   # rows at or beyond count[i] are undefined (never zero-filled)
+    range_flags: torch.Tensor = None   # [4] int32 device: the step's f16x3 range-contract words (ops.range_bits), or None
+
+
+def range_message(bits: int) -> str:
+    """What the f16x3 range-contract bits of a step (ops.range_bits) mean for its caller."""
+    from ._lib import RANGE_ACTIVATION, RANGE_INPUT, RANGE_INPUT_NONFINITE
+    if bits & RANGE_INPUT_NONFINITE:
+        return ("the inputs hold non-finite values (NaN / inf pixels): frames whose depth crop holds one return NaN "
+                "keypoints, as the reference does; non-finite RGB pixels give undefined detections")
+    if bits & RANGE_INPUT:
+        return ("an input value lies outside the range of the f16x3 split format (|v| > 65504): RGB must be 0..1 and depth "
+                "METRES (ros_demo.py:230-231 divides 16UC1 millimetres by 1000); or build the engines with precision='f32'")
+    if bits & RANGE_ACTIVATION:
+        return ("an activation left the range of the f16x3 split format (|v| > 65504) although the inputs are in range: "
+                "results would be inf / NaN or silently wrong.  Build the engines with precision='f32' for this checkpoint")
+    return "in range"
 
 
 class HandNetEngine:
@@ -38,9 +54,14 @@ class HandNetEngine:
         self.fcos, self.a2j, self.num_classes = fcos, a2j, num_classes
         self.device = fcos.device
         self._graphs = {}
-        # f16x3 range contract as a debug switch: every split producer flags values outside the fp16 range and
-        # forward_device raises instead of returning inf / NaN keypoints (costs one device -> host sync per call)
-        self.check_range = os.environ.get("HN_CHECK_RANGE", "0") == "1"
+        # f16x3 range contract.  Always on (HN_CHECK_RANGE=0 turns it off for A/B timing): every split producer of a step
+        # notes values outside the fp16 range into this engine's flag block and the step ends with ONE tiny launch that
+        # hands the words over as HandNetOutput.range_flags -- no sync; the drop-in HandNet.forward reads them with the
+        # copy of the keypoints it makes anyway.  check_range (HN_CHECK_RANGE=1) is the synchronous debug form:
+        # forward_device itself reads the words (one device -> host sync per call) and raises.
+        self.note_range = os.environ.get("HN_CHECK_RANGE", "1") != "0"
+        self.check_range = os.environ.get("HN_CHECK_RANGE", "") == "1"
+        self._range_block = torch.zeros((4,), device=self.device, dtype=torch.int32) if self.note_range else None
         # Sparse streams: A2J runs on all N frames with a validity mask (static launch sequence, capturable), which wastes
         # its time on frames without a hand.  When the PREVIOUS step had a hand in fewer than half of its frames (read
         # back asynchronously: no sync on the dense path), this step reads its own count (one sync) and runs A2J on the
@@ -57,20 +78,27 @@ class HandNetEngine:
         if depth.dim() != 4 or depth.shape[1] != want_c or depth.shape[0] != len(images):
             raise ValueError(f"depth_images must be [N,{want_c},H,W] matching images"
                              + (" (RGB + depth, ros_demo.py:268-270)" if self.a2j.rgbd else ""))
-        if self.check_range:
-            ops.range_check_enable(True)
-            ops.range_check_fetch(reset=True)
-        det, cand = self.fcos.detect(images)
-        crop_box, has_hand, crops = ops.crop_resize(det, self.num_classes - 1, depth.float().contiguous(), CROP, 4,
-                                                    reorder_bgr=self.a2j.rgbd)
-        kp = self._a2j_sparse(crops, has_hand) if self._use_compaction(len(images)) else None
-        if kp is None:
-            kp = self.a2j.forward_nhwc(crops, valid=has_hand)
+        noting = self.note_range or self.check_range
+        if noting and self._range_block is None:
+            self._range_block = torch.zeros((4,), device=self.device, dtype=torch.int32)
+        ops.range_check_enable(noting)
+        ops.range_check_bind(self._range_block if noting else None)
+        try:
+            det, cand = self.fcos.detect(images)
+            crop_box, has_hand, crops = ops.crop_resize(det, self.num_classes - 1, depth.float().contiguous(), CROP, 4,
+                                                        reorder_bgr=self.a2j.rgbd)
+            kp = self._a2j_sparse(crops, has_hand) if self._use_compaction(len(images)) else None
+            if kp is None:
+                kp = self.a2j.forward_nhwc(crops, valid=has_hand)
+            flags = ops.range_check_collect(self._range_block) if noting else None
+        finally:
+            ops.range_check_bind(None)
         self._note_hand_count(has_hand, len(images))
-        if self.check_range and ops.range_check_fetch(reset=True):
-            raise ops.RangeError("an activation left the fp16 range (|v| > 65504 or non-finite) on the f16x3 path: "
-                                 "results would be inf/NaN.  Run the engines with precision='f32' for this model")
-        return HandNetOutput(kp, crops, crop_box, has_hand, det, cand)
+        if self.check_range:
+            bits = ops.range_bits(flags.cpu().tolist())
+            if bits:
+                raise ops.RangeError(range_message(bits))
+        return HandNetOutput(kp, crops, crop_box, has_hand, det, cand, flags)
 
     # -------------------------------------------------------------------------------
     # sparse streams: A2J on the frames with a hand only
@@ -104,7 +132,7 @@ class HandNetEngine:
             return None
         kp = torch.zeros((n, self.a2j.joints, 3), device=crops.device, dtype=torch.float32)
         if k:
-            kp[idx] = self.a2j.forward_nhwc(crops[idx].contiguous())
+            kp[idx] = self.a2j.forward_nhwc(crops[idx].contiguous(), valid=has_hand[idx].contiguous())
         return kp
 
     # -------------------------------------------------------------------------------
@@ -121,6 +149,27 @@ class HandNetEngine:
         g, s_img, s_dep, out = self._graphs[key]
         return g.replay, s_img, s_dep, out
 
+    def has_graph(self, image_shape, depth_shape) -> bool:
+        return (tuple(image_shape), tuple(depth_shape)) in self._graphs
+
+    def graph_count(self) -> int:
+        return len(self._graphs)
+
+    def replay_frames(self, frames, depth):
+        """Steady state of the live caller (ros_demo.py:270: a list of equally sized frames per call): when a captured
+        step for these shapes exists, stack the frames straight into its input buffer (one kernel instead of stack + copy),
+        copy the depth map and replay.  Returns the step's static HandNetOutput, or None when nothing is captured for
+        these shapes (or the frames differ in shape / dtype)."""
+        first = frames[0]
+        hit = self._graphs.get(((len(frames),) + tuple(first.shape), tuple(depth.shape)))
+        if hit is None or any(f.shape != first.shape for f in frames):
+            return None
+        g, s_img, s_dep, out = hit
+        torch.stack(list(frames), out=s_img)
+        s_dep.copy_(depth)
+        g.replay()
+        return out
+
     def _capture(self, key, images, depth):
         # static buffers are ordinary (non-inference) tensors so that later copy_() works in any mode
         s_img, s_dep = torch.empty_like(images), torch.empty_like(depth)
@@ -134,7 +183,9 @@ class HandNetEngine:
                     self.forward_device(s_img, s_dep)
             torch.cuda.current_stream().wait_stream(side)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread_local: GPU work another thread of the host process issues meanwhile (a ROS node's other callbacks)
+            # does not invalidate the capture
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 out = self.forward_device(s_img, s_dep)
         self._graphs[key] = (g, s_img, s_dep, out)
         return g.replay, s_img, s_dep, out

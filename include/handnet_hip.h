@@ -33,7 +33,7 @@ extern "C" {
 #define HN_ERR_HIP 2
 
 /* ABI version; bumped whenever a struct below changes. */
-#define HN_ABI_VERSION 30
+#define HN_ABI_VERSION 31
 int hn_abi_version(void);
 const char* hn_last_error(void);
 
@@ -51,14 +51,32 @@ int hn_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on 
  * (bench.py roofline leg: roofline.clock_mhz); the sampling loop is bounded by real time. */
 int hn_clock_sample(int micros, float* mhz, void* stream);
 
-/* ---- f16x3 range contract (debug switch; engines: HN_CHECK_RANGE=1) -------------------------------------
+/* ---- f16x3 range contract ---------------------------------------------------------------------------------
  * A value that is stored in the split format must be finite and |v| <= 65504 (hi = fp16(v) would be +-inf).
- * hn_range_check_enable(1) makes every later launch of a split PRODUCER (f16x3 conv epilogue / split-K tail,
- * hn_affine_split_f32, hn_fcos_preprocess_split / _list) set a sticky per-device flag when it meets such a
- * value; hn_range_check_fetch copies it to *flag (host), optionally clearing it, and synchronises `stream`.
- * Weight banks are checked on the host when they are split (hn_amd.weights.split_f16x3 raises). */
+ * While hn_range_check_enable(1) is in force (the engines' default; HN_CHECK_RANGE=0 turns it off for A/B timing) every
+ * launch of a split PRODUCER (f16x3 conv epilogue / split-K tail, hn_affine_split_f32, hn_fcos_preprocess_split / _list,
+ * hn_stem_image_nhwc4) sets a sticky per-device flag word when it meets such a value:
+ *   HN_RANGE_ACTIVATION        an intermediate activation (results would be inf / NaN or -- ReLU maps NaN to 0 -- silently
+ *                              wrong: this model needs the exact f32 mode)
+ *   HN_RANGE_INPUT             a finite INPUT value beyond the range (preprocessed RGB; a depth crop: depth is metres)
+ *   HN_RANGE_INPUT_NONFINITE   a NaN / inf input value (invalid pixels of a 32FC1 depth image, which the reference passes
+ *                              through, ros_demo.py:227-231; see hn_stem_image_nhwc4_valid)
+ * The words live in a block of 4 device int32 (activation, input, input-non-finite, 0): the library's own, or -- after
+ * hn_range_check_bind(block), which like the switch is read on the host at LAUNCH time -- the caller's (an engine binds its
+ * block around its launches, so two engines of one process never see each other's flags; NULL unbinds).
+ * hn_range_check_collect enqueues ONE tiny kernel on `stream` that copies the words of `block` (NULL: the library's) to
+ * dst[0..3] and clears them -- no synchronisation; the host reads dst with the copy of the results it makes anyway (the
+ * drop-in HandNet.forward does).  hn_range_check_fetch is the synchronous form: *flag (host)
+ * = OR of the HN_RANGE_* bits, optionally clearing them.  Weight banks are checked on the host when they are split
+ * (hn_amd.weights.split_f16x3 raises; hn_finalize fails). */
+#define HN_RANGE_ACTIVATION 1
+#define HN_RANGE_INPUT 2
+#define HN_RANGE_INPUT_NONFINITE 4
 int hn_range_check_enable(int on);
+int hn_range_check_enabled(void);
 int hn_range_check_fetch(int* flag /* host */, int reset, void* stream);
+int hn_range_check_bind(int32_t* block /* device, 4 words, zeroed by the caller; or NULL */);
+int hn_range_check_collect(int32_t* block /* or NULL */, int32_t* dst /* device, 4 words */, void* stream);
 
 /* The library's A/B switches (HN_CONV_NO_RS, HN_CONV_NO_RS32, HN_SPLIT_GENERIC: select the older kernel forms, results
  * unchanged) are read from the environment once, at first use; a host that changes them later calls this. */
@@ -394,7 +412,8 @@ int hn_nms(const float* boxes, const float* scores, int k, double iou_thresh,
  * Crop: top-1 hand box -> int box -> pad 40 % -> clamp -> nearest resize to out x out.
  * Replaces handnet_pipeline/handnet_pipeline.py:74-105.
  * For each image: first detection (score order) with label == hand_label.  Writes
- *   crop_box [n][4] int64 (x1,y1,x2,y2 after padding; zeros if none), has_hand [n] int32,
+ *   crop_box [n][4] int64 (x1,y1,x2,y2 after padding; zeros if none), has_hand [n] int32 (0 / 1; the A2J stage of
+ *   the pipeline raises it to 2 for a frame whose depth crop holds non-finite pixels: NaN keypoints, like the reference),
  *   crops [n][out][out][cpad] fp32 NHWC with depth in channel 0, other channels 0.
  * depth is [n][in_ch][h][w] fp32, in_ch = 1 (depth) or 4 (RGB-D; reorder_bgr = 1 applies the
  * reference's channel permutation [2,1,0,3], handnet_pipeline.py:102); crops channel c = image channel.
@@ -408,6 +427,12 @@ int hn_crop_resize(const float* det_boxes, const int32_t* det_labels, const int3
  * [n][h + 2*border][w + 2*border][4], zero border): the A2J crops on their way to the split-precision stem
  * (a2j/resnet.py:155-158 conv1 -> bn1 -> relu -> maxpool). */
 int hn_stem_image_nhwc4(const float* x, int n, int h, int w, int border, void* dst16, void* stream);
+/* The same with the per-image flags of the aggregation (valid [n] int32 on the device, or NULL): an image with
+ * valid[i] == 1 that holds a non-finite pixel gets valid[i] = 2.  The reference's network returns NaN for EVERY joint of
+ * such a crop (each cell of its 11 x 11 maps sees every pixel of the crop; ReLU and max pooling propagate NaN in torch),
+ * and hn_a2j_aggregate_f32 writes exactly that for valid[i] == 2 -- the split-precision convolutions in between need not
+ * (and do not) propagate NaN. */
+int hn_stem_image_nhwc4_valid(const float* x, int n, int h, int w, int border, void* dst16, int32_t* valid, void* stream);
 
 /* Pack [n][1][h][w] depth crops into NHWC(cpad) for the A2J stem (A2J-only entry). */
 int hn_pack_depth_nhwc(const float* src, float* dst, int n, int hw, int cpad, void* stream);
@@ -419,7 +444,8 @@ int hn_pack_depth_nhwc(const float* src, float* dst, int n, int hw, int cpad, vo
  * out [k][J][3] = (sum w*(anchor_0 + reg_0), sum w*(anchor_1 + reg_1), sum w*depth),
  * w = softmax over all fh*fw*A anchors per joint.  Anchor coords follow
  * a2j/anchor.py:7-42: coordinate 0 = h*stride + P[a/4], coordinate 1 = w*stride + P[a%4].
- * Rows with valid[k] == 0 (if valid != NULL) are written as zeros.
+ * With valid != NULL: rows with valid[k] == 0 are written as zeros (no crop), rows with valid[k] == 2 as NaN (a crop
+ * with non-finite pixels, see hn_stem_image_nhwc4_valid), rows with valid[k] == 1 are computed.
  * ------------------------------------------------------------------------------------ */
 int hn_a2j_aggregate_f32(const float* cls, const float* reg, const float* dep,
                          const int32_t* valid, int k, int fh, int fw, int joints, int stride,

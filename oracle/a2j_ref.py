@@ -116,18 +116,24 @@ def post_process(cls, reg, dep, anchors=None):
     return torch.stack(outs)
 
 
-def a2j_forward(x, sd, channel_in=1, return_heads=False):
-    """a2j/a2j.py:243-250 (gt=None): x [B,1,176,176] metres -> [B,21,3] on CPU."""
+def a2j_forward(x, sd, channel_in=1, return_heads=False, dtype=torch.float32):
+    """a2j/a2j.py:243-250 (gt=None): x [B,1,176,176] metres -> [B,21,3] on CPU.  dtype=torch.float64 (with a state_dict
+    converted by `to_dtype`) runs the same operations in double: the yardstick for the fp32 path's own rounding noise."""
     with torch.no_grad():
-        x3, x4 = backbone(x.float(), sd, channel_in)
+        x3, x4 = backbone(x.to(dtype), sd, channel_in)
         raw = heads_raw(x3, x4, sd)
         joints = raw[0].shape[1] // 16
         cls, reg, dep = heads_to_reference_layout(*raw, joints=joints)
-        anchors = all_anchors((x.shape[2] // 16, x.shape[3] // 16))
+        anchors = all_anchors((x.shape[2] // 16, x.shape[3] // 16)).to(dtype)
         out = post_process(cls, reg, dep, anchors)
     if return_heads:
         return out, (x3, x4), raw
     return out
+
+
+def to_dtype(sd, dtype):
+    """state_dict with every floating-point tensor converted (integer buffers untouched)"""
+    return {k: (v.to(dtype) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in sd.items()}
 
 
 def convert_joints(jt_uvd, box, paras, crop_w=176, crop_h=176):

@@ -55,7 +55,7 @@ def transform(images, min_size=800, max_size=1333, size_divisible=32):
     mw = max(s[1] for s in sizes)
     ph = int(math.ceil(mh / size_divisible) * size_divisible)
     pw = int(math.ceil(mw / size_divisible) * size_divisible)
-    batched = torch.zeros((len(out), 3, ph, pw))
+    batched = torch.zeros((len(out), 3, ph, pw), dtype=out[0].dtype)   # (fp64 when the caller passes fp64 images)
     for i, img in enumerate(out):
         batched[i, :, : img.shape[1], : img.shape[2]].copy_(img)
     return batched, sizes

@@ -386,8 +386,105 @@ def test_handnet_refuses_nonfinite_keypoints(fcos_sd, a2j_sd):
     rgb, depth = synth.make_rgb(1, seed=1000).cuda(), synth.make_depth(1, seed=2000).cuda()
     with torch.inference_mode():
         assert not torch.isfinite(net.forward_device([rgb[0]], depth).keypoints).all()   # the engine itself returns them
-        with pytest.raises(ops.RangeError):
+        with pytest.raises(ops.RangeError, match="checkpoint"):
             net([rgb[0]], depth_images=depth)
+
+
+def _dropin(fcos_sd, a2j_sd):
+    from handnet_pipeline.handnet_pipeline import HandNet
+    net = HandNet(types.SimpleNamespace(pretrained_fcos="-", pretrained_a2j="-"), num_classes=3)
+    net.detector.load_state_dict(fcos_sd, strict=False)
+    net.a2j.load_state_dict(a2j_sd, strict=False)
+    return net.cuda().eval()
+
+
+def test_nan_depth_pixels_give_nan_keypoints_like_the_reference(fcos_sd, a2j_sd):
+    """ROS 32FC1 depth marks invalid pixels with NaN and the reference's caller passes them on (ros_demo.py:227-231): its
+    network then returns NaN for every joint of a frame whose CROP holds one (oracle: the same plain torch ops) and finite
+    keypoints for the other frames.  The drop-in must do the same -- not raise, not return finite garbage (the split
+    convolutions' ReLUs map NaN to 0) -- eagerly, through the automatic graph replay, and through the C++ layer graph."""
+    from hn_amd import synth
+    from hn_amd.native_model import NativeModel
+    from oracle import handnet_ref
+    net = _dropin(fcos_sd, a2j_sd)
+    rgb, depth = synth.make_rgb(3, seed=1000), synth.make_depth(3, seed=2000)
+    clean = handnet_ref.handnet_forward(list(rgb), depth, fcos_sd, a2j_sd, 3)
+    x1, y1, x2, y2 = clean[2][1].tolist()
+    depth[1, 0, (y1 + y2) // 2, (x1 + x2) // 2] = float("nan")        # inside frame 1's crop
+    bx = clean[2][2].tolist()
+    oy, ox = (0, 0) if bx[1] > 8 and bx[0] > 8 else (479, 639)          # a pixel OUTSIDE frame 2's crop
+    assert not (bx[0] <= ox <= bx[2] and bx[1] <= oy <= bx[3])
+    depth[2, 0, oy, ox] = float("inf")
+    rkp, rdb, rcrops = handnet_ref.handnet_forward(list(rgb), depth, fcos_sd, a2j_sd, 3)
+    assert torch.isnan(rkp[1]).all() and torch.isfinite(rkp[0]).all() and torch.isfinite(rkp[2]).all()
+    with torch.inference_mode():
+        for call in range(6):                                           # eager, then captured + replayed
+            kp, db, crops = net([r.cuda() for r in rgb], depth_images=depth.cuda())
+            assert torch.isnan(kp[1]).all(), call
+            assert (kp[[0, 2]] - rkp[[0, 2]]).abs().max().item() < 1e-3
+            assert torch.equal(crops.cpu(), rcrops)
+            assert torch.equal(torch.nan_to_num(db.cpu(), nan=-1.0), torch.nan_to_num(rdb, nan=-1.0))
+    assert net.engine().graph_count() == 1
+    out = net.forward_device(rgb.cuda(), depth.cuda(), _graph=False)
+    assert out.has_hand.cpu().tolist() == [1, 2, 1]
+    m = NativeModel(fcos_sd, a2j_sd, num_classes=3)
+    try:
+        nkp, nbox, nhas = m.handnet(rgb.cuda(), depth.cuda())
+        assert nhas.cpu().tolist() == [1, 2, 1] and torch.isnan(nkp[1]).all()
+        assert torch.equal(nkp[[0, 2]], out.keypoints[[0, 2]]) and torch.equal(nbox, out.crop_box)
+    finally:
+        m.close()
+
+
+def test_a2j_dropin_nan_crop_gives_nan_row(a2j_sd):
+    """a2j.a2j.A2JModel (a2j_infer.py:25,59) on crops of which one holds a NaN pixel: NaN keypoints for that crop, like the
+    reference's plain torch forward; the other crops are untouched."""
+    from a2j.a2j import A2JModel
+    from hn_amd import synth
+    from oracle import a2j_ref
+    model = A2JModel(21, crop_height=176, crop_width=176)
+    model.load_state_dict(a2j_sd, strict=False)
+    model = model.cuda().eval()
+    x = synth.make_crops(3, seed=3000)
+    x[2, 0, 17, 130] = float("nan")
+    ref = a2j_ref.a2j_forward(x, a2j_sd)
+    assert torch.isnan(ref[2]).all() and torch.isfinite(ref[:2]).all()
+    with torch.inference_mode():
+        kp = model(x.cuda())
+    assert kp.device.type == "cpu" and torch.isnan(kp[2]).all()
+    assert (kp[:2] - ref[:2]).abs().max().item() < 1e-3
+
+
+def test_dropin_range_contract_is_always_on(fcos_sd, a2j_sd):
+    """The f16x3 range contract needs no switch: HandNet.forward reads the step's flag words with the
+    keypoints.  Depth in raw millimetres x 1000 (finite, far beyond 65504 after the first layers) raises ops.RangeError
+    instead of returning finite-but-wrong keypoints (the ReLUs launder the NaNs: forward_device shows what would have
+    been returned); saturated 16UC1 depth left unscaled (65535 > 65504) is refused as an INPUT; ordinary frames pass, also
+    on the calls that replay a captured graph."""
+    from hn_amd import _lib, ops, synth
+    net = _dropin(fcos_sd, a2j_sd)
+    assert net.engine().note_range
+    rgb, depth = synth.make_rgb(1, seed=1000).cuda(), synth.make_depth(1, seed=2000).cuda()
+    with torch.inference_mode():
+        for _ in range(6):
+            kp, _, _ = net([rgb[0]], depth_images=depth)
+            assert torch.isfinite(kp).all()
+        out = net.forward_device(rgb, depth, _graph=False)
+        assert out.range_flags.cpu().tolist() == [0, 0, 0, 0]
+        # a depth scale that keeps the INPUT in range (max 1.5 x scale < 65504) but not the activations behind it
+        scale = None
+        for sc in (1.0e4, 2.0e4, 4.0e4):
+            words = net.forward_device(rgb, depth * sc, _graph=False).range_flags.cpu().tolist()
+            if ops.range_bits(words) == _lib.RANGE_ACTIVATION:
+                scale = sc
+                break
+        assert scale is not None, words
+        with pytest.raises(ops.RangeError, match="activation"):
+            net([rgb[0]], depth_images=depth * scale)
+        with pytest.raises(ops.RangeError, match="METRES"):
+            net([rgb[0]], depth_images=torch.full_like(depth, 65535.0))
+        kp, _, _ = net([rgb[0]], depth_images=depth)                      # the flags are per step: the next call is clean
+        assert torch.isfinite(kp).all()
 
 
 def test_sparse_stream_compacts_a2j(fcos_sd, a2j_sd, monkeypatch):
@@ -445,10 +542,10 @@ def test_dropin_forward_switches_itself_to_graph_replay(fcos_sd, a2j_sd):
     frames = [(synth.make_rgb(1, seed=1000 + i).cuda(), synth.make_depth(1, seed=2000 + i).cuda()) for i in range(3)]
     with torch.inference_mode():
         eager = [net([rgb[0]], depth_images=dep) for rgb, dep in frames]            # calls 1-3: eager
-        assert len(net.engine()._graphs) == 0
+        assert net.engine().graph_count() == 0
         held = net([frames[0][0][0]], depth_images=frames[0][1])                     # call 4: still eager (streak == 3)
         again = [net([rgb[0]], depth_images=dep) for rgb, dep in frames]            # calls 5-7: captured, then replayed
-        assert len(net.engine()._graphs) == 1
+        assert net.engine().graph_count() == 1
         for (kp, db, box), (kp2, db2, box2) in zip(eager, again):
             assert kp2.device.type == "cpu" and torch.equal(kp, kp2) and torch.equal(db, db2) and torch.equal(box, box2)
         assert torch.equal(held[0], eager[0][0]) and torch.equal(held[1], eager[0][1])   # earlier results are not overwritten
@@ -457,11 +554,11 @@ def test_dropin_forward_switches_itself_to_graph_replay(fcos_sd, a2j_sd):
         assert torch.equal(again[0][1], first)                                         # ... nor are results of replayed calls
         wide = synth.make_rgb(1, seed=5).cuda()[:, :, :400, :]
         kp_w, _, _ = net([wide[0]], depth_images=frames[0][1][:, :, :400, :].contiguous())   # another shape: eager again
-        assert len(net.engine()._graphs) == 1 and tuple(kp_w.shape) == (1, 21, 3)
+        assert net.engine().graph_count() == 1 and tuple(kp_w.shape) == (1, 21, 3)
         net.enable_graph(False)
         for rgb, dep in frames * 2:
             net([rgb[0]], depth_images=dep)
-        assert len(net.engine()._graphs) == 1
+        assert net.engine().graph_count() == 1
 
 
 def test_pipeline_is_deterministic_over_many_steps(fcos_sd, a2j_sd):
