@@ -306,7 +306,10 @@ def dropin_leg(args, sds, dev, batch):
     net.a2j.load_state_dict(a2j_sd, strict=False)
     net = net.to(dev).eval()
     out = {"call": "handnet_pipeline.HandNet.forward(list of [3,H,W], depth_images=[N,1,H,W]) -> (keypoints on the CPU, "
-                   "depth_batch, crops), ros_demo.py:270-273", "precision": args.precision,
+                   "depth_batch, crops), ros_demo.py:270-273",
+           # the precision the drop-in's engines REALLY run at (its constructor has no precision argument: always the
+           # parity-grade default, whatever --precision the engine-level legs of this run use)
+           "precision": "f16x1" if net.engine().fcos.terms == 1 else net.engine().fcos.precision,
            "host": "forward() has switched itself to hipGraph replay (its default once the input shapes repeat on a dense "
                    "stream; results are fresh tensors either way)"}
     for b, steps in ((batch, args.steps), (1, max(50, args.steps))):
@@ -408,7 +411,11 @@ def main():
     from hn_amd import dist as hdist
     if args.share_gpu:
         os.environ["LOCAL_RANK"] = "0"
-    rank, local, world = hdist.init_from_env(args.dist_backend if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    try:
+        rank, local, world = hdist.init_from_env(args.dist_backend if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    except Exception as e:  # noqa: BLE001 -- RCCL / rendezvous failure: report it and stop; never a fallback, never a re-exec
+        raise SystemExit(f"[bench] rank {os.environ.get('RANK', '0')}: torch.distributed ({args.dist_backend}) failed to "
+                         f"initialise for --gpus {args.gpus}: {type(e).__name__}: {e}")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as "
                          f"{args.gpus} GPUs")

@@ -28,9 +28,12 @@ class FCOS(EngineOwner):
                  topk_candidates: int = 1000):
         super().__init__()
         if anchor_generator is not None or head is not None:
+            # (the reference accepts torch modules here, fcos.py:483-494; this class runs fixed HIP layer graphs --
+            # listed under "deviations" in INTEGRATION.md)
             raise NotImplementedError("custom anchor_generator / head modules are not supported")
-        if image_mean not in (None, [0.485, 0.456, 0.406]) or image_std not in (None, [0.229, 0.224, 0.225]):
-            raise NotImplementedError("only the default ImageNet mean/std of the reference are supported")
+        # forwarded to the transform like the reference does (fcos.py:501-505)
+        self.image_mean = [0.485, 0.456, 0.406] if image_mean is None else [float(v) for v in image_mean]
+        self.image_std = [0.229, 0.224, 0.225] if image_std is None else [float(v) for v in image_std]
         self.ext = ext
         self.num_classes = num_classes
         self.min_size, self.max_size = min_size, max_size
@@ -47,7 +50,8 @@ class FCOS(EngineOwner):
         if self._engine is None:
             sd = {k: v.detach().cpu() for k, v in self.state_dict().items()}
             self._engine = FCOSEngine(sd, self.num_classes, device=dev, min_size=self.min_size,
-                                      max_size=self.max_size, ext=self.ext)
+                                      max_size=self.max_size, ext=self.ext, image_mean=self.image_mean,
+                                      image_std=self.image_std)
         return self._engine
 
     def forward(self, images: List[torch.Tensor], targets=None) -> List[Dict[str, torch.Tensor]]:

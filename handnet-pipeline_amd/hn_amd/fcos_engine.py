@@ -44,8 +44,9 @@ def resized_size(h: int, w: int, min_size: int = 800, max_size: int = 1333):
 
 class FCOSEngine:
     def __init__(self, state_dict, num_classes: int, device="cuda", min_size=800, max_size=1333,
-                 precision="f16x3", ext=False, head_streams=None):
-        """precision: "f16x3" (split-fp16 operands, fp32-grade; default) or "f32" (exact f32 MFMA)."""
+                 precision="f16x3", ext=False, head_streams=None, image_mean=None, image_std=None):
+        """precision: "f16x3" (split-fp16 operands, fp32-grade; default) or "f32" (exact f32 MFMA).
+        image_mean / image_std: the transform's normalisation (fcos.py:501-505; default: ImageNet's)."""
         if precision not in ("f32", "f16x3", "f16x1"):
             raise ValueError("precision must be 'f32', 'f16x3' or 'f16x1'")
         # "f16x1": the f16x3 engine with the hi*hi term alone (plain fp16 operands, one MFMA per MAC): the throughput mode
@@ -59,6 +60,10 @@ class FCOSEngine:
         self.device = dev
         self.num_classes = num_classes
         self.min_size, self.max_size = min_size, max_size
+        self.image_mean = tuple(float(v) for v in (IMAGE_MEAN if image_mean is None else image_mean))
+        self.image_std = tuple(float(v) for v in (IMAGE_STD if image_std is None else image_std))
+        if len(self.image_mean) != 3 or len(self.image_std) != 3 or any(v == 0.0 for v in self.image_std):
+            raise ValueError("image_mean / image_std must hold three values (std non-zero)")
         p = "backbone.body."
 
         def cbn(conv, bn, **kw):
@@ -370,7 +375,7 @@ class FCOSEngine:
         -> per-level head tensors + geometry."""
         if not torch.is_tensor(images):
             geom, ph, pw = self.list_geometry(images)
-            x = ops.fcos_preprocess_list(images, geom, ph, pw, IMAGE_MEAN, IMAGE_STD, split=self.precision == "f16x3")
+            x = ops.fcos_preprocess_list(images, geom, ph, pw, self.image_mean, self.image_std, split=self.precision == "f16x3")
             oh, ow = [g[2] for g in geom], [g[3] for g in geom]
         else:
             if images.dim() != 4 or images.shape[1] != 3:
@@ -378,7 +383,7 @@ class FCOSEngine:
             n, _, h, w = images.shape
             oh, ow, ph, pw = self.geometry(h, w)
             pre = ops.fcos_preprocess_split if self.precision == "f16x3" else ops.fcos_preprocess
-            x = pre(images.float().contiguous(), oh, ow, ph, pw, IMAGE_MEAN, IMAGE_STD)
+            x = pre(images.float().contiguous(), oh, ow, ph, pw, self.image_mean, self.image_std)
         feats = self.backbone(x)
         outs = self.heads(feats)
         strides = [ph // f.shape[1] for f in feats]

@@ -35,10 +35,11 @@ NMS_THRESH = 0.3     # hard-coded, fcos_utils/fcos.py:635
 # ---------------------------------------------------------------------------------------
 # torchvision GeneralizedRCNNTransform (min_size 800, max_size 1333, size_divisible 32)
 # ---------------------------------------------------------------------------------------
-def transform(images, min_size=800, max_size=1333, size_divisible=32):
-    """list of [3,H,W] in 0..1 -> (tensor [N,3,PH,PW], image_sizes [(h,w)])."""
-    mean = torch.tensor(IMAGE_MEAN)[:, None, None]
-    std = torch.tensor(IMAGE_STD)[:, None, None]
+def transform(images, min_size=800, max_size=1333, size_divisible=32, image_mean=None, image_std=None):
+    """list of [3,H,W] in 0..1 -> (tensor [N,3,PH,PW], image_sizes [(h,w)]).  image_mean / image_std: the FCOS ctor's
+    (fcos.py:501-505), default ImageNet's."""
+    mean = torch.tensor(IMAGE_MEAN if image_mean is None else list(image_mean))[:, None, None]
+    std = torch.tensor(IMAGE_STD if image_std is None else list(image_std))[:, None, None]
     out, sizes = [], []
     for img in images:
         img = (img - mean) / std
@@ -299,11 +300,11 @@ def postprocess(cands, image_sizes, original_sizes):
     return dets
 
 
-def fcos_forward(images, sd, num_classes=3, return_intermediates=False, ext=False):
+def fcos_forward(images, sd, num_classes=3, return_intermediates=False, ext=False, image_mean=None, image_std=None):
     """fcos_utils/fcos.py:675-767 (eval): list of [3,H,W] -> list of detection dicts."""
     with torch.no_grad():
         original_sizes = [tuple(img.shape[-2:]) for img in images]
-        x, image_sizes = transform(images)
+        x, image_sizes = transform(images, image_mean=image_mean, image_std=image_std)
         feats = list(backbone(x, sd).values())[:-1]
         ho = head(feats, sd, num_classes, ext)
         grid = [tuple(f.shape[-2:]) for f in feats]

@@ -3,6 +3,7 @@ their shard, all-gather the fixed-size records with hn_amd.dist.gather_results, 
 rank must end up with exactly the single-process result in global frame order."""
 import os
 import socket
+import subprocess
 import sys
 from pathlib import Path
 
@@ -137,3 +138,20 @@ def test_gather_is_one_collective_with_reused_buffers(monkeypatch):
     assert gk.shape == (8, 21, 3) and torch.equal(gk[:3], kp) and torch.equal(gk[4:7], kp)
     assert torch.equal(gb[4:7], box) and gh.tolist() == [1, 0, 1, 0, 1, 0, 1, 0]
     assert valid.tolist() == [True, True, True, False] * 2
+
+
+def test_bench_fails_loudly_when_the_process_group_cannot_start():
+    """`--gpus 2` under a torchrun-style environment whose rendezvous cannot complete (nobody listens for rank 1's peer):
+    bench.py must exit non-zero with the backend's error text -- never fall back to a single-rank run, never re-exec."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(RANK="1", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               TORCH_DIST_INIT_BARRIER="0")
+    # rank 1 of 2 with no rank 0: the TCP store client cannot connect -> init_process_group raises after its timeout
+    code = ("import sys, datetime, torch.distributed as d; sys.argv = ['bench.py', '--gpus', '2', '--share-gpu', "
+            "'--dist-backend', 'gloo', '--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--no-roofline'];"
+            "orig = d.init_process_group;"
+            "d.init_process_group = lambda *a, **k: orig(*a, timeout=datetime.timedelta(seconds=5), **k);"
+            f"import runpy; runpy.run_path({str(REPO / 'bench.py')!r}, run_name='__main__')")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "failed to initialise" in (r.stdout + r.stderr) and not any(l.startswith("{") for l in r.stdout.splitlines())

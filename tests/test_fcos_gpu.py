@@ -307,6 +307,29 @@ def test_fcos_dropin_contract(fcos_sd, oracle_run):
     assert abs(len(d["scores"]) - len(dets[0]["scores"])) <= 3
 
 
+def test_fcos_dropin_honours_image_mean_std(fcos_sd):
+    """FCOS(image_mean=..., image_std=...) forwards them to the transform (fcos.py:501-505): detections of the drop-in with
+    a non-default normalisation equal the oracle's with the same one -- and differ from the default's."""
+    from fcos_utils.fcos import FCOS
+    from hn_amd import synth
+    from oracle import fcos_ref
+    mean, std = [0.40, 0.50, 0.45], [0.20, 0.25, 0.30]
+    rgb = synth.make_rgb(2, seed=1234)
+    ref = fcos_ref.fcos_forward([rgb[0], rgb[1]], fcos_sd, 3, image_mean=mean, image_std=std)
+    base = fcos_ref.fcos_forward([rgb[0], rgb[1]], fcos_sd, 3)
+    assert [len(d["keep"]) for d in ref] != [len(d["keep"]) for d in base] or \
+        not torch.equal(ref[0]["boxes"], base[0]["boxes"])
+    model = FCOS(num_classes=3, ext=False, image_mean=mean, image_std=std).cuda().eval()
+    model.load_state_dict(fcos_sd, strict=False)
+    with torch.inference_mode():
+        out = model([rgb[0].cuda(), rgb[1].cuda()], None)
+    for d, r in zip(out, ref):
+        assert len(d["scores"]) == len(r["scores"])
+        assert torch.equal(d["labels"].cpu(), r["labels"])
+        assert (d["boxes"].cpu() - r["boxes"]).abs().max().item() < 2e-2
+        assert (d["scores"].cpu() - r["scores"]).abs().max().item() < 1e-4
+
+
 def test_fcos_ext_matches_reference_golden(golden_dir):
     """FCOS(ext=True) (class default, trainval_net_fcos.py --test-only) vs the imported reference:
     dict keys of fcos.py:637-647; per matched detection the contact state and side are identical and
