@@ -7,21 +7,24 @@ detectors whose output biases are raised until one image yields > 1000 and > 400
 batched_nms branch, fcos_utils/fcos.py:635) and lowered until a batch mixes frames with and without a hand and frames with
 no candidate at all.  Every case also runs with the range check on (HN_CHECK_RANGE=1's flag).
 
-What is asserted per frame, against the oracle on the same inputs:
+What is asserted per frame, against the oracle on the same inputs (delta = max |HIP score - oracle score| over ALL 17 850
+anchor points of the frame, itself asserted <= 3e-5; measured 1.3e-5 -- the fp32 oracle is 6e-5..1e-4 from its own fp64 run):
   candidate set (anchor-point indices that pass `scores_max > 0.7`, fcos.py:600) ......... identical
-  NMS survivors (indices into the candidate list, score order) and labels ............... identical
-  top-1 hand crop box (int64 truncation + 0.4 padding + clamp, handnet_pipeline.py:88-97) identical
+  NMS survivors: the REFERENCE batched_nms, fed the oracle's boxes and labels in the HIP engine's score order, returns
+      exactly the HIP survivor list (indices and order) .................................. always (bit-exact NMS)
+  survivor list vs the oracle's own ...................................................... identical, or differing only
+      through pairs of candidates whose oracle scores are closer than 2 delta (near / exact score TIES: the order of two
+      scores that close is not determined by fp32-grade arithmetic -- the reference's own CPU and CUDA runs would not agree
+      on it either); such frames are counted and reported ("order" frames)
+  top-1 hand crop box (int64 truncation + 0.4 padding + clamp, handnet_pipeline.py:88-97) identical (else diagnosed)
   depth crops (pure gather) ............................................................. identical
-  keypoints ............................................................................. |d| < max(1e-3, 3 x the
-                                    oracle's own fp32-vs-fp64 difference on the same crops), both printed
-A frame whose INTEGER results differ is never waved through: `_diagnose` re-runs the oracle for that frame in fp64 and the
-frame is tolerated only if the deciding quantity (a score against 0.7, the gap of two scores the two sides RANK differently,
-a box coordinate against an integer) sits inside 3 x max(the fp32 oracle's distance from its fp64 self, the measured HIP-vs-
-oracle score difference of the frame, itself bounded by 5e-5) -- i.e. fp32-grade arithmetic does not determine the
-decision: the reference's own CPU and CUDA runs would not agree on it either.  For a different survivor list it must also
-hold that the REFERENCE NMS, fed the oracle's boxes in the HIP engine's score order, returns exactly the HIP survivors.
-The offending values are printed and collected (gpurun_out/parity_sweep_report.json); the number of such frames is bounded
-by `test_tolerated_frames_are_rare`.
+  keypoints, EVERY frame with a hand ..................................................... |d| < max(1e-3, 3 x the
+      oracle's own fp32-vs-fp64 difference on the same crops), both printed; where a tolerated decision moved the crop box the
+      oracle's A2J runs on the HIP engine's crop, so no frame escapes the keypoint comparison
+A frame whose candidate set or crop box differs is never waved through: `_diagnose` re-runs the oracle for that frame in
+fp64 and the frame is tolerated only if the deciding quantity (a score against 0.7, a box coordinate against an integer)
+sits inside max(2 delta, 3 x the fp32 oracle's distance from its fp64 self).  The offending values are printed and
+collected (gpurun_out/parity_sweep_report.json, copied to profiles/); `test_tolerated_frames_are_rare` bounds their number.
 """
 import json
 import os
@@ -38,7 +41,7 @@ pytestmark = pytest.mark.gpu
 NUM_CLASSES = 3
 HAND = NUM_CLASSES - 1
 KP_TOL = 1e-3                     # north_star: keypoints within 1e-3 of the fp32 reference
-REPORT = {"cases": {}, "tolerated": []}
+REPORT = {"cases": {}, "tolerated": [], "order": []}
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -122,11 +125,13 @@ def _oracle(name):
     c = _case(name)
     fsd, asd = _fcos_sd(c["weights"][0]), _a2j_sd(c["weights"][1])
     frames, depth = c["frames"], c["depth"]
-    dets, cands = [], []
+    dets, cands, smax = [], [], []
     for lo in range(0, len(frames), 4):
         d, inter = fcos_ref.fcos_forward(frames[lo:lo + 4], fsd, NUM_CLASSES, return_intermediates=True)
         dets += d
         cands += inter["candidates"]
+        ho = inter["head"]
+        smax += list(torch.sqrt(torch.sigmoid(ho["cls_logits"]) * torch.sigmoid(ho["bbox_ctrness"])).max(dim=-1)[0])
     mask, boxes, dcrops = handnet_ref.select_and_crop(dets, depth, NUM_CLASSES)
     kp = torch.zeros((len(frames), 21, 3))
     noise64 = 0.0
@@ -142,120 +147,80 @@ def _oracle(name):
     _FACTS[name] = dict(candidates=[len(x["index"]) for x in cands], mask=mask.tolist(), names=c.get("names"))
     _ORACLE.clear()
     _ORACLE[name] = dict(case=c, dets=dets, cands=cands, mask=mask, boxes=boxes, dcrops=dcrops, kp=kp, noise64=noise64,
-                         ref_tuple=ref_tuple)
+                         ref_tuple=ref_tuple, smax=smax)
     return _ORACLE[name]
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# diagnosis of a frame whose integer results differ
+# the HIP side's scores of ALL anchor points, and the fp64 diagnosis of a frame whose candidate set or crop box differs
 # ---------------------------------------------------------------------------------------------------------------------
-def _hip_scores(eng, frame):
-    """scores_max of every anchor point from the HIP engine's own head tensors (fcos.py:593-598 on the device)"""
-    cls_lr, reg_ctr, _, _ = eng.fcos.forward_heads(frame[None].cuda())
-    cls = torch.cat([t.reshape(-1, t.shape[-1])[:, :NUM_CLASSES] for t in cls_lr])
-    ctr = torch.cat([t.reshape(-1, t.shape[-1])[:, 4:5] for t in reg_ctr])
+SCORE_TOL = 3e-5      # max |HIP score - oracle fp32 score| over all points of a frame (measured: 1.3e-5)
+
+
+def _hip_scores(eng, batch):
+    """scores_max [N, P] of every anchor point from the HIP engine's own head tensors (fcos.py:593-598 on the device)"""
+    cls_lr, reg_ctr, _, _ = eng.fcos.forward_heads(batch)
+    n = batch.shape[0]
+    cls = torch.cat([t.reshape(n, -1, t.shape[-1])[..., :NUM_CLASSES] for t in cls_lr], dim=1)
+    ctr = torch.cat([t.reshape(n, -1, t.shape[-1])[..., 4:5] for t in reg_ctr], dim=1)
     return torch.sqrt(torch.sigmoid(cls) * torch.sigmoid(ctr)).max(dim=-1)[0].cpu()
 
 
-def _iou(a, b):
-    w = max(0.0, min(a[2], b[2]) - max(a[0], b[0]))
-    h = max(0.0, min(a[3], b[3]) - max(a[1], b[1]))
-    inter = w * h
-    return inter / ((a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - inter)
-
-
-def _diagnose(name, i, eng, ora, hip_points, hip_keep, hip_box, hip_scores):
-    """-> (tolerated?, record).  Re-runs the oracle for frame i in fp64 and looks for the decision the fp32 oracle
-    itself does not determine.  hip_scores: the HIP engine's scores of its candidates (anchor order)."""
-    from oracle import a2j_ref, fcos_ref, handnet_ref
+def _oracle64(ora, i):
+    """the oracle for frame i in fp64: (detections, all-point scores)"""
+    from oracle import a2j_ref, fcos_ref
     c = ora["case"]
-    frame = c["frames"][i]
     fsd = _fcos_sd(c["weights"][0])
-    _, i32 = fcos_ref.fcos_forward([frame], fsd, NUM_CLASSES, return_intermediates=True)
-    d64, i64 = fcos_ref.fcos_forward([frame.double()], a2j_ref.to_dtype(fsd, torch.float64), NUM_CLASSES,
+    d64, i64 = fcos_ref.fcos_forward([c["frames"][i].double()], a2j_ref.to_dtype(fsd, torch.float64), NUM_CLASSES,
                                      return_intermediates=True)
+    ho = i64["head"]
+    return d64[0], torch.sqrt(torch.sigmoid(ho["cls_logits"][0]) * torch.sigmoid(ho["bbox_ctrness"][0])).max(dim=-1)[0]
 
-    def smax(inter):
-        ho = inter["head"]
-        return torch.sqrt(torch.sigmoid(ho["cls_logits"][0]) * torch.sigmoid(ho["bbox_ctrness"][0])).max(dim=-1)[0].double()
 
-    s32, s64, sh = smax(i32), smax(i64), _hip_scores(eng, frame).double()
-    noise = float((s32 - s64).abs().max())                       # the fp32 oracle's own score noise on this frame
-    hipdiff = float((sh - s32).abs().max())
-    rec = {"case": name, "frame": i, "frame_name": (c.get("names") or [None] * (i + 1))[i],
-           "oracle_fp32_vs_fp64_score_noise": noise, "hip_vs_oracle_fp32_score_diff": hipdiff}
-    # the arithmetic contract on the scores themselves: whatever is tolerated below, the HIP scores stay this close
-    if hipdiff > 5e-5:
-        rec["kind"] = "scores differ by more than 5e-5"
-        return False, rec
-    margin = 3.0 * max(noise, hipdiff)
-    rec["decision_margin"] = margin
-    cand = ora["cands"][i]
-    ref_points = cand["index"]
-    sym = sorted(set(hip_points.tolist()) ^ set(ref_points.tolist()))
-    if sym:
-        rec["kind"] = "candidate set (score vs 0.7, fcos.py:600)"
-        rec["points"] = [{"point": p, "oracle_fp32": float(s32[p]), "oracle_fp64": float(s64[p]), "hip": float(sh[p])}
-                         for p in sym]
-        worst = max(abs(float(s32[p]) - 0.7) for p in sym)
-        rec["worst_margin_to_0.7"] = worst
-        return worst <= margin, rec
-    ref_keep = ora["dets"][i]["keep"]
-    if hip_keep.tolist() != ref_keep.tolist():
-        # Same candidates, different survivor list.  (1) the score ORDER: pairs of candidates the two sides rank differently
-        # must be (near-)ties of the oracle; (2) given the HIP engine's order, the REFERENCE NMS on the oracle's boxes must
-        # return exactly the HIP survivors -- then the order of (near-)tied scores is the whole difference.
-        os_, hs = cand["scores"].double(), hip_scores.double()
-        order_o = sorted(range(len(os_)), key=lambda k: (-float(os_[k]), k))
-        order_h = sorted(range(len(hs)), key=lambda k: (-float(hs[k]), k))
-        rank_h = {k: r for r, k in enumerate(order_h)}
-        seq = [rank_h[k] for k in order_o]           # HIP ranks in the oracle's order: inversions = pairs ranked differently
-        worst_gap, inversions, ties = 0.0, 0, int((os_[order_o][:-1] == os_[order_o][1:]).sum()) if len(os_) > 1 else 0
-        for a_ in range(len(seq)):
-            for b_ in range(a_ + 1, len(seq)):
-                if seq[a_] > seq[b_]:
-                    inversions += 1
-                    worst_gap = max(worst_gap, abs(float(os_[order_o[a_]] - os_[order_o[b_]])))
-        rec.update(kind="NMS survivors / score order (fcos.py:635)", candidates=len(os_), pairs_ranked_differently=inversions,
-                   largest_oracle_score_gap_of_such_a_pair=worst_gap, exact_score_ties_in_the_oracle=ties)
-        redo = fcos_ref.batched_nms(cand["boxes"], hip_scores.float(), cand["labels"], 0.3)
-        rec["reference_nms_on_hip_score_order_gives_hip_survivors"] = redo.tolist() == hip_keep.tolist()
-        if inversions and worst_gap <= margin and rec["reference_nms_on_hip_score_order_gives_hip_survivors"]:
-            return True, rec
-        # otherwise an IoU decided differently: report the margins of the candidates that changed sides
-        cb, lab, sc = cand["boxes"], cand["labels"], cand["scores"]
-        margins = []
-        for j in sorted(set(hip_keep.tolist()) ^ set(ref_keep.tolist()))[:16]:
-            best = None
-            for k in range(len(sc)):
-                if k != j and lab[k] == lab[j] and sc[k] >= sc[j]:
-                    v = _iou(cb[k].tolist(), cb[j].tolist())
-                    if best is None or abs(v - 0.3) < abs(best - 0.3):
-                        best = v
-            margins.append({"candidate": j, "closest_iou_to_0.3": best})
-        rec["iou_margins"] = margins
-        return False, rec
-    # same survivors: the crop box differs through a coordinate that straddles an integer (handnet_pipeline.py:88-97)
+def _diagnose_candidates(name, i, ora, hip_points, s_hip, delta):
+    """candidate sets differ: every point that changed sides must sit on the 0.7 threshold (fcos.py:600)"""
+    s32 = ora["smax"][i].double()
+    _, s64 = _oracle64(ora, i)
+    noise = float((s32 - s64).abs().max())
+    sym = sorted(set(hip_points.tolist()) ^ set(ora["cands"][i]["index"].tolist()))
+    margin = max(2.0 * delta, 3.0 * noise)
+    worst = max(abs(float(s32[p]) - 0.7) for p in sym)
+    rec = {"case": name, "frame": i, "kind": "candidate set (score vs 0.7, fcos.py:600)", "hip_vs_oracle_score_delta": delta,
+           "oracle_fp32_vs_fp64_score_noise": noise, "decision_margin": margin, "worst_margin_to_0.7": worst,
+           "points": [{"point": q, "oracle_fp32": float(s32[q]), "oracle_fp64": float(s64[q]), "hip": float(s_hip[q])}
+                      for q in sym]}
+    return worst <= margin, rec
+
+
+def _diagnose_crop(name, i, ora, hip_box, delta):
+    """same survivors, different integer crop box: a coordinate of the top-1 hand box straddles an integer
+    (handnet_pipeline.py:88-97)"""
+    from oracle import handnet_ref
     d = ora["dets"][i]
+    d64, _ = _oracle64(ora, i)
     hb = d["boxes"][d["labels"] == HAND][:1]
-    hb64 = d64[0]["boxes"][d64[0]["labels"] == HAND][:1]
-    rec["kind"] = "crop box (int64 truncation, handnet_pipeline.py:88)"
-    rec["oracle_fp32_top_hand_box"] = hb.tolist()
-    rec["oracle_fp64_top_hand_box"] = hb64.tolist()
-    rec["hip_crop"] = hip_box.tolist()
-    rec["oracle_crop"] = handnet_ref.crop_box(hb, pc.W, pc.H).tolist() if len(hb) else None
+    hb64 = d64["boxes"][d64["labels"] == HAND][:1]
+    rec = {"case": name, "frame": i, "kind": "crop box (int64 truncation, handnet_pipeline.py:88)",
+           "oracle_fp32_top_hand_box": hb.tolist(), "oracle_fp64_top_hand_box": hb64.tolist(), "hip_crop": hip_box.tolist(),
+           "oracle_crop": handnet_ref.crop_box(hb, pc.W, pc.H).tolist() if len(hb) else None}
     if not len(hb) or not len(hb64):
         return False, rec
     coord_noise = float((hb.double() - hb64).abs().max())
-    dist = float((hb - hb.round()).abs().min())
+    # distance of a coordinate, and of its 0.4-padded self, to the next integer
+    x = hb.reshape(4).double()
+    w, h = torch.trunc(x[2]) - torch.trunc(x[0]), torch.trunc(x[3]) - torch.trunc(x[1])
+    padded = torch.stack([torch.trunc(x[0]) - 0.4 * w, torch.trunc(x[1]) - 0.4 * h, torch.trunc(x[2]) + 0.4 * w,
+                          torch.trunc(x[3]) + 0.4 * h])
+    dist = min(float((x - x.round()).abs().min()), float((padded - padded.round()).abs().min()))
     rec.update(oracle_fp32_vs_fp64_coordinate_noise=coord_noise, min_distance_to_integer=dist)
-    return dist <= 3.0 * coord_noise, rec
+    return dist <= max(3.0 * coord_noise, 1e-3), rec
 
 
 # ---------------------------------------------------------------------------------------------------------------------
 # the sweep
 # ---------------------------------------------------------------------------------------------------------------------
 def _compare(name, check_range):
+    from oracle import a2j_ref, fcos_ref, handnet_ref
     ora = _oracle(name)
     c = ora["case"]
     frames, depth = c["frames"], c["depth"]
@@ -263,64 +228,125 @@ def _compare(name, check_range):
     net = _net(c["weights"])
     eng = net.engine()
     eng.check_range = bool(check_range)
+    batch = torch.stack(frames).cuda()
     try:
         with torch.inference_mode():
-            out = net.forward_device(torch.stack(frames).cuda(), depth.cuda(), _graph=False)
+            out = net.forward_device(batch, depth.cuda(), _graph=False)
             tup = net([f.cuda() for f in frames], depth_images=depth.cuda())
             tup2 = net([f.cuda() for f in frames], depth_images=depth.cuda())      # (second call: the sparse-stream path)
+            s_hip = _hip_scores(eng, batch)
     finally:
         eng.check_range = False
+    if out.range_flags is not None:
+        assert out.range_flags.cpu().tolist() == [0, 0, 0, 0]
     cnt = out.candidates.count.cpu().tolist()
     pts = out.candidates.point.cpu()
     cscores = out.candidates.scores.cpu()
     det = out.detections
     dcount = det.count.cpu().tolist()
     keep, labels, boxes = det.keep.cpu(), det.labels.cpu(), det.boxes.cpu()
-    has = out.has_hand.bool().cpu()
+    has = out.has_hand.cpu()
     box = out.crop_box.cpu()
     kp = out.keypoints.cpu()
     crops = out.crops_nhwc[..., 0].cpu()
-    tolerated = []
+    asd = _a2j_sd(c["weights"][1])
+    identical, order_frames, tolerated, moved = 0, [], [], []   # moved: frames whose crop box differs for a tolerated reason
+    deltas, worst_gap = [], 0.0
     for i in range(n):
-        rp, rd = ora["cands"][i]["index"], ora["dets"][i]
+        cand, rd = ora["cands"][i], ora["dets"][i]
+        rp = cand["index"]
         hp, hk = pts[i, :cnt[i]].long(), keep[i, :dcount[i]].long()
-        integer_ok = (hp.tolist() == rp.tolist() and hk.tolist() == rd["keep"].tolist()
-                      and labels[i, :dcount[i]].long().tolist() == rd["labels"].tolist()
-                      and bool(has[i]) == bool(ora["mask"][i]))
-        if integer_ok and ora["mask"][i]:
-            j = int(ora["mask"][:i].sum())
-            integer_ok = box[i].tolist() == ora["boxes"][j].tolist()
-        if not integer_ok:
-            ok, rec = _diagnose(name, i, eng, ora, hp, hk, box[i], cscores[i, :cnt[i]])
-            rec["check_range"] = bool(check_range)
-            print(("TOLERATED (the fp32 oracle does not determine this decision either): " if ok else "MISMATCH: ")
-                  + json.dumps(rec))
+        delta = float((s_hip[i].double() - ora["smax"][i].double()).abs().max())
+        deltas.append(delta)
+        assert delta <= SCORE_TOL, (name, i, delta)
+        frame_name = (c.get("names") or [None] * n)[i]
+        same_box = True
+        if hp.tolist() != rp.tolist():
+            ok, rec = _diagnose_candidates(name, i, ora, hp, s_hip[i].double(), delta)
+            rec.update(check_range=bool(check_range), frame_name=frame_name)
+            print(("TOLERATED (fp32-grade arithmetic does not determine this decision): " if ok else "MISMATCH: ") + json.dumps(rec))
             assert ok, rec
             tolerated.append(i)
             REPORT["tolerated"].append(rec)
-            continue
-        # detection boxes / scores: fp32 values computed from logits that differ in the last bits
-        if dcount[i]:
-            assert (boxes[i, :dcount[i]] - rd["boxes"]).abs().max().item() < 2e-2, (name, i)
-        if ora["mask"][i]:
-            j = int(ora["mask"][:i].sum())
-            assert torch.equal(crops[i], ora["dcrops"][j][0]), (name, i)       # pure gather: bit-exact
+            same_box = False        # (whatever follows works on another candidate list)
         else:
-            assert box[i].tolist() == [0, 0, 0, 0] and float(kp[i].abs().max()) == 0.0
-    good = [i for i in range(n) if i not in tolerated and bool(ora["mask"][i])]
+            hs = cscores[i, :cnt[i]]
+            # bit-exact NMS: the reference algorithm on the oracle's boxes / labels in the HIP score order = the HIP survivors
+            redo = fcos_ref.batched_nms(cand["boxes"], hs, cand["labels"], 0.3)
+            assert redo.tolist() == hk.tolist(), (name, i, "NMS survivors differ from the reference NMS on the same score order")
+            assert labels[i, :dcount[i]].long().tolist() == cand["labels"][hk].tolist(), (name, i)
+            if hk.tolist() != rd["keep"].tolist():
+                # the score ORDER differs: every pair the two sides rank differently must be closer than 2 delta
+                os_ = cand["scores"].double()
+                order_o = sorted(range(len(os_)), key=lambda k: (-float(os_[k]), k))
+                rank_h = {k: r for r, k in enumerate(sorted(range(len(hs)), key=lambda k: (-float(hs[k]), k)))}
+                seq = [rank_h[k] for k in order_o]
+                inv, gap = 0, 0.0
+                for a_ in range(len(seq)):
+                    for b_ in range(a_ + 1, len(seq)):
+                        if seq[a_] > seq[b_]:
+                            inv += 1
+                            gap = max(gap, abs(float(os_[order_o[a_]] - os_[order_o[b_]])))
+                ties = int((os_[order_o][:-1] == os_[order_o][1:]).sum()) if len(os_) > 1 else 0
+                rec = {"case": name, "frame": i, "frame_name": frame_name, "kind": "score order of near-tied candidates",
+                       "candidates": len(os_), "pairs_ranked_differently": inv, "largest_oracle_score_gap_of_such_a_pair": gap,
+                       "exact_score_ties_in_the_oracle": ties, "hip_vs_oracle_score_delta": delta,
+                       "survivor_set_identical": sorted(hk.tolist()) == sorted(rd["keep"].tolist()),
+                       "check_range": bool(check_range)}
+                assert inv > 0 and gap <= 2.0 * delta, rec
+                worst_gap = max(worst_gap, gap)
+                order_frames.append(i)
+                REPORT["order"].append(rec)
+            else:
+                assert (boxes[i, :dcount[i]] - rd["boxes"]).abs().max().item() < 2e-2 if dcount[i] else True
+        # ---- crop stage ----
+        if bool(has[i]) != bool(ora["mask"][i]):
+            same_box = False
+        elif ora["mask"][i]:
+            j = int(ora["mask"][:i].sum())
+            same_box = same_box and box[i].tolist() == ora["boxes"][j].tolist()
+        if not same_box and i not in tolerated and i not in order_frames:
+            ok, rec = _diagnose_crop(name, i, ora, box[i], delta)
+            rec.update(check_range=bool(check_range), frame_name=frame_name)
+            print(("TOLERATED (fp32-grade arithmetic does not determine this decision): " if ok else "MISMATCH: ") + json.dumps(rec))
+            assert ok, rec
+            tolerated.append(i)
+            REPORT["tolerated"].append(rec)
+        if same_box:
+            identical += int(i not in order_frames)
+            if ora["mask"][i]:
+                j = int(ora["mask"][:i].sum())
+                assert torch.equal(crops[i], ora["dcrops"][j][0]), (name, i)       # pure gather: bit-exact
+            else:
+                assert box[i].tolist() == [0, 0, 0, 0] and float(kp[i].abs().max()) == 0.0
+        else:
+            moved.append(i)
+    # ---- keypoints, every frame with a hand: the oracle's A2J on the oracle's crop, or (moved frames) on the HIP crop ----
+    ref_kp = ora["kp"].clone()
+    for i in moved:
+        if has[i]:
+            dc = handnet_ref.crop_depth(depth[i], box[i])
+            assert dc is not None and torch.equal(crops[i], dc[0]), (name, i)
+            ref_kp[i] = a2j_ref.a2j_forward(dc[None], asd)[0]
+        else:
+            ref_kp[i] = 0.0
     tol = max(KP_TOL, 3.0 * ora["noise64"])
-    err = float((kp[good] - ora["kp"][good]).abs().max()) if good else 0.0
-    assert torch.isfinite(kp).all()
+    sel = has.bool()
+    err = float((kp[sel] - ref_kp[sel]).abs().max()) if bool(sel.any()) else 0.0
+    assert torch.isfinite(kp).all() and float(kp[~sel].abs().max() if bool((~sel).any()) else 0.0) == 0.0
     print(f"[parity sweep] {name} check_range={int(check_range)}: {n} frames, {int(ora['mask'].sum())} with a hand, candidates "
-          f"{min(cnt)}..{max(cnt)}, survivors {min(dcount)}..{max(dcount)}, max |dkp| {err:.2e} (oracle fp32-vs-fp64 on the "
-          f"same crops {ora['noise64']:.2e}, bound {tol:.1e}), tolerated frames {tolerated}")
+          f"{min(cnt)}..{max(cnt)}, survivors {min(dcount)}..{max(dcount)}; identical in every integer {identical}, order of "
+          f"near-tied scores differs {order_frames} (largest gap {worst_gap:.1e}), tolerated decisions {tolerated}, crop box "
+          f"moved {moved}; score delta {max(deltas):.1e}; max |dkp| {err:.2e} over {int(sel.sum())} frames (oracle fp32-vs-fp64 "
+          f"on the same crops {ora['noise64']:.2e}, bound {tol:.1e})")
     assert err < tol, (name, err, tol)
     REPORT["cases"][f"{name}/{int(check_range)}"] = {
         "frames": n, "frames_with_hand": int(ora["mask"].sum()), "candidates": [min(cnt), max(cnt)],
-        "survivors": [min(dcount), max(dcount)], "max_abs_keypoint_diff": err, "oracle_fp32_vs_fp64": ora["noise64"],
-        "bound": tol, "tolerated_frames": tolerated}
+        "survivors": [min(dcount), max(dcount)], "frames_identical_in_every_integer": identical,
+        "frames_with_score_order_differences": order_frames, "tolerated_frames": tolerated, "crop_box_moved": moved,
+        "max_score_delta": max(deltas), "max_abs_keypoint_diff": err, "oracle_fp32_vs_fp64": ora["noise64"], "bound": tol}
     # ---- the reference's return tuple through the drop-in callable (handnet_pipeline.py:107-116) ----
-    if tolerated:
+    if moved:
         return
     rkp, rdb, rcrops = ora["ref_tuple"]
     for t in (tup, tup2):
@@ -361,9 +387,18 @@ def test_cases_reach_the_decision_points():
 
 
 def test_tolerated_frames_are_rare():
-    """Runs last in this module: every tolerated frame was printed with its offending values; they must stay the
-    exception (<= 2 % of the frame evaluations) -- and the report is written where gpurun brings it back."""
+    """Runs last in this module: every tolerated decision was printed with its offending values; they must stay the
+    exception -- candidate-set / crop-box decisions on the threshold in <= 2 % of the frame evaluations, frames whose
+    crop box moved (through those or through the order of tied scores) in <= 5 % -- and the report is written where
+    gpurun brings it back."""
     frames = sum(v["frames"] for v in REPORT["cases"].values())
+    moved = sum(len(v["crop_box_moved"]) for v in REPORT["cases"].values())
+    order = sum(len(v["frames_with_score_order_differences"]) for v in REPORT["cases"].values())
+    REPORT["summary"] = {"frame_evaluations": frames, "tolerated_decisions": len(REPORT["tolerated"]),
+                         "frames_with_score_order_differences": order, "frames_whose_crop_box_moved": moved,
+                         "frames_identical_in_every_integer": sum(v["frames_identical_in_every_integer"]
+                                                                  for v in REPORT["cases"].values())}
+    print("[parity sweep] summary:", json.dumps(REPORT["summary"]))
     out = Path(os.environ.get("GRAFT_REPO_ROOT", Path(__file__).resolve().parent.parent)) / "gpurun_out"
     try:
         out.mkdir(exist_ok=True)
@@ -372,3 +407,4 @@ def test_tolerated_frames_are_rare():
         pass
     if frames:
         assert len(REPORT["tolerated"]) <= 0.02 * frames, REPORT["tolerated"]
+        assert moved <= 0.05 * frames, REPORT["summary"]
