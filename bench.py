@@ -155,8 +155,6 @@ def build_workload(args, dev, rank):
     if args.native:
         from hn_amd.native_model import NativeModel
         from hn_amd.pipeline import HandNetOutput
-        if args.precision == "f32":
-            raise SystemExit("--native: the model-level C ABI has the f16x3 and f16x1 modes (hn_model_config.f16_terms)")
         native = NativeModel(fcos_sd, a2j_sd, num_classes=3, device=dev, precision=args.precision)
         info["native"] = native
 

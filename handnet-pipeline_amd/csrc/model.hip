@@ -10,7 +10,7 @@
 //                    repacking, hi/lo fp16 splitting, upload (the only place weights are allocated)
 //   hn_fcos_forward  fcos_utils/fcos.py:675-767 (eval)      hn_a2j_forward   a2j/a2j.py:243-250
 //   hn_handnet_forward  handnet_pipeline/handnet_pipeline.py:58-116
-// Default precision (f16x3) only; the exact-f32 mode and mixed-size image lists stay op-level / Python.
+// Precision per hn_model_config: f16x3 (default), f16x1 (f16_terms = 1) or the exact f32 MFMA (precision = HN_PRECISION_F32).
 // Memory: activations live in one arena per model that is sized by a dry pass over the graph and (re)allocated only
 // when a forward needs more than any earlier one -- steady-state calls neither allocate nor synchronise.
 #include "hn_common.h"
@@ -104,6 +104,7 @@ struct hn_model {
   ConvW a_cls[4], a_reg[3], a_dep[3], a_regdep1, a_cls_out, a_reg_out, a_dep_out;
   // ---- FCOS ----
   ConvW f_stem16;  // w16 = [64][7][2][32] stem rows, bias
+  ConvW f_stem;    // exact-f32 mode: [64][7][7][4] fp32 bank of conv1 + bn1
   struct Basic { ConvW c1, c2, ds; bool has_ds = false; int layer = 0; bool last = false; };
   std::vector<Basic> f_blocks;
   ConvW f_inner[3], f_layer[3], f_tower0, f_cls_t[3], f_reg_t[3], f_cls_out, f_reg_out, f_ext_out;  // f_ext_out: cfg.ext only
@@ -217,11 +218,12 @@ int pack_conv(const hn_model* m, const std::string& wname, const std::string& bn
       cw.hb[o] = (float)v;
     }
   }
-  if (cp % 32 == 0) HN_TRY(split_bank(cw.hw, cout, r, s, cp, cw.hw16, wname.c_str()));
+  // (the exact-f32 mode keeps the fp32 bank: no split, no fp16-range condition on the folded weights)
+  if (cp % 32 == 0 && m->cfg.precision != HN_PRECISION_F32) HN_TRY(split_bank(cw.hw, cout, r, s, cp, cw.hw16, wname.c_str()));
   return HN_OK;
 }
 
-int concat_cout(const ConvW& a, const ConvW& b, ConvW& out, const char* what) {
+int concat_cout(const ConvW& a, const ConvW& b, ConvW& out, const char* what, bool f32 = false) {
   if (a.r != b.r || a.s != b.s || a.cin != b.cin || a.stride != b.stride || a.pad != b.pad || a.dil != b.dil)
     return hn::fail(HN_ERR_ARG, "%s: stacked convolutions differ in geometry", what);
   out = a;
@@ -234,7 +236,7 @@ int concat_cout(const ConvW& a, const ConvW& b, ConvW& out, const char* what) {
     for (int i = 0; i < b.cout && b.has_bias; ++i) out.hb[a.cout + i] = b.hb[i];
   }
   out.hw16.clear();
-  if (out.cin % 32 == 0) HN_TRY(split_bank(out.hw, out.cout, out.r, out.s, out.cin, out.hw16, what));
+  if (out.cin % 32 == 0 && !f32) HN_TRY(split_bank(out.hw, out.cout, out.r, out.s, out.cin, out.hw16, what));
   return HN_OK;
 }
 
@@ -410,6 +412,99 @@ int conv_thin_levels(Ctx& cx, const GroupSpec& g, int relu_cols) {
                                       cx.stream);
 }
 
+// one exact-f32 convolution (ops.conv2d_nhwc without w16 -> hn_conv2d_nhwc_f32): fp32 NHWC in and out; in_scale / in_shift =
+// the GroupNorm of the PREVIOUS layer applied (with its ReLU) while the input is staged
+int conv32(Ctx& cx, const T& x, const ConvW& cw, int relu_cols, const T* res, bool res_up, const float* in_scale,
+           const float* in_shift, int affine_stride, T& y) {
+  if (x.split || x.c != cw.cin) return hn::fail(HN_ERR_ARG, "model graph (f32): conv input mismatch (c %d vs cin %d)", x.c, cw.cin);
+  hn_conv_desc d = make_desc(x, cw, relu_cols);
+  d.terms = 0;
+  y = alloc(cx, x.n, d.oh, d.ow, cw.cout, false);
+  if (res) {
+    d.res_mode = res_up ? 2 : 1;
+    if (res_up) { d.res_h = res->h; d.res_w = res->w; }
+  }
+  if (in_scale) {
+    d.in_affine = 1;
+    d.in_affine_stride = affine_stride == cw.cin ? 0 : affine_stride;
+  }
+  if (cx.dry) return HN_OK;
+  return hn_conv2d_nhwc_f32(&d, (const float*)x.p, cw.w, cw.bias, res ? (const float*)res->p : nullptr, in_scale, in_shift,
+                            (float*)y.p, cx.stream);
+}
+
+// channel slice of a dense fp32 tensor (no copy)
+T slice_channels(const T& x, int c0, int c1) {
+  T s = x;
+  s.p = x.p + (size_t)c0 * 4;
+  s.c = c1 - c0;
+  s.bytes = 0;
+  return s;
+}
+
+int maxpool32(Ctx& cx, const T& x, T& y) {
+  y = alloc(cx, x.n, (x.h + 2 - 3) / 2 + 1, (x.w + 2 - 3) / 2 + 1, x.c, false);
+  if (cx.dry) return HN_OK;
+  return hn_maxpool3x3s2_nhwc_f32((const float*)x.p, (float*)y.p, x.n, x.h, x.w, x.c, y.h, y.w, cx.stream);
+}
+
+// A2J in the exact-f32 mode (A2JEngine(precision="f32"): every convolution on the f32-MFMA kernel, heads ungrouped)
+int a2j_graph_f32(Ctx& cx, const T& crops /* fp32 [k][176][176][4] */, const int32_t* valid, float* keypoints) {
+  hn_model* m = cx.m;
+  const int k = crops.n;
+  T s0, x;
+  HN_TRY(conv32(cx, crops, m->a_stem, m->a_stem.cout, nullptr, false, nullptr, nullptr, 0, s0));
+  HN_TRY(maxpool32(cx, s0, x));
+  release(cx, s0);
+  T x3;
+  for (size_t i = 0; i < m->a_blocks.size(); ++i) {
+    auto& b = m->a_blocks[i];
+    T o, o2, idn, y;
+    HN_TRY(conv32(cx, x, b.c1, b.c1.cout, nullptr, false, nullptr, nullptr, 0, o));
+    HN_TRY(conv32(cx, o, b.c2, b.c2.cout, nullptr, false, nullptr, nullptr, 0, o2));
+    if (b.has_ds) HN_TRY(conv32(cx, x, b.ds, 0, nullptr, false, nullptr, nullptr, 0, idn));
+    else idn = x;
+    HN_TRY(conv32(cx, o2, b.c3, b.c3.cout, &idn, false, nullptr, nullptr, 0, y));
+    release(cx, o);
+    release(cx, o2);
+    if (b.has_ds) release(cx, idn);
+    if (x.p != x3.p) release(cx, x);
+    x = y;
+    const bool last_of_layer = i + 1 == m->a_blocks.size() || m->a_blocks[i + 1].layer != b.layer;
+    if (b.layer == 3 && last_of_layer) x3 = x;
+  }
+  const T x4 = x;
+  T c, rd;
+  HN_TRY(conv32(cx, x3, m->a_cls[0], 256, nullptr, false, nullptr, nullptr, 0, c));
+  HN_TRY(conv32(cx, x4, m->a_regdep1, 512, nullptr, false, nullptr, nullptr, 0, rd));
+  T r = slice_channels(rd, 0, 256), dd = slice_channels(rd, 256, 512);
+  for (int i = 1; i <= 3; ++i) {
+    T t2;
+    HN_TRY(conv32(cx, c, m->a_cls[i], 256, nullptr, false, nullptr, nullptr, 0, t2));
+    release(cx, c);
+    c = t2;
+  }
+  T cls, reg, dep;
+  HN_TRY(conv32(cx, c, m->a_cls_out, 0, nullptr, false, nullptr, nullptr, 0, cls));
+  for (int i = 0; i < 3; ++i) {
+    T t2;
+    HN_TRY(conv32(cx, r, m->a_reg[i], 256, nullptr, false, nullptr, nullptr, 0, t2));
+    release(cx, r);
+    r = t2;
+  }
+  for (int i = 0; i < 3; ++i) {
+    T t2;
+    HN_TRY(conv32(cx, dd, m->a_dep[i], 256, nullptr, false, nullptr, nullptr, 0, t2));
+    release(cx, dd);
+    dd = t2;
+  }
+  HN_TRY(conv32(cx, r, m->a_reg_out, 0, nullptr, false, nullptr, nullptr, 0, reg));
+  HN_TRY(conv32(cx, dd, m->a_dep_out, 0, nullptr, false, nullptr, nullptr, 0, dep));
+  if (cx.dry) return HN_OK;
+  return hn_a2j_aggregate_f32((const float*)cls.p, (const float*)reg.p, (const float*)dep.p, valid, k, cls.h, cls.w,
+                              m->cfg.num_joints, 16, keypoints, cx.stream);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // A2J (hn_amd/a2j_engine.py)
 // ------------------------------------------------------------------------------------------------------------------
@@ -418,6 +513,7 @@ int conv_thin_levels(Ctx& cx, const GroupSpec& g, int relu_cols) {
 int a2j_graph(Ctx& cx, const T& crops /* fp32 [k][176][176][4] */, const int32_t* valid, float* keypoints,
               int32_t* valid_rw = nullptr) {
   hn_model* m = cx.m;
+  if (m->cfg.precision == HN_PRECISION_F32) return a2j_graph_f32(cx, crops, valid, keypoints);
   const int k = crops.n;
   // stem: conv1 + bn1 + relu + maxpool as ONE split-precision kernel on the crops' stem image (like hn_amd/a2j_engine.py)
   const int border = 3;
@@ -536,39 +632,103 @@ Geometry list_canvas(const hn_model_config& c, const ImageList& ls, int n) {
   return g;
 }
 
-int fcos_graph(Ctx& cx, const float* rgb, int n, int h, int w, const FcosOut& out, const ImageList* ls = nullptr) {
+// The detector's network in the exact-f32 mode (FCOSEngine(precision="f32"): every convolution on the f32-MFMA kernel,
+// GroupNorm statistics by a separate pass, its affine + ReLU applied while the next convolution stages its input; one
+// FPN level after the other, FCOSEngine.head_level).  Fills lv (+ ext_lv) like the split-precision graph does.
+int fcos_net_f32(Ctx& cx, const float* rgb, int n, int h, int w, const Geometry& g, const float* const* ptrs_dev,
+                 const int32_t* geom_dev, const float* mean, const float* stdv, bool want_ext, hn_fcos_levels& lv, T* ext_lv,
+                 int* hw) {
   hn_model* m = cx.m;
-  const Geometry g = ls ? list_canvas(m->cfg, *ls, n) : geometry(m->cfg, h, w);
-  const int want_cap = (g.ph / 8) * (g.pw / 8) + (g.ph / 16) * (g.pw / 16) + (g.ph / 32) * (g.pw / 32);
-  if (out.cap != want_cap)
-    return hn::fail(HN_ERR_ARG, "detection arrays must have hn_fcos_capacity%s = %d rows per image (got %d)", ls ? "_list" : "",
-                    want_cap, out.cap);
-  const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+  T canvas = alloc(cx, n, g.ph, g.pw, 4, false);
+  if (!cx.dry) {
+    if (ptrs_dev) HN_TRY(hn_fcos_preprocess_list(ptrs_dev, geom_dev, canvas.p, 0, n, g.ph, g.pw, 0, mean, stdv, cx.stream));
+    else HN_TRY(hn_fcos_preprocess_f32(rgb, (float*)canvas.p, n, h, w, g.oh, g.ow, g.ph, g.pw, mean, stdv, cx.stream));
+  }
+  T s0, x;
+  HN_TRY(conv32(cx, canvas, m->f_stem, m->f_stem.cout, nullptr, false, nullptr, nullptr, 0, s0));
+  release(cx, canvas);
+  HN_TRY(maxpool32(cx, s0, x));
+  release(cx, s0);
+  T feats_c[3];
+  int nf = 0;
+  for (auto& b : m->f_blocks) {
+    T o, idn, y;
+    HN_TRY(conv32(cx, x, b.c1, b.c1.cout, nullptr, false, nullptr, nullptr, 0, o));
+    if (b.has_ds) HN_TRY(conv32(cx, x, b.ds, 0, nullptr, false, nullptr, nullptr, 0, idn));
+    else idn = x;
+    HN_TRY(conv32(cx, o, b.c2, b.c2.cout, &idn, false, nullptr, nullptr, 0, y));
+    release(cx, o);
+    if (b.has_ds) release(cx, idn);
+    bool saved = false;
+    for (int f = 0; f < nf; ++f) saved = saved || feats_c[f].p == x.p;
+    if (!saved) release(cx, x);
+    x = y;
+    if (b.last && b.layer >= 2) feats_c[nf++] = x;
+  }
+  T lat5, lat4, lat3;
+  HN_TRY(conv32(cx, feats_c[2], m->f_inner[2], 0, nullptr, false, nullptr, nullptr, 0, lat5));
+  HN_TRY(conv32(cx, feats_c[1], m->f_inner[1], 0, &lat5, true, nullptr, nullptr, 0, lat4));
+  HN_TRY(conv32(cx, feats_c[0], m->f_inner[0], 0, &lat4, true, nullptr, nullptr, 0, lat3));
+  const T lat[3] = {lat3, lat4, lat5};
+  memset(&lv, 0, sizeof(lv));
+  lv.num_levels = 3;
+  for (int l = 0; l < 3; ++l) {
+    T feat, t0;
+    HN_TRY(conv32(cx, lat[l], m->f_layer[l], 0, nullptr, false, nullptr, nullptr, 0, feat));
+    const int fh = feat.h, fw = feat.w;
+    hw[l] = fh * fw;
+    float* part = (float*)alloc_bytes(cx, (size_t)hn_groupnorm_scratch_floats(n, hw[l], 512, 64) * 4);
+    float* sc0 = (float*)alloc_bytes(cx, (size_t)n * 512 * 4);
+    float* sh0 = (float*)alloc_bytes(cx, (size_t)n * 512 * 4);
+    HN_TRY(conv32(cx, feat, m->f_tower0, 0, nullptr, false, nullptr, nullptr, 0, t0));
+    if (!cx.dry)
+      HN_TRY(hn_groupnorm_affine_f32((const float*)t0.p, m->f_gn0_gamma, m->f_gn0_beta, n, hw[l], 512, 64, 1e-5f, part, sc0, sh0,
+                                     cx.stream));
+    T tower_out[2];
+    const float *tsc[2], *tsh[2];
+    int tstride[2];
+    for (int tw = 0; tw < 2; ++tw) {   // 0: classification tower, 1: regression tower (fcos.py:267-329, 373-395)
+      T xin = slice_channels(t0, tw * 256, tw * 256 + 256);
+      const float *sc = sc0 + tw * 256, *sh = sh0 + tw * 256;
+      int stride = 512;
+      for (int layer = 0; layer < 3; ++layer) {
+        T y;
+        HN_TRY(conv32(cx, xin, tw == 0 ? m->f_cls_t[layer] : m->f_reg_t[layer], 0, nullptr, false, sc, sh, stride, y));
+        float* nsc = (float*)alloc_bytes(cx, (size_t)n * 256 * 4);
+        float* nsh = (float*)alloc_bytes(cx, (size_t)n * 256 * 4);
+        if (!cx.dry)
+          HN_TRY(hn_groupnorm_affine_f32((const float*)y.p, m->f_gn_gamma[layer] + tw * 256, m->f_gn_beta[layer] + tw * 256, n,
+                                         hw[l], 256, 32, 1e-5f, part, nsc, nsh, cx.stream));
+        release(cx, xin);   // (no-op for the slice of t0)
+        xin = y;
+        sc = nsc; sh = nsh; stride = 256;
+      }
+      tower_out[tw] = xin; tsc[tw] = sc; tsh[tw] = sh; tstride[tw] = stride;
+    }
+    T cls_lr, reg_ctr;
+    HN_TRY(conv32(cx, tower_out[0], m->f_cls_out, 0, nullptr, false, tsc[0], tsh[0], tstride[0], cls_lr));
+    if (want_ext) HN_TRY(conv32(cx, tower_out[0], m->f_ext_out, 3, nullptr, false, tsc[0], tsh[0], tstride[0], ext_lv[l]));
+    HN_TRY(conv32(cx, tower_out[1], m->f_reg_out, 4, nullptr, false, tsc[1], tsh[1], tstride[1], reg_ctr));
+    release(cx, tower_out[0]);
+    release(cx, tower_out[1]);
+    release(cx, t0);
+    release(cx, feat);
+    lv.h[l] = fh; lv.w[l] = fw; lv.stride[l] = g.ph / fh;
+    lv.cls_lr[l] = (const float*)cls_lr.p; lv.reg_ctr[l] = (const float*)reg_ctr.p;
+  }
+  return HN_OK;
+}
+
+// The detector's network in the default split-precision mode (FCOSEngine, f16x3 / f16x1): fills lv (+ ext_lv) and hw.
+int fcos_net_f16(Ctx& cx, const float* rgb, int n, int h, int w, const Geometry& g, const float* const* ptrs_dev,
+                 const int32_t* geom_dev, const float* mean, const float* stdv, bool want_ext, hn_fcos_levels& lv, T* ext_lv,
+                 int* hw) {
+  hn_model* m = cx.m;
   const int border = 3;
   char* img16 = alloc_bytes(cx, (size_t)2 * n * (g.ph + 2 * border) * (g.pw + 2 * border) * 4 * 2);
-  float* ratios_dev = nullptr;
-  if (ls) {   // device tables: image pointers, (h, w, oh, ow) rows, (ratio_h, ratio_w) rows; uploaded from pageable host memory,
-              // which hipMemcpyAsync stages before it returns
-    const float** ptrs_dev = (const float**)alloc_bytes(cx, (size_t)n * 8);
-    int32_t* geom_dev = (int32_t*)alloc_bytes(cx, (size_t)n * 16);
-    ratios_dev = (float*)alloc_bytes(cx, (size_t)n * 8);
-    if (!cx.dry) {
-      std::vector<int32_t> geom(4 * (size_t)n);
-      std::vector<float> ratios(2 * (size_t)n);
-      for (int i = 0; i < n; ++i) {
-        const Geometry gi = geometry(m->cfg, ls->hs[i], ls->ws[i]);
-        geom[4 * i] = ls->hs[i]; geom[4 * i + 1] = ls->ws[i]; geom[4 * i + 2] = gi.oh; geom[4 * i + 3] = gi.ow;
-        ratios[2 * i] = (float)ls->hs[i] / (float)gi.oh;       // resize_boxes (fcos.py:770-783): fp32 / fp32
-        ratios[2 * i + 1] = (float)ls->ws[i] / (float)gi.ow;
-      }
-      hipStream_t st = (hipStream_t)cx.stream;
-      HN_CHECK_HIP(hipMemcpyAsync((void*)ptrs_dev, ls->images, (size_t)n * 8, hipMemcpyHostToDevice, st));
-      HN_CHECK_HIP(hipMemcpyAsync(geom_dev, geom.data(), (size_t)n * 16, hipMemcpyHostToDevice, st));
-      HN_CHECK_HIP(hipMemcpyAsync(ratios_dev, ratios.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
-      HN_TRY(hn_fcos_preprocess_list(ptrs_dev, geom_dev, img16, 1, n, g.ph, g.pw, border, mean, stdv, cx.stream));
-    }
-  } else if (!cx.dry) {
-    HN_TRY(hn_fcos_preprocess_split(rgb, img16, n, h, w, g.oh, g.ow, g.ph, g.pw, border, mean, stdv, cx.stream));
+  if (!cx.dry) {
+    if (ptrs_dev) HN_TRY(hn_fcos_preprocess_list(ptrs_dev, geom_dev, img16, 1, n, g.ph, g.pw, border, mean, stdv, cx.stream));
+    else HN_TRY(hn_fcos_preprocess_split(rgb, img16, n, h, w, g.oh, g.ow, g.ph, g.pw, border, mean, stdv, cx.stream));
   }
   int sh, sw;
   out_size(g.ph + 2 * border, g.pw + 2 * border, 7, 7, 2, 0, 1, sh, sw);
@@ -610,7 +770,6 @@ int fcos_graph(Ctx& cx, const float* rgb, int n, int h, int w, const FcosOut& ou
     HN_TRY(conv_grouped(cx, gs, 0, true, 512, 0));
   }
   // ---- heads in lock-step over levels and towers (FCOSEngine.heads_grouped) ----
-  int hw[3];
   float* parts[3];
   for (int l = 0; l < L; ++l) {
     hw[l] = feats[l].h * feats[l].w;
@@ -673,13 +832,12 @@ int fcos_graph(Ctx& cx, const float* rgb, int n, int h, int w, const FcosOut& ou
   memset(&tl, 0, sizeof(tl));
   tl.count = L;
   for (int l = 0; l < L; ++l) { tl.h[l] = t[l].h; tl.w[l] = t[l].w; }
-  const bool fuse_gn = !hn::env_flags().no_thin && !hn::env_flags().no_fuse_last_gn && t_terms != 1 && !out.contacts &&
+  const bool fuse_gn = !hn::env_flags().no_thin && !hn::env_flags().no_fuse_last_gn && t_terms != 1 && !want_ext &&
                        hn_conv3x3_thin_affine_applies(&tl, n, 256, m->f_cls_out.cout) &&
                        hn_conv3x3_thin_affine_applies(&tl, n, 256, m->f_reg_out.cout);
-  hn_fcos_levels lv;
   memset(&lv, 0, sizeof(lv));
   lv.num_levels = L;
-  T cls_lr[3], reg_ctr[3], ext_lv[3];
+  T cls_lr[3], reg_ctr[3];
   if (fuse_gn) {
     hn_thin_affine ac, ar;
     hn_thin_levels yc = tl, yr = tl;
@@ -713,7 +871,7 @@ int fcos_graph(Ctx& cx, const float* rgb, int n, int h, int w, const FcosOut& ou
       lv.cls_lr[l] = (const float*)cls_lr[l].p; lv.reg_ctr[l] = (const float*)reg_ctr[l].p;
     }
     HN_TRY(conv_thin_levels(cx, gc, 0));
-    if (out.contacts) {  // ext heads: relu(hand_dydx_layer)[3] | hand_contact_state_layer[5] from the cls tower (fcos.py:255-264)
+    if (want_ext) {  // ext heads: relu(hand_dydx_layer)[3] | hand_contact_state_layer[5] from the cls tower (fcos.py:255-264)
       GroupSpec ge;
       ge.count = L;
       for (int l = 0; l < L; ++l) {
@@ -723,6 +881,53 @@ int fcos_graph(Ctx& cx, const float* rgb, int n, int h, int w, const FcosOut& ou
       HN_TRY(conv_thin_levels(cx, ge, 3));
     }
     HN_TRY(conv_thin_levels(cx, gr, 4));
+  }
+  return HN_OK;
+}
+
+int fcos_graph(Ctx& cx, const float* rgb, int n, int h, int w, const FcosOut& out, const ImageList* ls = nullptr) {
+  hn_model* m = cx.m;
+  const Geometry g = ls ? list_canvas(m->cfg, *ls, n) : geometry(m->cfg, h, w);
+  const int want_cap = (g.ph / 8) * (g.pw / 8) + (g.ph / 16) * (g.pw / 16) + (g.ph / 32) * (g.pw / 32);
+  if (out.cap != want_cap)
+    return hn::fail(HN_ERR_ARG, "detection arrays must have hn_fcos_capacity%s = %d rows per image (got %d)", ls ? "_list" : "",
+                    want_cap, out.cap);
+  // the transform's normalisation (fcos.py:501-505): hn_model_config.image_mean / image_std, default ImageNet's
+  float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+  if (m->cfg.image_std[0] != 0.f || m->cfg.image_std[1] != 0.f || m->cfg.image_std[2] != 0.f)
+    for (int c = 0; c < 3; ++c) { mean[c] = m->cfg.image_mean[c]; stdv[c] = m->cfg.image_std[c]; }
+  const bool f32 = m->cfg.precision == HN_PRECISION_F32;
+  float* ratios_dev = nullptr;
+  const float** ptrs_dev = nullptr;
+  int32_t* geom_dev = nullptr;
+  if (ls) {   // device tables: image pointers, (h, w, oh, ow) rows, (ratio_h, ratio_w) rows; uploaded from pageable host memory,
+              // which hipMemcpyAsync stages before it returns
+    ptrs_dev = (const float**)alloc_bytes(cx, (size_t)n * 8);
+    geom_dev = (int32_t*)alloc_bytes(cx, (size_t)n * 16);
+    ratios_dev = (float*)alloc_bytes(cx, (size_t)n * 8);
+    if (!cx.dry) {
+      std::vector<int32_t> geom(4 * (size_t)n);
+      std::vector<float> ratios(2 * (size_t)n);
+      for (int i = 0; i < n; ++i) {
+        const Geometry gi = geometry(m->cfg, ls->hs[i], ls->ws[i]);
+        geom[4 * i] = ls->hs[i]; geom[4 * i + 1] = ls->ws[i]; geom[4 * i + 2] = gi.oh; geom[4 * i + 3] = gi.ow;
+        ratios[2 * i] = (float)ls->hs[i] / (float)gi.oh;       // resize_boxes (fcos.py:770-783): fp32 / fp32
+        ratios[2 * i + 1] = (float)ls->ws[i] / (float)gi.ow;
+      }
+      hipStream_t st = (hipStream_t)cx.stream;
+      HN_CHECK_HIP(hipMemcpyAsync((void*)ptrs_dev, ls->images, (size_t)n * 8, hipMemcpyHostToDevice, st));
+      HN_CHECK_HIP(hipMemcpyAsync(geom_dev, geom.data(), (size_t)n * 16, hipMemcpyHostToDevice, st));
+      HN_CHECK_HIP(hipMemcpyAsync(ratios_dev, ratios.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+    }
+  }
+  hn_fcos_levels lv;
+  memset(&lv, 0, sizeof(lv));
+  T ext_lv[3];
+  int hw[3] = {0, 0, 0};
+  if (f32) {
+    HN_TRY(fcos_net_f32(cx, rgb, n, h, w, g, ptrs_dev, geom_dev, mean, stdv, out.contacts != nullptr, lv, ext_lv, hw));
+  } else {
+    HN_TRY(fcos_net_f16(cx, rgb, n, h, w, g, ptrs_dev, geom_dev, mean, stdv, out.contacts != nullptr, lv, ext_lv, hw));
   }
   const int cap = hw[0] + hw[1] + hw[2];
   if (out.cap != cap) return hn::fail(HN_ERR_ARG, "internal: %d anchor points but capacity %d", cap, out.cap);
@@ -824,6 +1029,11 @@ extern "C" int hn_create(const hn_model_config* cfg, hn_model** out) {
   HN_CHECK_ARG(cfg->parts & (HN_MODEL_FCOS | HN_MODEL_A2J), "hn_create: parts must name HN_MODEL_FCOS and / or HN_MODEL_A2J");
   HN_CHECK_ARG(cfg->num_classes >= 1 && cfg->num_classes <= 64 && cfg->num_joints >= 1, "bad class / joint count");
   HN_CHECK_ARG(cfg->f16_terms == 0 || cfg->f16_terms == 1 || cfg->f16_terms == 3, "f16_terms must be 0, 1 or 3");
+  HN_CHECK_ARG(cfg->precision == HN_PRECISION_SPLIT || cfg->precision == HN_PRECISION_F32, "precision must be HN_PRECISION_SPLIT or HN_PRECISION_F32");
+  HN_CHECK_ARG(cfg->precision != HN_PRECISION_F32 || cfg->f16_terms != 1, "f16_terms = 1 (f16x1) and HN_PRECISION_F32 exclude each other");
+  for (int c = 0; c < 3; ++c)
+    HN_CHECK_ARG(cfg->image_std[c] == cfg->image_std[c] && ((cfg->image_std[0] == 0.f) == (cfg->image_std[c] == 0.f)),
+                 "image_std must be three non-zero values (or all zero for the default normalisation)");
   hn_model* m = new hn_model();
   m->cfg = *cfg;
   if (m->cfg.min_size <= 0) m->cfg.min_size = 800;     // fcos.py:460-461
@@ -858,10 +1068,11 @@ extern "C" int hn_finalize(hn_model* m) {
   m->f_blocks.clear();
   for (void* q : m->owned) (void)hipFree(q);
   m->owned.clear();
+  const bool f32 = m->cfg.precision == HN_PRECISION_F32;   // exact mode: fp32 banks only, no fp16-range condition
   if (m->cfg.parts & HN_MODEL_A2J) {
     const std::string p = "Backbone.model.";
     HN_TRY(pack_conv(m, p + "conv1.weight", "", p + "bn1", 2, 3, 1, !m->cfg.rgbd, m->a_stem));
-    HN_TRY(pack_stem_split(m, p + "conv1.weight", p + "bn1", m->a_stem16, !m->cfg.rgbd));
+    if (!f32) HN_TRY(pack_stem_split(m, p + "conv1.weight", p + "bn1", m->a_stem16, !m->cfg.rgbd));
     const int planes[4] = {64, 128, 256, 512}, blocks[4] = {3, 4, 6, 3}, strides[4] = {1, 2, 2, 1}, dils[4] = {1, 1, 1, 2};
     (void)planes;
     for (int li = 1; li <= 4; ++li)
@@ -888,11 +1099,11 @@ extern "C" int hn_finalize(hn_model* m) {
     HN_TRY(head("classificationModel", m->a_cls, m->a_cls_out));
     HN_TRY(head("regressionModel", reg4, m->a_reg_out));
     HN_TRY(head("DepthRegressionModel", dep4, m->a_dep_out));
-    HN_TRY(concat_cout(reg4[0], dep4[0], m->a_regdep1, "A2J regression+depth conv1"));
+    HN_TRY(concat_cout(reg4[0], dep4[0], m->a_regdep1, "A2J regression+depth conv1", f32));
     for (int i = 0; i < 3; ++i) { m->a_reg[i] = reg4[i + 1]; m->a_dep[i] = dep4[i + 1]; }
     HN_CHECK_ARG(m->a_cls_out.cout == 16 * m->cfg.num_joints, "checkpoint does not match num_joints");
     HN_TRY(upload(m, m->a_stem));
-    HN_TRY(upload(m, m->a_stem16));
+    if (!f32) HN_TRY(upload(m, m->a_stem16));
     for (auto& k : m->a_blocks) {
       HN_TRY(upload(m, k.c1)); HN_TRY(upload(m, k.c2)); HN_TRY(upload(m, k.c3));
       if (k.has_ds) HN_TRY(upload(m, k.ds));
@@ -903,7 +1114,8 @@ extern "C" int hn_finalize(hn_model* m) {
   }
   if (m->cfg.parts & HN_MODEL_FCOS) {
     const std::string p = "backbone.body.";
-    HN_TRY(pack_stem_split(m, p + "conv1.weight", p + "bn1", m->f_stem16));
+    if (f32) HN_TRY(pack_conv(m, p + "conv1.weight", "", p + "bn1", 2, 3, 1, false, m->f_stem));
+    else HN_TRY(pack_stem_split(m, p + "conv1.weight", p + "bn1", m->f_stem16));
     const int blocks[4] = {3, 4, 6, 3}, strides[4] = {1, 2, 2, 2};
     for (int li = 1; li <= 4; ++li)
       for (int b = 0; b < blocks[li - 1]; ++b) {
@@ -932,7 +1144,7 @@ extern "C" int hn_finalize(hn_model* m) {
     ConvW c0, r0;
     HN_TRY(tconv(c, 0, c0));
     HN_TRY(tconv(r, 0, r0));
-    HN_TRY(concat_cout(c0, r0, m->f_tower0, "FCOS tower layer 0"));
+    HN_TRY(concat_cout(c0, r0, m->f_tower0, "FCOS tower layer 0", f32));
     for (int i = 1; i < 4; ++i) { HN_TRY(tconv(c, i, m->f_cls_t[i - 1])); HN_TRY(tconv(r, i, m->f_reg_t[i - 1])); }
     auto gn = [&](int i, const char* k, std::vector<float>& v) -> int {  // cls | reg stacked
       v.clear();
@@ -955,18 +1167,19 @@ extern "C" int hn_finalize(hn_model* m) {
     HN_TRY(pack_conv(m, c + ".hand_lr_layer.weight", c + ".hand_lr_layer.bias", "", 1, 1, 1, false, lr));
     HN_TRY(pack_conv(m, r + ".bbox_reg.weight", r + ".bbox_reg.bias", "", 1, 1, 1, false, br));
     HN_TRY(pack_conv(m, r + ".bbox_ctrness.weight", r + ".bbox_ctrness.bias", "", 1, 1, 1, false, bc));
-    HN_TRY(concat_cout(cl, lr, m->f_cls_out, "FCOS cls_logits+hand_lr"));
-    HN_TRY(concat_cout(br, bc, m->f_reg_out, "FCOS bbox_reg+ctrness"));
+    HN_TRY(concat_cout(cl, lr, m->f_cls_out, "FCOS cls_logits+hand_lr", f32));
+    HN_TRY(concat_cout(br, bc, m->f_reg_out, "FCOS bbox_reg+ctrness", f32));
     HN_CHECK_ARG(m->f_cls_out.cout == m->cfg.num_classes + 2, "checkpoint does not match num_classes");
     if (m->cfg.ext) {
       ConvW dx, ct;
       HN_TRY(pack_conv(m, c + ".hand_dydx_layer.weight", c + ".hand_dydx_layer.bias", "", 1, 1, 1, false, dx));
       HN_TRY(pack_conv(m, c + ".hand_contact_state_layer.weight", c + ".hand_contact_state_layer.bias", "", 1, 1, 1, false, ct));
-      HN_TRY(concat_cout(dx, ct, m->f_ext_out, "FCOS ext heads"));
+      HN_TRY(concat_cout(dx, ct, m->f_ext_out, "FCOS ext heads", f32));
       HN_CHECK_ARG(m->f_ext_out.cout == 8, "ext heads must have 3 + 5 output channels");
       HN_TRY(upload(m, m->f_ext_out));
     }
-    HN_TRY(upload(m, m->f_stem16));
+    if (f32) HN_TRY(upload(m, m->f_stem));
+    else HN_TRY(upload(m, m->f_stem16));
     for (auto& k : m->f_blocks) {
       HN_TRY(upload(m, k.c1)); HN_TRY(upload(m, k.c2));
       if (k.has_ds) HN_TRY(upload(m, k.ds));

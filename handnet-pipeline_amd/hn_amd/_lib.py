@@ -40,10 +40,12 @@ class ConvGroup(C.Structure):  # == struct hn_conv_group
 
 
 class ModelConfig(C.Structure):  # == struct hn_model_config
-    _fields_ = [(k, C.c_int32) for k in ("parts", "num_classes", "num_joints", "rgbd", "min_size", "max_size", "ext", "f16_terms")]
+    _fields_ = [(k, C.c_int32) for k in ("parts", "num_classes", "num_joints", "rgbd", "min_size", "max_size", "ext", "f16_terms",
+                                          "precision")] + [("image_mean", C.c_float * 3), ("image_std", C.c_float * 3)]
 
 
 MODEL_FCOS, MODEL_A2J = 1, 2
+PRECISION_SPLIT, PRECISION_F32 = 0, 1
 RANGE_ACTIVATION, RANGE_INPUT, RANGE_INPUT_NONFINITE = 1, 2, 4
 
 

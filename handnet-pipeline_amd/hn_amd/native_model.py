@@ -18,7 +18,9 @@ from .ops import _stream, on_device
 
 class NativeModel:
     def __init__(self, fcos_sd=None, a2j_sd=None, num_classes=3, num_joints=21, rgbd=False, device="cuda",
-                 min_size=0, max_size=0, ext=False, precision="f16x3"):
+                 min_size=0, max_size=0, ext=False, precision="f16x3", image_mean=None, image_std=None):
+        """precision: "f16x3" (default), "f16x1" (throughput mode) or "f32" (hn_model_config.precision = HN_PRECISION_F32: the
+        exact f32-MFMA kernels, the reference's own arithmetic); image_mean / image_std: the FCOS transform's normalisation."""
         if fcos_sd is None and a2j_sd is None:
             raise ValueError("give a FCOS and / or an A2J state_dict (reference layouts, SURVEY A.6)")
         self.device = torch.device(device)
@@ -29,7 +31,13 @@ class NativeModel:
         parts = (_lib.MODEL_FCOS if fcos_sd is not None else 0) | (_lib.MODEL_A2J if a2j_sd is not None else 0)
         cfg = _lib.ModelConfig(parts=parts, num_classes=num_classes, num_joints=num_joints, rgbd=1 if rgbd else 0,
                                min_size=min_size, max_size=max_size, ext=1 if ext else 0,
-                               f16_terms={"f16x3": 3, "f16x1": 1}[precision])
+                               f16_terms={"f16x3": 3, "f16x1": 1, "f32": 0}[precision],
+                               precision=_lib.PRECISION_F32 if precision == "f32" else _lib.PRECISION_SPLIT)
+        if (image_mean is None) != (image_std is None):
+            raise ValueError("give image_mean and image_std together")
+        if image_std is not None:
+            cfg.image_mean = (C.c_float * 3)(*[float(v) for v in image_mean])
+            cfg.image_std = (C.c_float * 3)(*[float(v) for v in image_std])
         h = C.c_void_p()
         check(self.lib.hn_create(C.byref(cfg), C.byref(h)), "hn_create")
         self._h = h

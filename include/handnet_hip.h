@@ -523,6 +523,8 @@ int hn_feat_interp_add_f32(const float* xin, const float* y, float* out, int64_t
  * ------------------------------------------------------------------------------------ */
 #define HN_MODEL_FCOS 1
 #define HN_MODEL_A2J 2
+#define HN_PRECISION_SPLIT 0
+#define HN_PRECISION_F32 1
 typedef struct hn_model_config {
   int32_t parts;        /* HN_MODEL_FCOS | HN_MODEL_A2J */
   int32_t num_classes;  /* FCOS classes (ros_demo.py:374 uses 3); hand class = num_classes - 1 */
@@ -534,6 +536,13 @@ typedef struct hn_model_config {
   int32_t f16_terms;    /* 0 or 3: f16x3, the parity-grade default.  1: the f16x1 THROUGHPUT mode -- every convolution of
                            the layer graphs issues the hi*hi term only (hn_conv_desc.terms = 1): 1.4x faster, keypoints
                            ~0.08 px from the reference, outside the 1e-3 contract */
+  int32_t precision;    /* HN_PRECISION_SPLIT (0): the split-fp16 kernels above.  HN_PRECISION_F32 (1): the reference's own
+                           arithmetic -- every convolution on the exact f32-MFMA kernel (hn_conv2d_nhwc_f32), fp32 activations,
+                           GroupNorm applied while the next convolution stages its input; ~4x slower, no fp16-range contract
+                           (the mode to run a checkpoint in that trips hn_finalize's / the engines' range check).  Same
+                           launches as FCOSEngine / A2JEngine(precision="f32"): bit-identical results */
+  float image_mean[3], image_std[3]; /* the transform's normalisation (FCOS ctor arguments, fcos.py:501-505); image_std all
+                           zero = the reference's default (ImageNet's 0.485 / 0.456 / 0.406, 0.229 / 0.224 / 0.225) */
 } hn_model_config;
 typedef struct hn_model hn_model;
 
