@@ -253,9 +253,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const HaloParams p
         for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
       }
       f16x8 hi, lo;
+      if (p.range_flag) hn::range_note_n<8>(p.range_flag, v);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        if (p.range_flag) hn::range_note(p.range_flag, v[e]);
         const _Float16 hh = (_Float16)v[e];
         hi[e] = hh;
         lo[e] = (_Float16)(v[e] - (float)hh);

@@ -203,10 +203,7 @@ __device__ __forceinline__ void epi_finish8(const ConvParams16& p, int m, int n,
       if (n + e < p.relu_cols) v[e] = fmaxf(v[e], 0.f);
   }
   if (p.out_split) {
-    if (p.range_flag) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) hn::range_note(p.range_flag, v[e]);
-    }
+    if (p.range_flag) hn::range_note_n<8>(p.range_flag, v);
     f16x8 hi, lo;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -979,10 +976,7 @@ void conv_igemm_f16x3_kernel(const ConvParams16 p) {
       f16x8 hi, lo;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        if (p.range_flag) {
-          hn::range_note(p.range_flag, m0v[e]);
-          hn::range_note(p.range_flag, m1v[e]);
-        }
+        if (p.range_flag && hn::range_mag(m0v[e], m1v[e]) > 65504.f) *p.range_flag = 1;
         const _Float16 h0 = (_Float16)m0v[e], h1 = (_Float16)m1v[e];
         hi[e] = h0;
         hi[4 + e] = h1;

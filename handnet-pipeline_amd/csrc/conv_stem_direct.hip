@@ -190,12 +190,14 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool_direct_kernel(const Ste
         }
       }
     f16x8 hi, lo;
+    if (p.range_flag) {
+      float mg = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mg = fmaxf(mg, hn::range_mag(m0[e], m1[e]));
+      if (mg > 65504.f) *p.range_flag = 1;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      if (p.range_flag) {
-        hn::range_note(p.range_flag, m0[e]);
-        hn::range_note(p.range_flag, m1[e]);
-      }
       const _Float16 h0 = (_Float16)m0[e], h1 = (_Float16)m1[e];
       hi[e] = h0;
       hi[4 + e] = h1;
