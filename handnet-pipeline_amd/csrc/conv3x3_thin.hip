@@ -314,7 +314,7 @@ __global__ __launch_bounds__(kNT, 1) void conv3x3_thin_flat_kernel(const FlatPar
               b[e] = b[e] * s1[e] + t1[e];
               a[e] = fmaxf(a[e], 0.f);
               b[e] = fmaxf(b[e], 0.f);
-              if (p.range_flag && hn::range_mag(a[e], b[e]) > 65504.f) *p.range_flag = 1;
+              if (p.range_flag && (hn::range_bad(a[e]) | hn::range_bad(b[e]))) *p.range_flag = 1;
               const _Float16 h0 = (_Float16)a[e], h1 = (_Float16)b[e];
               hi[e] = h0;
               hi[4 + e] = h1;

@@ -115,6 +115,12 @@ struct ConvParams16 {
   unsigned ga_records[HN_CONV_MAX_GROUP];
 };
 
+#define HN_TRY16(expr)          \
+  do {                          \
+    const int st_ = (expr);     \
+    if (st_ != HN_OK) return st_; \
+  } while (0)
+
 constexpr int BK = 32;    // k values per tile
 constexpr int ROWH = 64;  // halfs per LDS row (hi 32 | lo 32) = 128 bytes
 
@@ -228,7 +234,7 @@ __device__ __forceinline__ void epi_finish8(const ConvParams16& p, int m, int n,
 }
 
 // z-ordered sum of the split-K partial tiles + bias + the common epilogue tail; one thread = 8 channels of a pixel
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams16 p) {
+__device__ __forceinline__ void splitk_reduce_body(const ConvParams16& p) {
   const int units = p.Cout >> 3;
   const long total = (long)p.M * units;
   const int ohow = p.OH * p.OW;
@@ -256,6 +262,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams16 p
     epi_finish8(p, m, n, v, ohow);
   }
 }
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams16 p) { splitk_reduce_body(p); }
 
 // TERMS == 1 (f16x1): the lo fragments are never read -- NOT "read and ignored": an asynchronous LDS read into a register the
 // compiler considers dead lands in whatever that register holds by then (seen as nondeterministic garbage) -- so the list has
@@ -298,9 +306,11 @@ constexpr int kPoolRows = 15, kPoolCols = 17, kPoolPR = 7, kPoolPC = 8;
 // TERMS = 3: the split-precision product (lo*hi + hi*lo + hi*hi, fp32-grade).  TERMS = 1 ("f16x1", the THROUGHPUT mode SURVEY D6
 // plans beside the parity mode; never the default): only hi*hi is issued -- one MFMA per MAC on plain fp16 operands, identical
 // data movement -- so that "what does the 1e-3 contract cost" has a measured answer (bench.py --precision f16x1).
+// The kernel's body as a device function of (parameter block, workgroup coordinates): conv_igemm_f16x3_kernel passes its own
+// kernel argument and blockIdx; conv_igemm_f16x3_multi_kernel (heterogeneous launches, below) the member's block and the
+// member-local coordinates.  Always inlined: the single-problem kernel compiles to what it was.
 template <int BM, int BN, int WM, int WN, int NBUF, bool BUF, bool RS = false, bool POOL = false, int TERMS = 3>
-__global__ __launch_bounds__(WM* WN * 64, (BM * BN / (WM * WN) > 64 * 64 ? 1 : 2))
-void conv_igemm_f16x3_kernel(const ConvParams16 p) {
+__device__ __forceinline__ void conv_igemm_f16x3_body(const ConvParams16& p, const int blk_x, const int blk_y, const int blk_z) {
   static_assert(TERMS == 3 || TERMS == 1, "three terms (fp32-grade) or the hi*hi term alone");
   static_assert(NBUF >= 2 && NBUF <= 6, "2..6 LDS stages");
   static_assert(!POOL || (BUF && !RS && BM == 256 && BN == 64 && WN == 1), "the pooling epilogue is written for the 256x64 tile");
@@ -327,10 +337,10 @@ void conv_igemm_f16x3_kernel(const ConvParams16 p) {
     // in the prologue of EVERY convolution, grouped or not.)
     typedef __attribute__((address_space(4))) const ConvParams16 KArgs;
     KArgs* kp = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    const int gz = (int)blockIdx.z;
+    const int gz = blk_z;
     static_assert(HN_CONV_MAX_GROUP == 6, "member tables hold six entries");
     o.nblocks = kp->gnblocks[gz];
-    if ((int)blockIdx.x >= o.nblocks) return;
+    if (blk_x >= o.nblocks) return;
     o.x = kp->gx[gz];
     o.w = kp->gw[gz];
     o.bias = kp->gbias[gz];
@@ -372,7 +382,7 @@ void conv_igemm_f16x3_kernel(const ConvParams16 p) {
 
   int lid;
   {
-    const int bid = blockIdx.x, nb = o.nblocks;
+    const int bid = blk_x, nb = o.nblocks;
     const int q = nb >> 3, rr = nb & 7, xcd = bid & 7, loc = bid >> 3;
     lid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
   }
@@ -506,7 +516,7 @@ void conv_igemm_f16x3_kernel(const ConvParams16 p) {
   // input 3-7x over the fabric: FETCH_SIZE, profiles/).  Per step the tap offset is wave-uniform
   // (SALU); per lane only the two bounds checks and one 64-bit add remain.
   // this workgroup's k tiles: [t_begin, t_end) (everything unless split-K)
-  const int t_begin = p.splits > 1 ? (int)blockIdx.y * p.kt_per : 0;
+  const int t_begin = p.splits > 1 ? blk_y * p.kt_per : 0;
   const int t_end = p.splits > 1 ? min(t_begin + p.kt_per, p.ktiles) : p.ktiles;
   int load_t = t_begin, cur_cb = t_begin / (p.R * p.S);
   int cur_r = (t_begin - cur_cb * p.R * p.S) / p.S, cur_s = t_begin - cur_cb * p.R * p.S - cur_r * p.S;
@@ -889,7 +899,7 @@ void conv_igemm_f16x3_kernel(const ConvParams16 p) {
   q.x = o.x; q.w = o.w; q.bias = o.bias; q.y = o.y; q.gn_partial = o.gn_partial;
   q.H = o.H; q.W = o.W; q.pitch = o.pitch; q.OH = o.OH; q.OW = o.OW; q.M = o.M;
   if (p.splits > 1) {
-    q.y = p.split_ws + (long)blockIdx.y * o.M * p.Cout;
+    q.y = p.split_ws + (long)blk_y * o.M * p.Cout;
     q.ys = p.Cout;
     q.bias = nullptr;
     q.res_mode = 0;
@@ -1140,6 +1150,66 @@ void conv_igemm_f16x3_kernel(const ConvParams16 p) {
   }
 }
 
+template <int BM, int BN, int WM, int WN, int NBUF, bool BUF, bool RS = false, bool POOL = false, int TERMS = 3>
+__global__ __launch_bounds__(WM* WN * 64, (BM * BN / (WM * WN) > 64 * 64 ? 1 : 2))
+void conv_igemm_f16x3_kernel(const ConvParams16 p) {
+  conv_igemm_f16x3_body<BM, BN, WM, WN, NBUF, BUF, RS, POOL, TERMS>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
+// ---- heterogeneous launches (hn_conv2d_nhwc_f16x3_multi): up to HN_CONV_MULTI_MAX INDEPENDENT convolutions of different shapes
+// (channels, filter, stride, residual, split-K plan: anything) in ONE grid.  The kernel argument is a table of complete
+// parameter blocks; a workgroup finds its member from the prefix sums of the members' workgroup counts, copies that member's
+// block out of the kernel-argument segment (scalar loads at a uniform offset) and runs the ordinary body on it with
+// member-local coordinates.  What it buys: small grids that are independent of each other (the downsample 1x1 beside conv1 of
+// a residual block, the classification head beside layer4 of the A2J trunk) fill each other's idle CUs and cost one launch --
+// and ONE reduction launch for all their split-K members -- instead of one each.
+constexpr int kMultiMax = HN_CONV_MULTI_MAX;
+struct MultiParams16 {
+  int count;
+  int start[kMultiMax + 1];   // first workgroup of member i (member grids are nblocks x splits, split-major)
+  ConvParams16 m[kMultiMax];
+};
+
+__device__ __forceinline__ void load_member16(const MultiParams16& unused_by_value_copy, int g, ConvParams16& p) {
+  (void)unused_by_value_copy;
+  typedef __attribute__((address_space(4))) const unsigned KW;
+  typedef __attribute__((address_space(4))) const char KB;
+  KB* base = (KB*)__builtin_amdgcn_kernarg_segment_ptr();
+  KW* src = (KW*)(base + offsetof(MultiParams16, m) + (size_t)g * sizeof(ConvParams16));
+  unsigned* dst = reinterpret_cast<unsigned*>(&p);
+  static_assert(sizeof(ConvParams16) % 4 == 0, "parameter block is copied word by word");
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(ConvParams16) / 4); ++i) dst[i] = src[i];
+}
+
+template <int BM, int BN, int WM, int WN, int NBUF>
+__global__ __launch_bounds__(WM* WN * 64, (BM * BN / (WM * WN) > 64 * 64 ? 1 : 2))
+void conv_igemm_f16x3_multi_kernel(const MultiParams16 mp) {
+  typedef __attribute__((address_space(4))) const MultiParams16 KM;
+  KM* km = (KM*)__builtin_amdgcn_kernarg_segment_ptr();
+  const int bid = (int)blockIdx.x;
+  int g = 0;
+#pragma unroll
+  for (int i = 1; i < kMultiMax; ++i) g = (i < km->count && bid >= km->start[i]) ? i : g;
+  int local = bid - km->start[g];
+  ConvParams16 p;
+  load_member16(mp, g, p);
+  int by = 0;
+  while (local >= p.nblocks) {   // wave-uniform: at most 16 splits
+    local -= p.nblocks;
+    ++by;
+  }
+  conv_igemm_f16x3_body<BM, BN, WM, WN, NBUF, true, false, false, 3>(p, local, by, 0);
+}
+
+// the reductions of a multi launch's split-K members as ONE launch: gridDim.y = member
+__global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(const MultiParams16 mp) {
+  ConvParams16 p;
+  load_member16(mp, (int)blockIdx.y, p);
+  if (p.splits <= 1) return;
+  splitk_reduce_body(p);
+}
+
 // ---- host-side launch planning, shared by the launcher and by hn_conv2d_f16x3_uses_rs (ONE definition of each decision) ----
 // Split-K for grids that leave most of the chip idle AND have a long serial k loop (~0.33 us per 32-deep
 // tile): e.g. the 2048->512 3x3 A2J layer at batch 1 is 8 workgroups x 576 tiles = 190 us.  Up to 16
@@ -1265,9 +1335,9 @@ static void magic_u31(unsigned d, unsigned& mg, unsigned& sh) {
 // Operand extents for the buffer descriptors of the v6 addressing.  Falls back to the pointer-form kernel (one
 // instantiation, 128x128) when an operand spans 2 GB or more (bit 31 of an offset must stay out of range) or the
 // filter has more than 32 taps.
-template <int BM, int BN, int WM, int WN, int NBUF, bool ALLOW_F16X1 = true>
-int launch16(const ConvParams16& p0, hipStream_t st) {
-  ConvParams16 p = p0;
+// Magic numbers of the index divisions and the extents of the buffer descriptors (v6 addressing).  Returns false when an operand
+// spans 2 GB or more (bit 31 of an offset must stay out of range) or the filter has more than 32 taps: the pointer-form kernel.
+static bool finish_params16(ConvParams16& p) {
   magic_u31((unsigned)(p.OH * p.OW), p.mg_ohow, p.sh_ohow);
   magic_u31((unsigned)p.OW, p.mg_ow, p.sh_ow);
   magic_u31((unsigned)p.W + 1u, p.mg_w1, p.sh_w1);
@@ -1303,6 +1373,13 @@ int launch16(const ConvParams16& p0, hipStream_t st) {
       ok = ok && ea < lim;
       p.ga_records[g] = (unsigned)(ea < lim ? ea : 0);
     }
+  return ok;
+}
+
+template <int BM, int BN, int WM, int WN, int NBUF, bool ALLOW_F16X1 = true>
+int launch16(const ConvParams16& p0, hipStream_t st) {
+  ConvParams16 p = p0;
+  const bool ok = finish_params16(p);
   if (p.terms == 1) {   // throughput mode: descriptor-form kernels of the tiles the engines use
     if constexpr (ALLOW_F16X1) {
       if (ok) return launch16_impl<BM, BN, WM, WN, NBUF, true, 1>(p, st);
@@ -1449,9 +1526,10 @@ extern "C" int hn_conv2d_nhwc_f16x3_grouped(const hn_conv_desc* d, const hn_conv
 
 static inline bool gn_of_group_needs_32(const hn_conv_group* group, int g) { return group->gn_partial[g] != nullptr; }
 
-static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, const float* bias, const void* residual,
-                      void* y, float* gn_partial, void* workspace, int64_t workspace_bytes, void* stream,
-                      const hn_conv_group* group) {
+// Argument checks + the parameter block of ONE plain convolution (no group): shared by conv16_run and the heterogeneous
+// launch hn_conv2d_nhwc_f16x3_multi, so that a member of a multi launch is set up exactly like the same convolution alone.
+static int fill_params16(const hn_conv_desc* d, const void* x16, const void* w16, const float* bias, const void* residual,
+                         void* y, float* gn_partial, void* workspace, int64_t workspace_bytes, ConvParams16& p) {
   HN_CHECK_ARG(d && x16 && w16 && y, "hn_conv2d_nhwc_f16x3: null pointer");
   HN_CHECK_ARG(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, "bad tensor dims");
   HN_CHECK_ARG(d->cin % 32 == 0, "f16x3 conv needs cin %% 32 == 0 (got %d); use hn_conv2d_nhwc_f32", d->cin);
@@ -1468,12 +1546,6 @@ static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, c
   HN_CHECK_ARG(d->in_pix_stride == 0 || (d->in_pix_stride >= 2 * d->cin && d->in_pix_stride % 64 == 0), "bad in_pix_stride");
   HN_CHECK_ARG(d->out_pix_stride == 0 || d->out_pix_stride >= (d->out_split ? 2 : 1) * d->cout, "bad out_pix_stride");
   HN_CHECK_ARG((int64_t)d->n * d->oh * d->ow < (int64_t)1 << 31, "too many output pixels");
-  // 64-output-channel 3x3 / stride-1 layers with many tiles (ResNet-34 layer1): direct convolution from an LDS halo patch
-  // (conv3x3_halo.hip; same k order, bit-identical results; HN_CONV_NO_HALO=1 keeps them on this kernel)
-  if (d->terms != 1 && hn::conv3x3_halo_applies(d, gn_partial != nullptr, group != nullptr, residual))
-    return hn::conv3x3_halo(d, x16, w16, bias, residual, y, (hipStream_t)stream);
-
-  ConvParams16 p;
   p.x = (const _Float16*)x16; p.w = (const _Float16*)w16; p.bias = bias; p.res = residual; p.y = y;
   p.N = d->n; p.H = d->h; p.W = d->w; p.Cin = d->cin; p.Cout = d->cout; p.R = d->r; p.S = d->s;
   p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.OH = d->oh; p.OW = d->ow;
@@ -1502,6 +1574,19 @@ static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, c
   p.terms = d->terms == 1 ? 1 : 3;
   p.pool_ty = p.pool_tx = p.pool_oh = p.pool_ow = 0;
   p.gn_units = d->cout >> 3;
+  return HN_OK;
+}
+
+static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, const float* bias, const void* residual,
+                      void* y, float* gn_partial, void* workspace, int64_t workspace_bytes, void* stream,
+                      const hn_conv_group* group) {
+  ConvParams16 p;
+  HN_TRY16(fill_params16(d, x16, w16, bias, residual, y, gn_partial, workspace, workspace_bytes, p));
+  // 64-output-channel 3x3 / stride-1 layers with many tiles (ResNet-34 layer1): direct convolution from an LDS halo patch
+  // (conv3x3_halo.hip; same k order, bit-identical results; HN_CONV_NO_HALO=1 keeps them on this kernel)
+  if (d->terms != 1 && hn::conv3x3_halo_applies(d, gn_partial != nullptr, group != nullptr, residual))
+    return hn::conv3x3_halo(d, x16, w16, bias, residual, y, (hipStream_t)stream);
+
   hn_conv_desc tile_desc = *d;  // what the tile heuristic sees: for a group, all members' rows together
   if (group) {
     p.groups = group->count;
@@ -1572,6 +1657,109 @@ static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, c
     case HN_TILE_256x64_W8: return launch16<256, 64, 4, 2, 2, false>(p, st);
     default: return hn::fail(HN_ERR_ARG, "unknown tile id %d", d->tile);
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Heterogeneous launch (include/handnet_hip.h: hn_conv2d_nhwc_f16x3_multi)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int NBUF>
+static int launch_multi(MultiParams16& mp, hipStream_t st) {
+  int total = 0, any_split = 0, red_grid = 1;
+  for (int g = 0; g < mp.count; ++g) {
+    ConvParams16& p = mp.m[g];
+    mp.start[g] = total;
+    total += p.nblocks * p.splits;
+    if (p.splits > 1) {
+      any_split = 1;
+      const long units = (long)p.M * (p.Cout >> 3);
+      const int grid = (int)((units + 255) / 256 < 4096 ? (units + 255) / 256 : 4096);
+      red_grid = red_grid > grid ? red_grid : grid;
+    }
+  }
+  for (int g = mp.count; g <= kMultiMax; ++g) mp.start[g] = total;
+  hipLaunchKernelGGL((conv_igemm_f16x3_multi_kernel<BM, BN, WM, WN, NBUF>), dim3(total), dim3(WM * WN * 64), 0, st, mp);
+  HN_CHECK_LAUNCH("conv_igemm_f16x3_multi_kernel");
+  if (any_split) {
+    hipLaunchKernelGGL(splitk_reduce_multi_kernel, dim3(red_grid, mp.count), dim3(256), 0, st, mp);
+    HN_CHECK_LAUNCH("splitk_reduce_multi_kernel");
+  }
+  return HN_OK;
+}
+
+// Would these convolutions run as ONE multi launch?  They do when every member, launched alone through
+// hn_conv2d_nhwc_f16x3_ws, would take the implicit-GEMM kernel of one and the same tile form in its descriptor form; the
+// members then keep their own split-K plans (the plan a member would get alone: its result does not depend on the grouping).
+static bool multi_plan(const hn_conv_multi* mm, void* workspace, int64_t workspace_bytes, MultiParams16& mp, int& tile) {
+  tile = -1;
+  int64_t ws_off = 0;
+  for (int g = 0; g < mm->count; ++g) {
+    const hn_conv_desc* d = &mm->desc[g];
+    ConvParams16& p = mp.m[g];
+    if (fill_params16(d, mm->x16[g], mm->w16[g], mm->bias[g], mm->residual[g], mm->y[g], nullptr, workspace, workspace_bytes, p) !=
+        HN_OK)
+      return false;
+    if (p.terms != 3 || hn::conv3x3_halo_applies(d, false, false, mm->residual[g])) return false;
+    const int t = hn_conv2d_f16x3_pick_tile(d);
+    if (tile >= 0 && t != tile) return false;
+    tile = t;
+    TileForm f = tile_form(t, false);
+    if (t == HN_TILE_128x32 || f.bm == 0) return false;   // (its stage count depends on the row-shared form: not worth a table)
+    if (!finish_params16(p)) return false;
+    p.tiles_m = hn::cdiv(p.M, f.bm);
+    p.tiles_n = hn::cdiv(p.Cout, f.bn);
+    p.nblocks = p.tiles_m * p.tiles_n;
+    plan_splits(p);
+    p.rs_ok = 0;
+    if (p.splits > 1) {   // the member's partial planes: its own slice of the workspace
+      const int64_t bytes = (int64_t)p.splits * p.M * p.Cout * 4;
+      if (ws_off + bytes > workspace_bytes) return false;
+      p.split_ws = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ws_off);
+      ws_off += (bytes + 255) & ~(int64_t)255;
+    }
+  }
+  return true;
+}
+
+extern "C" int hn_conv2d_nhwc_f16x3_multi(const hn_conv_multi* mm, void* workspace, int64_t workspace_bytes, void* stream) {
+  HN_CHECK_ARG(mm && mm->count >= 1 && mm->count <= HN_CONV_MULTI_MAX, "hn_conv2d_nhwc_f16x3_multi: count must be 1..%d",
+               HN_CONV_MULTI_MAX);
+  HN_CHECK_ARG(workspace == nullptr || ((uintptr_t)workspace % 16 == 0 && workspace_bytes >= 0), "bad workspace");
+  for (int g = 0; g < mm->count; ++g)
+    for (int h = 0; h < mm->count; ++h)
+      HN_CHECK_ARG(g == h || mm->y[g] != mm->y[h], "members %d and %d write the same output", g, h);
+  MultiParams16 mp;
+  mp.count = mm->count;
+  int tile = -1;
+  const bool together = mm->count > 1 && !hn::env_flags().no_multi && multi_plan(mm, workspace, workspace ? workspace_bytes : 0, mp, tile);
+  if (!together) {   // one after the other: the same results by the members' own launches
+    for (int g = 0; g < mm->count; ++g)
+      HN_TRY16(conv16_run(&mm->desc[g], mm->x16[g], mm->w16[g], mm->bias[g], mm->residual[g], mm->y[g], nullptr, workspace,
+                          workspace_bytes, stream));
+    return HN_OK;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  switch (tile) {
+    case HN_TILE_128x128: return launch_multi<128, 128, 2, 2, 2>(mp, st);
+    case HN_TILE_128x64: return launch_multi<128, 64, 2, 2, 2>(mp, st);
+    case HN_TILE_64x64: return launch_multi<64, 64, 2, 2, 3>(mp, st);
+    case HN_TILE_64x128: return launch_multi<64, 128, 2, 2, 3>(mp, st);
+    case HN_TILE_32x64: return launch_multi<32, 64, 1, 2, 4>(mp, st);
+    default: break;
+  }
+  for (int g = 0; g < mm->count; ++g)
+    HN_TRY16(conv16_run(&mm->desc[g], mm->x16[g], mm->w16[g], mm->bias[g], mm->residual[g], mm->y[g], nullptr, workspace,
+                        workspace_bytes, stream));
+  return HN_OK;
+}
+
+// 1 when hn_conv2d_nhwc_f16x3_multi would run these members as one launch (host-only; tests / planning)
+extern "C" int hn_conv2d_f16x3_multi_fuses(const hn_conv_multi* mm, int64_t workspace_bytes) {
+  if (!mm || mm->count < 2 || mm->count > HN_CONV_MULTI_MAX || hn::env_flags().no_multi) return 0;
+  MultiParams16 mp;
+  mp.count = mm->count;
+  int tile = -1;
+  if (!multi_plan(mm, reinterpret_cast<void*>(256), workspace_bytes, mp, tile)) return 0;
+  return tile == HN_TILE_128x128 || tile == HN_TILE_128x64 || tile == HN_TILE_64x64 || tile == HN_TILE_64x128 || tile == HN_TILE_32x64;
 }
 
 static int stem16_run(const void* x16, int n, int ph, int pw, int pad, int r, int stride, int cout, const void* w16,

@@ -17,7 +17,7 @@ int* range_flag_ptr();
 // A/B switches read from the environment ONCE (hn_reread_env() refreshes them): getenv per launch costs more host time
 // than the rest of a small launch's argument checks.
 struct EnvFlags {
-  bool no_rs, no_rs32, split_generic, stem_generic, no_halo, no_thin, thin_tap, thin_flat, no_fuse_last_gn, pre_generic;
+  bool no_rs, no_rs32, split_generic, stem_generic, no_halo, no_thin, thin_tap, thin_flat, no_fuse_last_gn, pre_generic, no_multi;
 };
 const EnvFlags& env_flags();
 // conv_stem_direct.hip: the 7x7 / stride-2 / 64-channel stem + ReLU + max pooling as a direct convolution from an LDS patch

@@ -59,6 +59,7 @@ static void read_env() {
   g_env.stem_generic = getenv("HN_STEM_POOL_GENERIC") != nullptr;
   g_env.no_halo = getenv("HN_CONV_NO_HALO") != nullptr;
   g_env.pre_generic = getenv("HN_PREPROCESS_GENERIC") != nullptr;
+  g_env.no_multi = getenv("HN_CONV_NO_MULTI") != nullptr;   // hn_conv2d_nhwc_f16x3_multi: members one after the other (A/B)
   g_env.no_fuse_last_gn = getenv("HN_FUSE_LAST_GN") != nullptr && getenv("HN_FUSE_LAST_GN")[0] == '0';
   g_env.no_thin = getenv("HN_THIN_OUTPUTS") != nullptr && getenv("HN_THIN_OUTPUTS")[0] == '0';   // model.hip: grouped implicit GEMM
   g_env.thin_tap = getenv("HN_THIN_FORM") != nullptr && getenv("HN_THIN_FORM")[0] == 't';          // thin kernel: never the P form

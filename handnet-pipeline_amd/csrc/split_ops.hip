@@ -59,10 +59,10 @@ __global__ __launch_bounds__(256) void affine_split_kernel(const float* __restri
       }
     }
     if (range_flag) {
-      float mg = 0.f;
+      bool bad = false;   // (NaN-aware: this pass is HBM-bound, and its input may be any fp32 tensor)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) mg = fmaxf(mg, hn::range_mag(a[e], b[e]));
-      if (mg > 65504.f) *range_flag = 1;
+      for (int e = 0; e < 4; ++e) bad |= hn::range_bad(a[e]) | hn::range_bad(b[e]);
+      if (bad) *range_flag = 1;
     }
     f16x8 hi, lo;
     split8(a, b, hi, lo);
@@ -116,10 +116,10 @@ __global__ __launch_bounds__(256) void affine_split_pow2_kernel(const float* __r
       }
     }
     if (range_flag) {
-      float mg = 0.f;
+      bool bad = false;   // (NaN-aware: this pass is HBM-bound, and its input may be any fp32 tensor)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) mg = fmaxf(mg, hn::range_mag(a[e], b[e]));
-      if (mg > 65504.f) *range_flag = 1;
+      for (int e = 0; e < 4; ++e) bad |= hn::range_bad(a[e]) | hn::range_bad(b[e]);
+      if (bad) *range_flag = 1;
     }
     f16x8 hi, lo;
     split8(a, b, hi, lo);
@@ -202,10 +202,10 @@ __global__ __launch_bounds__(256) void affine_split_pow2_levels_kernel(const Spl
       }
     }
     if (range_flag) {
-      float mg = 0.f;
+      bool bad = false;   // (NaN-aware: this pass is HBM-bound, and its input may be any fp32 tensor)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) mg = fmaxf(mg, hn::range_mag(a[e], b[e]));
-      if (mg > 65504.f) *range_flag = 1;
+      for (int e = 0; e < 4; ++e) bad |= hn::range_bad(a[e]) | hn::range_bad(b[e]);
+      if (bad) *range_flag = 1;
     }
     f16x8 hi, lo;
     split8(a, b, hi, lo);

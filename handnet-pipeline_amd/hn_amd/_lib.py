@@ -39,6 +39,15 @@ class ConvGroup(C.Structure):  # == struct hn_conv_group
                 ("w", C.c_int32 * CONV_MAX_GROUP), ("gn_units", C.c_int32)]
 
 
+CONV_MULTI_MAX = 4
+
+
+class ConvMulti(C.Structure):  # == struct hn_conv_multi
+    _fields_ = [("count", C.c_int32), ("desc", ConvDesc * CONV_MULTI_MAX), ("x16", C.c_void_p * CONV_MULTI_MAX),
+                ("w16", C.c_void_p * CONV_MULTI_MAX), ("bias", C.c_void_p * CONV_MULTI_MAX),
+                ("residual", C.c_void_p * CONV_MULTI_MAX), ("y", C.c_void_p * CONV_MULTI_MAX)]
+
+
 class ModelConfig(C.Structure):  # == struct hn_model_config
     _fields_ = [(k, C.c_int32) for k in ("parts", "num_classes", "num_joints", "rgbd", "min_size", "max_size", "ext", "f16_terms",
                                           "precision")] + [("image_mean", C.c_float * 3), ("image_std", C.c_float * 3)]
@@ -92,6 +101,8 @@ SIGNATURES = {
     "hn_event_record": (C.c_int, [VP, VP]),
     "hn_event_elapsed_ms": (C.c_int, [VP, VP, c_f32p]),
     "hn_clock_sample": (C.c_int, [C.c_int, VP, VP]),
+    "hn_conv2d_nhwc_f16x3_multi": (C.c_int, [C.POINTER(ConvMulti), VP, C.c_int64, VP]),
+    "hn_conv2d_f16x3_multi_fuses": (C.c_int, [C.POINTER(ConvMulti), C.c_int64]),
     "hn_range_check_enable": (C.c_int, [C.c_int]),
     "hn_range_check_fetch": (C.c_int, [c_i32p, C.c_int, VP]),
     "hn_range_check_enabled": (C.c_int, []),

@@ -38,6 +38,9 @@ class A2JEngine:
         self.joints = num_joints
         self.rgbd = rgbd
         self.group_heads = os.environ.get("HN_GROUP_CONVS", "1") != "0"
+        # heterogeneous launches (ops.conv2d_nhwc_multi): the downsample beside conv1 of a block, the classification head
+        # beside layer4, the regression / depth towers beside each other.  HN_CONV_MULTI=0: the round-3 launch structure (A/B)
+        self.multi = os.environ.get("HN_CONV_MULTI", "1") != "0" and precision == "f16x3"
         p = "Backbone.model."
         dev = self.device
 
@@ -108,6 +111,8 @@ class A2JEngine:
         else:
             x = self._conv(x, self.stem, algo_cin=4 if self.rgbd else 3)
             x = ops.maxpool3x3s2_nhwc(x)
+        if self.multi:
+            return self._trunk_multi(x)
         x3 = None
         for i, blk in enumerate(self.blocks):
             o = self._conv(x, blk["c1"])
@@ -119,8 +124,72 @@ class A2JEngine:
                 x3 = x
         return x3, x
 
+    def _trunk_multi(self, x):
+        """The trunk as heterogeneous launches: conv1 of a block together with its downsample (both read the block input), and
+        -- from the first block of layer4 on, when x3 exists -- one stage of the classification head (four 3x3 convolutions and
+        the output convolution, a2j/a2j.py:162-181, which read x3 and nothing of layer4) in each of layer4's launches.  Every
+        member computes what its own conv2d_nhwc call would; the library runs members of one tile form in one grid.
+        The classification head's output is kept for heads() (self._cls_ready)."""
+        cls_stages = [(cw, dict(relu=True)) for cw in self.cls_convs] + [(self.cls_out, dict(relu=False, out_split=False))]
+
+        def launch(items):
+            if len(items) > 1:
+                return ops.conv2d_nhwc_multi(items)
+            x_, cw_, o_ = items[0]
+            return [self._conv(x_, cw_, relu=o_.get("relu", False), residual=o_.get("residual"),
+                               out_f32=not o_.get("out_split", True))]
+        c, stage, x3 = None, 0, None
+        for i, blk in enumerate(self.blocks):
+            in_l4 = blk["tap"] == 4
+            if in_l4 and c is None:
+                c = x3 = x                                              # x3: the output of layer3's last block
+            items = [(x, blk["c1"], dict(relu=True))]
+            if blk["ds"] is not None:
+                items.append((x, blk["ds"], dict(relu=False)))
+
+            def ride(items):
+                if in_l4 and stage < len(cls_stages):
+                    items.append((c, cls_stages[stage][0], cls_stages[stage][1]))
+                    return True
+                return False
+            rides = ride(items)
+            outs = launch(items)
+            o = outs[0]
+            idn = outs[1] if blk["ds"] is not None else x
+            if rides:
+                c, stage = outs[-1], stage + 1
+            items = [(o, blk["c2"], dict(relu=True))]
+            rides = ride(items)
+            outs = launch(items)
+            o = outs[0]
+            if rides:
+                c, stage = outs[-1], stage + 1
+            items = [(o, blk["c3"], dict(relu=True, residual=idn))]
+            rides = ride(items)
+            outs = launch(items)
+            x = outs[0]
+            if rides:
+                c, stage = outs[-1], stage + 1
+        while stage < len(cls_stages):                                  # (a trunk with a shorter layer4 than the head chain)
+            c = launch([(c, cls_stages[stage][0], cls_stages[stage][1])])[0]
+            stage += 1
+        self._cls_ready = (x3, c)
+        return x3, x
+
     def heads(self, x3, x4):
         ops.PROFILE_STAGE = "a2j_heads"
+        ready = getattr(self, "_cls_ready", None)
+        self._cls_ready = None
+        if self.multi and ready is not None and ready[0] is x3:
+            # the classification head has run beside layer4 (_trunk_multi); the regression and depth towers run side by side
+            cls = ready[1]
+            rd = self._conv(x4, self.regdep_conv1)
+            r, d = rd[:, :, :, :8], rd[:, :, :, 8:]
+            for cr, cd in zip(self.reg_convs, self.dep_convs):
+                r, d = ops.conv2d_nhwc_multi([(r, cr, dict(relu=True)), (d, cd, dict(relu=True))])
+            reg, dep = ops.conv2d_nhwc_multi([(r, self.reg_out, dict(relu=False, out_split=False)),
+                                              (d, self.dep_out, dict(relu=False, out_split=False))])
+            return cls, reg, dep
         c = self._conv(x3, self.cls_convs[0])
         rd = self._conv(x4, self.regdep_conv1)
         # the fused tensor has 512 channels: 0..255 regression tower, 256..511 depth tower

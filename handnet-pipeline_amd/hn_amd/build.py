@@ -26,7 +26,7 @@ EXTRA_FLAGS = {"fcos_post.hip": ["-ffp-contract=off"]}
 # Kernels that request operands with `asm volatile` loads / LDS-DMA and retire them with hand-counted s_waitcnt: the
 # compiler cannot see that such a register is still in flight, so a SPILL of it stores garbage (profiles/NOTEBOOK.md, round
 # 3).  The build records every kernel's resource usage (csrc/build/<file>.resources.txt) and refuses a spill in these.
-NO_SPILL_KERNELS = ("conv_igemm_f16x3_kernel", "conv3x3_halo_kernel", "conv_stem_pool_direct_kernel", "conv3x3_thin")
+NO_SPILL_KERNELS = ("conv_igemm_f16x3_kernel", "conv_igemm_f16x3_multi_kernel", "conv3x3_halo_kernel", "conv_stem_pool_direct_kernel", "conv3x3_thin")
 
 
 def _check_resources(src: Path, remarks: str, objdir: Path) -> None:

@@ -126,6 +126,8 @@ class FCOSEngine:
         self.fuse_stem_pool = os.environ.get("HN_FUSE_STEM_POOL", "1") != "0"   # A/B switch (results are bit-identical)
         self.fuse_last_gn = os.environ.get("HN_FUSE_LAST_GN", "1") != "0"   # A/B switch, bit-identical
         self.thin_outputs = os.environ.get("HN_THIN_OUTPUTS", "1") != "0" and self.cls_out.cout <= 16   # A/B switch (tap form bit-identical, P form to fp32 rounding)
+        # conv1 of a downsampling block together with its 1x1 downsample (ops.conv2d_nhwc_multi); HN_CONV_MULTI=0: apart (A/B)
+        self.multi = os.environ.get("HN_CONV_MULTI", "1") != "0" and precision == "f16x3"
 
     # -----------------------------------------------------------------------------------
     def _conv(self, x, cw: ConvW, relu=False, out_f32=False, **kw):
@@ -156,8 +158,12 @@ class FCOSEngine:
             x = ops.maxpool3x3s2_nhwc(x)
         feats = []
         for blk in self.blocks:
-            o = self._conv(x, blk["c1"], relu=True)
-            idn = self._conv(x, blk["ds"]) if blk["ds"] is not None else x
+            if blk["ds"] is not None and self.multi and x.dtype == torch.float16:
+                # both read the block input and neither reads the other: one grid (same bits as the two launches)
+                o, idn = ops.conv2d_nhwc_multi([(x, blk["c1"], dict(relu=True)), (x, blk["ds"], dict(relu=False))])
+            else:
+                o = self._conv(x, blk["c1"], relu=True)
+                idn = self._conv(x, blk["ds"]) if blk["ds"] is not None else x
             x = self._conv(o, blk["c2"], relu=True, residual=idn)
             if blk["last"] and blk["layer"] >= 2:
                 feats.append(x)

@@ -117,6 +117,7 @@ def _pixel_stride(t: torch.Tensor, name: str) -> int:
 
 
 _DESC_TEMPLATES = {}
+_MULTI_PLANS = {}
 _CONV_PLANS = {}
 
 
@@ -185,6 +186,7 @@ PROFILE_STAGE = None
 TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x64", 4: "128x32", 5: "256x128", 6: "64x128", 7: "32x64", 8: "256x64", 9: "256x128w8", 10: "256x64w8"}
 TILE_RS = 0x100  # profile records: tile id | TILE_RS when the launch ran the row-shared-A instantiation of that tile
 TILE_HALO = 0x200  # ... | TILE_HALO when it was routed to the halo-patch kernel (conv3x3_halo_kernel)
+TILE_MULTI = 0x400  # ... | TILE_MULTI for a heterogeneous launch (conv_igemm_f16x3_multi_kernel): several convolutions, one record
 
 
 def tile_name(tile) -> str:
@@ -192,7 +194,8 @@ def tile_name(tile) -> str:
     if isinstance(tile, int) and tile & TILE_HALO:
         return "halo16x16"
     base = TILE_NAMES.get(tile & 0xFF, str(tile & 0xFF)) if isinstance(tile, int) else str(tile)
-    return base + ("+rs" if isinstance(tile, int) and tile & TILE_RS else "")
+    return base + ("+rs" if isinstance(tile, int) and tile & TILE_RS else "") + \
+        ("+multi" if isinstance(tile, int) and tile & TILE_MULTI else "")
 
 
 # Term count of the f16x3 kernels for the launches issued from now on: 3 = the split-precision product (default),
@@ -220,6 +223,7 @@ def clear_plan_caches():
     they are rebuilt, so that a recycled address can never meet a stale plan and the caches stay bounded)."""
     _CONV_PLANS.clear()
     _DESC_TEMPLATES.clear()
+    _MULTI_PLANS.clear()
 
 
 # split-K workspace: one fp32 buffer per (device, stream) -- a convolution only uses it between its own two
@@ -397,6 +401,101 @@ def conv2d_nhwc(x, w, bias=None, *, stride=1, pad=0, dil=1, relu=False, relu_col
             kind = ("f32", lib.hn_conv2d_pick_tile(C.byref(d)))
         prof.append((kind, macs, timer, (n, h, wd, cin, cout, r, stride, dil), PROFILE_STAGE))
     return out
+
+
+def conv2d_nhwc_multi(items, fused=None):
+    """INDEPENDENT f16x3 convolutions of different shapes as one launch (hn_conv2d_nhwc_f16x3_multi; at most
+    _lib.CONV_MULTI_MAX members).  items: [(x S32, ConvW-like cw, opts)], opts = dict(relu=False, relu_cols=None,
+    residual=None, out_split=True); every member computes exactly what conv2d_nhwc(x, cw.w, cw.bias, stride=cw.stride,
+    pad=cw.pad, dil=cw.dil, w16=cw.w16, **opts) would (bit-identical: same kernel body, same split-K plan) -- the library
+    falls back to that, member after member, when the members' tile forms differ.  Returns the outputs.
+    fused: optional one-element list that receives whether the members ran as one launch (tests)."""
+    lib = _lib.load()
+    k = len(items)
+    if k == 0 or k > _lib.CONV_MULTI_MAX:
+        raise ValueError(f"need 1..{_lib.CONV_MULTI_MAX} members")
+    splitk = SPLITK
+    # Plan cache (like conv2d_nhwc's): the validated descriptor table of an earlier call with the same shapes / strides /
+    # weights is stamped out again; only the activation pointers change.
+    key = [splitk, SPLITK_EAGER, F16_TERMS]
+    for x, cw, opts in items:
+        res = opts.get("residual")
+        key.append((x.device.index, x.shape, x.stride(), x.dtype, cw.w16.data_ptr() if cw.w16 is not None else None,
+                    None if cw.bias is None else cw.bias.data_ptr(), cw.stride, cw.pad, cw.dil, opts.get("relu", False),
+                    opts.get("relu_cols"), opts.get("out_split", True),
+                    None if res is None else (res.shape, res.stride(), res.dtype)))
+    key = tuple(key)
+    plan = _MULTI_PLANS.get(key) if CONV_PROFILE is None and fused is None else None
+    if plan is not None:
+        tpl, out_specs, use_ws = plan
+        mm = _lib.ConvMulti.from_buffer_copy(tpl)
+        outs = []
+        for i, ((x, _cw, opts), (shape, dtype)) in enumerate(zip(items, out_specs)):
+            _check_device(x, "x")
+            y = torch.empty(shape, device=x.device, dtype=dtype)
+            mm.x16[i], mm.residual[i], mm.y[i] = x.data_ptr(), ptr(opts.get("residual")), y.data_ptr()
+            outs.append(y)
+        ws = _conv_workspace(items[0][0].device) if use_ws else None
+        check(lib.hn_conv2d_nhwc_f16x3_multi(C.byref(mm), ptr(ws), ws.numel() * 4 if use_ws else 0, _stream()),
+              "hn_conv2d_nhwc_f16x3_multi")
+        return outs
+    mm = _lib.ConvMulti()
+    mm.count = k
+    outs = []
+    macs, shapes = 0, []
+    for i, (x, cw, opts) in enumerate(items):
+        if not is_split(x) or cw.w16 is None:
+            raise TypeError("multi launches take S32 inputs and split filter banks")
+        _req(x, torch.float16, "x")
+        relu, relu_cols = opts.get("relu", False), opts.get("relu_cols")
+        residual, out_split = opts.get("residual"), opts.get("out_split", True)
+        cout, r, s_, cin = cw.w.shape
+        n, h, wd = x.shape[:3]
+        if channels(x) != cin:
+            raise ValueError(f"member {i}: weight Cin {cin} != input channels {channels(x)}")
+        xs = _pixel_stride(x, "x")
+        rc = (cout if relu else 0) if relu_cols is None else relu_cols
+        d = make_conv_desc(n, h, wd, cin, cout, r, s_, cw.stride, cw.pad, cw.dil, rc, 1 if residual is not None else 0, 0, 0,
+                           0, 0, in_pix_stride=0 if xs == 2 * cin else xs)
+        if out_split:
+            if cout % 32:
+                raise ValueError("out_split needs Cout % 32 == 0")
+            y = torch.empty((n, d.oh, d.ow, cout // 32, 2, 32), device=x.device, dtype=torch.float16)
+        else:
+            y = torch.empty((n, d.oh, d.ow, cout), device=x.device, dtype=torch.float32)
+        d.out_split = 1 if out_split else 0
+        d.terms = 1 if F16_TERMS == 1 else 0
+        d.splitk = (1 if SPLITK_EAGER else 0) if splitk else -1
+        if residual is not None:
+            if tuple(residual.shape[:3]) != (n, d.oh, d.ow) or channels(residual) != cout:
+                raise ValueError(f"member {i}: residual shape mismatch")
+            d.res_split = 1 if is_split(residual) else 0
+            d.res_pix_stride = _pixel_stride(residual, "residual")
+        if cw.bias is not None:
+            _req(cw.bias, name="bias")
+        mm.desc[i] = d
+        mm.x16[i], mm.w16[i], mm.bias[i] = ptr(x), ptr(cw.w16), ptr(cw.bias)
+        mm.residual[i], mm.y[i] = ptr(residual), ptr(y)
+        outs.append(y)
+        macs += n * d.oh * d.ow * cout * r * s_ * cin
+        shapes.append((n, h, wd, cin, cout, r, cw.stride, cw.dil))
+    ws = _conv_workspace(items[0][0].device) if splitk else None
+    if fused is not None:
+        fused.append(bool(lib.hn_conv2d_f16x3_multi_fuses(C.byref(mm), ws.numel() * 4 if splitk else 0)))
+    prof = CONV_PROFILE
+    if prof is not None:
+        timer = HipTimer()
+        timer.start()
+    check(lib.hn_conv2d_nhwc_f16x3_multi(C.byref(mm), ptr(ws), ws.numel() * 4 if splitk else 0, _stream()),
+          "hn_conv2d_nhwc_f16x3_multi")
+    if prof is not None:
+        timer.stop()
+        big = max(range(k), key=lambda i: shapes[i][0] * shapes[i][1] * shapes[i][2] * shapes[i][3] * shapes[i][4] * shapes[i][5] ** 2)
+        prof.append((("f16x3", lib.hn_conv2d_f16x3_pick_tile(C.byref(mm.desc[big])) | TILE_MULTI), macs, timer, shapes[big],
+                     PROFILE_STAGE))
+    else:
+        _MULTI_PLANS[key] = (_lib.ConvMulti.from_buffer_copy(mm), [(tuple(y.shape), y.dtype) for y in outs], bool(splitk))
+    return outs
 
 
 def conv2d_nhwc_grouped(xs, ws, *, pad=0, relu=False, relu_cols=None, out_split=False, tile=0, gn_partials=None,
@@ -1098,12 +1197,16 @@ def range_check_enable(on=True):
     check(_lib.load().hn_range_check_enable(1 if on else 0), "hn_range_check_enable")
 
 
-def range_check_fetch(reset=True) -> int:
-    """OR of the _lib.RANGE_* bits a split producer has set in the LIBRARY's flag block since the last reset (non-zero: a
-    value was out of range / non-finite; synchronises)."""
+def range_check_bits(reset=True) -> int:
+    """OR of the _lib.RANGE_* bits a split producer has set in the LIBRARY's flag block since the last reset (synchronises)."""
     flag = C.c_int32(0)
     check(_lib.load().hn_range_check_fetch(C.byref(flag), 1 if reset else 0, _stream()), "hn_range_check_fetch")
     return int(flag.value)
+
+
+def range_check_fetch(reset=True) -> bool:
+    """True if a split producer met an out-of-range / non-finite value since the last reset (synchronises)."""
+    return range_check_bits(reset) != 0
 
 
 def range_check_bind(block=None):

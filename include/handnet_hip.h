@@ -226,6 +226,29 @@ typedef struct hn_conv_group {
 } hn_conv_group;
 int hn_conv2d_nhwc_f16x3_grouped(const hn_conv_desc* desc, const hn_conv_group* group, void* stream);
 
+/* Up to HN_CONV_MULTI_MAX INDEPENDENT convolutions of DIFFERENT shapes as one launch (plus one reduction launch for all their
+ * split-K members): each member has its own descriptor (channels, filter, stride, dilation, residual, ReLU, output format,
+ * splitk mode) and tensors, exactly as for hn_conv2d_nhwc_f16x3_ws, and computes exactly what that call would -- same
+ * kernel body, same k order, the split-K plan it would get alone -- so results are bit-identical to separate calls.
+ * The members run together when each of them alone would take the implicit-GEMM kernel of one common tile form
+ * (hn_conv2d_f16x3_pick_tile); otherwise, or with HN_CONV_NO_MULTI=1, the call issues them one after the other.
+ * Used where the layer graph has independent small grids: the 1x1 downsample beside conv1 of a residual block
+ * (a2j/resnet.py:78-96, tv BasicBlock), the classification head beside layer4 of the A2J trunk (a2j/a2j.py:194-210,
+ * 226-250).  No member may read another member's output. */
+#define HN_CONV_MULTI_MAX 4
+typedef struct hn_conv_multi {
+  int32_t count;
+  hn_conv_desc desc[HN_CONV_MULTI_MAX];
+  const void* x16[HN_CONV_MULTI_MAX];
+  const void* w16[HN_CONV_MULTI_MAX];
+  const float* bias[HN_CONV_MULTI_MAX];      /* or NULL */
+  const void* residual[HN_CONV_MULTI_MAX];   /* or NULL */
+  void* y[HN_CONV_MULTI_MAX];
+} hn_conv_multi;
+int hn_conv2d_nhwc_f16x3_multi(const hn_conv_multi* mm, void* workspace, int64_t workspace_bytes, void* stream);
+/* 1 when the call above would run these members as ONE launch (host-only). */
+int hn_conv2d_f16x3_multi_fuses(const hn_conv_multi* mm, int64_t workspace_bytes);
+
 /* Fused variant for the f16x3 path: hn_conv2d_nhwc_f16x3_gn is hn_conv2d_nhwc_f16x3 (fp32 output, no
  * residual / ReLU, cout % 8 == 0, oh*ow >= 32) whose epilogue also writes GroupNorm partial sums
  * gn_partial [ceil(n*oh*ow / 32)][cout/8][4] (hn_groupnorm_rows32_scratch_floats floats);

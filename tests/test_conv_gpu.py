@@ -829,3 +829,57 @@ def test_fused_groupnorm_apply_on_a_wide_frame_pyramid():
     got = ops.conv3x3_thin_affine_levels(ts, aff, 256, cw, relu_cols=4)
     for u, v in zip(got, want):
         assert torch.equal(u, v)
+
+
+def _multi_member(rng_seed, n, h, w, cin, cout, r, stride=1, dil=1, relu=True, residual=False, out_split=True):
+    """(x S32, ConvW, opts) with random data; pad = the 'same' padding of the filter"""
+    from hn_amd import ops
+    from hn_amd.weights import ConvW
+    g = torch.Generator().manual_seed(rng_seed)
+    x = torch.randn((n, h, w, cin), generator=g).cuda()
+    wt = (torch.randn((cout, r, r, cin), generator=g) * (2.0 / (r * r * cin)) ** 0.5)
+    cw = ConvW(wt, torch.randn((cout,), generator=g) * 0.1, stride, dil * (r // 2), dil).to("cuda")
+    oh, ow = ops.conv_out_size(h, w, r, r, stride, cw.pad, dil)
+    res = ops.to_split(torch.randn((n, oh, ow, cout), generator=g).cuda()) if residual else None
+    return ops.to_split(x), cw, dict(relu=relu, residual=res, out_split=out_split)
+
+
+@pytest.mark.parametrize("case", ["bottleneck_ds", "basic_ds", "layer4_cls", "four", "mixed_tiles", "big_and_small"])
+def test_multi_launch_is_bit_identical_to_separate_launches(case):
+    """hn_conv2d_nhwc_f16x3_multi: independent convolutions of DIFFERENT shapes in one grid (the 1x1 downsample beside conv1 of
+    a residual block, the classification head beside layer4) must return, member for member, the very bits of separate
+    hn_conv2d_nhwc_f16x3_ws calls -- split-K members (with ONE reduction launch for all of them), residual / ReLU epilogues,
+    fp32 and S32 outputs, strides and dilation included; members of different tile forms fall back to separate launches."""
+    from hn_amd import ops
+    members = {
+        # A2J block 0 of layer2 at batch 1: conv1 1x1 256->128 beside the downsample 1x1 / stride 2 256->512
+        "bottleneck_ds": [_multi_member(1, 1, 44, 44, 256, 128, 1), _multi_member(2, 1, 44, 44, 256, 512, 1, stride=2, relu=False)],
+        # ResNet-34 layer3 block 0 at batch 1: conv1 3x3 / stride 2 128->256 beside the downsample 1x1 / stride 2
+        "basic_ds": [_multi_member(3, 1, 100, 136, 128, 256, 3, stride=2), _multi_member(4, 1, 100, 136, 128, 256, 1, stride=2, relu=False)],
+        # A2J layer4 block 1 conv2 (dilated) beside the classification head's first conv, batch 2; one member with a residual
+        "layer4_cls": [_multi_member(5, 2, 11, 11, 512, 512, 3, dil=2), _multi_member(6, 2, 11, 11, 1024, 256, 3),
+                       _multi_member(7, 2, 11, 11, 2048, 512, 1, residual=True)],
+        "four": [_multi_member(8, 1, 22, 22, 128, 128, 3), _multi_member(9, 1, 22, 22, 512, 128, 1),
+                 _multi_member(10, 1, 11, 11, 256, 336, 3, relu=False, out_split=False), _multi_member(11, 1, 22, 22, 128, 512, 1)],
+        # a 128x128-tile member and a small one: different tile forms -> the library issues them separately
+        "mixed_tiles": [_multi_member(12, 8, 100, 136, 128, 256, 3), _multi_member(13, 1, 11, 11, 256, 256, 3)],
+        "big_and_small": [_multi_member(14, 16, 22, 22, 128, 128, 3), _multi_member(15, 16, 22, 22, 512, 128, 1)],
+    }[case]
+    ref = [ops.conv2d_nhwc(x, cw.w, cw.bias, stride=cw.stride, pad=cw.pad, dil=cw.dil, w16=cw.w16, relu=o["relu"],
+                           residual=o["residual"], out_split=o["out_split"]) for x, cw, o in members]
+    fused = []
+    got = ops.conv2d_nhwc_multi(members, fused=fused)
+    assert fused[0] == (case != "mixed_tiles"), (case, fused)
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape and a.dtype == b.dtype and torch.equal(a, b), case
+    # against fp64 as well (the separate launches are themselves checked elsewhere; this pins the multi path on its own)
+    x, cw, o = members[0]
+    xf = ops.from_split(x).double().permute(0, 3, 1, 2)
+    y = torch.nn.functional.conv2d(xf, cw.w.double().permute(0, 3, 1, 2), cw.bias.double(), stride=cw.stride, padding=cw.pad,
+                                   dilation=cw.dil)
+    if o["residual"] is not None:
+        y = y + ops.from_split(o["residual"]).double().permute(0, 3, 1, 2)
+    if o["relu"]:
+        y = y.relu()
+    out = got[0] if not o["out_split"] else ops.from_split(got[0])
+    assert (out.double().permute(0, 3, 1, 2) - y).abs().max().item() <= 2e-5 * max(1.0, y.abs().max().item())
