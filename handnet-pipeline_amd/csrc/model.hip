@@ -368,6 +368,42 @@ T slice_blocks(const T& x, int b0, int b1) {
   return s;
 }
 
+// ops.conv2d_nhwc_multi: independent convolutions of different shapes as ONE launch (hn_conv2d_nhwc_f16x3_multi); every member
+// computes what its own conv16 call would, bit for bit
+struct MultiItem {
+  T x;
+  const ConvW* w = nullptr;
+  bool relu = false, out_split = true;
+  const T* res = nullptr;
+  T y;   // out
+};
+
+int conv_multi(Ctx& cx, MultiItem* it, int count) {
+  if (count < 1 || count > HN_CONV_MULTI_MAX) return hn::fail(HN_ERR_ARG, "model graph: multi launch of %d members", count);
+  hn_conv_multi mm;
+  memset(&mm, 0, sizeof(mm));
+  mm.count = count;
+  for (int i = 0; i < count; ++i) {
+    const ConvW& cw = *it[i].w;
+    if (!it[i].x.split || it[i].x.c != cw.cin) return hn::fail(HN_ERR_ARG, "model graph: multi member %d input mismatch", i);
+    hn_conv_desc d = make_desc(it[i].x, cw, it[i].relu ? cw.cout : 0);
+    it[i].y = alloc(cx, it[i].x.n, d.oh, d.ow, cw.cout, it[i].out_split);
+    d.out_split = it[i].out_split ? 1 : 0;
+    if (it[i].res) {
+      d.res_mode = 1;
+      d.res_split = it[i].res->split ? 1 : 0;
+      d.res_pix_stride = it[i].res->ps;
+    }
+    d.splitk = 1;
+    mm.desc[i] = d;
+    mm.x16[i] = it[i].x.p; mm.w16[i] = cw.w16; mm.bias[i] = cw.bias;
+    mm.residual[i] = it[i].res ? it[i].res->p : nullptr;
+    mm.y[i] = it[i].y.p;
+  }
+  if (cx.dry) return HN_OK;
+  return hn_conv2d_nhwc_f16x3_multi(&mm, cx.ws, kConvWorkspaceBytes, cx.stream);
+}
+
 struct GroupSpec {
   int count = 0;
   T x[HN_CONV_MAX_GROUP];
@@ -508,6 +544,82 @@ int a2j_graph_f32(Ctx& cx, const T& crops /* fp32 [k][176][176][4] */, const int
 // ------------------------------------------------------------------------------------------------------------------
 // A2J (hn_amd/a2j_engine.py)
 // ------------------------------------------------------------------------------------------------------------------
+// The A2J layers behind the stem for SMALL batches (A2JEngine._trunk_multi + heads, k <= A2JEngine.MULTI_MAX_CROPS): launch-bound,
+// so independent convolutions share launches -- the downsample beside conv1 of a block, one stage of the classification head
+// (which reads x3 only) in each of layer4's launches, the regression tower beside the depth tower.
+constexpr int kA2jMultiMaxCrops = 4;
+int a2j_tail_small(Ctx& cx, T x, const int32_t* valid, float* keypoints) {
+  hn_model* m = cx.m;
+  const int k = x.n;
+  struct Stage { const ConvW* w; bool relu, out_split; };
+  const Stage st[5] = {{&m->a_cls[0], true, true}, {&m->a_cls[1], true, true}, {&m->a_cls[2], true, true},
+                       {&m->a_cls[3], true, true}, {&m->a_cls_out, false, false}};
+  auto launch = [&](MultiItem* it, int n) -> int {
+    if (n > 1) return conv_multi(cx, it, n);
+    return conv16(cx, it[0].x, *it[0].w, it[0].relu, it[0].out_split, it[0].res, false, it[0].y);
+  };
+  T c, x3;
+  int stage = 0;
+  bool have_c = false;
+  for (auto& b : m->a_blocks) {
+    const bool in_l4 = b.layer == 4;
+    if (in_l4 && !have_c) { c = x3 = x; have_c = true; }
+    auto ride = [&](MultiItem* it, int& n) -> bool {
+      if (!in_l4 || stage >= 5) return false;
+      it[n].x = c; it[n].w = st[stage].w; it[n].relu = st[stage].relu; it[n].out_split = st[stage].out_split;
+      ++n;
+      return true;
+    };
+    MultiItem it[3];
+    int n = 0;
+    it[n].x = x; it[n].w = &b.c1; it[n].relu = true; ++n;
+    if (b.has_ds) { it[n].x = x; it[n].w = &b.ds; it[n].relu = false; ++n; }
+    bool rides = ride(it, n);
+    HN_TRY(launch(it, n));
+    T o = it[0].y;
+    const T idn = b.has_ds ? it[1].y : x;
+    if (rides) { c = it[n - 1].y; ++stage; }
+    MultiItem i2[2];
+    n = 0;
+    i2[n].x = o; i2[n].w = &b.c2; i2[n].relu = true; ++n;
+    rides = ride(i2, n);
+    HN_TRY(launch(i2, n));
+    o = i2[0].y;
+    if (rides) { c = i2[n - 1].y; ++stage; }
+    MultiItem i3[2];
+    n = 0;
+    i3[n].x = o; i3[n].w = &b.c3; i3[n].relu = true; i3[n].res = &idn; ++n;
+    rides = ride(i3, n);
+    HN_TRY(launch(i3, n));
+    x = i3[0].y;
+    if (rides) { c = i3[n - 1].y; ++stage; }
+  }
+  while (stage < 5) {
+    T y;
+    HN_TRY(conv16(cx, c, *st[stage].w, st[stage].relu, st[stage].out_split, nullptr, false, y));
+    c = y;
+    ++stage;
+  }
+  const T cls = c;
+  T rd;
+  HN_TRY(conv16(cx, x, m->a_regdep1, true, true, nullptr, false, rd));
+  T r = slice_blocks(rd, 0, 8), dd = slice_blocks(rd, 8, 16);
+  for (int i = 0; i < 3; ++i) {
+    MultiItem it[2];
+    it[0].x = r; it[0].w = &m->a_reg[i]; it[0].relu = true;
+    it[1].x = dd; it[1].w = &m->a_dep[i]; it[1].relu = true;
+    HN_TRY(conv_multi(cx, it, 2));
+    r = it[0].y; dd = it[1].y;
+  }
+  MultiItem io[2];
+  io[0].x = r; io[0].w = &m->a_reg_out; io[0].relu = false; io[0].out_split = false;
+  io[1].x = dd; io[1].w = &m->a_dep_out; io[1].relu = false; io[1].out_split = false;
+  HN_TRY(conv_multi(cx, io, 2));
+  if (cx.dry) return HN_OK;
+  return hn_a2j_aggregate_f32((const float*)cls.p, (const float*)io[0].y.p, (const float*)io[1].y.p, valid, k, cls.h, cls.w,
+                              m->cfg.num_joints, 16, keypoints, cx.stream);
+}
+
 // valid_rw: the per-crop flags when they are the model's own to update (hn_handnet_forward's has_hand: a crop with non-finite
 // pixels becomes 2 = NaN keypoints, like the Python engine); null for a caller's read-only flags
 int a2j_graph(Ctx& cx, const T& crops /* fp32 [k][176][176][4] */, const int32_t* valid, float* keypoints,
@@ -525,6 +637,7 @@ int a2j_graph(Ctx& cx, const T& crops /* fp32 [k][176][176][4] */, const int32_t
   if (!cx.dry)
     HN_TRY(hn_conv_stem_pool_f16x3_terms(img16, k, crops.h, crops.w, border, 7, 2, 64, m->a_stem16.w16, m->a_stem16.bias, x.p, t_terms,
                                          cx.stream));
+  if (k <= kA2jMultiMaxCrops) return a2j_tail_small(cx, x, valid, keypoints);
   T x3;
   for (size_t i = 0; i < m->a_blocks.size(); ++i) {
     auto& b = m->a_blocks[i];
@@ -741,9 +854,16 @@ int fcos_net_f16(Ctx& cx, const float* rgb, int n, int h, int w, const Geometry&
   int nf = 0;
   for (auto& b : m->f_blocks) {
     T o, idn, y;
-    HN_TRY(conv16(cx, x, b.c1, true, true, nullptr, false, o));
-    if (b.has_ds) HN_TRY(conv16(cx, x, b.ds, false, true, nullptr, false, idn));
-    else idn = x;
+    if (b.has_ds) {   // both read the block input: one grid (FCOSEngine.backbone)
+      MultiItem it[2];
+      it[0].x = x; it[0].w = &b.c1; it[0].relu = true;
+      it[1].x = x; it[1].w = &b.ds; it[1].relu = false;
+      HN_TRY(conv_multi(cx, it, 2));
+      o = it[0].y; idn = it[1].y;
+    } else {
+      HN_TRY(conv16(cx, x, b.c1, true, true, nullptr, false, o));
+      idn = x;
+    }
     HN_TRY(conv16(cx, o, b.c2, true, true, &idn, false, y));
     release(cx, o);
     if (b.has_ds) release(cx, idn);

@@ -111,7 +111,10 @@ class A2JEngine:
         else:
             x = self._conv(x, self.stem, algo_cin=4 if self.rgbd else 3)
             x = ops.maxpool3x3s2_nhwc(x)
-        if self.multi:
+        if self.multi and x.shape[0] <= self.MULTI_MAX_CROPS:
+            # small batches are launch-bound: the downsample runs beside conv1 and the classification head rides on layer4's
+            # launches (measured, A2J alone: 1 crop 0.909 -> 0.799 ms, 2 crops 0.873 -> 0.831, 4 crops even; from 8 crops on
+            # the grouped head layers of the other form win -- their members would go split-K one by one here)
             return self._trunk_multi(x)
         x3 = None
         for i, blk in enumerate(self.blocks):
@@ -124,7 +127,9 @@ class A2JEngine:
                 x3 = x
         return x3, x
 
-    def _trunk_multi(self, x):
+    MULTI_MAX_CROPS = 4
+
+    def _trunk_multi(self, x, ride_cls=True):
         """The trunk as heterogeneous launches: conv1 of a block together with its downsample (both read the block input), and
         -- from the first block of layer4 on, when x3 exists -- one stage of the classification head (four 3x3 convolutions and
         the output convolution, a2j/a2j.py:162-181, which read x3 and nothing of layer4) in each of layer4's launches.  Every
@@ -148,7 +153,7 @@ class A2JEngine:
                 items.append((x, blk["ds"], dict(relu=False)))
 
             def ride(items):
-                if in_l4 and stage < len(cls_stages):
+                if ride_cls and in_l4 and stage < len(cls_stages):
                     items.append((c, cls_stages[stage][0], cls_stages[stage][1]))
                     return True
                 return False
@@ -170,6 +175,9 @@ class A2JEngine:
             x = outs[0]
             if rides:
                 c, stage = outs[-1], stage + 1
+        if not ride_cls:
+            self._cls_ready = None
+            return x3, x
         while stage < len(cls_stages):                                  # (a trunk with a shorter layer4 than the head chain)
             c = launch([(c, cls_stages[stage][0], cls_stages[stage][1])])[0]
             stage += 1

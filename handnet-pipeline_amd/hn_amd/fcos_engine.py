@@ -127,7 +127,7 @@ class FCOSEngine:
         self.fuse_last_gn = os.environ.get("HN_FUSE_LAST_GN", "1") != "0"   # A/B switch, bit-identical
         self.thin_outputs = os.environ.get("HN_THIN_OUTPUTS", "1") != "0" and self.cls_out.cout <= 16   # A/B switch (tap form bit-identical, P form to fp32 rounding)
         # conv1 of a downsampling block together with its 1x1 downsample (ops.conv2d_nhwc_multi); HN_CONV_MULTI=0: apart (A/B)
-        self.multi = os.environ.get("HN_CONV_MULTI", "1") != "0" and precision == "f16x3"
+        self.multi = os.environ.get("HN_CONV_MULTI_FCOS", os.environ.get("HN_CONV_MULTI", "1")) != "0" and precision == "f16x3"
 
     # -----------------------------------------------------------------------------------
     def _conv(self, x, cw: ConvW, relu=False, out_f32=False, **kw):

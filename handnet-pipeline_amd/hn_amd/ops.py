@@ -446,7 +446,9 @@ def conv2d_nhwc_multi(items, fused=None):
     for i, (x, cw, opts) in enumerate(items):
         if not is_split(x) or cw.w16 is None:
             raise TypeError("multi launches take S32 inputs and split filter banks")
-        _req(x, torch.float16, "x")
+        if not x.is_cuda:
+            raise RuntimeError("x must live on the GPU (no CPU fallback in handnet-pipeline_amd)")
+        _check_device(x, "x")
         relu, relu_cols = opts.get("relu", False), opts.get("relu_cols")
         residual, out_split = opts.get("residual"), opts.get("out_split", True)
         cout, r, s_, cin = cw.w.shape
