@@ -157,7 +157,9 @@ def test_four_ranks_equal_single_process_batch(tmp_path, fcos_sd, a2j_sd):
 
 def test_bench_four_rank_rehearsal():
     """`bench.py --gpus 4 --share-gpu --dist-backend gloo --batch 8`: the self-launch path at a world size > 2 (global
-    batch 32 as 4 x 8), one JSON line from rank 0."""
+    batch 32 as 4 x 8), one JSON line from rank 0.  FOUR is the largest world this box rehearses: its process guard allows
+    six processes with the device open, and this test process, bench.py's launching parent (torch.cuda.device_count() opens
+    the device node) and the ranks all count -- a five-rank run was killed by the guard (round 4)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "4", "--share-gpu", "--dist-backend", "gloo",
                         "--steps", "2", "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--no-roofline"],
@@ -167,20 +169,4 @@ def test_bench_four_rank_rehearsal():
     assert len(lines) == 1, r.stdout
     line = json.loads(lines[0])
     assert line["n_gpus"] == 4 and line["config"]["global_batch"] == 32 and line["config"]["rccl_ranks"] == 4
-
-
-def test_bench_five_rank_rehearsal():
-    """The largest world this box can rehearse through `bench.py`'s own self-launch: the process guard allows six processes on
-    the card and this test process is one of them, so FIVE ranks (`--gpus 5 --share-gpu --dist-backend gloo --batch 4`); the
-    line must report five ranks seen by the gather (config 5's launch path, BASELINE.json, at the size one GPU allows)."""
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "5", "--share-gpu", "--dist-backend", "gloo",
-                        "--steps", "2", "--warmup", "1", "--batch", "4", "--no-cpu-baseline", "--no-roofline"],
-                       env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout + r.stderr
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout
-    line = json.loads(lines[0])
-    assert line["n_gpus"] == 5 and line["config"]["global_batch"] == 20 and line["config"]["rccl_ranks"] == 5
-    assert line["scaling"] == "weak" and line["config"]["collective_backend"] == "gloo"
 
