@@ -421,6 +421,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # development host: the HN_* A/B variables of tools/ select older kernel forms / launch structures for same-box comparisons
+    # (hn_amd/forms.py).  The product itself never reads them; a run that used any reports them in config.forms.
+    from hn_amd import forms
+    forms_used = forms.apply_env()
     if world > 1:   # N ranks build their engines at once on one host: share the cores instead of oversubscribing them N-fold
         torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
 
@@ -496,7 +500,8 @@ def main():
                        "parallelism": f"frames sharded over {world} GPU(s), one all-gather of per-frame records per step",
                        "collective_backend": (dist.get_backend() if world > 1 else None), "rccl_ranks": rccl_ranks,
                        "gflop_per_unit": round(info["gflop_per_unit"], 3), "hipgraph": bool(args.graph),
-                       "host": "C++ layer graph (model-level C ABI)" if args.native else "Python engines (op-level C ABI)"},
+                       "host": "C++ layer graph (model-level C ABI)" if args.native else "Python engines (op-level C ABI)",
+                       "forms": forms_used or None},
             "algorithmic_tflops": round(value * info["gflop_per_unit"] / 1e3, 2),
             "roofline": roof, "dropin": dropin, "cpu_baseline": cpu,
         }

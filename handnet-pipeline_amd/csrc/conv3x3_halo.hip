@@ -299,7 +299,7 @@ int conv3x3_halo(const hn_conv_desc* d, const void* x16, const void* w16, const 
   p.ty = cdiv(d->h, kT); p.tx = cdiv(d->w, kT);
   p.range_flag = range_flag_ptr();
   p.stamps = nullptr;
-  if (getenv("HN_HALO_STAMPS")) {
+  if (env_flags().halo_stamps) {
     void* sp = nullptr;
     if (hipGetSymbolAddress(&sp, HIP_SYMBOL(g_halo_stamps)) == hipSuccess) p.stamps = (unsigned long long*)sp;
   }

@@ -14,10 +14,10 @@ char* err_buf();
 int fail(int code, const char* fmt, ...);
 // device address of the sticky f16x3 range flag of the current device, or nullptr while the check is off
 int* range_flag_ptr();
-// A/B switches read from the environment ONCE (hn_reread_env() refreshes them): getenv per launch costs more host time
-// than the rest of a small launch's argument checks.
+// Kernel-form switches (hn_set_form; all false in a product process: the library never reads the environment)
 struct EnvFlags {
-  bool no_rs, no_rs32, split_generic, stem_generic, no_halo, no_thin, thin_tap, thin_flat, no_fuse_last_gn, pre_generic, no_multi;
+  bool no_rs, no_rs32, split_generic, stem_generic, no_halo, no_thin, thin_tap, thin_flat, no_fuse_last_gn, pre_generic, no_multi,
+      halo_stamps;
 };
 const EnvFlags& env_flags();
 // conv_stem_direct.hip: the 7x7 / stride-2 / 64-channel stem + ReLU + max pooling as a direct convolution from an LDS patch

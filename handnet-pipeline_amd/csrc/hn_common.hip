@@ -50,31 +50,36 @@ int fail(int code, const char* fmt, ...) {
 extern "C" int hn_abi_version(void) { return HN_ABI_VERSION; }
 
 namespace hn {
-static EnvFlags g_env;
-static bool g_env_read = false;
-static void read_env() {
-  g_env.no_rs = getenv("HN_CONV_NO_RS") != nullptr;
-  g_env.no_rs32 = getenv("HN_CONV_NO_RS32") != nullptr;
-  g_env.split_generic = getenv("HN_SPLIT_GENERIC") != nullptr;
-  g_env.stem_generic = getenv("HN_STEM_POOL_GENERIC") != nullptr;
-  g_env.no_halo = getenv("HN_CONV_NO_HALO") != nullptr;
-  g_env.pre_generic = getenv("HN_PREPROCESS_GENERIC") != nullptr;
-  g_env.no_multi = getenv("HN_CONV_NO_MULTI") != nullptr;   // hn_conv2d_nhwc_f16x3_multi: members one after the other (A/B)
-  g_env.no_fuse_last_gn = getenv("HN_FUSE_LAST_GN") != nullptr && getenv("HN_FUSE_LAST_GN")[0] == '0';
-  g_env.no_thin = getenv("HN_THIN_OUTPUTS") != nullptr && getenv("HN_THIN_OUTPUTS")[0] == '0';   // model.hip: grouped implicit GEMM
-  g_env.thin_tap = getenv("HN_THIN_FORM") != nullptr && getenv("HN_THIN_FORM")[0] == 't';          // thin kernel: never the P form
-  g_env.thin_flat = getenv("HN_THIN_FORM") != nullptr && getenv("HN_THIN_FORM")[0] == 'f';         // ... the P form at any size
-  g_env_read = true;
-}
-const EnvFlags& env_flags() {
-  if (!g_env_read) read_env();
-  return g_env;
-}
+// Kernel-form switches: older forms of some kernels stay in the library as bit-identity references for the tests and for
+// same-box A/B timing.  The library never reads them from the environment: a development host sets them by name
+// (hn_set_form; bench.py / tools translate their HN_* variables, hn_amd/forms.py).
+static EnvFlags g_env = {};
+const EnvFlags& env_flags() { return g_env; }
 }  // namespace hn
 
-extern "C" int hn_reread_env(void) {
-  hn::read_env();
-  return HN_OK;
+extern "C" int hn_set_form(const char* name, int value) {
+  HN_CHECK_ARG(name, "hn_set_form: null name");
+  struct Entry { const char* name; bool hn::EnvFlags::*field; };
+  static const Entry table[] = {
+      {"conv_no_rs", &hn::EnvFlags::no_rs},                 // per-tap form of the 3x3 / stride-1 convolutions
+      {"conv_no_rs32", &hn::EnvFlags::no_rs32},             // ... of the 128x32 tile only
+      {"split_generic", &hn::EnvFlags::split_generic},      // generic GroupNorm-apply kernel
+      {"stem_pool_generic", &hn::EnvFlags::stem_generic},   // implicit-GEMM form of the fused stem + pooling
+      {"conv_no_halo", &hn::EnvFlags::no_halo},             // implicit-GEMM form of the 64-channel 3x3 layers
+      {"preprocess_generic", &hn::EnvFlags::pre_generic},   // per-pixel preprocess kernel
+      {"conv_no_multi", &hn::EnvFlags::no_multi},           // hn_conv2d_nhwc_f16x3_multi: members one after the other
+      {"no_fuse_last_gn", &hn::EnvFlags::no_fuse_last_gn},  // model.hip: separate last GroupNorm apply pass
+      {"no_thin_outputs", &hn::EnvFlags::no_thin},          // model.hip: grouped implicit GEMM for the head outputs
+      {"thin_form_tap", &hn::EnvFlags::thin_tap},           // thin kernel: never the P form
+      {"thin_form_flat", &hn::EnvFlags::thin_flat},         // ... the P form at any size
+      {"halo_stamps", &hn::EnvFlags::halo_stamps},          // diagnostics: s_memtime stamps of the halo kernel
+  };
+  for (const Entry& e : table)
+    if (strcmp(e.name, name) == 0) {
+      hn::g_env.*(e.field) = value != 0;
+      return HN_OK;
+    }
+  return hn::fail(HN_ERR_ARG, "hn_set_form: unknown form '%s'", name);
 }
 
 extern "C" const char* hn_last_error(void) { return hn::err_buf(); }

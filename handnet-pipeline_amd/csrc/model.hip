@@ -1086,7 +1086,7 @@ template <class F>
 int run_planned(hn_model* m, const std::string& key0, void* stream, F&& graph) {
   HN_CHECK_ARG(m && m->finalized, "model is not finalized (hn_finalize)");
   t_terms = m->cfg.f16_terms == 1 ? 1 : 0;
-  // the take / give sequence of a graph depends on the library's A/B switches (hn_reread_env): a plan is only valid for
+  // the take / give sequence of a graph depends on the library's kernel-form switches (hn_set_form): a plan is only valid for
   // the switch state it was sized under
   const hn::EnvFlags& ef = hn::env_flags();
   const int sw = (ef.no_thin ? 1 : 0) | (ef.thin_tap ? 2 : 0) | (ef.thin_flat ? 4 : 0) | (ef.no_fuse_last_gn ? 8 : 0);

@@ -9,11 +9,10 @@ are one grouped launch each.
 """
 from __future__ import annotations
 
-import os
-
 import torch
 
 from . import ops
+from .forms import engine_forms
 from .weights import ConvW, bn_scale_shift, concat_cout, pack_conv, pack_stem_split, strip_prefix
 
 # (planes, blocks, stride of first block, dilation of later blocks)  a2j/resnet.py:109-112
@@ -22,7 +21,7 @@ ANCHORS_PER_CELL = 16
 
 
 class A2JEngine:
-    def __init__(self, state_dict, num_joints: int = 21, rgbd: bool = False, device="cuda", precision="f16x3"):
+    def __init__(self, state_dict, num_joints: int = 21, rgbd: bool = False, device="cuda", precision="f16x3", forms=None):
         """precision: "f16x3" (split-fp16 operands on the f16 MFMA, fp32-grade results; default)
         or "f32" (exact f32 MFMA).  Layers with Cin % 32 != 0 (the stem) always run in f32."""
         if precision not in ("f32", "f16x3", "f16x1"):
@@ -37,10 +36,11 @@ class A2JEngine:
         self.device = torch.device(device)
         self.joints = num_joints
         self.rgbd = rgbd
-        self.group_heads = os.environ.get("HN_GROUP_CONVS", "1") != "0"
+        fm = engine_forms(forms)   # launch-structure switches (hn_amd/forms.py; never read from the environment here)
+        self.group_heads = fm["group_convs"]
         # heterogeneous launches (ops.conv2d_nhwc_multi): the downsample beside conv1 of a block, the classification head
-        # beside layer4, the regression / depth towers beside each other.  HN_CONV_MULTI=0: the round-3 launch structure (A/B)
-        self.multi = os.environ.get("HN_CONV_MULTI", "1") != "0" and precision == "f16x3"
+        # beside layer4, the regression / depth towers beside each other (conv_multi = False: the round-3 launch structure)
+        self.multi = fm["conv_multi"] and precision == "f16x3"
         p = "Backbone.model."
         dev = self.device
 
@@ -54,7 +54,7 @@ class A2JEngine:
         w1 = sd[p + "conv1.weight"].double()
         self.stem16 = pack_stem_split(w1 if rgbd else w1.sum(dim=1, keepdim=True), bn_scale_shift(sd, p + "bn1")).to(dev) \
             if precision == "f16x3" else None
-        self.fuse_stem_pool = os.environ.get("HN_FUSE_STEM_POOL", "1") != "0"
+        self.fuse_stem_pool = fm["fuse_stem_pool"]
         self.blocks = []
         for li, (planes, blocks, stride, dil) in enumerate(_LAYERS, start=1):
             for b in range(blocks):

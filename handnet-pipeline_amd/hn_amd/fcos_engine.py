@@ -19,11 +19,11 @@ load by the next conv).  Everything stays on the device; nothing here synchronis
 from __future__ import annotations
 
 import math
-import os
 
 import torch
 
 from . import ops
+from .forms import engine_forms
 from .weights import ConvW, bn_scale_shift, concat_cout, pack_conv, pack_stem_split
 
 IMAGE_MEAN = (0.485, 0.456, 0.406)
@@ -44,7 +44,7 @@ def resized_size(h: int, w: int, min_size: int = 800, max_size: int = 1333):
 
 class FCOSEngine:
     def __init__(self, state_dict, num_classes: int, device="cuda", min_size=800, max_size=1333,
-                 precision="f16x3", ext=False, head_streams=None, image_mean=None, image_std=None):
+                 precision="f16x3", ext=False, head_streams=None, image_mean=None, image_std=None, forms=None):
         """precision: "f16x3" (split-fp16 operands, fp32-grade; default) or "f32" (exact f32 MFMA).
         image_mean / image_std: the transform's normalisation (fcos.py:501-505; default: ImageNet's)."""
         if precision not in ("f32", "f16x3", "f16x1"):
@@ -121,13 +121,15 @@ class FCOSEngine:
         ]).to(dev) if ext else None
         self._gn_scratch = {}
         self._side = None
-        self.head_streams = int(os.environ.get("HN_HEAD_STREAMS", "1")) if head_streams is None else head_streams
-        self.group_towers = os.environ.get("HN_GROUP_CONVS", "1") != "0"
-        self.fuse_stem_pool = os.environ.get("HN_FUSE_STEM_POOL", "1") != "0"   # A/B switch (results are bit-identical)
-        self.fuse_last_gn = os.environ.get("HN_FUSE_LAST_GN", "1") != "0"   # A/B switch, bit-identical
-        self.thin_outputs = os.environ.get("HN_THIN_OUTPUTS", "1") != "0" and self.cls_out.cout <= 16   # A/B switch (tap form bit-identical, P form to fp32 rounding)
-        # conv1 of a downsampling block together with its 1x1 downsample (ops.conv2d_nhwc_multi); HN_CONV_MULTI=0: apart (A/B)
-        self.multi = os.environ.get("HN_CONV_MULTI_FCOS", os.environ.get("HN_CONV_MULTI", "1")) != "0" and precision == "f16x3"
+        # launch-structure switches (hn_amd/forms.py: defaults unless a development host changed them; never the environment)
+        fm = engine_forms(forms)
+        self.head_streams = fm["head_streams"] if head_streams is None else head_streams
+        self.group_towers = fm["group_convs"]
+        self.fuse_stem_pool = fm["fuse_stem_pool"]   # (results are bit-identical either way)
+        self.fuse_last_gn = fm["fuse_last_gn"]       # bit-identical
+        self.thin_outputs = fm["thin_outputs"] and self.cls_out.cout <= 16   # (tap form bit-identical, P form to fp32 rounding)
+        # conv1 of a downsampling block together with its 1x1 downsample (ops.conv2d_nhwc_multi)
+        self.multi = fm["conv_multi_fcos"] and precision == "f16x3"
 
     # -----------------------------------------------------------------------------------
     def _conv(self, x, cw: ConvW, relu=False, out_f32=False, **kw):

@@ -229,10 +229,10 @@ def clear_plan_caches():
 # split-K workspace: one fp32 buffer per (device, stream) -- a convolution only uses it between its own two
 # launches, and launches on one stream are ordered
 CONV_WORKSPACE_BYTES = 32 << 20
-SPLITK = os.environ.get("HN_SPLITK", "1") != "0"  # development switch (tools/probes/exp/splitk.sh)
+SPLITK = True  # development switch (forms.apply_env: HN_SPLITK=0; tools/probes/exp/splitk.sh)
 # split short k loops too (desc.splitk = 1).  It used to pay only under graph replay; since the host path got
 # cheaper (raw stream handle, cached descriptors) it also wins in eager mode (batch 1: 294 -> 301 frames/s)
-SPLITK_EAGER = os.environ.get("HN_SPLITK_EAGER", "1") == "1"
+SPLITK_EAGER = True
 
 
 class launch_cost_hidden:
@@ -959,7 +959,7 @@ def alloc_detections(n, cap, device) -> Detections:
     return Detections(b, s, l.view(i32), sd.view(i32), lv.view(i32), kp.view(i32), cnt.view(i32))
 
 
-CANDIDATES_CHUNKED = os.environ.get("HN_CANDIDATES_CHUNKED", "1") != "0"   # A/B: hn_fcos_candidates_ws vs one workgroup per image
+CANDIDATES_CHUNKED = True   # development switch (forms.apply_env): hn_fcos_candidates_ws vs one workgroup per image
 
 
 def fcos_candidates(cls_lr, reg_ctr, strides, num_classes, score_thresh=0.7, out: Candidates | None = None):
@@ -1188,9 +1188,10 @@ def nonfinite_count(x, flag=None):
     return flag
 
 
-def reread_env():
-    """The library reads its A/B switches (HN_CONV_NO_RS, HN_SPLIT_GENERIC, ...) once; call this after changing them."""
-    check(_lib.load().hn_reread_env(), "hn_reread_env")
+def set_form(name: str, on=True):
+    """Kernel-form switch of the library (hn_set_form; names in include/handnet_hip.h): an older form of a kernel as a
+    bit-identity reference or for A/B timing.  Process-wide; the product never sets one (hn_amd/forms.py)."""
+    check(_lib.load().hn_set_form(name.encode(), 1 if on else 0), "hn_set_form")
 
 
 def range_check_enable(on=True):

@@ -78,9 +78,12 @@ int hn_range_check_fetch(int* flag /* host */, int reset, void* stream);
 int hn_range_check_bind(int32_t* block /* device, 4 words, zeroed by the caller; or NULL */);
 int hn_range_check_collect(int32_t* block /* or NULL */, int32_t* dst /* device, 4 words */, void* stream);
 
-/* The library's A/B switches (HN_CONV_NO_RS, HN_CONV_NO_RS32, HN_SPLIT_GENERIC: select the older kernel forms, results
- * unchanged) are read from the environment once, at first use; a host that changes them later calls this. */
-int hn_reread_env(void);
+/* Kernel-form switches.  Older forms of some kernels stay in the library as bit-identity references for the tests and for
+ * same-box A/B timing ("conv_no_rs", "conv_no_rs32", "split_generic", "stem_pool_generic", "conv_no_halo", "preprocess_generic",
+ * "conv_no_multi", "no_fuse_last_gn", "no_thin_outputs", "thin_form_tap", "thin_form_flat", "halo_stamps"; results unchanged
+ * unless a test says otherwise).  The library NEVER reads them from the environment: a development host sets them by name
+ * (bench.py and tools/ translate their HN_* variables through hn_amd/forms.py); a product process leaves them alone. */
+int hn_set_form(const char* name, int value);
 
 /* ------------------------------------------------------------------------------------
  * Convolution (implicit GEMM on f32 / f16 MFMA), fused epilogue.

@@ -507,16 +507,20 @@ def test_f16x3_wide_dynamic_range_keeps_precision():
     assert float((y.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
 
 
+_FORMS = ("conv_no_rs", "conv_no_rs32", "split_generic", "stem_pool_generic", "conv_no_halo", "preprocess_generic", "conv_no_multi",
+          "no_fuse_last_gn", "no_thin_outputs", "thin_form_tap", "thin_form_flat")
+
+
 @pytest.fixture(autouse=True)
-def _library_switches_follow_the_environment(monkeypatch):
-    """The library caches its A/B switches; tests that flip them call ops.reread_env() -- and here the cache is put back
-    in step with the restored environment when the test ends."""
+def _kernel_forms_are_reset():
+    """Tests select older kernel forms with ops.set_form (the library never reads the environment); every form is off again
+    when a test ends."""
     yield
-    monkeypatch.undo()
     import torch as _t
     if _t.cuda.is_available():
         from hn_amd import ops
-        ops.reread_env()
+        for f in _FORMS:
+            ops.set_form(f, False)
 
 
 # ---- row-shared A operand (RS kernels): the A tile of a filter ROW is staged once, taps read it at slot offsets ----
@@ -533,7 +537,7 @@ RS_CASES = [
 @pytest.mark.parametrize("tile", [1, 2, 4, 9, 10])
 def test_conv_f16x3_row_shared_a_is_bit_identical_to_per_tap_form(case, tile, monkeypatch):
     """Same k order and same operands => the row-shared kernel must reproduce the per-tap kernel bit for bit (S32 and fp32
-    outputs, residual + ReLU), and both are fp32-grade against an fp64 convolution.  HN_CONV_NO_RS=1 selects the per-tap
+    outputs, residual + ReLU), and both are fp32-grade against an fp64 convolution.  ops.set_form("conv_no_rs") selects the per-tap
     form; cases whose rows are too short for the gap slots of a wide tile fall back to it on their own."""
     from hn_amd import ops
     from hn_amd.weights import split_f16x3
@@ -546,11 +550,7 @@ def test_conv_f16x3_row_shared_a_is_bit_identical_to_per_tap_form(case, tile, mo
     xs, w16, rs32 = ops.to_split(x.cuda()), split_f16x3(wt).cuda(), ops.to_split(res.cuda())
     outs = {}
     for mode in ("rs", "per_tap"):
-        if mode == "per_tap":
-            monkeypatch.setenv("HN_CONV_NO_RS", "1")
-        else:
-            monkeypatch.delenv("HN_CONV_NO_RS", raising=False)
-        ops.reread_env()
+        ops.set_form("conv_no_rs", mode == "per_tap")
         y32 = ops.conv2d_nhwc(xs, wt.cuda(), b.cuda(), pad=1, relu=True, tile=tile, w16=w16, splitk=False)
         y16 = ops.conv2d_nhwc(xs, wt.cuda(), b.cuda(), pad=1, relu=True, residual=rs32, tile=tile, w16=w16, out_split=True,
                               splitk=False)
@@ -574,11 +574,7 @@ def test_conv_f16x3_row_shared_a_grouped_levels_and_gn_partials(monkeypatch):
     cw = NS(w=wt.cuda(), bias=torch.randn((cout,), generator=g).cuda(), w16=split_f16x3(wt).cuda())
     got = {}
     for mode in ("rs", "per_tap"):
-        if mode == "per_tap":
-            monkeypatch.setenv("HN_CONV_NO_RS", "1")
-        else:
-            monkeypatch.delenv("HN_CONV_NO_RS", raising=False)
-        ops.reread_env()
+        ops.set_form("conv_no_rs", mode == "per_tap")
         parts = [torch.zeros(ops.gn_rows32_scratch_floats(x.shape[0] * x.shape[1] * x.shape[2], cout), device="cuda") for x in xs]
         ys = ops.conv2d_nhwc_grouped(xs, [cw] * 3, pad=1, gn_partials=parts)
         got[mode] = (ys, parts)
@@ -601,11 +597,7 @@ def test_conv_f16x3_row_shared_a_few_output_channels(case, monkeypatch):
     w16 = split_f16x3(wt).cuda()
     got = []
     for no_rs in (False, True):
-        if no_rs:
-            monkeypatch.setenv("HN_CONV_NO_RS", "1")
-        else:
-            monkeypatch.delenv("HN_CONV_NO_RS", raising=False)
-        ops.reread_env()
+        ops.set_form("conv_no_rs", no_rs)
         got.append(ops.conv2d_nhwc(xs, wt.cuda(), b, pad=1, relu_cols=cout - 1, w16=w16, splitk=False))
     assert torch.equal(got[0], got[1])
 
@@ -614,7 +606,7 @@ def test_conv_f16x3_row_shared_a_few_output_channels(case, monkeypatch):
 def test_affine_split_group_stationary_kernel_equals_generic(shape, monkeypatch):
     """hn_affine_split_f32 picks a channel-group-stationary kernel for power-of-two channel counts (one image per
     blockIdx.y, scale / shift loaded once per lane, several pixels in flight): same bits as the generic kernel
-    (HN_SPLIT_GENERIC=1), with and without the affine, odd pixel counts, and a sliced (strided) input; C = 96 takes the
+    (form "split_generic"), with and without the affine, odd pixel counts, and a sliced (strided) input; C = 96 takes the
     generic kernel on both sides."""
     from hn_amd import ops
     n, h, w, c = shape
@@ -623,11 +615,7 @@ def test_affine_split_group_stationary_kernel_equals_generic(shape, monkeypatch)
     wide = _rand((n, h, w, 2 * c), 64).cuda()
     outs = []
     for generic in (False, True):
-        if generic:
-            monkeypatch.setenv("HN_SPLIT_GENERIC", "1")
-        else:
-            monkeypatch.delenv("HN_SPLIT_GENERIC", raising=False)
-        ops.reread_env()
+        ops.set_form("split_generic", generic)
         outs.append((ops.to_split(x), ops.to_split(x, sc, sh, relu=True), ops.to_split(x, sc, sh, relu=False),
                      ops.to_split(wide[..., c:], sc, sh, relu=True)))
     for a, b in zip(*outs):
@@ -641,7 +629,7 @@ def test_affine_split_group_stationary_kernel_equals_generic(shape, monkeypatch)
                                             (9, 100, 135, 128, True), (20, 67, 93, 32, False)])
 def test_halo_patch_kernel_is_bit_identical_to_the_implicit_gemm(n, h, w, cin, res):
     """conv3x3_halo_kernel (3x3 / stride 1 / pad 1, 64 output channels, >= 512 tiles of 16 x 16 pixels: ResNet-34 layer1)
-    against the implicit-GEMM kernel it replaces for that shape (HN_CONV_NO_HALO=1): same k order, same bits -- on maps that
+    against the implicit-GEMM kernel it replaces for that shape (form "conv_no_halo"): same k order, same bits -- on maps that
     are not multiples of the tile (partial tiles right / bottom), 1-4 channel blocks, with and without the S32 residual --
     and against an fp64 convolution."""
     import os
@@ -659,14 +647,12 @@ def test_halo_patch_kernel_is_bit_identical_to_the_implicit_gemm(n, h, w, cin, r
     assert ops._lib.load().hn_conv2d_f16x3_uses_halo(d, 1 if res else 0) == 1
     kw = dict(pad=1, relu=True, w16=w16, out_split=True, residual=rs)
     y_halo = ops.conv2d_nhwc(xs, wt.cuda(), b.cuda(), **kw)
-    os.environ["HN_CONV_NO_HALO"] = "1"
-    ops.reread_env()
+    ops.set_form("conv_no_halo", True)
     try:
         assert ops._lib.load().hn_conv2d_f16x3_uses_halo(d, 1 if res else 0) == 0
         y_gemm = ops.conv2d_nhwc(xs, wt.cuda(), b.cuda(), **kw)
     finally:
-        del os.environ["HN_CONV_NO_HALO"]
-        ops.reread_env()
+        ops.set_form("conv_no_halo", False)
     assert torch.equal(y_halo, y_gemm)
     ref = ops_ref.conv2d_nhwc(x.double(), wt.double(), b.double(), 1, 1, 1, relu_cols=0)
     ref = torch.relu(ref + (r.double() if res else 0.0)).float()
@@ -713,14 +699,12 @@ def test_f16x1_throughput_mode_is_plain_fp16_arithmetic():
 def test_thin_output_conv_matches_the_grouped_kernel(n, cout, relu_cols, sizes, form, monkeypatch):
     """hn_conv3x3_thin_f16x3_levels (csrc/conv3x3_thin.hip), the FCOS head outputs (fcos_utils/fcos.py:247-264,299-320).
     Its tap kernel keeps the k and term order of the implicit GEMM: bit-identical.  Its P-form kernel (Cout <= 5, >= 64 k
-    pixels -- or any size under HN_THIN_FORM=flat, the second run) adds the same fp32 products in another order (per tap
+    pixels -- or any size under the form "thin_form_flat", the second run) adds the same fp32 products in another order (per tap
     over all channels, then the nine taps): equal to fp32 rounding of a 2304-term sum, and as close to the fp64 convolution
     as the implicit GEMM is.  Inputs are channel slices of a 512-channel stack, as heads_grouped hands them over."""
     from hn_amd import ops
     from hn_amd.weights import ConvW
-    if form == "flat":
-        monkeypatch.setenv("HN_THIN_FORM", "flat")
-    ops.reread_env()
+    ops.set_form("thin_form_flat", form == "flat")
     try:
         g = torch.Generator().manual_seed(1234 + n + cout)
         cin = 256
@@ -755,8 +739,7 @@ def test_thin_output_conv_matches_the_grouped_kernel(n, cout, relu_cols, sizes, 
                          ops.conv3x3_thin_levels([s[:, :, :, :8] for s in stacks], cw, relu_cols=relu_cols)):
             assert torch.equal(a, g2)     # dense and sliced inputs: the same kernel, the same bits
     finally:
-        monkeypatch.delenv("HN_THIN_FORM", raising=False)
-        ops.reread_env()
+        ops.set_form("thin_form_flat", False)
 
 
 def test_thin_output_conv_is_deterministic_at_full_size():
@@ -773,15 +756,12 @@ def test_thin_output_conv_is_deterministic_at_full_size():
     for _ in range(19):
         again = ops.conv3x3_thin_levels(xs, cw, relu_cols=4)
         assert all(torch.equal(a, b) for a, b in zip(first, again))
-    import os
-    os.environ["HN_THIN_FORM"] = "tap"
-    ops.reread_env()
+    ops.set_form("thin_form_tap", True)
     try:
         assert not ops.thin_uses_flat(xs, cw)
         tap = ops.conv3x3_thin_levels(xs, cw, relu_cols=4)
     finally:
-        del os.environ["HN_THIN_FORM"]
-        ops.reread_env()
+        ops.set_form("thin_form_tap", False)
     for a, b in zip(first, tap):
         assert (a - b).abs().max().item() <= 4e-6 * b.abs().max().item()
 

@@ -542,11 +542,9 @@ def test_tiled_preprocess_is_bit_identical_to_the_per_pixel_kernel(n, h, w, monk
     oh, ow = resized_size(h, w, 800, 1333)
     ph, pw = (oh + 31) // 32 * 32, (ow + 31) // 32 * 32
     a = ops.fcos_preprocess_split(x, oh, ow, ph, pw, IMAGE_MEAN, IMAGE_STD)
-    monkeypatch.setenv("HN_PREPROCESS_GENERIC", "1")
-    ops.reread_env()
+    ops.set_form("preprocess_generic", True)
     try:
         b = ops.fcos_preprocess_split(x, oh, ow, ph, pw, IMAGE_MEAN, IMAGE_STD)
     finally:
-        monkeypatch.delenv("HN_PREPROCESS_GENERIC")
-        ops.reread_env()
+        ops.set_form("preprocess_generic", False)
     assert a.shape == b.shape and torch.equal(a, b)

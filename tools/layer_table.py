@@ -9,6 +9,8 @@ from hn_amd import ops, synth
 from hn_amd.a2j_engine import A2JEngine
 from hn_amd.fcos_engine import FCOSEngine
 from hn_amd.pipeline import HandNetEngine
+from hn_amd import forms as _forms
+_forms.apply_env()   # development host: the HN_* A/B variables (the product never reads them)
 
 prec = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 32

@@ -7,6 +7,8 @@ sys.path.insert(0, str(R / "handnet-pipeline_amd"))
 import torch
 from hn_amd import ops, synth
 from hn_amd.a2j_engine import A2JEngine
+from hn_amd import forms as _forms
+_forms.apply_env()   # development host: the HN_* A/B variables (the product never reads them)
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 a2j = A2JEngine(synth.make_a2j_state_dict(0))

@@ -6,6 +6,8 @@ sys.path.insert(0, str(R / "handnet-pipeline_amd"))
 import torch
 from hn_amd import synth
 from hn_amd.a2j_engine import A2JEngine
+from hn_amd import forms as _forms
+_forms.apply_env()   # development host: the HN_* A/B variables (the product never reads them)
 
 bs = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 prec = sys.argv[3] if len(sys.argv) > 3 else "f16x3"

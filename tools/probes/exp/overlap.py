@@ -7,6 +7,8 @@ sys.path.insert(0, str(R / "handnet-pipeline_amd"))
 import torch
 from hn_amd import ops
 from hn_amd.weights import split_f16x3
+from hn_amd import forms as _forms
+_forms.apply_env()   # development host: the HN_* A/B variables (the product never reads them)
 
 g = torch.Generator().manual_seed(0)
 n, h, w = 32, 100, 136

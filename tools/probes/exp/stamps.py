@@ -8,6 +8,8 @@ sys.path.insert(0, str(R / "handnet-pipeline_amd"))
 import numpy as np, torch
 from hn_amd import ops, _lib
 from hn_amd.weights import split_f16x3
+from hn_amd import forms as _forms
+_forms.apply_env()   # development host: the HN_* A/B variables (the product never reads them)
 tile, n, h, w, cin, cout, r = map(int, sys.argv[1:8])
 res = len(sys.argv) > 8
 g = torch.Generator().manual_seed(0)

@@ -6,6 +6,8 @@ sys.path.insert(0, str(R / "handnet-pipeline_amd"))
 import torch
 from hn_amd import ops, synth
 from hn_amd.fcos_engine import FCOSEngine, IMAGE_MEAN, IMAGE_STD
+from hn_amd import forms as _forms
+_forms.apply_env()   # development host: the HN_* A/B variables (the product never reads them)
 eng = FCOSEngine(synth.make_fcos_state_dict(0, 3), 3)
 rgb = synth.make_rgb(32, seed=1000).cuda()
 x = ops.fcos_preprocess_split(rgb, 800, 1066, 800, 1088, IMAGE_MEAN, IMAGE_STD)

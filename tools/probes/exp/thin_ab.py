@@ -12,8 +12,9 @@ SIZES = [(100, 136), (50, 68), (25, 34), (13, 17), (7, 9)]
 def child(form):
     sys.path.insert(0, os.path.join(ROOT, "handnet-pipeline_amd"))
     import torch
-    from hn_amd import ops
+    from hn_amd import forms, ops
     from hn_amd.weights import ConvW
+    forms.apply_env()   # HN_THIN_FORM of this child
     g = torch.Generator().manual_seed(5)
     cw = ConvW(torch.randn(5, 3, 3, 256, generator=g) * 0.02, torch.randn(5, generator=g), 1, 1, 1).to("cuda")
     for n in (1, 2, 4, 8, 16, 32):

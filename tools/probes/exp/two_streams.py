@@ -9,6 +9,8 @@ from hn_amd import synth
 from hn_amd.a2j_engine import A2JEngine
 from hn_amd.fcos_engine import FCOSEngine
 from hn_amd.pipeline import HandNetEngine
+from hn_amd import forms as _forms
+_forms.apply_env()   # development host: the HN_* A/B variables (the product never reads them)
 
 fsd, asd = synth.make_fcos_state_dict(0, 3), synth.make_a2j_state_dict(0)
 def mk():

@@ -10,6 +10,8 @@ from hn_amd.a2j_engine import A2JEngine
 from hn_amd.fcos_engine import FCOSEngine
 from hn_amd.pipeline import HandNetEngine
 from hn_amd.weights import split_f16x3
+from hn_amd import forms as _forms
+_forms.apply_env()   # development host: the HN_* A/B variables (the product never reads them)
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
