@@ -287,6 +287,19 @@ bool conv3x3_halo_applies(const hn_conv_desc* d, bool has_gn, bool has_group, co
          (int64_t)d->n * cdiv(d->h, kT) * cdiv(d->w, kT) >= 512;
 }
 
+// the operand conditions of the halo kernel (16-byte alignment, S32 pixel strides, extents below 2 GB): a call that the shape
+// predicate above routes here but that does not meet them takes the implicit-GEMM kernels instead of failing
+bool conv3x3_halo_operands_ok(const hn_conv_desc* d, const void* x16, const void* w16, const float* bias, const void* residual,
+                              const void* y) {
+  const int xs = d->in_pix_stride ? d->in_pix_stride : 2 * d->cin;
+  const int ys = d->out_pix_stride ? d->out_pix_stride : 2 * d->cout;
+  const int rs = d->res_pix_stride ? d->res_pix_stride : 2 * d->cout;
+  const int64_t xbytes = (int64_t)d->n * d->h * d->w * xs * 2, wbytes = (int64_t)64 * (d->cin / 32) * 9 * 128;
+  return xbytes < ((int64_t)1 << 31) && wbytes < ((int64_t)1 << 31) && (uintptr_t)x16 % 16 == 0 && (uintptr_t)w16 % 16 == 0 &&
+         (uintptr_t)y % 16 == 0 && (!bias || (uintptr_t)bias % 16 == 0) && (!residual || (uintptr_t)residual % 16 == 0) &&
+         xs % 64 == 0 && ys % 64 == 0 && rs % 64 == 0;
+}
+
 int conv3x3_halo(const hn_conv_desc* d, const void* x16, const void* w16, const float* bias, const void* residual, void* y,
                  hipStream_t st) {
   HaloParams p;

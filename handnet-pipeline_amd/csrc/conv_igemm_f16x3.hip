@@ -1584,7 +1584,8 @@ static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, c
   HN_TRY16(fill_params16(d, x16, w16, bias, residual, y, gn_partial, workspace, workspace_bytes, p));
   // 64-output-channel 3x3 / stride-1 layers with many tiles (ResNet-34 layer1): direct convolution from an LDS halo patch
   // (conv3x3_halo.hip; same k order, bit-identical results; HN_CONV_NO_HALO=1 keeps them on this kernel)
-  if (d->terms != 1 && hn::conv3x3_halo_applies(d, gn_partial != nullptr, group != nullptr, residual))
+  if (d->terms != 1 && hn::conv3x3_halo_applies(d, gn_partial != nullptr, group != nullptr, residual) &&
+      hn::conv3x3_halo_operands_ok(d, x16, w16, bias, residual, y))
     return hn::conv3x3_halo(d, x16, w16, bias, residual, y, (hipStream_t)stream);
 
   hn_conv_desc tile_desc = *d;  // what the tile heuristic sees: for a group, all members' rows together
@@ -1698,7 +1699,9 @@ static bool multi_plan(const hn_conv_multi* mm, void* workspace, int64_t workspa
     if (fill_params16(d, mm->x16[g], mm->w16[g], mm->bias[g], mm->residual[g], mm->y[g], nullptr, workspace, workspace_bytes, p) !=
         HN_OK)
       return false;
-    if (p.terms != 3 || hn::conv3x3_halo_applies(d, false, false, mm->residual[g])) return false;
+    if (p.terms != 3 || (hn::conv3x3_halo_applies(d, false, false, mm->residual[g]) &&
+                         hn::conv3x3_halo_operands_ok(d, mm->x16[g], mm->w16[g], mm->bias[g], mm->residual[g], mm->y[g])))
+      return false;
     const int t = hn_conv2d_f16x3_pick_tile(d);
     if (tile >= 0 && t != tile) return false;
     tile = t;
@@ -1800,7 +1803,7 @@ static int stem16_run(const void* x16, int n, int ph, int pw, int pad, int r, in
     HN_CHECK_ARG((uintptr_t)y % 16 == 0 && (uintptr_t)bias % 16 == 0, "unaligned output / bias");
     // the ResNet stem shape: direct convolution from an LDS-resident image patch (conv_stem_direct.hip); other filter sizes,
     // and HN_STEM_POOL_GENERIC=1, take the implicit-GEMM form below (same results bit for bit)
-    if (r == 7 && stride == 2 && pad == 3 && !hn::env_flags().stem_generic && terms != 1)
+    if (r == 7 && stride == 2 && pad == 3 && !hn::env_flags().stem_generic && terms != 1 && (uintptr_t)w16 % 16 == 0)
       return hn::stem_pool_direct(x16, n, ph, pw, w16, bias, y, st);
     p.pool_oh = (oh + 2 - 3) / 2 + 1;
     p.pool_ow = (ow + 2 - 3) / 2 + 1;

@@ -23,6 +23,8 @@ const EnvFlags& env_flags();
 // conv_stem_direct.hip: the 7x7 / stride-2 / 64-channel stem + ReLU + max pooling as a direct convolution from an LDS patch
 // conv3x3_halo.hip: 3x3 / stride 1 / pad 1, 64 output channels, as a direct convolution from an LDS-resident halo patch
 bool conv3x3_halo_applies(const hn_conv_desc* d, bool has_gn, bool has_group, const void* residual);
+bool conv3x3_halo_operands_ok(const hn_conv_desc* d, const void* x16, const void* w16, const float* bias, const void* residual,
+                              const void* y);
 int conv3x3_halo(const hn_conv_desc* d, const void* x16, const void* w16, const float* bias, const void* residual, void* y,
                  hipStream_t st);
 int stem_pool_direct(const void* x16, int n, int ph, int pw, const void* w16, const float* bias, void* y, hipStream_t st);

@@ -863,3 +863,22 @@ def test_multi_launch_is_bit_identical_to_separate_launches(case):
         y = y.relu()
     out = got[0] if not o["out_split"] else ops.from_split(got[0])
     assert (out.double().permute(0, 3, 1, 2) - y).abs().max().item() <= 2e-5 * max(1.0, y.abs().max().item())
+
+
+def test_halo_shape_with_unaligned_operands_takes_the_implicit_gemm():
+    """A call whose SHAPE routes to the halo-patch kernel (64 -> 64 3x3, >= 512 tiles) but whose bias is not 16-byte aligned must
+    not fail: it falls through to the implicit-GEMM kernels, with the same bits as the aligned call."""
+    from hn_amd import ops
+    from hn_amd.weights import split_f16x3
+    n, h, w = 2, 200, 272
+    x = ops.to_split(_rand((n, h, w, 64), 91).cuda())
+    wt = _rand((64, 3, 3, 64), 92, (2.0 / 576) ** 0.5)
+    w16 = split_f16x3(wt).cuda()
+    pad = torch.zeros((65,), device="cuda")
+    pad[1:] = _rand((64,), 93, 0.1).cuda()
+    bias_unaligned = pad[1:]                       # 4 bytes past a 16-byte boundary
+    assert bias_unaligned.data_ptr() % 16 == 4
+    bias_aligned = bias_unaligned.clone()
+    y0 = ops.conv2d_nhwc(x, wt.cuda(), bias_aligned, pad=1, relu=True, w16=w16, out_split=True)
+    y1 = ops.conv2d_nhwc(x, wt.cuda(), bias_unaligned, pad=1, relu=True, w16=w16, out_split=True)
+    assert torch.equal(y0, y1)
