@@ -1211,27 +1211,59 @@ __global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(const MultiPar
 }
 
 // ---- host-side launch planning, shared by the launcher and by hn_conv2d_f16x3_uses_rs (ONE definition of each decision) ----
-// Split-K for grids that leave most of the chip idle AND have a long serial k loop (~0.33 us per 32-deep
-// tile): e.g. the 2048->512 3x3 A2J layer at batch 1 is 8 workgroups x 576 tiles = 190 us.  Up to 16
-// workgroups then share an output tile, each keeping >= 16 tiles.  Shorter loops stay single-pass unless
-// the caller says launches are free (desc.splitk = 1, graph replay): in eager mode the second launch
-// costs more than it saves (measured in-pipeline, tools/probes/exp/splitk.sh).
-static void plan_splits(ConvParams16& p) {   // needs p.nblocks; sets p.splits / p.kt_per
+// Split-K: S workgroups share an output tile, each sums ceil(ktiles / S) k tiles into its own fp32 plane, a second launch
+// adds the planes in z order.  Round 4: the split count comes from a small cost model fitted to tools/splitk_sweep.py
+// (profiles/r04_splitk_sweep_b1.txt) instead of "fill 512 slots whenever the grid is below 256 workgroups" -- that rule split
+// grids of ~200 workgroups three ways (1.25 rounds of workgroups plus a reduction that streams three planes: ResNet-34 layer2
+// at batch 1 30.8 us against 20.4 us unsplit) and gave 11 x 11 layers 16 planes whose serial reads cost the reduction more
+// than the shorter k loops gave back.
+//   time(S) = ceil(nblocks * S / slots) * (t_fix + ceil(ktiles / S) * t_k)  +  (S > 1: t_red0 + S * max(t_plane_min, plane_bytes / bw))
+// slots = resident workgroups of the tile form on the chip; t_fix / t_k = fixed time of a workgroup (prologue, pipeline fill,
+// epilogue) and time per k tile, from pairs of sweep rows (the 4-wave tiles spend 12-16 us outside their k loop at these grid
+// sizes, which is why halving a 36-tile loop does not pay for a reduction; the 2-wave 32x64 tile 3 us).
+struct SplitModel { int slots; double t_fix, t_k; };
+static SplitModel split_model(int bm, int bn) {
+  const int cus = 256;
+  if (bm == 32 && bn == 64) return {3 * cus, 3.0, 0.27};
+  if (bm == 64 && bn == 64) return {3 * cus, 12.0, 0.12};
+  if (bm == 64 && bn == 128) return {2 * cus, 16.0, 0.12};
+  if (bm == 128 && bn == 64) return {2 * cus, 16.0, 0.20};
+  if (bm == 128 && bn == 32) return {2 * cus, 12.0, 0.15};
+  return {2 * cus, 20.0, 0.40};   // 128x128 and the 256-row tiles
+}
+static void plan_splits(ConvParams16& p, int bm, int bn) {   // needs p.nblocks; sets p.splits / p.kt_per
   p.splits = 1;
   p.kt_per = p.ktiles;
   if (p.groups > 1) return;  // grouped problems never split (the grid is already groups x larger)
-  const int min_tiles = p.splitk_mode > 0 ? 8 : 128;  // hn_conv_desc.splitk
-  const int min_per = p.splitk_mode > 0 ? 4 : 16;
-  if (p.split_ws && p.splitk_mode >= 0 && p.vec_epi && !p.gn_partial && p.nblocks < 256 && p.ktiles >= min_tiles) {
-    int want = hn::cdiv(512, p.nblocks);
-    want = want < p.ktiles / min_per ? want : p.ktiles / min_per;
-    want = want < 16 ? want : 16;
-    const int64_t plane_bytes = (int64_t)p.M * p.Cout * 4;
-    if ((int64_t)want * plane_bytes > p.split_ws_bytes) want = (int)(p.split_ws_bytes / plane_bytes);
-    if (want > 1) {
-      p.kt_per = hn::cdiv(p.ktiles, want);
-      p.splits = hn::cdiv(p.ktiles, p.kt_per);  // every split has at least one tile
+  if (!(p.split_ws && p.splitk_mode >= 0 && p.vec_epi && !p.gn_partial)) return;
+  const int64_t plane_bytes = (int64_t)p.M * p.Cout * 4;
+  int want = 1;
+  if (p.splitk_mode >= 2) {   // sweeps (tools/splitk_sweep.py): exactly this many
+    want = p.splitk_mode < 16 ? p.splitk_mode : 16;
+    want = want < p.ktiles ? want : p.ktiles;
+  } else {
+    // eager callers that pay for the second launch on the host (desc.splitk = 0) split long loops only
+    const int min_tiles = p.splitk_mode > 0 ? 8 : 128, min_per = p.splitk_mode > 0 ? 4 : 16;
+    if (p.ktiles < min_tiles) return;
+    const SplitModel sm = split_model(bm, bn);
+    const double t_red0 = 4.5, t_plane_min = 0.3, bw = 3.0e6;   // us, us per plane, bytes per us
+    double best = (double)hn::cdiv(p.nblocks, sm.slots) * (sm.t_fix + p.ktiles * sm.t_k);
+    for (int s = 2; s <= 16 && p.ktiles / s >= min_per; ++s) {
+      const int kt = hn::cdiv(p.ktiles, s), se = hn::cdiv(p.ktiles, kt);
+      if (se != s) continue;   // (the same plan as a smaller s)
+      const double per_plane = (double)plane_bytes / bw;
+      const double t = (double)hn::cdiv((int64_t)p.nblocks * s, sm.slots) * (sm.t_fix + kt * sm.t_k) + t_red0 +
+                       s * (per_plane > t_plane_min ? per_plane : t_plane_min);
+      if (t < best) {
+        best = t;
+        want = s;
+      }
     }
+  }
+  if ((int64_t)want * plane_bytes > p.split_ws_bytes) want = (int)(p.split_ws_bytes / plane_bytes);
+  if (want > 1) {
+    p.kt_per = hn::cdiv(p.ktiles, want);
+    p.splits = hn::cdiv(p.ktiles, p.kt_per);  // every split has at least one tile
   }
 }
 
@@ -1261,7 +1293,7 @@ int launch16_impl(const ConvParams16& p0, hipStream_t st) {
   p.tiles_m = hn::cdiv(p.M, BM);
   p.tiles_n = hn::cdiv(p.Cout, BN);
   p.nblocks = p.tiles_m * p.tiles_n;
-  plan_splits(p);
+  plan_splits(p, BM, BN);
   int grid_x = p.nblocks;
   if (p.groups > 1) {
     grid_x = 0;
@@ -1469,7 +1501,7 @@ extern "C" int hn_conv2d_f16x3_uses_rs(const hn_conv_desc* d) {
   TileForm f = tile_form(tile, tile == HN_TILE_128x32 && rs32_preferred(d));
   if (f.bm == 0) return 0;
   p.nblocks = hn::cdiv(p.M, f.bm) * hn::cdiv(p.Cout, f.bn);
-  plan_splits(p);
+  plan_splits(p, f.bm, f.bn);
   if (tile == HN_TILE_128x32 && f.nbuf == 2 && !rs_will_run(p, f.bm, f.bn, f.waves, 2, true)) return 0;
   return rs_will_run(p, f.bm, f.bn, f.waves, f.nbuf, true) ? 1 : 0;
 }
@@ -1642,7 +1674,7 @@ static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, c
           q.nblocks = 0;
           for (int g = 0; g < q.groups; ++g) q.nblocks += hn::cdiv(q.gM[g], 128) * hn::cdiv(q.Cout, 32);
         }
-        plan_splits(q);
+        plan_splits(q, 128, 32);
         rs2 = rs_will_run(q, 128, 32, 4, 2, true);
       }
       if (rs2) return launch16<128, 32, 4, 1, 2>(p, st);
@@ -1711,7 +1743,7 @@ static bool multi_plan(const hn_conv_multi* mm, void* workspace, int64_t workspa
     p.tiles_m = hn::cdiv(p.M, f.bm);
     p.tiles_n = hn::cdiv(p.Cout, f.bn);
     p.nblocks = p.tiles_m * p.tiles_n;
-    plan_splits(p);
+    plan_splits(p, f.bm, f.bn);
     p.rs_ok = 0;
     if (p.splits > 1) {   // the member's partial planes: its own slice of the workspace
       const int64_t bytes = (int64_t)p.splits * p.M * p.Cout * 4;

@@ -259,7 +259,7 @@ def _conv_workspace(device):
 
 def conv2d_nhwc(x, w, bias=None, *, stride=1, pad=0, dil=1, relu=False, relu_cols=None,
                 residual=None, res_upsample=False, in_scale=None, in_shift=None, out=None, tile=0,
-                algo_cin=None, w16=None, out_split=False, gn_partial=None, splitk=True):
+                algo_cin=None, w16=None, out_split=False, gn_partial=None, splitk=True, force_splits=None):
     """Convolution with fused epilogue.  x: fp32 [N,H,W,Cin] or S32 split; w [Cout,R,S,Cin] fp32.
 
     w16 given  -> f16x3 kernel (split-fp16 operands on the f16 MFMA, fp32-grade results); an fp32
@@ -376,6 +376,9 @@ def conv2d_nhwc(x, w, bias=None, *, stride=1, pad=0, dil=1, relu=False, relu_col
         else:
             splitk = splitk and SPLITK
             d.splitk = (1 if SPLITK_EAGER else 0) if splitk else -1
+            if force_splits is not None:      # sweeps only: exactly this many splits (1 = none)
+                d.splitk = int(force_splits) if force_splits >= 2 else -1
+                plan_key = None
             ws = _conv_workspace(x.device) if splitk else None
             if plan_key is not None:
                 if bias is not None and not bias.is_contiguous():

@@ -117,7 +117,8 @@ typedef struct hn_conv_desc {
   int32_t in_affine_stride;  /* floats between rows of in_scale / in_shift; 0 = cin     */
   int32_t splitk;            /* f16x3 + workspace: 0 = split-K only for long k loops (an extra launch
                               * per conv costs eager callers more than it saves), 1 = also for short
-                              * ones (launch cost hidden, e.g. under hipGraph replay), -1 = never */
+                              * ones (launch cost hidden, e.g. under hipGraph replay), -1 = never; >= 2 = exactly that many
+                              * splits, whatever the grid (sweeps: tools/splitk_sweep.py) */
   int32_t terms;             /* f16x3 kernels: 0 / 3 = the three-term split product (fp32-grade, the default);
                               * 1 = hi*hi only ("f16x1": plain fp16 operands, ONE MFMA per MAC, same data movement) --
                               * the throughput mode SURVEY D6 plans beside the parity mode; misses the 1e-3 keypoint

@@ -28,7 +28,7 @@ eng.forward_device(rgb, depth)
 torch.cuda.synchronize()
 recs, ops.CONV_PROFILE = ops.CONV_PROFILE, None
 shapes = {}
-for kind, macs, timer, shape in recs:
+for kind, macs, timer, shape, _stage in recs:
     if kind[0] == "f16x3" and shape[3] % 32 == 0:
         shapes.setdefault(shape, [kind[1], 0])[1] += 1
 del eng, fcos, a2j
