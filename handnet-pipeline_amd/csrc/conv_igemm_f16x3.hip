@@ -1443,7 +1443,9 @@ extern "C" int hn_conv2d_f16x3_pick_tile(const hn_conv_desc* d) {
   // mid-size grids: 128 columns per workgroup when there are that many (fewer weight re-reads), else 128 rows
   if (d->cout >= 128 && nblocks16(d, 64, 128) >= 192) return HN_TILE_64x128;
   if (nblocks16(d, 128, 64) >= want) return HN_TILE_128x64;
-  // tiny grids (11x11 maps, batch 1): 2-wave workgroups double the number of CUs that have work
+  // tiny grids (11x11 maps, batch 1): 2-wave workgroups double the number of CUs that have work.  (Round 4: in isolation
+  // tools/tile_sweep.py prefers 64x64 for the long-k layers here -- 512 -> 512 3x3 on 11 x 11 17.9 -> 15.1 us -- but inside the
+  // batch-1 frame the rule costs 15 us, 2.327 -> 2.342 ms over three same-box pairs: not taken.)
   if (nblocks16(d, 64, 64) < 128) return HN_TILE_32x64;
   return HN_TILE_64x64;
 }

@@ -30,7 +30,8 @@ recs, ops.CONV_PROFILE = ops.CONV_PROFILE, None
 shapes = {}
 for kind, macs, timer, shape, _stage in recs:
     if kind[0] == "f16x3" and shape[3] % 32 == 0:
-        shapes.setdefault(shape, [kind[1], 0])[1] += 1
+        if isinstance(kind[1], int):   # (thin-N / direct kernels record a name: not igemm tiles)
+            shapes.setdefault(shape, [kind[1] & 0xFF, 0])[1] += 1
 del eng, fcos, a2j
 torch.cuda.empty_cache()
 TILES = [1, 2, 3, 4, 6, 7, 8]
