@@ -1241,12 +1241,21 @@ static void plan_splits(ConvParams16& p, int bm, int bn) {   // needs p.nblocks;
   if (p.splitk_mode >= 2) {   // sweeps (tools/splitk_sweep.py): exactly this many
     want = p.splitk_mode < 16 ? p.splitk_mode : 16;
     want = want < p.ktiles ? want : p.ktiles;
+  } else if (hn::env_flags().splitk_fill512) {   // the round-1..3 rule (A/B reference): fill 512 slots below 256 workgroups
+    const int min_tiles = p.splitk_mode > 0 ? 8 : 128, min_per = p.splitk_mode > 0 ? 4 : 16;
+    if (p.nblocks >= 256 || p.ktiles < min_tiles) return;
+    want = hn::cdiv(512, p.nblocks);
+    want = want < p.ktiles / min_per ? want : p.ktiles / min_per;
+    want = want < 16 ? want : 16;
   } else {
     // eager callers that pay for the second launch on the host (desc.splitk = 0) split long loops only
     const int min_tiles = p.splitk_mode > 0 ? 8 : 128, min_per = p.splitk_mode > 0 ? 4 : 16;
     if (p.ktiles < min_tiles) return;
-    const SplitModel sm = split_model(bm, bn);
-    const double t_red0 = 4.5, t_plane_min = 0.3, bw = 3.0e6;   // us, us per plane, bytes per us
+    SplitModel sm = split_model(bm, bn);
+    const hn::Tuning& tn = hn::tuning();   // development: scale factors of the model's constants (hn_set_tuning; all 1.0)
+    sm.t_fix *= tn.splitk_fix;
+    sm.t_k *= tn.splitk_tk;
+    const double t_red0 = 4.5 * tn.splitk_red0, t_plane_min = 0.3 * tn.splitk_plane, bw = 3.0e6;   // us, us per plane, bytes per us
     double best = (double)hn::cdiv(p.nblocks, sm.slots) * (sm.t_fix + p.ktiles * sm.t_k);
     for (int s = 2; s <= 16 && p.ktiles / s >= min_per; ++s) {
       const int kt = hn::cdiv(p.ktiles, s), se = hn::cdiv(p.ktiles, kt);

@@ -17,9 +17,14 @@ int* range_flag_ptr();
 // Kernel-form switches (hn_set_form; all false in a product process: the library never reads the environment)
 struct EnvFlags {
   bool no_rs, no_rs32, split_generic, stem_generic, no_halo, no_thin, thin_tap, thin_flat, no_fuse_last_gn, pre_generic, no_multi,
-      halo_stamps;
+      halo_stamps, splitk_fill512;
 };
 const EnvFlags& env_flags();
+// development: scale factors of planning constants (hn_set_tuning; 1.0 in a product process)
+struct Tuning {
+  double splitk_fix = 1.0, splitk_tk = 1.0, splitk_red0 = 1.0, splitk_plane = 1.0;
+};
+const Tuning& tuning();
 // conv_stem_direct.hip: the 7x7 / stride-2 / 64-channel stem + ReLU + max pooling as a direct convolution from an LDS patch
 // conv3x3_halo.hip: 3x3 / stride 1 / pad 1, 64 output channels, as a direct convolution from an LDS-resident halo patch
 bool conv3x3_halo_applies(const hn_conv_desc* d, bool has_gn, bool has_group, const void* residual);

@@ -55,7 +55,22 @@ namespace hn {
 // (hn_set_form; bench.py / tools translate their HN_* variables, hn_amd/forms.py).
 static EnvFlags g_env = {};
 const EnvFlags& env_flags() { return g_env; }
+static Tuning g_tuning;
+const Tuning& tuning() { return g_tuning; }
 }  // namespace hn
+
+extern "C" int hn_set_tuning(const char* name, double value) {
+  HN_CHECK_ARG(name && value > 0.0, "hn_set_tuning: null name or non-positive value");
+  struct Entry { const char* name; double hn::Tuning::*field; };
+  static const Entry table[] = {{"splitk_fix", &hn::Tuning::splitk_fix}, {"splitk_tk", &hn::Tuning::splitk_tk},
+                                {"splitk_red0", &hn::Tuning::splitk_red0}, {"splitk_plane", &hn::Tuning::splitk_plane}};
+  for (const Entry& e : table)
+    if (strcmp(e.name, name) == 0) {
+      hn::g_tuning.*(e.field) = value;
+      return HN_OK;
+    }
+  return hn::fail(HN_ERR_ARG, "hn_set_tuning: unknown constant '%s'", name);
+}
 
 extern "C" int hn_set_form(const char* name, int value) {
   HN_CHECK_ARG(name, "hn_set_form: null name");
@@ -73,6 +88,7 @@ extern "C" int hn_set_form(const char* name, int value) {
       {"thin_form_tap", &hn::EnvFlags::thin_tap},           // thin kernel: never the P form
       {"thin_form_flat", &hn::EnvFlags::thin_flat},         // ... the P form at any size
       {"halo_stamps", &hn::EnvFlags::halo_stamps},          // diagnostics: s_memtime stamps of the halo kernel
+      {"splitk_fill512", &hn::EnvFlags::splitk_fill512},    // split-K plan of rounds 1-3 (fill 512 slots below 256 workgroups)
   };
   for (const Entry& e : table)
     if (strcmp(e.name, name) == 0) {

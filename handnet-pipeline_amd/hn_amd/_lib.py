@@ -109,6 +109,7 @@ SIGNATURES = {
     "hn_range_check_bind": (C.c_int, [VP]),
     "hn_range_check_collect": (C.c_int, [VP, VP, VP]),
     "hn_set_form": (C.c_int, [C.c_char_p, C.c_int]),
+    "hn_set_tuning": (C.c_int, [C.c_char_p, C.c_double]),
     "hn_conv2d_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), VP, VP, VP, VP, VP, VP, VP, VP]),
     "hn_conv2d_pick_tile": (C.c_int, [C.POINTER(ConvDesc)]),
     "hn_conv2d_nhwc_f16x3": (C.c_int, [C.POINTER(ConvDesc), VP, VP, VP, VP, VP, VP]),

@@ -30,6 +30,7 @@ _LIB_ENV = {
     "HN_SPLIT_GENERIC": ("split_generic", None), "HN_STEM_POOL_GENERIC": ("stem_pool_generic", None),
     "HN_CONV_NO_HALO": ("conv_no_halo", None), "HN_PREPROCESS_GENERIC": ("preprocess_generic", None),
     "HN_CONV_NO_MULTI": ("conv_no_multi", None), "HN_HALO_STAMPS": ("halo_stamps", None),
+    "HN_SPLITK_FILL512": ("splitk_fill512", None),
 }
 
 
@@ -80,6 +81,11 @@ def apply_env(environ=None) -> dict:
     if "HN_SPLITK_EAGER" in env:
         ops.SPLITK_EAGER = env["HN_SPLITK_EAGER"] == "1"
         done["HN_SPLITK_EAGER"] = env["HN_SPLITK_EAGER"]
+    for var in env:
+        if var.startswith("HN_TUNE_"):           # e.g. HN_TUNE_SPLITK_RED0=1.5 -> hn_set_tuning("splitk_red0", 1.5)
+            from . import _lib
+            ops.check(_lib.load().hn_set_tuning(var[8:].lower().encode(), float(env[var])), "hn_set_tuning")
+            done[var] = env[var]
     if "HN_CANDIDATES_CHUNKED" in env:
         ops.CANDIDATES_CHUNKED = env["HN_CANDIDATES_CHUNKED"] != "0"
         done["HN_CANDIDATES_CHUNKED"] = env["HN_CANDIDATES_CHUNKED"]

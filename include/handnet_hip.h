@@ -80,10 +80,13 @@ int hn_range_check_collect(int32_t* block /* or NULL */, int32_t* dst /* device,
 
 /* Kernel-form switches.  Older forms of some kernels stay in the library as bit-identity references for the tests and for
  * same-box A/B timing ("conv_no_rs", "conv_no_rs32", "split_generic", "stem_pool_generic", "conv_no_halo", "preprocess_generic",
- * "conv_no_multi", "no_fuse_last_gn", "no_thin_outputs", "thin_form_tap", "thin_form_flat", "halo_stamps"; results unchanged
+ * "conv_no_multi", "no_fuse_last_gn", "no_thin_outputs", "thin_form_tap", "thin_form_flat", "halo_stamps", "splitk_fill512"; results unchanged
  * unless a test says otherwise).  The library NEVER reads them from the environment: a development host sets them by name
  * (bench.py and tools/ translate their HN_* variables through hn_amd/forms.py); a product process leaves them alone. */
 int hn_set_form(const char* name, int value);
+/* Development: scale factor (default 1.0) of a constant of the split-K cost model -- "splitk_fix", "splitk_tk", "splitk_red0",
+ * "splitk_plane" (csrc/conv_igemm_f16x3.hip: plan_splits) -- for in-frame scans of the model; never set by the product. */
+int hn_set_tuning(const char* name, double value);
 
 /* ------------------------------------------------------------------------------------
  * Convolution (implicit GEMM on f32 / f16 MFMA), fused epilogue.

@@ -508,7 +508,7 @@ def test_f16x3_wide_dynamic_range_keeps_precision():
 
 
 _FORMS = ("conv_no_rs", "conv_no_rs32", "split_generic", "stem_pool_generic", "conv_no_halo", "preprocess_generic", "conv_no_multi",
-          "no_fuse_last_gn", "no_thin_outputs", "thin_form_tap", "thin_form_flat")
+          "no_fuse_last_gn", "no_thin_outputs", "thin_form_tap", "thin_form_flat", "splitk_fill512")
 
 
 @pytest.fixture(autouse=True)
