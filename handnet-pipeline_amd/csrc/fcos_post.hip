@@ -685,32 +685,42 @@ __global__ __launch_bounds__(1024) void nms_kernel(const NmsArgs a) {
         const int pos = nk + __popcll(alive_bits & ((1ull << lane) - 1ull));
         float* kr = kept + (long)pos * kKeptRec;
         kr[0] = x1; kr[1] = y1; kr[2] = x2; kr[3] = y2; kr[4] = area; kr[5] = __int_as_float(lab);
-        const long o = (long)img * a.cap + pos;
-        if (a.det_boxes) {
-          float ox1 = raw[0], oy1 = raw[1], ox2 = raw[2], oy2 = raw[3];
-          if (a.rescale) {
-            const float rh = a.ratios ? a.ratios[img * 2] : a.ratio_h, rw = a.ratios ? a.ratios[img * 2 + 1] : a.ratio_w;
-            ox1 = ox1 * rw; ox2 = ox2 * rw;
-            oy1 = oy1 * rh; oy2 = oy2 * rh;
-          }
-          a.det_boxes[o * 4 + 0] = ox1; a.det_boxes[o * 4 + 1] = oy1;
-          a.det_boxes[o * 4 + 2] = ox2; a.det_boxes[o * 4 + 3] = oy2;
-        }
-        if (a.det_scores) a.det_scores[o] = scores[idx];
-        if (a.det_labels) a.det_labels[o] = lab;
-        if (a.det_sides) a.det_sides[o] = a.sides[(long)img * a.cap + idx];
-        if (a.det_level) a.det_level[o] = a.level[(long)img * a.cap + idx];
-        if (a.det_keep) a.det_keep[o] = idx;
+        // the kept candidate's index goes where the sorted keys were: pos <= t, and this tile's keys have been read by every
+        // lane already, so no unread key is overwritten.  The output rows are written after the loop, by all waves at once
+        // (round 4: gathering scores / sides / levels here stalled wave 0 for a memory round trip per tile).
+        keys[pos] = (unsigned long long)(unsigned)idx;
       }
       nk += __popcll(alive_bits);
       if (lane == 0) nk_s = nk;
       __threadfence_block();  // kept[] written above is read by every lane in the next tile
     }
     if (W > 1) {
-      __threadfence();   // kept[] may live in global scratch (K > 2048): make it visible to the other waves
+      if (npad > kSortLds) __threadfence();   // kept[] / keys[] live in global scratch (K > 2048): make them visible to the other waves
       __syncthreads();
       nk = nk_s;
     }
+  }
+  // ---- output rows: kept candidate pos -> boxes (rescaled), score, label, side, level, index ----
+  if (W == 1) __threadfence_block();
+  for (int pos = wave * 64 + lane; pos < nk; pos += W * 64) {
+    const int idx = (int)(unsigned)(keys[pos] & 0xFFFFFFFFull);
+    const long o = (long)img * a.cap + pos;
+    if (a.det_boxes) {
+      const f32x4 raw = *reinterpret_cast<const f32x4*>(boxes + (long)idx * 4);
+      float ox1 = raw[0], oy1 = raw[1], ox2 = raw[2], oy2 = raw[3];
+      if (a.rescale) {
+        const float rh = a.ratios ? a.ratios[img * 2] : a.ratio_h, rw = a.ratios ? a.ratios[img * 2 + 1] : a.ratio_w;
+        ox1 = ox1 * rw; ox2 = ox2 * rw;
+        oy1 = oy1 * rh; oy2 = oy2 * rh;
+      }
+      a.det_boxes[o * 4 + 0] = ox1; a.det_boxes[o * 4 + 1] = oy1;
+      a.det_boxes[o * 4 + 2] = ox2; a.det_boxes[o * 4 + 3] = oy2;
+    }
+    if (a.det_scores) a.det_scores[o] = scores[idx];
+    if (a.det_labels) a.det_labels[o] = labels ? labels[idx] : 0;
+    if (a.det_sides) a.det_sides[o] = a.sides[(long)img * a.cap + idx];
+    if (a.det_level) a.det_level[o] = a.level[(long)img * a.cap + idx];
+    if (a.det_keep) a.det_keep[o] = idx;
   }
   if (wave != 0) return;
   if (lane == 0 && a.det_count) a.det_count[img] = nk;
