@@ -24,6 +24,7 @@ import torch
 
 from hn_amd import synth
 from hn_amd.a2j_engine import A2JEngine
+from hn_amd.pipeline import check_range_contract
 from hn_amd.state import EngineOwner, build_state_tree
 
 
@@ -63,7 +64,19 @@ class A2JModel(EngineOwner):
     def forward(self, x, gt=None):
         if gt is not None:
             raise NotImplementedError("training losses (a2j/anchor.py:84-152) are outside the inference hot path")
-        return self.forward_device(x).cpu()
+        # keypoints and the step's range-contract words in ONE device -> host copy (the reference's .data.cpu(), a2j.py:229);
+        # an overflowing activation or a finite input beyond the fp16 range raises instead of returning inf / NaN or silently
+        # wrong keypoints, a crop with NaN / inf pixels gives NaN keypoints like the reference (hn_amd.pipeline)
+        kp, flags = self.engine().forward_flags(x)
+        if flags is None:
+            out = kp.cpu()
+            check_range_contract(out, None, x)
+            return out
+        k, j3 = kp.shape[0], kp.shape[1] * kp.shape[2]
+        flat = torch.cat([kp.contiguous().reshape(-1).view(torch.int32), flags[:3]]).cpu()
+        out = flat[:k * j3].contiguous().view(torch.float32).reshape(kp.shape)
+        check_range_contract(out, flat[k * j3:].tolist(), x)
+        return out
 
 
 class A2JModelLightning(EngineOwner):

@@ -25,7 +25,7 @@ from a2j.a2j import A2JModel
 from fcos_utils.fcos import FCOS
 from a2j.a2j import A2JModelLightning
 from hn_amd import ops
-from hn_amd.pipeline import HandNetEngine
+from hn_amd.pipeline import HandNetEngine, check_range_contract
 from hn_amd.state import EngineOwner
 
 
@@ -151,30 +151,6 @@ class HandNet(EngineOwner):
                               "staying eager from now on (enable_graph(True) forces a new attempt)")
         return self.forward_device(batch, depth_images, _graph=False)
 
-    def _check_range_contract(self, keypoints_cpu, words, depth_images):
-        """The f16x3 range contract, decided on values the call has copied to the host anyway (hn_amd.pipeline.range_message).
-        Non-finite INPUTS are the reference's business -- ROS 32FC1 depth marks invalid pixels with NaN and ros_demo.py:
-        227-231 passes them on; its network then returns NaN keypoints for the frames whose crop holds one, and so does
-        this one -- so they never raise.  A finite input beyond +-65504 or an activation that overflows with in-range
-        inputs WOULD give inf / NaN or (ReLU maps NaN to 0) silently wrong keypoints: those raise."""
-        from hn_amd._lib import RANGE_INPUT_NONFINITE
-        from hn_amd.pipeline import range_message
-        if words is not None:
-            bits = ops.range_bits(words)
-            if bits & RANGE_INPUT_NONFINITE:
-                return
-            if bits:
-                raise ops.RangeError(range_message(bits))
-            if not bool(torch.isfinite(keypoints_cpu).all()):    # (e.g. a non-finite bias of an output convolution)
-                raise ops.RangeError("non-finite keypoints from finite, in-range inputs: the checkpoint holds non-finite or "
-                                     "extreme values; build the engines with precision='f32' to compare")
-            return
-        # noting is off (HN_CHECK_RANGE=0): only the symptom is left -- non-finite keypoints from finite inputs
-        if not bool(torch.isfinite(keypoints_cpu).all()) and bool(torch.isfinite(depth_images).all()):
-            raise ops.RangeError("non-finite keypoints from finite inputs: a value left the range of the f16x3 split format "
-                                 "(|v| > 65504).  Unset HN_CHECK_RANGE=0 to locate the kind, or build the engines with "
-                                 "precision='f32'")
-
     def forward(self, images, depth_images=None, is_3D: bool = False, is_detect: bool = False):
         if is_detect or is_3D:
             return None
@@ -199,8 +175,9 @@ class HandNet(EngineOwner):
         final_results = flat[:, :j3].contiguous().view(torch.float32).reshape(kp.shape)   # the reference returns keypoints on the CPU
         mask_cpu = flat[:, j3] != 0
         self._last_sparse = n >= 8 and int(mask_cpu.sum()) * 2 < n      # (the engine's own threshold for compaction)
-        self._check_range_contract(final_results, flat[0, j3 + 1:].tolist() if out.range_flags is not None else None,
-                                   depth_images)
+        # the f16x3 range contract, decided on what has just been copied (hn_amd.pipeline.check_range_contract): overflow raises,
+        # non-finite depth pixels give NaN rows like the reference
+        check_range_contract(final_results, flat[0, j3 + 1:].tolist() if out.range_flags is not None else None, depth_images)
         if not bool(mask_cpu.any()):  # handnet_pipeline.py:107-108: the crops placeholder is a CPU float tensor
             return torch.zeros((n, 21, 3)), torch.zeros_like(depth_images), torch.zeros((n, 4))
         if bool(mask_cpu.all()):      # the usual case: no gather (a boolean-mask index would synchronise once more)

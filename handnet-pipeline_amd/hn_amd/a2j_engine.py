@@ -9,6 +9,8 @@ are one grouped launch each.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
@@ -36,6 +38,7 @@ class A2JEngine:
         self.device = torch.device(device)
         self.joints = num_joints
         self.rgbd = rgbd
+        self.note_range = os.environ.get("HN_CHECK_RANGE", "1") != "0"   # f16x3 range contract (forward_flags)
         fm = engine_forms(forms)   # launch-structure switches (hn_amd/forms.py; never read from the environment here)
         self.group_heads = fm["group_convs"]
         # heterogeneous launches (ops.conv2d_nhwc_multi): the downsample beside conv1 of a block, the classification head
@@ -238,6 +241,23 @@ class A2JEngine:
                 x3, x4 = ops.from_split(x3), ops.from_split(x4)
             return out, (x3, x4), (cls, reg, dep)
         return out
+
+    @ops.device_guarded
+    def forward_flags(self, depth):
+        """The A2J-only entry with the f16x3 range contract: -> (keypoints [K,J,3] on the GPU, flag words [4] int32 on the GPU
+        or None in the f32 mode / with HN_CHECK_RANGE=0).  No sync; the drop-in reads the words with the keypoints."""
+        if self.precision != "f16x3" or not self.note_range:
+            return self.forward(depth), None
+        if getattr(self, "_range_block", None) is None:
+            self._range_block = torch.zeros((4,), device=self.device, dtype=torch.int32)
+        ops.range_check_enable(True)
+        ops.range_check_bind(self._range_block)
+        try:
+            kp = self.forward(depth)
+            flags = ops.range_check_collect(self._range_block)
+        finally:
+            ops.range_check_bind(None)
+        return kp, flags
 
     @ops.device_guarded
     def forward(self, depth, valid=None):

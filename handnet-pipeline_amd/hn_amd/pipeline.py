@@ -47,6 +47,31 @@ def range_message(bits: int) -> str:
     return "in range"
 
 
+def check_range_contract(keypoints_cpu, words, inputs=None):
+    """The f16x3 range contract of a step, decided on values the caller has copied to the host anyway.  words: the collected
+    flag words (ops.range_check_collect) as a host list, or None when noting is off (HN_CHECK_RANGE=0).
+    Non-finite INPUTS are the reference's business -- ROS 32FC1 depth marks invalid pixels with NaN and ros_demo.py:227-231
+    passes them on; its network then returns NaN keypoints for the crops that hold one, and so does this one -- so they never
+    raise.  A finite input beyond +-65504 or an activation that overflows with in-range inputs WOULD give inf / NaN or (ReLU
+    maps NaN to 0) silently wrong keypoints: those raise ops.RangeError."""
+    from ._lib import RANGE_INPUT_NONFINITE
+    if words is not None:
+        bits = ops.range_bits(words)
+        if bits & RANGE_INPUT_NONFINITE:
+            return
+        if bits:
+            raise ops.RangeError(range_message(bits))
+        if not bool(torch.isfinite(keypoints_cpu).all()):    # (e.g. a non-finite bias of an output convolution)
+            raise ops.RangeError("non-finite keypoints from finite, in-range inputs: the checkpoint holds non-finite or "
+                                 "extreme values; build the engines with precision='f32' to compare")
+        return
+    # noting is off: only the symptom is left -- non-finite keypoints from finite inputs
+    if not bool(torch.isfinite(keypoints_cpu).all()) and (inputs is None or bool(torch.isfinite(inputs).all())):
+        raise ops.RangeError("non-finite keypoints from finite inputs: a value left the range of the f16x3 split format "
+                             "(|v| > 65504).  Unset HN_CHECK_RANGE=0 to locate the kind, or build the engines with "
+                             "precision='f32'")
+
+
 class HandNetEngine:
     def __init__(self, fcos: FCOSEngine, a2j: A2JEngine, num_classes: int):
         if fcos.device != a2j.device:

@@ -108,3 +108,22 @@ def test_a2j_rgbd_forward_matches_golden(golden_dir, a2j_rgbd_sd):
     out = model(x)
     assert out.device.type == "cpu" and out.shape == (2, 21, 3)
     assert np.abs(out.numpy() - g["keypoints"]).max() < 1e-3
+
+
+def test_a2jmodel_range_contract(a2j_sd):
+    """a2j.a2j.A2JModel (the A2J-only boundary, a2j_infer.py:25,59) carries the f16x3 range contract too: depth in raw
+    millimetres x 1000 -- finite, far outside the fp16 range -- raises ops.RangeError instead of returning inf / NaN; ordinary
+    crops pass and are untouched by the check."""
+    from a2j.a2j import A2JModel
+    from hn_amd import ops, synth
+    model = A2JModel(21, crop_height=176, crop_width=176)
+    model.load_state_dict(a2j_sd, strict=False)
+    model = model.cuda().eval()
+    x = synth.make_crops(2, seed=3000).cuda()
+    with torch.inference_mode():
+        kp = model(x)
+        assert kp.device.type == "cpu" and torch.isfinite(kp).all()
+        assert torch.equal(kp, model.forward_device(x).cpu())
+        with pytest.raises(ops.RangeError, match="METRES"):
+            model(x * 1.0e6)
+        assert torch.equal(model(x), kp)                     # the flags are per call
