@@ -7,6 +7,7 @@ when their source (or a header) is newer; the shared library lands next to the s
 from __future__ import annotations
 
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -21,7 +22,14 @@ ARCH = "gfx950"
 
 # decode / IoU arithmetic must round exactly like the reference's separate torch ops
 # (no FMA contraction), so that file is built with contraction off.
-EXTRA_FLAGS = {"fcos_post.hip": ["-ffp-contract=off"]}
+#
+# The same file is built without the SLP vectoriser: it packed the bilinear blend of the tiled preprocess kernel into
+# v_pk_mul_f32 / v_pk_fma_f32 with op_sel:[1,0] (low result from the HIGH register of a source pair), and exactly those
+# results -- lanes 48-63, channel 0 of the odd column, nothing else -- came out wrong on ~3 % of the waves whenever a second
+# process had work on the same card (tests/test_dist_gpu.py, tools/diag/preprocess_pattern.py, profiles/NOTEBOOK.md round 4);
+# alone on the card the same binary is bit-exact.  No other kernel of the library holds such an instruction, and the build
+# refuses one (_check_packed_opsel).
+EXTRA_FLAGS = {"fcos_post.hip": ["-ffp-contract=off", "-fno-slp-vectorize"]}
 
 # Kernels that request operands with `asm volatile` loads / LDS-DMA and retire them with hand-counted s_waitcnt: the
 # compiler cannot see that such a register is still in flight, so a SPILL of it stores garbage (profiles/NOTEBOOK.md, round
@@ -53,6 +61,36 @@ def _check_resources(src: Path, remarks: str, objdir: Path) -> None:
             raise RuntimeError(f"{src.name}: {name} spills registers ({res.get('VGPRs Spill')} VGPR, {res.get('SGPRs Spill')} SGPR): "
                                "its asm loads / counted waits are only correct without spills")
     (objdir / (src.stem + ".resources.txt")).write_text("\n".join(out) + "\n")
+
+
+def _llvm_tool(name: str):
+    for root in (os.environ.get("ROCM_PATH"), "/opt/rocm"):
+        if root and (Path(root) / "lib" / "llvm" / "bin" / name).exists():
+            return str(Path(root) / "lib" / "llvm" / "bin" / name)
+    return shutil.which(name)
+
+
+def _check_packed_opsel(obj: Path, objdir: Path) -> None:
+    """Refuse packed-fp32 VALU instructions whose op_sel selects the high source register for the low result (see
+    EXTRA_FLAGS): disassemble the gfx950 code object of `obj` and look for them."""
+    objcopy, bundler, objdump = (_llvm_tool(n) for n in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump"))
+    if not (objcopy and bundler and objdump):
+        raise RuntimeError("llvm-objcopy / clang-offload-bundler / llvm-objdump not found: cannot check the device code")
+    fat, co = objdir / (obj.stem + ".fatbin"), objdir / (obj.stem + ".co")
+    try:
+        subprocess.run([objcopy, "-O", "binary", "--only-section=.hip_fatbin", str(obj), str(fat)], check=True, capture_output=True)
+        if not fat.exists() or fat.stat().st_size == 0:
+            return                                   # no device code in this object
+        subprocess.run([bundler, "--type=o", f"--targets=hipv4-amdgcn-amd-amdhsa--{ARCH}", f"--input={fat}", f"--output={co}",
+                        "--unbundle"], check=True, capture_output=True)
+        dis = subprocess.run([objdump, "-d", str(co)], check=True, capture_output=True, text=True).stdout
+    finally:
+        fat.unlink(missing_ok=True)
+        co.unlink(missing_ok=True)
+    bad = [l.strip() for l in dis.splitlines() if re.search(r"v_pk_\w+_f32\b.*\bop_sel:\[[0-9,]*1", l)]
+    if bad:
+        raise RuntimeError(f"{obj.name}: {len(bad)} packed-fp32 instruction(s) with op_sel (unsafe on a shared card, see "
+                           f"hn_amd/build.py EXTRA_FLAGS), e.g. `{bad[0]}`")
 
 
 def _hipcc() -> str:
@@ -89,6 +127,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
                 raise RuntimeError(f"hipcc failed on {src.name}:\n{r.stdout}\n{r.stderr}")
             try:
                 _check_resources(src, r.stderr, objdir)
+                _check_packed_opsel(obj, objdir)
             except RuntimeError:
                 obj.unlink(missing_ok=True)   # do not leave an object behind that a later incremental build would link
                 raise

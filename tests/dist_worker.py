@@ -26,6 +26,8 @@ def main():
     from hn_amd.a2j_engine import A2JEngine
     from hn_amd.fcos_engine import FCOSEngine
     from hn_amd.pipeline import HandNetEngine
+    from hn_amd import forms
+    forms.apply_env()          # (test infrastructure: lets a diagnosis run select kernel forms through the HN_* variables)
     if backend == "gloo":
         os.environ["LOCAL_RANK"] = "0"
     rank, local, world = hdist.init_from_env(backend, force=True)

@@ -170,3 +170,42 @@ def test_bench_four_rank_rehearsal():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 4 and line["config"]["global_batch"] == 32 and line["config"]["rccl_ranks"] == 4
 
+
+
+def test_stages_are_repeatable_next_to_a_second_process(fcos_sd, a2j_sd):
+    """Round 4: with a second process at work on the same card the SLP-vectorised blend of the tiled preprocess kernel
+    (`v_pk_fma_f32 ... op_sel:[0,1,0]`) returned wrong values in lanes 48-63 of ~3 % of its waves -- alone on the card the same
+    binary is exact (profiles/NOTEBOOK.md, tools/probes/pk_opsel_probe.hip).  The library is built without such instructions now
+    (hn_amd/build.py); this test keeps a load process on the card and asserts that the preprocess equals its per-pixel form on
+    every call and that the whole pipeline is bit-identical from call to call."""
+    from hn_amd import ops, synth
+    from hn_amd.a2j_engine import A2JEngine
+    from hn_amd.fcos_engine import IMAGE_MEAN, IMAGE_STD, FCOSEngine
+    from hn_amd.pipeline import HandNetEngine
+    load = subprocess.Popen([sys.executable, str(REPO / "tests" / "card_load.py"), "25"], stdout=subprocess.PIPE,
+                            stderr=subprocess.STDOUT, text=True, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    try:
+        line = ""
+        while "loading" not in line:
+            line = load.stdout.readline()
+            assert line or load.poll() is None, "the load process ended before it produced work"
+        rgb = synth.make_rgb(16, seed=1000).cuda()
+        args = (rgb, 799, 1066, 800, 1088, IMAGE_MEAN, IMAGE_STD)
+        ops.set_form("preprocess_generic", True)
+        try:
+            ref = ops.fcos_preprocess_split(*args)
+        finally:
+            ops.set_form("preprocess_generic", False)
+        for _ in range(8):
+            assert torch.equal(ops.fcos_preprocess_split(*args), ref)
+        eng = HandNetEngine(FCOSEngine(fcos_sd, 3, device="cuda"), A2JEngine(a2j_sd, device="cuda"), 3)
+        depth = synth.make_depth(16, seed=2000).cuda()
+        first = eng.forward_device(rgb, depth)
+        for _ in range(5):
+            out = eng.forward_device(rgb, depth)
+            assert torch.equal(out.crop_box, first.crop_box)
+            assert torch.equal(out.keypoints.view(torch.int32), first.keypoints.view(torch.int32))
+        assert load.poll() is None, "the load process ended before the checks did: nothing shared the card"
+    finally:
+        load.kill()
+        load.wait()

@@ -78,13 +78,18 @@ def _case(name):
         return dict(weights=(("shift", -1.5), 0), frames=list(pc.noise_frames(16, 1500)), depth=pc.depth_noise(16, 2500))
     if name == "sparse_hands":   # 4 of 16 frames with a hand: the engine's sparse-stream path (A2J on those frames only)
         return dict(weights=(("shift", -1.75), 0), frames=list(pc.noise_frames(16, 1500)), depth=pc.depth_noise(16, 2500))
+    if name == "frames_360x480":   # another source size: other interpolation weights, other clamps of the crop rule (W = 480, H = 360)
+        return dict(weights=(("seed", 1), 1), frames=list(pc.noise_frames(8, 1700, 360, 480)),
+                    depth=pc.depth_noise(8, 2700, 360, 480))
+    if name == "two_classes":      # the constructor default num_classes = 2 (handnet_pipeline.py:47): hand class 1, Cout = 4 outputs
+        return dict(weights=(("seed2c", 2), 2), frames=list(pc.noise_frames(8, 1800)), depth=pc.depth_noise(8, 2800), classes=2)
     if name == "no_candidates":  # most frames without a single candidate
         return dict(weights=(("shift", -2.5), 0), frames=list(pc.noise_frames(8, 1600)), depth=pc.depth_noise(8, 2600))
     raise KeyError(name)
 
 
 CASES = ["seed1", "seed2", "seed3", "structured", "depth_holes", "depth_constant", "cands_1100", "cands_5200",
-         "mixed_hands", "sparse_hands", "no_candidates"]
+         "mixed_hands", "sparse_hands", "no_candidates", "frames_360x480", "two_classes"]
 
 _FCOS_SD, _A2J_SD, _NETS, _ORACLE, _FACTS = {}, {}, {}, {}, {}
 
@@ -93,6 +98,9 @@ def _fcos_sd(key):
     if key not in _FCOS_SD:
         from hn_amd import synth
         kind, v = key
+        if kind == "seed2c":
+            _FCOS_SD[key] = synth.make_fcos_state_dict(v, 2)
+            return _FCOS_SD[key]
         base = synth.make_fcos_state_dict(v if kind == "seed" else 0, NUM_CLASSES)
         _FCOS_SD[key] = base if kind == "seed" else pc.shift_detector_bias(base, cls_shift=v, num_classes=NUM_CLASSES)
     return _FCOS_SD[key]
@@ -105,11 +113,15 @@ def _a2j_sd(seed):
     return _A2J_SD[seed]
 
 
+def _classes(weights):
+    return 2 if weights[0][0] == "seed2c" else NUM_CLASSES
+
+
 def _net(weights):
     if weights not in _NETS:
         from handnet_pipeline.handnet_pipeline import HandNet
         args = types.SimpleNamespace(pretrained_fcos="unused.pth", pretrained_a2j="unused.pth")
-        net = HandNet(args, reload_detector=False, num_classes=NUM_CLASSES, reload_a2j=False, RGBD=False)
+        net = HandNet(args, reload_detector=False, num_classes=_classes(weights), reload_a2j=False, RGBD=False)
         net.detector.load_state_dict(_fcos_sd(weights[0]), strict=False)
         net.a2j.load_state_dict(_a2j_sd(weights[1]), strict=False)
         _NETS.clear()                  # one resident engine pair at a time
@@ -127,12 +139,12 @@ def _oracle(name):
     frames, depth = c["frames"], c["depth"]
     dets, cands, smax = [], [], []
     for lo in range(0, len(frames), 4):
-        d, inter = fcos_ref.fcos_forward(frames[lo:lo + 4], fsd, NUM_CLASSES, return_intermediates=True)
+        d, inter = fcos_ref.fcos_forward(frames[lo:lo + 4], fsd, _classes(c["weights"]), return_intermediates=True)
         dets += d
         cands += inter["candidates"]
         ho = inter["head"]
         smax += list(torch.sqrt(torch.sigmoid(ho["cls_logits"]) * torch.sigmoid(ho["bbox_ctrness"])).max(dim=-1)[0])
-    mask, boxes, dcrops = handnet_ref.select_and_crop(dets, depth, NUM_CLASSES)
+    mask, boxes, dcrops = handnet_ref.select_and_crop(dets, depth, _classes(c["weights"]))
     kp = torch.zeros((len(frames), 21, 3))
     noise64 = 0.0
     if dcrops:
@@ -161,7 +173,7 @@ def _hip_scores(eng, batch):
     """scores_max [N, P] of every anchor point from the HIP engine's own head tensors (fcos.py:593-598 on the device)"""
     cls_lr, reg_ctr, _, _ = eng.fcos.forward_heads(batch)
     n = batch.shape[0]
-    cls = torch.cat([t.reshape(n, -1, t.shape[-1])[..., :NUM_CLASSES] for t in cls_lr], dim=1)
+    cls = torch.cat([t.reshape(n, -1, t.shape[-1])[..., :eng.num_classes] for t in cls_lr], dim=1)
     ctr = torch.cat([t.reshape(n, -1, t.shape[-1])[..., 4:5] for t in reg_ctr], dim=1)
     return torch.sqrt(torch.sigmoid(cls) * torch.sigmoid(ctr)).max(dim=-1)[0].cpu()
 
@@ -171,7 +183,7 @@ def _oracle64(ora, i):
     from oracle import a2j_ref, fcos_ref
     c = ora["case"]
     fsd = _fcos_sd(c["weights"][0])
-    d64, i64 = fcos_ref.fcos_forward([c["frames"][i].double()], a2j_ref.to_dtype(fsd, torch.float64), NUM_CLASSES,
+    d64, i64 = fcos_ref.fcos_forward([c["frames"][i].double()], a2j_ref.to_dtype(fsd, torch.float64), _classes(c["weights"]),
                                      return_intermediates=True)
     ho = i64["head"]
     return d64[0], torch.sqrt(torch.sigmoid(ho["cls_logits"][0]) * torch.sigmoid(ho["bbox_ctrness"][0])).max(dim=-1)[0]
@@ -198,11 +210,13 @@ def _diagnose_crop(name, i, ora, hip_box, delta):
     from oracle import handnet_ref
     d = ora["dets"][i]
     d64, _ = _oracle64(ora, i)
-    hb = d["boxes"][d["labels"] == HAND][:1]
-    hb64 = d64["boxes"][d64["labels"] == HAND][:1]
+    hand = _classes(ora["case"]["weights"]) - 1
+    hb = d["boxes"][d["labels"] == hand][:1]
+    hb64 = d64["boxes"][d64["labels"] == hand][:1]
     rec = {"case": name, "frame": i, "kind": "crop box (int64 truncation, handnet_pipeline.py:88)",
            "oracle_fp32_top_hand_box": hb.tolist(), "oracle_fp64_top_hand_box": hb64.tolist(), "hip_crop": hip_box.tolist(),
-           "oracle_crop": handnet_ref.crop_box(hb, pc.W, pc.H).tolist() if len(hb) else None}
+           "oracle_crop": handnet_ref.crop_box(hb, ora["case"]["depth"].shape[-1], ora["case"]["depth"].shape[-2]).tolist()
+           if len(hb) else None}
     if not len(hb) or not len(hb64):
         return False, rec
     coord_noise = float((hb.double() - hb64).abs().max())
