@@ -1,7 +1,8 @@
-// Probe for the round-4 finding (hn_amd/build.py EXTRA_FLAGS, profiles/NOTEBOOK.md): packed-fp32 VALU instructions whose op_sel
+// Probe for the round-4 finding (hn_amd/build.py EXTRA_FLAGS, profiles/NOTEBOOK.md): a packed-fp32 VALU instruction whose op_sel
 // takes the LOW result from the HIGH register of a source pair gave wrong results in lanes 48-63 of the tiled preprocess kernel,
-// but only while a second process had work on the card.  This probe repeats each form on known operands and counts mismatches
-// per 16-lane group; run it alone and next to a load (e.g. `python tools/diag/race_hunt.py load 60 &`).
+// but only while a second process had work on the card.  This probe runs every packed-32-bit form the library's disassembly
+// holds (and the op_sel permutations around the failing one) on known operands and counts wrong results per 16-lane group; run
+// it alone and next to a load (e.g. `python tests/card_load.py 60 &`).
 //   hipcc --offload-arch=gfx950 -O2 -o pk_opsel_probe pk_opsel_probe.hip && ./pk_opsel_probe [launches]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -9,13 +10,57 @@
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// FORM 0: v_pk_mul_f32 d, a, b                     (low = a.lo * b.lo, high = a.hi * b.hi)
-// FORM 1: v_pk_mul_f32 d, a, b op_sel_hi:[0,1]     (low = a.lo * b.lo, high = a.lo * b.hi)     -- the form the j = 0 column used
-// FORM 2: v_pk_mul_f32 d, a, b op_sel:[1,0]        (low = a.hi * b.lo, high = a.hi * b.hi)     -- the form the j = 1 column used
-// FORM 3: v_pk_fma_f32 d, a, b, c op_sel:[0,1,0]   (low = a.lo * b.hi + c.lo, high = a.hi * b.hi + c.hi)
+// packed semantics: low result = op(src_i[o_i]), high result = op(src_i[h_i]); defaults o = 0, h = 1; neg_lo / neg_hi negate a source
+struct Form {
+  const char* text;
+  int kind;                 // 0 mul, 1 add, 2 fma, 3 mov
+  int o[3], h[3], nl[3], nh[3];
+};
+#define FORMS(X)                                                                                                                  \
+  X(0, "v_pk_mul_f32 %0, %1, %2", 0, 0, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0)                                                           \
+  X(1, "v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]", 0, 0, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0)                                           \
+  X(2, "v_pk_mul_f32 %0, %1, %2 op_sel:[1,0]", 0, 1, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0)                                              \
+  X(3, "v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]", 0, 0, 1, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0)                                              \
+  X(4, "v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0]", 0, 1, 1, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0)                              \
+  X(5, "v_pk_add_f32 %0, %1, %2", 1, 0, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0)                                                           \
+  X(6, "v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]", 1, 0, 0, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0)                                           \
+  X(7, "v_pk_add_f32 %0, %1, %2 op_sel:[1,0]", 1, 1, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0)                                              \
+  X(8, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1]", 1, 0, 1, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0)                                              \
+  X(9, "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]", 1, 0, 0, 0, 1, 1, 1, 0, 1, 0, 0, 1, 0)                                 \
+  X(10, "v_pk_fma_f32 %0, %1, %2, %3", 2, 0, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0)                                                      \
+  X(11, "v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,1,0]", 2, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0)                                    \
+  X(12, "v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]", 2, 0, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0)                                    \
+  X(13, "v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]", 2, 0, 0, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0)                                    \
+  X(14, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0]", 2, 0, 1, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0)                                       \
+  X(15, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0]", 2, 1, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0)                                       \
+  X(16, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1]", 2, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0)                                       \
+  X(17, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,1] op_sel_hi:[0,0,0]", 2, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0)                     \
+  X(18, "v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]", 2, 0, 0, 0, 1, 1, 1, 1, 0, 0, 1, 0, 0)                        \
+  X(19, "v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]", 3, 1, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0)                                             \
+  X(20, "v_pk_mov_b32 %0, %1, %2 op_sel:[0,1]", 3, 0, 1, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0)
+constexpr int kForms = 21;
+
+#define X_TABLE(id, text, kind, o0, o1, o2, h0, h1, h2, nl0, nl1, nl2, nh0, nh1, nh2) \
+  {text, kind, {o0, o1, o2}, {h0, h1, h2}, {nl0, nl1, nl2}, {nh0, nh1, nh2}},
+static const Form kTable[kForms] = {FORMS(X_TABLE)};
+
+template <int F>
+__device__ __forceinline__ f32x2 issue(f32x2 a, f32x2 b, f32x2 c) {
+  f32x2 d;
+#define X_ASM(id, text, kind, ...)                                                      \
+  if constexpr (F == id) asm volatile(text : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  FORMS(X_ASM)
+  return d;
+}
+
+__device__ __forceinline__ float half_of(f32x2 v, int hi, int neg) {
+  const float x = hi ? v.y : v.x;
+  return neg ? -x : x;
+}
+
 // LDS = 1: the b operand comes from LDS through ds_read2st64_b32 right before the instruction (as in the kernel)
-template <int FORM, int LDS>
-__global__ __launch_bounds__(256) void probe(const float* __restrict__ in, unsigned* __restrict__ bad, int iters) {
+template <int F, int LDS>
+__global__ __launch_bounds__(256) void probe(const float* __restrict__ in, unsigned* __restrict__ bad, int iters, Form f) {
   __shared__ float tile[2][1024];
   const int tid = threadIdx.x, lane = tid & 63;
   const long base = ((long)blockIdx.x * 256 + tid) * 6;
@@ -23,49 +68,79 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ in, unsig
   tile[0][tid] = b.x;
   tile[1][tid] = b.y;
   __syncthreads();
+  f32x2 want;
+  if (f.kind == 3) {   // v_pk_mov_b32: low = src0[o0], high = src1[o1]
+    want = f32x2{half_of(a, f.o[0], 0), half_of(b, f.o[1], 0)};
+  } else {
+    const float al = half_of(a, f.o[0], f.nl[0]), bl = half_of(b, f.o[1], f.nl[1]), cl = half_of(c, f.o[2], f.nl[2]);
+    const float ah = half_of(a, f.h[0], f.nh[0]), bh = half_of(b, f.h[1], f.nh[1]), ch = half_of(c, f.h[2], f.nh[2]);
+    want = f.kind == 0 ? f32x2{al * bl, ah * bh} : f.kind == 1 ? f32x2{al + bl, ah + bh}
+                                                               : f32x2{__builtin_fmaf(al, bl, cl), __builtin_fmaf(ah, bh, ch)};
+  }
   unsigned wrong = 0;
   for (int it = 0; it < iters; ++it) {
-    f32x2 bb = b, d;
+    f32x2 bb = b;
     if (LDS) {
       const unsigned addr = (unsigned)(size_t)&tile[0][tid];
       asm volatile("ds_read2st64_b32 %0, %1 offset1:16\n\ts_waitcnt lgkmcnt(0)" : "=v"(bb) : "v"(addr) : "memory");
     }
-    f32x2 want;
-    if (FORM == 0) {
-      asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(bb));
-      want = f32x2{a.x * b.x, a.y * b.y};
-    } else if (FORM == 1) {
-      asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(d) : "v"(a), "v"(bb));
-      want = f32x2{a.x * b.x, a.x * b.y};
-    } else if (FORM == 2) {
-      asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0]" : "=v"(d) : "v"(a), "v"(bb));
-      want = f32x2{a.y * b.x, a.y * b.y};
-    } else {
-      asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0]" : "=v"(d) : "v"(a), "v"(bb), "v"(c));
-      want = f32x2{__builtin_fmaf(a.x, b.y, c.x), __builtin_fmaf(a.y, b.y, c.y)};
-    }
-    if (d.x != want.x) wrong |= 1u;
-    if (d.y != want.y) wrong |= 2u;
-    a.x += 0.f * d.x;   // keep the loop from being hoisted
+    const f32x2 d = issue<F>(a, bb, c);
+    if (__float_as_uint(d.x) != __float_as_uint(want.x)) wrong |= 1u;
+    if (__float_as_uint(d.y) != __float_as_uint(want.y)) wrong |= 2u;
   }
   if (wrong & 1u) atomicAdd(&bad[(lane >> 4) * 2 + 0], 1u);
   if (wrong & 2u) atomicAdd(&bad[(lane >> 4) * 2 + 1], 1u);
 }
 
-template <int FORM, int LDS>
+// `self` mode: the competing work comes from THIS process on a second stream (MFMA loop, two workgroups per CU)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void burn(float* out, int iters) {
+  f16x8 a, b;
+  for (int i = 0; i < 8; ++i) {
+    a[i] = (_Float16)(threadIdx.x * 0.001f + i);
+    b[i] = (_Float16)(blockIdx.x * 0.002f - i);
+  }
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+  for (int it = 0; it < iters; ++it) {
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc1, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc2, 0, 0, 0);
+    acc3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc3, 0, 0, 0);
+  }
+  if (acc0[0] + acc1[1] + acc2[2] + acc3[3] == 12345.678f) out[0] = 1.f;
+}
+static hipStream_t g_side = nullptr;
+static float* g_burn_out = nullptr;
+
+template <int F, int LDS>
 void run(const float* din, unsigned* dbad, int launches) {
   (void)hipMemset(dbad, 0, 8 * sizeof(unsigned));
-  for (int l = 0; l < launches; ++l) hipLaunchKernelGGL((probe<FORM, LDS>), dim3(8192), dim3(256), 0, 0, din, dbad, 64);
+  (void)hipDeviceSynchronize();
+  if (g_side) hipLaunchKernelGGL(burn, dim3(512), dim3(256), 0, g_side, g_burn_out, 400000);   // ~0.1-0.2 s of MFMAs beside the probe
+  for (int l = 0; l < launches; ++l)
+    hipLaunchKernelGGL((probe<F, LDS>), dim3(8192), dim3(256), 0, 0, din, dbad, 64, kTable[F]);
   hipError_t e = hipDeviceSynchronize();
   unsigned h[8];
   (void)hipMemcpy(h, dbad, sizeof(h), hipMemcpyDeviceToHost);
-  printf("form %d lds %d: %s; wrong lanes (low, high) per 16-lane group: [%u %u] [%u %u] [%u %u] [%u %u] of %ld lane-results\n", FORM,
-         LDS, hipGetErrorString(e), h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], (long)launches * 8192 * 256 / 4);
+  unsigned total = 0;
+  for (int i = 0; i < 8; ++i) total += h[i];
+  printf("%-68s lds %d: %s; wrong (low high) per 16-lane group: [%u %u] [%u %u] [%u %u] [%u %u]%s\n", kTable[F].text, LDS,
+         hipGetErrorString(e), h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], total ? "   <-- WRONG" : "");
   fflush(stdout);
 }
 
+template <int F>
+void run_all(const float* din, unsigned* dbad, int launches) {
+  if constexpr (F < kForms) {
+    run<F, 0>(din, dbad, launches);
+    run<F, 1>(din, dbad, launches);
+    run_all<F + 1>(din, dbad, launches);
+  }
+}
+
 int main(int argc, char** argv) {
-  const int launches = argc > 1 ? atoi(argv[1]) : 200;
+  const int launches = argc > 1 ? atoi(argv[1]) : 50;
   const long n = 8192L * 256 * 6;
   float* h = (float*)malloc(n * sizeof(float));
   unsigned s = 12345u;
@@ -78,15 +153,13 @@ int main(int argc, char** argv) {
   (void)hipMalloc(&din, n * sizeof(float));
   (void)hipMalloc(&dbad, 8 * sizeof(unsigned));
   (void)hipMemcpy(din, h, n * sizeof(float), hipMemcpyHostToDevice);
-  for (int rep = 0; rep < 2; ++rep) {
-    run<0, 0>(din, dbad, launches);
-    run<1, 0>(din, dbad, launches);
-    run<2, 0>(din, dbad, launches);
-    run<3, 0>(din, dbad, launches);
-    run<0, 1>(din, dbad, launches);
-    run<1, 1>(din, dbad, launches);
-    run<2, 1>(din, dbad, launches);
-    run<3, 1>(din, dbad, launches);
+  if (argc > 2 && argv[2][0] == 's') {
+    (void)hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking);
+    (void)hipMalloc(&g_burn_out, 16);
+    printf("competing MFMA work from this process on a second stream\n");
   }
+  printf("%d launches x 8192 workgroups x 256 lanes x 64 issues per form = %ld lane-results per 16-lane group and half\n", launches,
+         (long)launches * 8192 * 256 / 4);
+  run_all<0>(din, dbad, launches);
   return 0;
 }
