@@ -15,6 +15,14 @@ GOLDEN = REPO / "tests" / "golden"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The CPU oracle (torch fp32 on the host) is the slow side of every parity test.  A GPU box shows the host's cores to
+    # torch but gives the job a share of 16: with the default thread count the oracle ran 3-4x slower than with 16 threads
+    # (2.0 vs 0.45 s per 800 x 1088 frame; the parity sweep took 290 of the suite's 550 s).
+    try:
+        import torch
+        torch.set_num_threads(max(1, min(16, os.cpu_count() or 16, torch.get_num_threads() or 16)))
+    except Exception:
+        pass
 
 
 def _has_gpu() -> bool:

@@ -234,8 +234,11 @@ def _diagnose_crop(name, i, ora, hip_box, delta):
 # the sweep
 # ---------------------------------------------------------------------------------------------------------------------
 def _compare(name, check_range):
+    import time
     from oracle import a2j_ref, fcos_ref, handnet_ref
+    t_start = time.time()
     ora = _oracle(name)
+    t_oracle = time.time()
     c = ora["case"]
     frames, depth = c["frames"], c["depth"]
     n = len(frames)
@@ -243,6 +246,7 @@ def _compare(name, check_range):
     eng = net.engine()
     eng.check_range = bool(check_range)
     batch = torch.stack(frames).cuda()
+    t_net = time.time()
     try:
         with torch.inference_mode():
             out = net.forward_device(batch, depth.cuda(), _graph=False)
@@ -253,6 +257,7 @@ def _compare(name, check_range):
         eng.check_range = False
     if out.range_flags is not None:
         assert out.range_flags.cpu().tolist() == [0, 0, 0, 0]
+    t_hip = time.time()
     cnt = out.candidates.count.cpu().tolist()
     pts = out.candidates.point.cpu()
     cscores = out.candidates.scores.cpu()
@@ -352,7 +357,8 @@ def _compare(name, check_range):
           f"{min(cnt)}..{max(cnt)}, survivors {min(dcount)}..{max(dcount)}; identical in every integer {identical}, order of "
           f"near-tied scores differs {order_frames} (largest gap {worst_gap:.1e}), tolerated decisions {tolerated}, crop box "
           f"moved {moved}; score delta {max(deltas):.1e}; max |dkp| {err:.2e} over {int(sel.sum())} frames (oracle fp32-vs-fp64 "
-          f"on the same crops {ora['noise64']:.2e}, bound {tol:.1e})")
+          f"on the same crops {ora['noise64']:.2e}, bound {tol:.1e}); seconds: oracle {t_oracle - t_start:.1f}, engines "
+          f"{t_net - t_oracle:.1f}, HIP {t_hip - t_net:.1f}, comparison {time.time() - t_hip:.1f}")
     assert err < tol, (name, err, tol)
     REPORT["cases"][f"{name}/{int(check_range)}"] = {
         "frames": n, "frames_with_hand": int(ora["mask"].sum()), "candidates": [min(cnt), max(cnt)],
