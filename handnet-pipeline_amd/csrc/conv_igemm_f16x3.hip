@@ -1476,6 +1476,7 @@ static TileForm tile_form(int tile, bool rs32) {
     case HN_TILE_256x64: return {256, 64, 4, 2};
     case HN_TILE_256x128_W8: return {256, 128, 8, 2};
     case HN_TILE_256x64_W8: return {256, 64, 8, 2};
+    case HN_TILE_128x256_W8: return {128, 256, 8, 2};
     default: return {0, 0, 0, 0};
   }
 }
@@ -1699,6 +1700,7 @@ static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, c
     case HN_TILE_256x64: return launch16<256, 64, 4, 1, 2>(p, st);
     case HN_TILE_256x128_W8: return launch16<256, 128, 4, 2, 2, false>(p, st);
     case HN_TILE_256x64_W8: return launch16<256, 64, 4, 2, 2, false>(p, st);
+    case HN_TILE_128x256_W8: return launch16<128, 256, 2, 4, 2, false>(p, st);
     default: return hn::fail(HN_ERR_ARG, "unknown tile id %d", d->tile);
   }
 }

@@ -140,6 +140,8 @@ typedef struct hn_conv_desc {
 #define HN_TILE_256x128_W8 9 /* f16x3 only: 256x128 with 8 waves (64x64 wave tiles), one workgroup per CU */
 #define HN_TILE_256x64_W8 10 /* f16x3 only: 256x64 with 8 waves (64x32 wave tiles), one workgroup per CU: the form in which the
                               * row-shared A operand fits for Cout <= 64 (W tile shared by 256 rows) */
+#define HN_TILE_128x256_W8 11 /* f16x3 only: 128x256 with 8 waves (64x64 wave tiles), one workgroup per CU: the A operand of a
+                               * Cout = 256 layer is fetched once instead of once per 128-column tile (sweeps / A-B) */
 
 int hn_conv2d_nhwc_f32(const hn_conv_desc* d, const float* x, const float* w,
                        const float* bias /* [cout] or NULL */,

@@ -138,7 +138,7 @@ F16X3_CASES = [
 
 
 @pytest.mark.parametrize("case", F16X3_CASES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 11])
 def test_conv_f16x3_matches_fp64_reference(case, tile):
     """Error budget: operands carry 22 bits (hi+lo), products exact, fp32 accumulate =>
     same 1e-4*scale bar as the exact-f32 kernel, checked against an fp64 convolution."""
@@ -534,7 +534,7 @@ RS_CASES = [
 
 
 @pytest.mark.parametrize("case", RS_CASES)
-@pytest.mark.parametrize("tile", [1, 2, 4, 9, 10])
+@pytest.mark.parametrize("tile", [1, 2, 4, 9, 10, 11])
 def test_conv_f16x3_row_shared_a_is_bit_identical_to_per_tap_form(case, tile, monkeypatch):
     """Same k order and same operands => the row-shared kernel must reproduce the per-tap kernel bit for bit (S32 and fp32
     outputs, residual + ReLU), and both are fp32-grade against an fp64 convolution.  ops.set_form("conv_no_rs") selects the per-tap
