@@ -495,7 +495,11 @@ __global__ __launch_bounds__(256) void fcos_ext_gather_kernel(const ExtTable et,
 // NMS
 // ---------------------------------------------------------------------------------------
 constexpr int kSortLds = 2048;  // keys sorted in LDS up to this many (padded) entries
+constexpr int kBitK = 512;      // ... and resolved by the bitmask form up to this many (its records and rows live where the kept list would)
+constexpr int kRankSort = 1024; // ... by rank counting up to this many (one key per thread), by the bitonic network beyond
+static_assert(2 * kRankSort <= kSortLds, "the rank sort writes into the upper half of the key array");
 constexpr int kKeptRec = 6;     // x1 y1 x2 y2 area label(as float bits)
+static_assert(kBitK * kKeptRec * 4 + kBitK * (kBitK / 64) * 8 <= kSortLds * kKeptRec * 4, "records + rows of the bitmask form must fit the kept list's LDS");
 
 __host__ __device__ inline int pow2_at_least(int v) {
   int p = 1;
@@ -547,7 +551,7 @@ __device__ __forceinline__ bool iou_gt(float ax1, float ay1, float ax2, float ay
 
 __global__ __launch_bounds__(1024) void nms_kernel(const NmsArgs a) {
   __shared__ unsigned long long keys_lds[kSortLds];
-  __shared__ float kept_lds[kSortLds * kKeptRec];
+  __shared__ __attribute__((aligned(16))) float kept_lds[kSortLds * kKeptRec];   // (the bitmask form keeps 8-byte words in it)
   __shared__ float red[16];
   __shared__ float maxc_s;
   const int img = blockIdx.x;
@@ -571,7 +575,9 @@ __global__ __launch_bounds__(1024) void nms_kernel(const NmsArgs a) {
 
   // only as many waves as the padded sort needs stay: every __syncthreads() below then rendezvous 4 waves
   // instead of 16 for the usual ~250 candidates (terminated waves do not take part in s_barrier)
-  const int nthreads = npad < 64 ? 64 : (npad < (int)blockDim.x ? npad : (int)blockDim.x);
+  // (the bitmask form below has ~K^2 / 64 independent work items and five barriers in all: four threads per padded key there)
+  const int nwant = npad <= kBitK ? 4 * npad : npad;
+  const int nthreads = nwant < 64 ? 64 : (nwant < (int)blockDim.x ? nwant : (int)blockDim.x);
   if (tid >= nthreads) return;
   // keys + max coordinate (torchvision's coordinate trick needs boxes.max())
   float mx = -3.402823466e38f;
@@ -590,6 +596,31 @@ __global__ __launch_bounds__(1024) void nms_kernel(const NmsArgs a) {
     for (int k = 1; k < (nthreads >> 6); ++k) m = fmaxf(m, red[k]);
     maxc_s = m;
   }
+  // Up to kRankSort keys: RANK sort -- the keys are distinct (the candidate index is their low word), so the position of a key
+  // in the sorted list is the number of smaller keys; every thread owns one key (nthreads == npad >= K), counts over all K with
+  // wave-uniform LDS reads (a broadcast, no bank conflict) and drops its key at that position of a second array: two barriers
+  // instead of the bitonic network's 36-55 (round 4: the sort was about half of the kernel's 66 us at ~260 candidates).  The
+  // order is the same total order, so everything downstream is bit-identical.
+  if (npad <= kRankSort) {   // (the keys are visible: the barrier of the maximum above)
+    unsigned long long* sorted_lds = keys_lds + kRankSort;   // the upper half of the key array is free at these sizes
+    unsigned long long mine = ~0ull;
+    int rank = 0;
+    if (tid < K) {
+      mine = keys_lds[tid];
+      int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+      int j = 0;
+      for (; j + 4 <= K; j += 4) {
+        r0 += keys_lds[j] < mine;
+        r1 += keys_lds[j + 1] < mine;
+        r2 += keys_lds[j + 2] < mine;
+        r3 += keys_lds[j + 3] < mine;
+      }
+      for (; j < K; ++j) r0 += keys_lds[j] < mine;
+      rank = (r0 + r1) + (r2 + r3);
+    }
+    if (tid < K) sorted_lds[rank] = mine;
+    keys = sorted_lds;
+  } else
   // bitonic sort (ascending keys = descending score, ties by ascending index)
   for (int k = 2; k <= npad; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
@@ -608,23 +639,123 @@ __global__ __launch_bounds__(1024) void nms_kernel(const NmsArgs a) {
     }
   }
   __syncthreads();
-  // Greedy pass, 64 candidates (one tile) at a time in score order.  Up to four waves share the two
-  // IoU-heavy parts of a tile -- the check against the boxes kept so far (wave w takes kept entries w, w+W, ..)
-  // and the in-tile suppression masks (wave w takes 64/W of the tile's columns) -- and wave 0 then resolves the
-  // tile sequentially.  Same comparisons as a single wave, only distributed: results are bit-identical.
-  const int W = (nthreads >> 6) < 4 ? (nthreads >> 6) : 4;
-  if (wave >= W) return;
   __shared__ unsigned long long alive_w[4];
   __shared__ unsigned long long mask_w[4][64];
   __shared__ int nk_s;
-
+  __shared__ unsigned long long kept_w[kBitK / 64];
   // batched_nms: coordinate trick iff boxes.numel() <= 4000, else per-class on raw boxes
   const bool classwise = labels != nullptr;
   const bool trick = classwise && (4 * K <= 4000);
   const float offs_unit = maxc_s + 1.0f;
   const double thr = a.thr;
   int nk = 0;
-  for (int t0 = 0; t0 < K; t0 += 64) {
+  bool resolved = false;
+  if (npad <= kBitK) {
+    // Up to kBitK candidates: the BITMASK form.  All waves compute the suppression matrix at once -- bit j of word (i, w) says
+    // "candidate i, if kept, suppresses the later candidate j = 64 w + bit" (the same iou_gt on the same operands as the greedy
+    // tiles below, for every pair i < j instead of for the pairs the greedy order happens to reach) -- and ONE wave then walks
+    // the candidates in score order with the removed set in registers: candidate i is kept iff its bit is still clear, and a
+    // kept candidate ORs its row into the set.  Same decisions as the tiles (a candidate is dropped iff a KEPT earlier one
+    // overlaps it), so survivors and their order are bit-identical; what goes is the per-tile chain of global gathers and
+    // rendezvous (round 4, ~260 candidates: 73 -> 41 us of the kernel in isolation).
+    float* rec = kept_lds;                                                                  // [K][6]: x1 y1 x2 y2 area label
+    unsigned long long* rows = reinterpret_cast<unsigned long long*>(kept_lds + kBitK * kKeptRec);   // [K][nw]
+    const int nw = (K + 63) >> 6;
+    unsigned long long* sk = keys_lds + kRankSort;   // = keys, as an LDS pointer (no flat accesses in the sequential walk)
+    if (tid < K) {
+      const int idx = (int)(unsigned)(sk[tid] & 0xFFFFFFFFull);
+      const f32x4 raw = *reinterpret_cast<const f32x4*>(boxes + (long)idx * 4);
+      const int lab = labels ? labels[idx] : 0;
+      float x1 = raw[0], y1 = raw[1], x2 = raw[2], y2 = raw[3];
+      if (trick) {
+        const float off = (float)lab * offs_unit;
+        x1 = x1 + off;
+        y1 = y1 + off;
+        x2 = x2 + off;
+        y2 = y2 + off;
+      }
+      float* r = rec + tid * kKeptRec;
+      r[0] = x1; r[1] = y1; r[2] = x2; r[3] = y2; r[4] = (x2 - x1) * (y2 - y1); r[5] = __int_as_float(lab);
+    }
+    __syncthreads();
+    // word-major work list: word w holds rows 0 .. min(K, 64 (w + 1)) - 1 (a row only suppresses LATER candidates), so the
+    // 64 lanes of a wave share w and read the same record j at a time (an LDS broadcast)
+    int total = 0;
+    for (int w = 0; w < nw; ++w) total += min(K, 64 * (w + 1));
+    for (int item = tid; item < total; item += nthreads) {
+      int w = 0, i = item;
+      while (i >= min(K, 64 * (w + 1))) {
+        i -= min(K, 64 * (w + 1));
+        ++w;
+      }
+      const float* ri = rec + i * kKeptRec;
+      const float ix1 = ri[0], iy1 = ri[1], ix2 = ri[2], iy2 = ri[3], ia = ri[4];
+      const int il = __float_as_int(ri[5]);
+      unsigned long long word = 0ull;
+      const int j0 = 64 * w, jn = min(64, K - j0);
+      for (int jj = 0; jj < jn; ++jj) {
+        const float* rj = rec + (j0 + jj) * kKeptRec;
+        const int jl = __float_as_int(rj[5]);
+        if (j0 + jj > i && (trick || !classwise || jl == il) &&
+            iou_gt(ix1, iy1, ix2, iy2, ia, rj[0], rj[1], rj[2], rj[3], rj[4], thr))
+          word |= 1ull << jj;
+      }
+      rows[i * nw + w] = word;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      // lane l < nw holds word l of the removed set; the rows of the next four candidates are fetched while the current four
+      // are decided (their addresses do not depend on the decisions).  Nothing else touches memory in this loop: a row only
+      // has bits of LATER candidates, so bit i of the set is final once candidate i has been visited -- the kept set is
+      // simply the complement of the removed set at the end.
+      unsigned long long remv = 0ull, cur[4], nxt[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) cur[u] = (lane < nw && u < K) ? rows[u * nw + lane] : 0ull;   // (u < 4: word 0 is their first)
+      for (int i0 = 0; i0 < K; i0 += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)   // (words in front of a row's own were never written: they read as zero)
+          nxt[u] = (lane < nw && lane >= ((i0 + 4 + u) >> 6) && i0 + 4 + u < K) ? rows[(i0 + 4 + u) * nw + lane] : 0ull;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u;   // (rows beyond K were fetched as zeros: visiting them changes nothing)
+          const int wi = i >> 6;
+          const unsigned lo = __builtin_amdgcn_readlane((unsigned)remv, wi);
+          const unsigned hi = __builtin_amdgcn_readlane((unsigned)(remv >> 32), wi);
+          const unsigned long long rw = ((unsigned long long)hi << 32) | lo;
+          if (!((rw >> (i & 63)) & 1ull)) remv |= cur[u];   // (wave-uniform condition)
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+      }
+      if (lane < nw) {
+        const int left = K - 64 * lane;
+        kept_w[lane] = ~remv & (left >= 64 ? ~0ull : ((1ull << left) - 1ull));
+      }
+    }
+    __syncthreads();
+    // compaction, all threads: kept candidate t goes to position (kept candidates before t); the list lands in the lower half
+    // of the key array (the unsorted keys are no longer needed), where the output loop below reads it
+    if (tid < K) {
+      const int wt = tid >> 6;
+      const unsigned long long kw = kept_w[wt];
+      if ((kw >> (tid & 63)) & 1ull) {
+        int pos = __popcll(kw & ((1ull << (tid & 63)) - 1ull));
+        for (int w = 0; w < wt; ++w) pos += __popcll(kept_w[w]);
+        keys_lds[pos] = sk[tid] & 0xFFFFFFFFull;
+      }
+    }
+    for (int w = 0; w < nw; ++w) nk += __popcll(kept_w[w]);
+    keys = keys_lds;
+    __syncthreads();
+    resolved = true;
+  }
+  // Greedy pass, 64 candidates (one tile) at a time in score order.  Up to four waves share the two
+  // IoU-heavy parts of a tile -- the check against the boxes kept so far (wave w takes kept entries w, w+W, ..)
+  // and the in-tile suppression masks (wave w takes 64/W of the tile's columns) -- and wave 0 then resolves the
+  // tile sequentially.  Same comparisons as a single wave, only distributed: results are bit-identical.
+  const int W = (nthreads >> 6) < 4 ? (nthreads >> 6) : 4;
+  if (wave >= W) return;
+  for (int t0 = 0; !resolved && t0 < K; t0 += 64) {
     const int t = t0 + lane;
     const bool has = t < K;
     const int idx = has ? (int)(unsigned)(keys[t] & 0xFFFFFFFFull) : 0;
