@@ -81,6 +81,12 @@ def _case(name):
     if name == "frames_360x480":   # another source size: other interpolation weights, other clamps of the crop rule (W = 480, H = 360)
         return dict(weights=(("seed", 1), 1), frames=list(pc.noise_frames(8, 1700, 360, 480)),
                     depth=pc.depth_noise(8, 2700, 360, 480))
+    if name == "frames_720x1280":  # upscale by 1.04 (max side 1333 binds): the <16, 160> LDS patch of the tiled preprocess, a 768 x 1344 canvas
+        return dict(weights=(("seed", 1), 1), frames=list(pc.noise_frames(4, 1900, 720, 1280)),
+                    depth=pc.depth_noise(4, 2900, 720, 1280))
+    if name == "frames_1080x1920":  # DOWNscale by 0.69: beyond the LDS patches, the per-pixel preprocess kernel
+        return dict(weights=(("seed", 1), 1), frames=list(pc.noise_frames(2, 1950, 1080, 1920)),
+                    depth=pc.depth_noise(2, 2950, 1080, 1920))
     if name == "two_classes":      # the constructor default num_classes = 2 (handnet_pipeline.py:47): hand class 1, Cout = 4 outputs
         return dict(weights=(("seed2c", 2), 2), frames=list(pc.noise_frames(8, 1800)), depth=pc.depth_noise(8, 2800), classes=2)
     if name == "no_candidates":  # most frames without a single candidate
@@ -89,7 +95,7 @@ def _case(name):
 
 
 CASES = ["seed1", "seed2", "seed3", "structured", "depth_holes", "depth_constant", "cands_1100", "cands_5200",
-         "mixed_hands", "sparse_hands", "no_candidates", "frames_360x480", "two_classes"]
+         "mixed_hands", "sparse_hands", "no_candidates", "frames_360x480", "frames_720x1280", "frames_1080x1920", "two_classes"]
 
 _FCOS_SD, _A2J_SD, _NETS, _ORACLE, _FACTS = {}, {}, {}, {}, {}
 
