@@ -57,7 +57,9 @@ __global__ __launch_bounds__(256) void pack_depth_kernel(const float* __restrict
 // Pass 2: e = exp(x - max); partial sums of e, e*(anchor+offset), e*depth per (group, anchor, joint), then
 // combined through LDS in a fixed order (group-major, then anchor): bitwise reproducible, and independent of the joint split.
 constexpr int kAnchorsPerCell = 16;
-constexpr int kMaxGroups = 3;
+constexpr int kMaxGroups = 9;   // (round 4: 3 -> 9 cell groups: on an 11 x 11 map a thread owns 14 cells = ONE batch of loads per pass
+                                // instead of three, 18 -> ~11 us at one crop; the group count fixes the summation order, so it is the
+                                // same for every batch size)
 constexpr int kJointSplit = 3;
 
 __global__ __launch_bounds__(1024) void a2j_aggregate_kernel(const float* __restrict__ cls,
@@ -104,10 +106,15 @@ __global__ __launch_bounds__(1024) void a2j_aggregate_kernel(const float* __rest
     }
   if (g < G) lds[g * AW + cl] = mx;
   __syncthreads();
+  if ((int)threadIdx.x < AW) {   // (group 0's threads: slot cl = threadIdx.x) maximum over the groups, then over the anchors below
+    float m = lds[threadIdx.x];
+    for (int gg = 1; gg < G; ++gg) m = fmaxf(m, lds[gg * AW + threadIdx.x]);
+    lds[threadIdx.x] = m;
+  }
+  __syncthreads();
   float mj = -FLT_MAX;
   if (active)
-    for (int gg = 0; gg < G; ++gg)
-      for (int aa = 0; aa < kAnchorsPerCell; ++aa) mj = fmaxf(mj, lds[gg * AW + aa * Jw + jl]);
+    for (int aa = 0; aa < kAnchorsPerCell; ++aa) mj = fmaxf(mj, lds[aa * Jw + jl]);
   __syncthreads();
 
   if (active) {
@@ -145,17 +152,22 @@ __global__ __launch_bounds__(1024) void a2j_aggregate_kernel(const float* __rest
     o[3 * AW + cl] = sd;
   }
   __syncthreads();
+  // fixed-order combination in two steps: thread (quantity q, anchor a, joint jl) of the first 4 * AW sums its slot over the
+  // groups 0 .. G-1, then thread jj sums the 16 anchors of its joint (G + 16 dependent additions instead of 16 G)
+  for (int s4 = threadIdx.x; s4 < 4 * AW; s4 += blockDim.x) {
+    float acc = lds[s4];
+    for (int gg = 1; gg < G; ++gg) acc += lds[(long)gg * 4 * AW + s4];
+    lds[s4] = acc;   // (group 0's slot: only this thread reads or writes it here)
+  }
+  __syncthreads();
   if ((int)threadIdx.x < jn) {
     const int jj = threadIdx.x;
     float t = 0.f, t0 = 0.f, t1 = 0.f, td = 0.f;
-    for (int gg = 0; gg < G; ++gg) {
-      const float* o = lds + (long)gg * 4 * AW;
-      for (int aa = 0; aa < kAnchorsPerCell; ++aa) {
-        t += o[aa * Jw + jj];
-        t0 += o[AW + aa * Jw + jj];
-        t1 += o[2 * AW + aa * Jw + jj];
-        td += o[3 * AW + aa * Jw + jj];
-      }
+    for (int aa = 0; aa < kAnchorsPerCell; ++aa) {
+      t += lds[aa * Jw + jj];
+      t0 += lds[AW + aa * Jw + jj];
+      t1 += lds[2 * AW + aa * Jw + jj];
+      td += lds[3 * AW + aa * Jw + jj];
     }
     float* o = out + ((long)k * J + j0 + jj) * 3;
     o[0] = t0 / t;
@@ -239,13 +251,13 @@ extern "C" int hn_a2j_aggregate_f32(const float* cls, const float* reg, const fl
   HN_CHECK_ARG(k >= 0 && fh > 0 && fw > 0 && stride > 0, "bad dims");
   HN_CHECK_ARG(joints > 0 && joints * kAnchorsPerCell <= 1024, "joints must be in [1, 64]");
   if (k == 0) return HN_OK;
-  // the cell-group count stays what it was with one workgroup per crop (it fixes the summation order): min(3, 1024 / (16 J))
-  const int aj = kAnchorsPerCell * joints;
-  int groups = 1024 / aj;
-  groups = groups > kMaxGroups ? kMaxGroups : groups;
+  // the cell-group count depends on the joint count only (it fixes the summation order): min(9, 1024 / (16 * joints per workgroup))
   const int split = joints >= 2 * kJointSplit ? kJointSplit : 1;
   const int jw = (joints + split - 1) / split;
   const int aw = kAnchorsPerCell * jw;
+  int groups = 1024 / aw;            // cell groups of a workgroup (16 * jw thread slots each)
+  groups = groups > kMaxGroups ? kMaxGroups : groups;
+  groups = groups < 1 ? 1 : groups;
   const int threads = ((groups * aw + 63) / 64) * 64;
   hipLaunchKernelGGL(a2j_aggregate_kernel, dim3(k, split), dim3(threads), groups * 4 * aw * sizeof(float),
                      (hipStream_t)stream, cls, reg, dep, valid, fh, fw, joints, jw, stride, groups, out);
