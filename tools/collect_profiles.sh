@@ -4,7 +4,7 @@
 #   usage: bash tools/collect_profiles.sh <tag>
 # Separate rocprofv3 passes: kernel trace + stats, then one --pmc pass per HBM counter (never combined with traces).
 set -u
-tag=${1:-r04c}
+tag=${1:-r04d}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$tag
 mkdir -p $O
