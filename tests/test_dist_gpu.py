@@ -182,7 +182,7 @@ def test_stages_are_repeatable_next_to_a_second_process(fcos_sd, a2j_sd):
     from hn_amd.a2j_engine import A2JEngine
     from hn_amd.fcos_engine import IMAGE_MEAN, IMAGE_STD, FCOSEngine
     from hn_amd.pipeline import HandNetEngine
-    load = subprocess.Popen([sys.executable, str(REPO / "tests" / "card_load.py"), "25"], stdout=subprocess.PIPE,
+    load = subprocess.Popen([sys.executable, str(REPO / "tests" / "card_load.py"), "90"], stdout=subprocess.PIPE,
                             stderr=subprocess.STDOUT, text=True, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     try:
         line = ""
