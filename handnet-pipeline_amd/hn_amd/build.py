@@ -74,8 +74,10 @@ def _check_packed_opsel(obj: Path, objdir: Path) -> None:
     """Refuse packed-fp32 VALU instructions whose op_sel selects the high source register for the low result (see
     EXTRA_FLAGS): disassemble the gfx950 code object of `obj` and look for them."""
     objcopy, bundler, objdump = (_llvm_tool(n) for n in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump"))
-    if not (objcopy and bundler and objdump):
-        raise RuntimeError("llvm-objcopy / clang-offload-bundler / llvm-objdump not found: cannot check the device code")
+    if not (objcopy and bundler and objdump):   # (a toolchain without the LLVM binutils: the library still builds, unchecked)
+        print(f"[build] warning: llvm-objcopy / clang-offload-bundler / llvm-objdump not found: {obj.name} not checked for "
+              "packed-fp32 op_sel instructions", file=sys.stderr)
+        return
     fat, co = objdir / (obj.stem + ".fatbin"), objdir / (obj.stem + ".co")
     try:
         subprocess.run([objcopy, "-O", "binary", "--only-section=.hip_fatbin", str(obj), str(fat)], check=True, capture_output=True)
