@@ -141,7 +141,7 @@ def _random_boxes(k, seed, spread=400.0, size=60.0):
     return boxes, scores, labels
 
 
-@pytest.mark.parametrize("k", [0, 1, 7, 64, 65, 257, 1000, 1001, 2500, 5000])
+@pytest.mark.parametrize("k", [0, 1, 7, 63, 64, 65, 128, 129, 257, 511, 512, 513, 1000, 1001, 1024, 1025, 2048, 2049, 2500, 5000])
 def test_batched_nms_bit_exact(k):
     """Both torchvision paths (coordinate trick for K <= 1000, per-class above) and the
     LDS / global-memory sort paths (K <= 2048 / above)."""
@@ -191,6 +191,14 @@ def _nms_case(name):
         b, s, l = _random_boxes(k, 11 + k, spread=900.0)
         s = (torch.randint(0, 40, (k,), generator=g).float() / 64.0 + 0.3)   # ~40 distinct scores: long tie runs
         return b, s, l
+    if name == "dense_chains_500":
+        # 500 heavily overlapping boxes with distinct scores (the bitmask form's largest size class): long suppression chains --
+        # A drops B, B would have dropped C but is gone, C must survive
+        return _random_boxes(500, 77, spread=160.0, size=80.0)
+    if name == "ties_500":
+        b, s, l = _random_boxes(500, 78, spread=300.0, size=60.0)
+        s = (torch.randint(0, 12, (500,), generator=g).float() / 16.0 + 0.2)   # 12 distinct scores: tie runs across the 64-bit words
+        return b, s, l
     if name == "one_class_1001":
         b, s, l = _random_boxes(1001, 33)
         return b, s, torch.full((1001,), 2, dtype=torch.long)
@@ -202,7 +210,7 @@ def _nms_case(name):
 
 
 @pytest.mark.parametrize("name", ["zero_area", "identical_across_tile", "ties_2049", "ties_4097", "one_class_1001",
-                                  "tie_run_over_tiles"])
+                                  "tie_run_over_tiles", "dense_chains_500", "ties_500"])
 def test_batched_nms_edge_fixtures(name):
     """Survivor indices bit-exact vs oracle/nms_ref.c on the inputs where a greedy NMS can go wrong: NaN IoUs,
     equal (score, box) runs across the 64-candidate tiles, K just past the LDS sort capacity (2048) and past 4096
