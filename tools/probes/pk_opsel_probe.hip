@@ -92,23 +92,84 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ in, unsig
   if (wrong & 2u) atomicAdd(&bad[(lane >> 4) * 2 + 1], 1u);
 }
 
-// `self` mode: the competing work comes from THIS process on a second stream (MFMA loop, two workgroups per CU)
+// `self` modes: the competing work comes from THIS process on a second stream, two workgroups per CU; the kind of work is
+// selectable so that the trigger can be narrowed down: m = MFMA loop, v = plain VALU (v_fma_f32) loop, l = LDS read / write loop,
+// g = global-memory read loop (L2-resident 64 KB), d = LDS-DMA loop (global_load_lds_dwordx4), t = transcendental (v_exp_f32) loop
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void burn(float* out, int iters) {
-  f16x8 a, b;
-  for (int i = 0; i < 8; ++i) {
-    a[i] = (_Float16)(threadIdx.x * 0.001f + i);
-    b[i] = (_Float16)(blockIdx.x * 0.002f - i);
+typedef __attribute__((address_space(3))) void lds_void;
+template <int KIND>
+__global__ __launch_bounds__(256) void burn(float* out, const float* src, int iters) {
+  __shared__ __attribute__((aligned(16))) float lds[4096];
+  float acc = threadIdx.x * 0.001f;
+  if constexpr (KIND == 0) {
+    f16x8 a, b;
+    for (int i = 0; i < 8; ++i) {
+      a[i] = (_Float16)(threadIdx.x * 0.001f + i);
+      b[i] = (_Float16)(blockIdx.x * 0.002f - i);
+    }
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+    for (int it = 0; it < iters; ++it) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc1, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc2, 0, 0, 0);
+      acc3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc3, 0, 0, 0);
+    }
+    acc = acc0[0] + acc1[1] + acc2[2] + acc3[3];
+  } else if constexpr (KIND == 1) {
+    float x0 = acc, x1 = acc + 1.f, x2 = acc + 2.f, x3 = acc + 3.f;
+    for (int it = 0; it < iters * 4; ++it) {
+      x0 = __builtin_fmaf(x0, 1.0000001f, 0.5f);
+      x1 = __builtin_fmaf(x1, 0.9999999f, 0.25f);
+      x2 = __builtin_fmaf(x2, 1.0000002f, 0.125f);
+      x3 = __builtin_fmaf(x3, 0.9999998f, 0.0625f);
+    }
+    acc = x0 + x1 + x2 + x3;
+  } else if constexpr (KIND == 2) {
+    for (int i = threadIdx.x; i < 4096; i += 256) lds[i] = (float)i;
+    __syncthreads();
+    int idx = threadIdx.x;
+    for (int it = 0; it < iters * 2; ++it) {
+      const float v = lds[idx & 4095];
+      lds[(idx + 1024) & 4095] = v + 1.f;
+      idx = idx * 5 + 17;
+      acc += v;
+    }
+  } else if constexpr (KIND == 3) {
+    int idx = threadIdx.x + blockIdx.x * 7;
+    for (int it = 0; it < iters; ++it) {
+      acc += src[idx & 16383];
+      idx = idx * 5 + 17;
+    }
+  } else if constexpr (KIND == 4) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 65536, 0x00020000);
+    const int wave_base = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * 64;
+    for (int it = 0; it < iters; ++it) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)((char*)lds + wave_base * 16), 16, (int)((threadIdx.x & 63) * 16), (it & 15) * 4096, 0, 0);
+      if ((it & 7) == 7) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    acc += lds[threadIdx.x];
+  } else {
+    float x = acc * 0.01f;
+    for (int it = 0; it < iters * 2; ++it) x = __builtin_amdgcn_exp2f(x) * 0.5f;
+    acc = x;
   }
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
-  for (int it = 0; it < iters; ++it) {
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc1, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc2, 0, 0, 0);
-    acc3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc3, 0, 0, 0);
+  if (acc == 12345.678f) out[0] = 1.f;
+}
+static int g_kind = 0;
+static float* g_burn_src = nullptr;
+static void launch_burn(hipStream_t st, float* out) {
+  const int it = 400000;
+  switch (g_kind) {
+    case 0: hipLaunchKernelGGL(burn<0>, dim3(512), dim3(256), 0, st, out, g_burn_src, it); break;
+    case 1: hipLaunchKernelGGL(burn<1>, dim3(512), dim3(256), 0, st, out, g_burn_src, it); break;
+    case 2: hipLaunchKernelGGL(burn<2>, dim3(512), dim3(256), 0, st, out, g_burn_src, it / 4); break;
+    case 3: hipLaunchKernelGGL(burn<3>, dim3(512), dim3(256), 0, st, out, g_burn_src, it / 8); break;
+    case 4: hipLaunchKernelGGL(burn<4>, dim3(512), dim3(256), 0, st, out, g_burn_src, it / 4); break;
+    default: hipLaunchKernelGGL(burn<5>, dim3(512), dim3(256), 0, st, out, g_burn_src, it); break;
   }
-  if (acc0[0] + acc1[1] + acc2[2] + acc3[3] == 12345.678f) out[0] = 1.f;
 }
 static hipStream_t g_side = nullptr;
 static float* g_burn_out = nullptr;
@@ -117,7 +178,7 @@ template <int F, int LDS>
 void run(const float* din, unsigned* dbad, int launches) {
   (void)hipMemset(dbad, 0, 8 * sizeof(unsigned));
   (void)hipDeviceSynchronize();
-  if (g_side) hipLaunchKernelGGL(burn, dim3(512), dim3(256), 0, g_side, g_burn_out, 400000);   // ~0.1-0.2 s of MFMAs beside the probe
+  if (g_side) launch_burn(g_side, g_burn_out);   // competing work beside the probe
   for (int l = 0; l < launches; ++l)
     hipLaunchKernelGGL((probe<F, LDS>), dim3(8192), dim3(256), 0, 0, din, dbad, 64, kTable[F]);
   hipError_t e = hipDeviceSynchronize();
@@ -153,10 +214,17 @@ int main(int argc, char** argv) {
   (void)hipMalloc(&din, n * sizeof(float));
   (void)hipMalloc(&dbad, 8 * sizeof(unsigned));
   (void)hipMemcpy(din, h, n * sizeof(float), hipMemcpyHostToDevice);
-  if (argc > 2 && argv[2][0] == 's') {
+  if (argc > 2 && argv[2][0] == 's') {   // "self" [m|v|l|g|d|t]
     (void)hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking);
     (void)hipMalloc(&g_burn_out, 16);
-    printf("competing MFMA work from this process on a second stream\n");
+    (void)hipMalloc(&g_burn_src, 65536 + 4096);
+    (void)hipMemset(g_burn_src, 0, 65536 + 4096);
+    const char kind = argc > 3 ? argv[3][0] : 'm';
+    const char* kinds = "mvlgdt";
+    for (int i = 0; kinds[i]; ++i)
+      if (kinds[i] == kind) g_kind = i;
+    const char* names[] = {"MFMA", "plain VALU", "LDS read/write", "global reads", "LDS-DMA", "transcendental"};
+    printf("competing %s work from this process on a second stream\n", names[g_kind]);
   }
   printf("%d launches x 8192 workgroups x 256 lanes x 64 issues per form = %ld lane-results per 16-lane group and half\n", launches,
          (long)launches * 8192 * 256 / 4);
