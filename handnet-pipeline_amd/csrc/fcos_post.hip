@@ -597,7 +597,7 @@ __global__ __launch_bounds__(1024) void nms_kernel(const NmsArgs a) {
     maxc_s = m;
   }
   // Up to kRankSort keys: RANK sort -- the keys are distinct (the candidate index is their low word), so the position of a key
-  // in the sorted list is the number of smaller keys; every thread owns one key (nthreads == npad >= K), counts over all K with
+  // in the sorted list is the number of smaller keys; a thread owns at most one key (nthreads >= npad >= K), counts over all K with
   // wave-uniform LDS reads (a broadcast, no bank conflict) and drops its key at that position of a second array: two barriers
   // instead of the bitonic network's 36-55 (round 4: the sort was about half of the kernel's 66 us at ~260 candidates).  The
   // order is the same total order, so everything downstream is bit-identical.

@@ -34,4 +34,4 @@ print(f"tile {tile} {n}x{h}x{w}x{cin}->{cout} r{r} residual={res}: {len(a)} work
 for i, nm in enumerate(names):
     print(f"  {nm:26s} {np.median(d[:, i]):9.0f}   (p10 {np.percentile(d[:, i], 10):.0f}, p90 {np.percentile(d[:, i], 90):.0f})")
 print(f"  {'total':26s} {np.median(a[:, 6] - a[:, 0]):9.0f}")
-print(f"  {'span over all workgroups':26s} {int(a[:, 6].max() - a[:, 0].min()):9d}   (first entry -> last store retired; entry spread {int(a[:, 0].max() - a[:, 0].min())})")
+print(f"  {'span over all workgroups':26s} {int(a[:, 6].max() - a[:, 0].min()):9d}   (first entry -> last store retired, only meaningful when the stamp buffer holds ONE launch; entry spread {int(a[:, 0].max() - a[:, 0].min())})")
