@@ -117,7 +117,9 @@ def test_bench_line_contract():
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
     assert 400.0 < roof["clock_mhz"] < 2600.0                       # s_memtime / s_memrealtime under load
     # batch 2 != the profiled batch 32 (or, between collections, a PMC file of an older kernel revision): never paired
-    assert roof["traffic"] is None and ("launches/step" in roof["traffic_source"] or "another revision" in roof["traffic_source"])
+    # (... or, on a box whose timing puts another kernel first at this small batch, "this run's dominant kernel is ...")
+    assert roof["traffic"] is None and any(why in roof["traffic_source"] for why in
+                                           ("launches/step", "another revision", "dominant kernel"))
     assert set(roof["stages"]) >= {"resnet34_body", "fpn", "towers", "head_outputs", "a2j_trunk", "a2j_heads"}
     dr = d["dropin"]
     assert dr["batch1"]["frames_per_s"] > 0 and dr["batch2"]["frames_per_s"] > 0 and "HandNet.forward" in dr["call"]
