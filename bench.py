@@ -4,10 +4,13 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Both forms run N ranks, one per GPU: started without a torchrun environment and with --gpus > 1, this
-file launches `python -m torch.distributed.run` on itself BEFORE anything touches the GPU (the parent
-never initialises HIP, relays the children's output and exits with their status).  A world size that
-differs from --gpus is an error, never a silent single-GPU run.
+Both forms run N ranks, one per GPU.  For N > 1 the process that is started (by hand, or by torchrun as one of its ranks)
+never touches the GPU: it is the SUPERVISOR of fresh worker processes (one per rank it owns) and runs the launch ladder --
+if the workers die BEFORE the first timed step because the process group / RCCL cannot start (the IPC-handle mode is a host
+property this file cannot know in advance), it starts ONE fresh set with HSA_ENABLE_IPC_MODE_LEGACY toggled (default "0" ->
+unset) and the line reports which mode ran (`config.ipc_mode`).  Never a gloo fallback, never a re-exec, never a silent
+single-GPU run: a world size that differs from --gpus is an error, and so is a second failed attempt (the backend's error
+text is printed).  Every attempt rendezvouses through its own file:// store with a bounded timeout (--init-timeout).
 
 One "step" = one pass of HandNet (FCOS detector, top-1 hand crop, A2J) over one batch of
 synthetic 640x480 RGB-D frames already resident in HBM, plus -- for N > 1 -- the all-gather
@@ -15,7 +18,15 @@ of the per-frame results (RCCL).  Weak scaling: every rank processes its own `--
 frames (BASELINE.json config 4: 32 frames on one GPU; config 5: 8 x 32).  Rank 0 prints ONE
 JSON line; `value` is whole-job frames/s = N * batch * K / max-over-ranks(time).
 
+For N > 1 the step is replayed from a captured hipGraph by default (N Python hosts share the box's cores; --eager turns it
+off); every rank reports its device (`config.devices`: PCI bus ids, asserted distinct) and its own time per step
+(`rank_ms`: [min, median, max] over the ranks of the HIP-event time of the engine's launches, so a straggler is visible
+beside the max-over-ranks wall time that `value` is computed from).
+
 Extra objects in the line:
+  other_configs the other single-GPU configurations of BASELINE.json, 5 timed steps each (default N = 1 run only): a2j_b64
+                (config 2), fcos_b16 (config 3), pipeline_b1 (the reference caller's own batch, ros_demo.py:270; hipGraph
+                replay) -- value, ms_per_step and the dominant kernel's roofline fraction of each.
   roofline      dominant kernel (the conv_igemm_f16x3_kernel instantiation with the largest share of
                 the step; conv_igemm_f32_kernel with --precision f32): ALGORITHMIC FLOP per launch /
                 average launch duration, both measured live with HIP events on the launch stream
@@ -71,7 +82,15 @@ def parse():
                     help="f16x3: split-fp16 operands on the f16 MFMA (fp32-grade results; the headline); f32: exact f32 MFMA; "
                          "f16x1: hi*hi term only = plain fp16 operands, 1 MFMA per MAC -- the THROUGHPUT mode SURVEY D6 plans "
                          "beside the parity mode: misses the 1e-3 contract, reported with its error figures, never the headline")
-    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (the default for --gpus > 1)")
+    ap.add_argument("--eager", action="store_true", help="--gpus > 1: issue the step's launches from Python instead of replaying a graph")
+    ap.add_argument("--init-timeout", type=float, default=180.0,
+                    help="--gpus > 1: seconds the process group may take to start (rendezvous + first collective) per attempt")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the other single-GPU BASELINE configurations (a2j_b64, fcos_b16, pipeline_b1) of the default run")
+    ap.add_argument("--stub-engine", action="store_true",
+                    help="TEST ONLY: a CPU stand-in for the engine (sleeps, deterministic records) so that the N-rank plumbing of "
+                         "this file -- ladder, rendezvous, gather, line -- runs on gloo without a GPU; the line says so")
     ap.add_argument("--native", action="store_true",
                     help="drive the step through the model-level C ABI (C++ layer graphs, csrc/model.hip) instead of "
                          "the Python engines; same launches, same results")
@@ -152,6 +171,7 @@ def build_workload(args, dev, rank):
     eng = HandNetEngine(fcos, a2j, 3)
     info.update(unit="frames/s", gflop_per_unit=2 * (fcos.macs_per_frame() + a2j.macs_per_crop()) / 1e9,
                 name="Full HandNet pipeline (FCOS -> crop -> A2J), 640x480 RGB-D (BASELINE config 4)", engine=eng)
+    info["eager_step"] = lambda: eng.forward_device(rgb, depth)  # noqa: E731 -- (the roofline leg instruments eager launches)
     if args.native:
         from hn_amd.native_model import NativeModel
         from hn_amd.pipeline import HandNetOutput
@@ -382,61 +402,299 @@ def cpu_baseline(args, sds, engine=None, dev=None):
     return res
 
 
-def self_launch(args):
-    """`python bench.py --gpus N` (N > 1) outside torchrun: start one rank per GPU with torch.distributed.run and
-    relay its output.  Runs BEFORE anything initialises HIP in this process (no torch.cuda.is_available(), no
-    library load): the parent only waits for the children and exits with their status -- it is never replaced by
-    another program."""
-    have = torch.cuda.device_count()          # does not initialise the GPU on this image
-    if not args.share_gpu and have < args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but only {have} GPU(s) are visible "
-                         "(--share-gpu --dist-backend gloo rehearses the plumbing on one)")
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
-    print(f"[bench] launching {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
-    sys.exit(subprocess.run(cmd).returncode)
+EXIT_INIT_FAILED = 75   # a worker's exit status when the process group could not start (before the first timed step)
+IPC_VAR = "HSA_ENABLE_IPC_MODE_LEGACY"
+
+
+def _ipc_label(env):
+    return f"{IPC_VAR}={env[IPC_VAR]}" if IPC_VAR in env else f"{IPC_VAR} unset"
+
+
+def _ladder_envs():
+    """The two rungs of the launch ladder: the environment as it is (this file defaults the IPC variable to "0", which the
+    one-GPU boxes need), then ONE alternative with the variable toggled ("0" -> unset; anything else -> "0")."""
+    first = dict(os.environ)
+    second = dict(os.environ)
+    if first.get(IPC_VAR) == "0":
+        second.pop(IPC_VAR)
+    else:
+        second[IPC_VAR] = "0"
+    return [first, second]
+
+
+def supervise(args):
+    """N > 1: this process never initialises HIP.  It owns the workers of one or more ranks (all N when started by hand, its
+    own rank when torchrun started it), relays their output (inherited stdout / stderr) and walks the launch ladder: a worker
+    that fails before it has written its `ready` marker -- i.e. before the process group has carried a collective -- marks the
+    attempt as failed; every supervisor of the job sees the mark (shared directory), stops ITS workers by pid, and all start
+    one fresh set on the next rung.  Returns the exit status."""
+    import signal
+    import tempfile
+    under_torchrun = "WORLD_SIZE" in os.environ
+    if under_torchrun:
+        world = int(os.environ["WORLD_SIZE"])
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as "
+                             f"{args.gpus} GPUs")
+        ranks = [(int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")))]
+        # one directory per job: the ranks of a torchrun job share their parent (the elastic agent)
+        ppid = os.getppid()
+        try:
+            start = Path(f"/proc/{ppid}/stat").read_text().rsplit(")", 1)[1].split()[19]
+        except Exception:  # noqa: BLE001
+            start = "0"
+        job_dir = Path(tempfile.gettempdir()) / f"hn_bench_{ppid}_{start}_{os.environ.get('MASTER_PORT', '0')}"
+        job_dir.mkdir(exist_ok=True)
+    else:
+        if not args.stub_engine and not args.share_gpu:
+            have = torch.cuda.device_count()          # does not initialise the GPU on this image
+            if have < args.gpus:
+                raise SystemExit(f"--gpus {args.gpus} but only {have} GPU(s) are visible "
+                                 "(--share-gpu --dist-backend gloo rehearses the plumbing on one)")
+        world = args.gpus
+        ranks = [(r, r) for r in range(world)]
+        job_dir = Path(tempfile.mkdtemp(prefix="hn_bench_"))
+    cmd = [sys.executable, str(Path(__file__).resolve())] + sys.argv[1:]
+    children = []
+
+    def stop_children(*_):
+        for c in children:
+            if c.poll() is None:
+                c.terminate()
+        for c in children:
+            try:
+                c.wait(timeout=15)
+            except subprocess.TimeoutExpired:
+                c.kill()
+                c.wait()
+
+    def on_signal(signum, _frame):
+        stop_children()
+        sys.exit(128 + signum)
+    signal.signal(signal.SIGTERM, on_signal)
+    signal.signal(signal.SIGINT, on_signal)
+
+    envs = _ladder_envs()
+    status = 1
+    for attempt, base in enumerate(envs):
+        failed = job_dir / f"attempt{attempt}.failed"
+        print(f"[bench] attempt {attempt + 1} of {len(envs)}: starting {len(ranks)} worker(s) of {world} ranks with "
+              f"{_ipc_label(base)}", file=sys.stderr, flush=True)
+        children.clear()
+        for rank, local in ranks:
+            env = dict(base, RANK=str(rank), LOCAL_RANK=str(local), WORLD_SIZE=str(world), HN_BENCH_WORKER="1",
+                       HN_BENCH_ATTEMPT=str(attempt), HN_BENCH_DIR=str(job_dir), HN_BENCH_IPC_MODE=_ipc_label(base))
+            env.setdefault("MASTER_ADDR", "127.0.0.1")
+            children.append(subprocess.Popen(cmd, env=env))
+        init_failed = False
+        while True:
+            codes = [c.poll() for c in children]
+            for (rank, _), code in zip(ranks, codes):
+                if code not in (None, 0) and not (job_dir / f"attempt{attempt}.rank{rank}.ready").exists():
+                    init_failed = True        # died before the group carried a collective (whatever the status: a watchdog abort too)
+                    if not failed.exists():
+                        try:
+                            failed.write_text(f"rank {rank}: worker exited with status {code} before the process group was up\n")
+                        except OSError:
+                            pass
+            if failed.exists():
+                init_failed = True
+            if init_failed or all(c is not None for c in codes):
+                break
+            time.sleep(0.1)
+        if init_failed:
+            stop_children()
+            why = failed.read_text().strip() if failed.exists() else "unknown"
+            print(f"[bench] attempt {attempt + 1} failed to initialise: {why}", file=sys.stderr, flush=True)
+            if attempt + 1 < len(envs):
+                (job_dir / f"attempt{attempt + 1}.why").write_text(why[:400])
+                continue
+            status = EXIT_INIT_FAILED
+            break
+        status = max((c.returncode for c in children), key=abs)
+        break
+    if not under_torchrun:
+        import shutil
+        shutil.rmtree(job_dir, ignore_errors=True)
+    return status
+
+
+class _StubOutput:
+    def __init__(self, keypoints, crop_box, has_hand):
+        self.keypoints, self.crop_box, self.has_hand = keypoints, crop_box, has_hand
+
+
+def stub_workload(args, rank):
+    """TEST ONLY (--stub-engine): a CPU stand-in for the engine, so that the N-rank plumbing of THIS file runs where there is
+    no GPU.  Records are a pure function of (rank, frame); rank r's step sleeps 2 + 0.5 r ms (a visible straggler)."""
+    batch = args.batch or 4
+    frames = torch.arange(batch, dtype=torch.float32) + 100.0 * rank
+    kp = frames.reshape(batch, 1, 1) + torch.arange(63, dtype=torch.float32).reshape(1, 21, 3) * 0.01
+    box = torch.stack([frames.to(torch.int64), frames.to(torch.int64) + 1, frames.to(torch.int64) + 30,
+                       frames.to(torch.int64) + 40], dim=1)
+    has = torch.ones((batch,), dtype=torch.int32)
+
+    def step():
+        time.sleep(0.002 + 0.0005 * rank)
+        return _StubOutput(kp, box, has)
+    info = {"batch_per_gpu": batch, "unit": "frames/s", "gflop_per_unit": 0.0,
+            "name": "STUB engine (plumbing test of bench.py on CPU: no GPU work, not a measurement)"}
+    return step, info, None
+
+
+def device_identity(args, local, rank):
+    """What this rank computes on: PCI bus id (+ uuid when torch exposes it) of its GPU."""
+    if args.stub_engine:
+        return f"cpu-stub:{rank}"
+    import ctypes
+    from hn_amd import _lib
+    buf = ctypes.create_string_buffer(64)
+    _lib.check(_lib.load().hn_device_pci_bus_id(buf, 64), "hn_device_pci_bus_id")     # (the current device = cuda:local)
+    p = torch.cuda.get_device_properties(local)
+    uuid = getattr(p, "uuid", None)
+    return f"{buf.value.decode()} {p.name}" + (f" uuid={uuid}" if uuid is not None else "")
+
+
+def other_configs_leg(args, info, dev):
+    """BASELINE.json's other single-GPU configurations on the engines this run has already built (5 timed steps each, inputs
+    resident in HBM): config 2 (A2J-only, batch 64; a2j_infer.py:58-60), config 3 (FCOS-only, batch 16;
+    trainval_net_fcos.py:124-130,173) and the full pipeline at batch 1 (the reference caller's own batch, ros_demo.py:270;
+    hipGraph replay, as the drop-in runs it).  Each: value, ms_per_step, and the dominant kernel's roofline fraction from
+    HIP-event-instrumented eager steps."""
+    from hn_amd import synth
+    eng = info["engine"]
+    terms = 1 if args.precision == "f16x1" else 3
+    out = {}
+
+    def timed(step, units, steps=5, warm=2):
+        for _ in range(warm):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return {"value": round(units * steps / dt, 2), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps}
+
+    def roof_of(step, ms):
+        r = roofline_leg(step, 2, ms, sample_clock=False, terms=terms)
+        if r is None:
+            return {}
+        return {"kernel": r["kernel"], "frac": r["frac"], "achieved_tflops": r["achieved"], "avg_launch_us": r["avg_launch_us"],
+                "launches_per_step": r["launches_per_step"], "all_conv_tflops": r["all_conv_achieved"]}
+
+    crops = synth.make_crops(64, 176, seed=3000).to(dev)
+    rec = timed(lambda: eng.a2j.forward(crops), 64)
+    rec.update(unit="crops/s", workload="A2J-only inference, batch 64 176x176 depth crops (BASELINE config 2)",
+               gflop_per_unit=round(2 * eng.a2j.macs_per_crop() / 1e9, 3), **roof_of(lambda: eng.a2j.forward(crops), rec["ms_per_step"]))
+    out["a2j_b64"] = rec
+    del crops
+    rgb16 = synth.make_rgb(16, seed=1000).to(dev)
+    rec = timed(lambda: eng.fcos.detect(rgb16), 16)
+    rec.update(unit="frames/s", workload="FCOS ResNet34-FPN detector, batch 16 640x480 RGB (BASELINE config 3)",
+               gflop_per_unit=round(2 * eng.fcos.macs_per_frame() / 1e9, 3), **roof_of(lambda: eng.fcos.detect(rgb16), rec["ms_per_step"]))
+    out["fcos_b16"] = rec
+    del rgb16
+    rgb1, dep1 = synth.make_rgb(1, seed=1000).to(dev), synth.make_depth(1, seed=2000).to(dev)
+    run, _, _, _ = eng.graphed(rgb1, dep1)
+    rec = timed(run, 1, steps=max(5, 50), warm=5)
+    rec.update(unit="frames/s", hipgraph=True,
+               workload="Full HandNet pipeline at batch 1 (the reference caller's batch, ros_demo.py:270), hipGraph replay",
+               **roof_of(lambda: eng.forward_device(rgb1, dep1), rec["ms_per_step"]))
+    out["pipeline_b1"] = rec
+    return out
 
 
 def main():
     args = parse()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        self_launch(args)
+    if args.gpus > 1 and "HN_BENCH_WORKER" not in os.environ:
+        sys.exit(supervise(args))
+    worker(args)
+
+
+def worker(args):
     from hn_amd import dist as hdist
+    multi = args.gpus > 1
+    attempt = int(os.environ.get("HN_BENCH_ATTEMPT", "0"))
+    job_dir = Path(os.environ["HN_BENCH_DIR"]) if multi else None
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}: refusing to report a {world_env}-rank run as "
+                         f"{args.gpus} GPUs")
     if args.share_gpu:
         os.environ["LOCAL_RANK"] = "0"
+    rank_env = int(os.environ.get("RANK", "0"))
+    devices = None
     try:
-        rank, local, world = hdist.init_from_env(args.dist_backend if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
-    except Exception as e:  # noqa: BLE001 -- RCCL / rendezvous failure: report it and stop; never a fallback, never a re-exec
-        raise SystemExit(f"[bench] rank {os.environ.get('RANK', '0')}: torch.distributed ({args.dist_backend}) failed to "
-                         f"initialise for --gpus {args.gpus}: {type(e).__name__}: {e}")
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as "
-                         f"{args.gpus} GPUs")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+        if multi and os.environ.get("HN_BENCH_INJECT_INIT_FAILURE") in (f"{rank_env}:{attempt}", f"{rank_env}:*"):
+            # (tests: what a host whose IPC-handle mode does not match looks like to this file)
+            raise RuntimeError("injected for the ladder test: hipIpcGetMemHandle: invalid argument")
+        rank, local, world = hdist.init_from_env(
+            args.dist_backend if multi else None,
+            init_method=f"file://{job_dir}/store{attempt}" if multi else None, timeout_s=args.init_timeout if multi else None)
+        if not args.stub_engine:
+            if not torch.cuda.is_available():
+                raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+            torch.cuda.set_device(local)
+        if multi:
+            # the first collective: every rank's device, on every rank (also what proves that the group carries data)
+            devices = [None] * world
+            dist.all_gather_object(devices, device_identity(args, local, rank))
+            (job_dir / f"attempt{attempt}.rank{rank}.ready").write_text("up\n")
+    except SystemExit:
+        raise
+    except Exception as e:  # noqa: BLE001 -- RCCL / rendezvous failure: report it; the supervisor decides about the second rung
+        msg = (f"rank {rank_env}: torch.distributed ({args.dist_backend}) failed to initialise for --gpus {args.gpus} with "
+               f"{os.environ.get('HN_BENCH_IPC_MODE', _ipc_label(os.environ))}: {type(e).__name__}: {e}")
+        print(f"[bench] {msg}", file=sys.stderr, flush=True)
+        if job_dir is not None:
+            try:
+                with open(job_dir / f"attempt{attempt}.failed", "x") as f:
+                    f.write(msg[:2000] + "\n")
+            except OSError:
+                pass
+        sys.exit(EXIT_INIT_FAILED)
+    if multi and not args.share_gpu and not args.stub_engine and len(set(devices)) != world:
+        raise SystemExit(f"[bench] {world} ranks but only {len(set(devices))} distinct devices: {devices}")
+    dev = torch.device("cpu") if args.stub_engine else torch.device("cuda", local)
     # development host: the HN_* A/B variables of tools/ select older kernel forms / launch structures for same-box comparisons
     # (hn_amd/forms.py).  The product itself never reads them; a run that used any reports them in config.forms.
-    from hn_amd import forms
-    forms_used = forms.apply_env()
+    forms_used = None
+    if not args.stub_engine:
+        from hn_amd import forms
+        forms_used = forms.apply_env()
     if world > 1:   # N ranks build their engines at once on one host: share the cores instead of oversubscribing them N-fold
         torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
+        if args.workload == "pipeline" and not args.eager and not args.native:
+            args.graph = True   # N Python hosts on one box: replay the step instead of issuing ~150-200 launches per rank from Python
 
-    step, info, sds = build_workload(args, dev, rank)
+    if args.stub_engine:
+        step, info, sds = stub_workload(args, rank)
+    else:
+        step, info, sds = build_workload(args, dev, rank)
     batch = info["batch_per_gpu"]
+    on_gpu = not args.stub_engine
 
     gathered = {"rows": None}
+    ev = {"pairs": [], "on": False}
 
     def full_step():
+        if ev["on"] and on_gpu:     # HIP events (torch's current stream = the launch stream) around THIS rank's engine work
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+        t_a = time.perf_counter()
         out = step()
+        if ev["on"]:
+            if on_gpu:
+                b.record()
+                ev["pairs"].append((a, b))
+            else:
+                ev["pairs"].append(time.perf_counter() - t_a)
         if world > 1 and args.workload == "pipeline":
-            if args.dist_backend == "gloo":  # rehearsal only: gloo gathers host tensors
+            if args.dist_backend == "gloo" and on_gpu:  # rehearsal only: gloo gathers host tensors
                 g = hdist.gather_results(out.keypoints.cpu(), out.crop_box.cpu(), out.has_hand.cpu(), per_rank=batch)
             else:
                 g = hdist.gather_results(out.keypoints, out.crop_box, out.has_hand, per_rank=batch)
@@ -444,23 +702,38 @@ def main():
         return out
 
     def fence():
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            if on_gpu:
+                torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         full_step()
     fence()
+    ev["on"] = world > 1
     t0 = time.perf_counter()
     for _ in range(args.steps):
         full_step()
     fence()
     elapsed = time.perf_counter() - t0
+    ev["on"] = False
+    rank_ms = None
     if world > 1:
-        t = torch.tensor([elapsed], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
+        on_dev = args.dist_backend == "nccl" and on_gpu
+        t = torch.tensor([elapsed], device=dev if on_dev else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # every rank's own engine time per step (HIP events; without the gather and without waiting for the others)
+        mine = (sum(a.elapsed_time(b) for a, b in ev["pairs"]) if on_gpu else 1e3 * sum(ev["pairs"])) / max(1, args.steps)
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, float(mine))
+        srt = sorted(per_rank)
+        rank_ms = {"min_median_max": [round(srt[0], 3), round(srt[len(srt) // 2] if len(srt) % 2 else
+                                      0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2]), 3), round(srt[-1], 3)],
+                   "per_rank": [round(v, 3) for v in per_rank],
+                   "what": "engine launches of one step on each rank's own stream (HIP events), without the all-gather"}
 
     # what the collective really spanned: ranks seen by an actual all_gather_into_tensor (not the --gpus flag)
     rccl_ranks = world
@@ -469,20 +742,28 @@ def main():
         if rccl_ranks != world or not bool(gathered["rows"].all()):
             raise SystemExit(f"all-gather returned {gathered['rows'].numel()} rows for {world} ranks x {batch} frames")
     roof = None
-    if not args.no_roofline and not args.graph and not args.native:
-        roof = roofline_leg(step, max(1, min(args.steps, 3)), 1e3 * elapsed / args.steps, not args.no_clock_sample,
-                            terms=1 if args.precision == "f16x1" else 3)
+    if on_gpu and not args.no_roofline and not args.native and (not args.graph or "eager_step" in info):
+        roof = roofline_leg(info.get("eager_step", step) if args.graph else step, max(1, min(args.steps, 3)),
+                            1e3 * elapsed / args.steps, not args.no_clock_sample, terms=1 if args.precision == "f16x1" else 3)
+    single = rank == 0 and world == 1 and on_gpu
     dropin = None
-    if (rank == 0 and world == 1 and args.workload == "pipeline" and not args.no_dropin and not args.native
-            and not args.graph):
+    if single and args.workload == "pipeline" and not args.no_dropin and not args.native and not args.graph:
         dropin = dropin_leg(args, sds, dev, batch)
+    others = None
+    if single and args.workload == "pipeline" and not args.no_other_configs and not args.native and not args.graph:
+        others = other_configs_leg(args, info, dev)
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if single and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, sds, info.get("engine"), dev)
 
     if rank == 0:
         units = world * batch * args.steps
         value = units / elapsed
+        why_file = job_dir / f"attempt{attempt}.why" if multi else None
+        ipc_mode = os.environ.get("HN_BENCH_IPC_MODE", _ipc_label(os.environ))
+        if multi:
+            ipc_mode += f" (attempt {attempt + 1} of 2" + (f"; the first set failed to initialise: {why_file.read_text().strip()}"
+                                                         if why_file.exists() else "") + ")"
         line = {
             "metric": "end-to-end frames/sec (FCOS+A2J, 640x480)" if args.workload == "pipeline"
             else f"{args.workload} throughput",
@@ -499,14 +780,18 @@ def main():
                        "frame": {"a2j": "176x176 depth crop", "pose2mesh": "21 x 2-D joints"}.get(args.workload, "640x480 RGB-D"),
                        "parallelism": f"frames sharded over {world} GPU(s), one all-gather of per-frame records per step",
                        "collective_backend": (dist.get_backend() if world > 1 else None), "rccl_ranks": rccl_ranks,
+                       "devices": devices, "ipc_mode": ipc_mode,
                        "gflop_per_unit": round(info["gflop_per_unit"], 3), "hipgraph": bool(args.graph),
-                       "host": "C++ layer graph (model-level C ABI)" if args.native else "Python engines (op-level C ABI)",
+                       "host": "STUB" if args.stub_engine else "C++ layer graph (model-level C ABI)" if args.native
+                       else "Python engines (op-level C ABI)",
                        "forms": forms_used or None},
             "algorithmic_tflops": round(value * info["gflop_per_unit"] / 1e3, 2),
-            "roofline": roof, "dropin": dropin, "cpu_baseline": cpu,
+            "rank_ms": rank_ms,
+            "roofline": roof, "other_configs": others, "dropin": dropin, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

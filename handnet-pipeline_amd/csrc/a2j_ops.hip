@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restri
         if ((unsigned)ix >= (unsigned)w) continue;
         const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((long)img * h + iy) * w + ix) * c4 * 4 + cc * 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+        for (int e = 0; e < 4; ++e) m[e] = hn::max_nan(m[e], v[e]);
       }
     }
     *reinterpret_cast<f32x4*>(y + i * 4) = m;
@@ -389,11 +389,17 @@ __global__ __launch_bounds__(256) void stem_image_kernel(const float* __restrict
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         if (range_flag) hn::range_note_input(range_flag, v[e]);
-        // a non-finite pixel: mark the image (every writer stores the same value; images with valid == 0 stay 0)
-        if (valid && !(fabsf(v[e]) <= 3.402823466e38f) && valid[img] == 1) valid[img] = 2;
-        const _Float16 hh = (_Float16)v[e];
+        float ve = v[e];
+        // a non-finite pixel: mark the image (every writer stores the same value; images with valid == 0 stay 0) and keep
+        // the value OUT of the network -- the aggregation writes the NaN row of a marked image whatever the convolutions
+        // compute for it, and with no NaN of the caller's inside, a NaN activation always means a defect (range contract)
+        if (valid && !(fabsf(ve) <= 3.402823466e38f)) {
+          if (valid[img] == 1) valid[img] = 2;
+          ve = 0.f;
+        }
+        const _Float16 hh = (_Float16)ve;
         hi[e] = hh;
-        lo[e] = (_Float16)(v[e] - (float)hh);
+        lo[e] = (_Float16)(ve - (float)hh);
       }
     }
     *reinterpret_cast<f16x4s*>(dst + i * 4) = hi;

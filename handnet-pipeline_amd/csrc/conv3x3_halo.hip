@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const HaloParams p
       }
       if (p.relu) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        for (int e = 0; e < 8; ++e) v[e] = hn::relu(v[e]);
       }
       f16x8 hi, lo;
       if (p.range_flag) hn::range_note_n<8>(p.range_flag, v);

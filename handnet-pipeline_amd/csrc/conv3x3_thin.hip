@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kNT, 2) void conv3x3_thin_kernel(const ThinParams p
       const int n = lg * 4 + r;
       if (n >= p.cout) continue;
       float v = acc[i][r] + (p.bias ? p.bias[n] : 0.f);
-      if (n < p.relu_cols) v = fmaxf(v, 0.f);
+      if (n < p.relu_cols) v = hn::relu(v);
       dst[n] = v;
     }
   }
@@ -312,8 +312,8 @@ __global__ __launch_bounds__(kNT, 1) void conv3x3_thin_flat_kernel(const FlatPar
             for (int e = 0; e < 4; ++e) {   // hn_affine_split_f32 with relu = 1, expression for expression
               a[e] = a[e] * s0[e] + t0[e];
               b[e] = b[e] * s1[e] + t1[e];
-              a[e] = fmaxf(a[e], 0.f);
-              b[e] = fmaxf(b[e], 0.f);
+              a[e] = hn::relu(a[e]);
+              b[e] = hn::relu(b[e]);
               if (p.range_flag && (hn::range_bad(a[e]) | hn::range_bad(b[e]))) *p.range_flag = 1;
               const _Float16 h0 = (_Float16)a[e], h1 = (_Float16)b[e];
               hi[e] = h0;
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(kNT, 1) void conv3x3_thin_flat_kernel(const FlatPar
       for (int oc = 0; oc < kFlatMaxC; ++oc)
         if (oc < cout) {
           float o = v[oc] + bv[oc];
-          if (oc < p.relu_cols) o = fmaxf(o, 0.f);
+          if (oc < p.relu_cols) o = hn::relu(o);
           dst[oc] = o;
         }
     }

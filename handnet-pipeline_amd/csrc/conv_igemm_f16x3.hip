@@ -202,11 +202,11 @@ __device__ __forceinline__ void epi_finish8(const ConvParams16& p, int m, int n,
   }
   if (p.relu_cols >= p.Cout) {  // the usual case (all columns): wave-uniform, 8 v_max
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+    for (int e = 0; e < 8; ++e) v[e] = hn::relu(v[e]);
   } else if (p.relu_cols > 0) {
 #pragma unroll
     for (int e = 0; e < 8; ++e)
-      if (n + e < p.relu_cols) v[e] = fmaxf(v[e], 0.f);
+      if (n + e < p.relu_cols) v[e] = hn::relu(v[e]);
   }
   if (p.out_split) {
     if (p.range_flag) hn::range_note_n<8>(p.range_flag, v);
@@ -956,8 +956,8 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(const ConvParams16& p, con
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(q.bias + n), b1 = *reinterpret_cast<const f32x4*>(q.bias + n + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          x[e] = ok ? fmaxf(x[e] + b0[e], 0.f) : 0.f;
-          y[e] = ok ? fmaxf(y[e] + b1[e], 0.f) : 0.f;
+          x[e] = ok ? hn::relu(x[e] + b0[e]) : 0.f;
+          y[e] = ok ? hn::relu(y[e] + b1[e]) : 0.f;
         }
         *reinterpret_cast<f32x4*>(patch + row * PITCH + n) = x;
         *reinterpret_cast<f32x4*>(patch + row * PITCH + n + 4) = y;
@@ -979,14 +979,14 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(const ConvParams16& p, con
           const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            m0v[e] = fmaxf(m0v[e], a[e]);
-            m1v[e] = fmaxf(m1v[e], b[e]);
+            m0v[e] = hn::max_nan(m0v[e], a[e]);
+            m1v[e] = hn::max_nan(m1v[e], b[e]);
           }
         }
       f16x8 hi, lo;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        if (p.range_flag && hn::range_mag(m0v[e], m1v[e]) > 65504.f) *p.range_flag = 1;
+        if (p.range_flag && !(hn::range_mag(m0v[e], m1v[e]) <= 65504.f)) *p.range_flag = 1;
         const _Float16 h0 = (_Float16)m0v[e], h1 = (_Float16)m1v[e];
         hi[e] = h0;
         hi[4 + e] = h1;
@@ -1135,7 +1135,7 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(const ConvParams16& p, con
             v += res32[rpix * p.rs + n];
           }
         }
-        if (n < p.relu_cols) v = fmaxf(v, 0.f);
+        if (n < p.relu_cols) v = hn::relu(v);
         if (p.out_split) {
           if (p.range_flag) hn::range_note(p.range_flag, v);
           _Float16* q = y16 + (long)m * p.ys + (n >> 5) * 64 + (n & 31);

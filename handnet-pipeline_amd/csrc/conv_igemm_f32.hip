@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
           const f32x4 sc = *reinterpret_cast<const f32x4*>(p.in_scale + o);
           const f32x4 sh = *reinterpret_cast<const f32x4*>(p.in_shift + o);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] * sc[e] + sh[e], 0.f);
+          for (int e = 0; e < 4; ++e) v[e] = hn::relu(v[e] * sc[e] + sh[e]);
         }
       }
       ra[it] = v;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-          if (n + e < p.relu_cols) v[e] = fmaxf(v[e], 0.f);
+          if (n + e < p.relu_cols) v[e] = hn::relu(v[e]);
         if (p.out_split) {
           f16x8 hi, lo;
 #pragma unroll
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
         float v = acc[i][j][r];
         if (p.bias) v += p.bias[n];
         if (p.res_mode) v += p.res[rbase + n];
-        if (n < p.relu_cols) v = fmaxf(v, 0.f);
+        if (n < p.relu_cols) v = hn::relu(v);
         if (p.out_split) {
           _Float16* q = reinterpret_cast<_Float16*>(p.y) + (long)m * p.ys + (n >> 5) * 64 + (n & 31);
           const _Float16 h = (_Float16)v;

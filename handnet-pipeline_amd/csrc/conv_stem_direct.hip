@@ -163,8 +163,8 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool_direct_kernel(const Ste
       const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        x[e] = ok[i] ? fmaxf(x[e] + b0[e], 0.f) : 0.f;
-        y[e] = ok[i] ? fmaxf(y[e] + b1[e], 0.f) : 0.f;
+        x[e] = ok[i] ? hn::relu(x[e] + b0[e]) : 0.f;
+        y[e] = ok[i] ? hn::relu(y[e] + b1[e]) : 0.f;
       }
       *reinterpret_cast<f32x4*>(fp + row * kPitch + n) = x;
       *reinterpret_cast<f32x4*>(fp + row * kPitch + n + 4) = y;
@@ -185,16 +185,16 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool_direct_kernel(const Ste
         const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          m0[e] = fmaxf(m0[e], a[e]);
-          m1[e] = fmaxf(m1[e], b[e]);
+          m0[e] = hn::max_nan(m0[e], a[e]);
+          m1[e] = hn::max_nan(m1[e], b[e]);
         }
       }
     f16x8 hi, lo;
     if (p.range_flag) {
       float mg = 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) mg = fmaxf(mg, hn::range_mag(m0[e], m1[e]));
-      if (mg > 65504.f) *p.range_flag = 1;
+      for (int e = 0; e < 4; ++e) mg = hn::max_nan(mg, hn::range_mag(m0[e], m1[e]));
+      if (!(mg <= 65504.f)) *p.range_flag = 1;
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {

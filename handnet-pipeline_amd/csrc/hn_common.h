@@ -61,19 +61,23 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 __device__ __forceinline__ void range_note(int* flag, float v) {
   if (!(fabsf(v) <= 65504.f)) *flag = 1;
 }
-// ACTIVATIONS, N values at once: one maximum of the magnitudes (v_max3_f32 with |.| modifiers) and ONE comparison -- a third of
-// the instructions of N separate range_note calls, which cost the short-k convolutions' epilogues +0.5 % of the batch-32
-// step.  The maximum ignores NaN operands, which is sound here: a NaN can only be computed from an infinity or another NaN,
-// and the FIRST non-finite value of a step is either an input (range_note_input below is NaN-aware) or an overflow to a
-// magnitude beyond 65504 / to +-inf, which this check sees when it is produced.
-__device__ __forceinline__ float range_mag(float a, float b) { return fmaxf(fabsf(a), fabsf(b)); }
+// NaN-PROPAGATING maximum (IEEE 754-2019 "maximum": v_maximum3_f32 on gfx950, same issue cost as v_max3_f32, which returns the
+// non-NaN operand).  ReLU and max pooling are built on it, so a NaN activation stays NaN -- as torch.relu / max_pool2d keep it --
+// instead of being laundered to 0, and the range notes below see it.
+__device__ __forceinline__ float max_nan(float a, float b) { return __builtin_elementwise_maximum(a, b); }
+__device__ __forceinline__ float relu(float v) { return max_nan(v, 0.f); }
+// ACTIVATIONS, N values at once: one NaN-propagating maximum of the magnitudes (v_maximum3_f32 with |.| modifiers) and ONE
+// comparison -- a third of the instructions of N separate range_note calls, which cost the short-k convolutions' epilogues
+// +0.5 % of the batch-32 step.  !(m <= 65504) is true for a magnitude beyond the fp16 range, for +-inf AND for NaN (an fp32
+// residual or bias that carries one, inf - inf inside an accumulator).
+__device__ __forceinline__ float range_mag(float a, float b) { return max_nan(fabsf(a), fabsf(b)); }
 __device__ __forceinline__ bool range_bad(float v) { return !(fabsf(v) <= 65504.f); }
 template <int N>
 __device__ __forceinline__ void range_note_n(int* flag, const float (&v)[N]) {
   float m = fabsf(v[0]);
 #pragma unroll
-  for (int e = 1; e < N; ++e) m = fmaxf(m, fabsf(v[e]));
-  if (m > 65504.f) *flag = 1;
+  for (int e = 1; e < N; ++e) m = max_nan(m, fabsf(v[e]));
+  if (!(m <= 65504.f)) *flag = 1;
 }
 // the same for a value that comes straight from the caller's INPUT (preprocessed RGB, depth crops): word 1 of the flag
 // block for a finite value beyond the fp16 range, word 2 for a non-finite one (NaN / inf pixels of a depth camera, which

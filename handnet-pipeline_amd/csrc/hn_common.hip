@@ -11,10 +11,17 @@
 // GroupNorm apply); word 1: a finite INPUT value beyond +-65504 (preprocessed RGB, depth crop); word 2: a non-finite input
 // value (a depth camera's NaN / inf pixels); word 3 unused.
 __device__ int g_range_flag[4];
-static int g_range_check_on = 0;
-// hn_range_check_bind: the caller's own flag block (4 device words) instead of the library's, so that two engines of one
-// process never see each other's flags; read at LAUNCH time on the host, like the switch itself
-static int* g_range_bound = nullptr;
+// The switch and the bound block are state of the calling HOST THREAD, read at LAUNCH time: an engine that opens a scope
+// (hn_range_scope_begin) around its launches never changes what another thread's launches note into -- two engines driven
+// from two threads of one process (a ROS node's callbacks) keep their flags apart, and an engine that runs with noting off
+// does not turn it off for anybody else.
+static thread_local int g_range_check_on = 0;
+// hn_range_check_bind / hn_range_scope_begin: the caller's own flag block (4 device words) instead of the library's
+static thread_local int* g_range_bound = nullptr;
+// saved (switch, block) pairs of the open scopes of this thread
+struct RangeScope { int on; int* bound; };
+static thread_local RangeScope g_range_stack[8];
+static thread_local int g_range_depth = 0;
 
 namespace hn {
 
@@ -114,6 +121,14 @@ extern "C" int hn_device_info(int* cu_count, int* clock_khz, char* arch_name, in
   return HN_OK;
 }
 
+extern "C" int hn_device_pci_bus_id(char* out, int out_len) {
+  HN_CHECK_ARG(out && out_len >= 16, "hn_device_pci_bus_id: buffer of at least 16 bytes");
+  int dev = 0;
+  HN_CHECK_HIP(hipGetDevice(&dev));
+  HN_CHECK_HIP(hipDeviceGetPCIBusId(out, out_len, dev));
+  return HN_OK;
+}
+
 extern "C" int hn_event_create(void** ev) {
   HN_CHECK_ARG(ev, "hn_event_create: null");
   hipEvent_t e;
@@ -149,6 +164,22 @@ extern "C" int hn_range_check_enabled(void) { return g_range_check_on; }
 
 extern "C" int hn_range_check_bind(int32_t* block) {
   g_range_bound = block;
+  return HN_OK;
+}
+
+extern "C" int hn_range_scope_begin(int32_t* block, int on) {
+  HN_CHECK_ARG(g_range_depth < 8, "hn_range_scope_begin: more than 8 nested scopes on this thread");
+  g_range_stack[g_range_depth++] = RangeScope{g_range_check_on, g_range_bound};
+  g_range_check_on = on ? 1 : 0;
+  g_range_bound = on ? block : nullptr;
+  return HN_OK;
+}
+
+extern "C" int hn_range_scope_end(void) {
+  HN_CHECK_ARG(g_range_depth > 0, "hn_range_scope_end: no open scope on this thread");
+  const RangeScope s = g_range_stack[--g_range_depth];
+  g_range_check_on = s.on;
+  g_range_bound = s.bound;
   return HN_OK;
 }
 

@@ -1355,8 +1355,15 @@ extern "C" int hn_a2j_forward(hn_model* m, const float* crops, int k, int h, int
     T x;
     x.n = k; x.h = h; x.w = w; x.c = 4; x.ps = 4; x.split = false;
     x.p = cx.m->arena.take((size_t)k * h * w * 16);
-    if (!cx.dry) HN_TRY(hn_pack_depth_nhwc(crops, (float*)x.p, k, h * w, 4, cx.stream));
-    return a2j_graph(cx, x, valid, keypoints);
+    // flags of the call's own, like A2JEngine.forward: the stem marks a crop that holds NaN / inf pixels (2) and the
+    // aggregation writes its NaN row (a2j/a2j.py:243-250 returns NaN for such a crop); the caller's `valid` stays read-only
+    int32_t* flags = (int32_t*)alloc_bytes(cx, (size_t)k * 4);
+    if (!cx.dry) {
+      HN_TRY(hn_pack_depth_nhwc(crops, (float*)x.p, k, h * w, 4, cx.stream));
+      if (valid) HN_CHECK_HIP(hipMemcpyAsync(flags, valid, (size_t)k * 4, hipMemcpyDeviceToDevice, (hipStream_t)cx.stream));
+      else HN_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)flags, 1, (size_t)k, (hipStream_t)cx.stream));
+    }
+    return a2j_graph(cx, x, flags, keypoints, flags);
   });
 }
 

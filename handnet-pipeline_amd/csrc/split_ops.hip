@@ -54,8 +54,8 @@ __global__ __launch_bounds__(256) void affine_split_kernel(const float* __restri
     if (relu) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        a[e] = fmaxf(a[e], 0.f);
-        b[e] = fmaxf(b[e], 0.f);
+        a[e] = hn::relu(a[e]);
+        b[e] = hn::relu(b[e]);
       }
     }
     if (range_flag) {
@@ -111,8 +111,8 @@ __global__ __launch_bounds__(256) void affine_split_pow2_kernel(const float* __r
     if (relu) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        a[e] = fmaxf(a[e], 0.f);
-        b[e] = fmaxf(b[e], 0.f);
+        a[e] = hn::relu(a[e]);
+        b[e] = hn::relu(b[e]);
       }
     }
     if (range_flag) {
@@ -197,8 +197,8 @@ __global__ __launch_bounds__(256) void affine_split_pow2_levels_kernel(const Spl
     if (relu) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        a[e] = fmaxf(a[e], 0.f);
-        b[e] = fmaxf(b[e], 0.f);
+        a[e] = hn::relu(a[e]);
+        b[e] = hn::relu(b[e]);
       }
     }
     if (range_flag) {
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void maxpool_s32_kernel(const _Float16* __rest
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float v = (float)hi[e] + (float)lo[e];
-          if (v > best[e]) {
+          if (v > best[e] || v != v) {   // (a NaN wins and stays: torch max_pool2d propagates it)
             best[e] = v;
             bh[e] = hi[e];
             bl[e] = lo[e];

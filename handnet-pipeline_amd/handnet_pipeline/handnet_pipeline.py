@@ -177,7 +177,8 @@ class HandNet(EngineOwner):
         self._last_sparse = n >= 8 and int(mask_cpu.sum()) * 2 < n      # (the engine's own threshold for compaction)
         # the f16x3 range contract, decided on what has just been copied (hn_amd.pipeline.check_range_contract): overflow raises,
         # non-finite depth pixels give NaN rows like the reference
-        check_range_contract(final_results, flat[0, j3 + 1:].tolist() if out.range_flags is not None else None, depth_images)
+        check_range_contract(final_results, flat[0, j3 + 1:].tolist() if out.range_flags is not None else None, depth_images,
+                             has_hand=flat[:, j3])
         if not bool(mask_cpu.any()):  # handnet_pipeline.py:107-108: the crops placeholder is a CPU float tensor
             return torch.zeros((n, 21, 3)), torch.zeros_like(depth_images), torch.zeros((n, 4))
         if bool(mask_cpu.all()):      # the usual case: no gather (a boolean-mask index would synchronise once more)

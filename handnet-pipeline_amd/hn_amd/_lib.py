@@ -12,7 +12,7 @@ from pathlib import Path
 
 from . import build as _build
 
-ABI_VERSION = 31
+ABI_VERSION = 32
 
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, TILE_256x128, TILE_64x128 = range(7)
 HN_FCOS_MAX_LEVELS = 5
@@ -103,10 +103,13 @@ SIGNATURES = {
     "hn_clock_sample": (C.c_int, [C.c_int, VP, VP]),
     "hn_conv2d_nhwc_f16x3_multi": (C.c_int, [C.POINTER(ConvMulti), VP, C.c_int64, VP]),
     "hn_conv2d_f16x3_multi_fuses": (C.c_int, [C.POINTER(ConvMulti), C.c_int64]),
+    "hn_device_pci_bus_id": (C.c_int, [C.c_char_p, C.c_int]),
     "hn_range_check_enable": (C.c_int, [C.c_int]),
     "hn_range_check_fetch": (C.c_int, [c_i32p, C.c_int, VP]),
     "hn_range_check_enabled": (C.c_int, []),
     "hn_range_check_bind": (C.c_int, [VP]),
+    "hn_range_scope_begin": (C.c_int, [VP, C.c_int]),
+    "hn_range_scope_end": (C.c_int, []),
     "hn_range_check_collect": (C.c_int, [VP, VP, VP]),
     "hn_set_form": (C.c_int, [C.c_char_p, C.c_int]),
     "hn_set_tuning": (C.c_int, [C.c_char_p, C.c_double]),

@@ -250,13 +250,9 @@ class A2JEngine:
             return self.forward(depth), None
         if getattr(self, "_range_block", None) is None:
             self._range_block = torch.zeros((4,), device=self.device, dtype=torch.int32)
-        ops.range_check_enable(True)
-        ops.range_check_bind(self._range_block)
-        try:
+        with ops.range_scope(self._range_block):
             kp = self.forward(depth)
             flags = ops.range_check_collect(self._range_block)
-        finally:
-            ops.range_check_bind(None)
         return kp, flags
 
     @ops.device_guarded

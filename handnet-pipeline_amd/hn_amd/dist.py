@@ -14,10 +14,13 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: str | None = None, force: bool = False) -> tuple[int, int, int]:
+def init_from_env(backend: str | None = None, force: bool = False, init_method: str | None = None,
+                  timeout_s: float | None = None) -> tuple[int, int, int]:
     """torchrun-style env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*) -> (rank, local_rank, world).
     A process group is created for world > 1, or for a single rank when `force` is set (then gather_results() still
-    goes through the collective: the one-GPU rehearsal of the RCCL path)."""
+    goes through the collective: the one-GPU rehearsal of the RCCL path).  init_method: a rendezvous of the caller's own
+    (bench.py's launch ladder gives every attempt a fresh `file://` store) instead of env://; timeout_s bounds the
+    rendezvous and -- through the backend's watchdog -- every collective of the group."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -28,7 +31,13 @@ def init_from_env(backend: str | None = None, force: bool = False) -> tuple[int,
             backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" is RCCL on ROCm
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if init_method is not None:
+            kw["init_method"] = init_method
+        if timeout_s is not None:
+            import datetime
+            kw["timeout"] = datetime.timedelta(seconds=float(timeout_s))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local, world
 
 

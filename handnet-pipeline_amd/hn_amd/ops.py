@@ -6,6 +6,7 @@ there is deliberately no CPU or eager fallback.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 from dataclasses import dataclass
@@ -1219,6 +1220,20 @@ def range_check_bind(block=None):
     """Split producers launched from now on note into `block` (4 zeroed int32 on the GPU) instead of the library's own
     flag words; None unbinds.  Host-side state, read at launch time."""
     check(_lib.load().hn_range_check_bind(ptr(block) if block is not None else None), "hn_range_check_bind")
+
+
+@contextlib.contextmanager
+def range_scope(block=None, on=True):
+    """The f16x3 range contract for the launches of ONE step of ONE engine: inside the scope the split producers this HOST
+    THREAD launches note into `block` (4 zeroed int32 on the GPU; on=False: nowhere); on exit the thread's previous switch and
+    block are back (hn_range_scope_begin / _end: per-thread state in the library, so engines on other threads of the process
+    are never redirected or switched off)."""
+    lib = _lib.load()
+    check(lib.hn_range_scope_begin(ptr(block) if (block is not None and on) else None, 1 if on else 0), "hn_range_scope_begin")
+    try:
+        yield
+    finally:
+        check(lib.hn_range_scope_end(), "hn_range_scope_end")
 
 
 def range_check_collect(block=None, out=None):

@@ -47,21 +47,37 @@ def range_message(bits: int) -> str:
     return "in range"
 
 
-def check_range_contract(keypoints_cpu, words, inputs=None):
+def check_range_contract(keypoints_cpu, words, inputs=None, has_hand=None):
     """The f16x3 range contract of a step, decided on values the caller has copied to the host anyway.  words: the collected
-    flag words (ops.range_check_collect) as a host list, or None when noting is off (HN_CHECK_RANGE=0).
+    flag words (ops.range_check_collect) as a host list, or None when noting is off (HN_CHECK_RANGE=0); has_hand: the step's
+    per-frame flags on the host (2 = a frame whose crop holds non-finite pixels; None: A2J-only callers).
     Non-finite INPUTS are the reference's business -- ROS 32FC1 depth marks invalid pixels with NaN and ros_demo.py:227-231
     passes them on; its network then returns NaN keypoints for the crops that hold one, and so does this one -- so they never
     raise.  A finite input beyond +-65504 or an activation that overflows with in-range inputs WOULD give inf / NaN or (ReLU
     maps NaN to 0) silently wrong keypoints: those raise ops.RangeError."""
-    from ._lib import RANGE_INPUT_NONFINITE
+    from ._lib import RANGE_ACTIVATION, RANGE_INPUT, RANGE_INPUT_NONFINITE
     if words is not None:
         bits = ops.range_bits(words)
+        # an overflow raises whether or not the step ALSO saw non-finite input pixels (one NaN depth pixel in one frame of a
+        # batch must not switch the safety net off for the other frames)
+        if bits & (RANGE_ACTIVATION | RANGE_INPUT):
+            msg = range_message(bits & (RANGE_ACTIVATION | RANGE_INPUT))
+            if bits & RANGE_INPUT_NONFINITE:
+                msg += ("  (The step also saw non-finite input pixels.  NaN / inf DEPTH pixels are kept out of the network and "
+                        "give NaN keypoints for their frame, like the reference; non-finite RGB pixels are not supported: "
+                        "they propagate as NaN activations, which is what was flagged if the checkpoint is sound.)")
+            raise ops.RangeError(msg)
+        finite = torch.isfinite(keypoints_cpu)
         if bits & RANGE_INPUT_NONFINITE:
-            return
-        if bits:
-            raise ops.RangeError(range_message(bits))
-        if not bool(torch.isfinite(keypoints_cpu).all()):    # (e.g. a non-finite bias of an output convolution)
+            # rows of frames whose crop holds a non-finite pixel are NaN by contract (has_hand == 2); the others must be finite
+            if has_hand is not None:
+                marked = torch.as_tensor(has_hand).reshape(-1) == 2
+            elif inputs is not None and inputs.shape[0] == finite.shape[0]:   # the A2J-only entry: one crop per row
+                marked = ~torch.isfinite(inputs).flatten(1).all(dim=1).cpu()
+            else:
+                return
+            finite = finite.reshape(finite.shape[0], -1)[~marked]
+        if not bool(finite.all()):    # (e.g. a non-finite bias of an output convolution)
             raise ops.RangeError("non-finite keypoints from finite, in-range inputs: the checkpoint holds non-finite or "
                                  "extreme values; build the engines with precision='f32' to compare")
         return
@@ -106,9 +122,8 @@ class HandNetEngine:
         noting = self.note_range or self.check_range
         if noting and self._range_block is None:
             self._range_block = torch.zeros((4,), device=self.device, dtype=torch.int32)
-        ops.range_check_enable(noting)
-        ops.range_check_bind(self._range_block if noting else None)
-        try:
+        # (the scope is this host thread's: another engine on another thread keeps its own switch and block)
+        with ops.range_scope(self._range_block, on=noting):
             det, cand = self.fcos.detect(images)
             crop_box, has_hand, crops = ops.crop_resize(det, self.num_classes - 1, depth.float().contiguous(), CROP, 4,
                                                         reorder_bgr=self.a2j.rgbd)
@@ -116,8 +131,6 @@ class HandNetEngine:
             if kp is None:
                 kp = self.a2j.forward_nhwc(crops, valid=has_hand)
             flags = ops.range_check_collect(self._range_block) if noting else None
-        finally:
-            ops.range_check_bind(None)
         self._note_hand_count(has_hand, len(images))
         if self.check_range:
             bits = ops.range_bits(flags.cpu().tolist())
@@ -142,7 +155,7 @@ class HandNetEngine:
         if not self.compact_sparse or n < 8 or torch.cuda.is_current_stream_capturing() or self._hand_stat is not None:
             return
         pinned = torch.empty((1,), dtype=torch.int64, pin_memory=True)
-        pinned.copy_(has_hand.sum(dtype=torch.int64).reshape(1), non_blocking=True)
+        pinned.copy_((has_hand != 0).sum(dtype=torch.int64).reshape(1), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self._hand_stat = (ev, pinned, n)
@@ -157,7 +170,9 @@ class HandNetEngine:
             return None
         kp = torch.zeros((n, self.a2j.joints, 3), device=crops.device, dtype=torch.float32)
         if k:
-            kp[idx] = self.a2j.forward_nhwc(crops[idx].contiguous(), valid=has_hand[idx].contiguous())
+            v = has_hand[idx].contiguous()
+            kp[idx] = self.a2j.forward_nhwc(crops[idx].contiguous(), valid=v)
+            has_hand[idx] = v       # (the stem raises a flag to 2 for a crop with non-finite pixels: report it like the dense path)
         return kp
 
     # -------------------------------------------------------------------------------

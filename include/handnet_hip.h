@@ -33,12 +33,15 @@ extern "C" {
 #define HN_ERR_HIP 2
 
 /* ABI version; bumped whenever a struct below changes. */
-#define HN_ABI_VERSION 31
+#define HN_ABI_VERSION 32
 int hn_abi_version(void);
 const char* hn_last_error(void);
 
 /* Device facts used by bench.py (no allocation; queries the current device). */
 int hn_device_info(int* cu_count, int* clock_khz, char* arch_name, int arch_name_len);
+/* PCI bus id ("0000:c1:00.0") of the current device: what a rank of an N > 1 run reports so that N ranks on fewer than N
+ * devices cannot pass as N GPUs (bench.py config.devices). */
+int hn_device_pci_bus_id(char* out /* host */, int out_len /* >= 16 */);
 
 /* ---- timing helper: HIP events on the caller's stream (bench.py roofline leg) ---- */
 int hn_event_create(void** ev);
@@ -62,8 +65,11 @@ int hn_clock_sample(int micros, float* mhz, void* stream);
  *   HN_RANGE_INPUT_NONFINITE   a NaN / inf input value (invalid pixels of a 32FC1 depth image, which the reference passes
  *                              through, ros_demo.py:227-231; see hn_stem_image_nhwc4_valid)
  * The words live in a block of 4 device int32 (activation, input, input-non-finite, 0): the library's own, or -- after
- * hn_range_check_bind(block), which like the switch is read on the host at LAUNCH time -- the caller's (an engine binds its
- * block around its launches, so two engines of one process never see each other's flags; NULL unbinds).
+ * hn_range_check_bind(block), which like the switch is read on the host at LAUNCH time -- the caller's (NULL unbinds).
+ * The switch and the bound block are state of the calling HOST THREAD.  An engine brackets the launches of one step with
+ * hn_range_scope_begin(block, on) / hn_range_scope_end(): inside the scope this thread's producers note into `block` (on = 0:
+ * nowhere), afterwards the thread's previous switch and block are back -- so engines driven from different threads of one
+ * process never see, redirect or switch off each other's flags, and scopes nest (at most 8 deep).
  * hn_range_check_collect enqueues ONE tiny kernel on `stream` that copies the words of `block` (NULL: the library's) to
  * dst[0..3] and clears them -- no synchronisation; the host reads dst with the copy of the results it makes anyway (the
  * drop-in HandNet.forward does).  hn_range_check_fetch is the synchronous form: *flag (host)
@@ -76,6 +82,8 @@ int hn_range_check_enable(int on);
 int hn_range_check_enabled(void);
 int hn_range_check_fetch(int* flag /* host */, int reset, void* stream);
 int hn_range_check_bind(int32_t* block /* device, 4 words, zeroed by the caller; or NULL */);
+int hn_range_scope_begin(int32_t* block /* device, 4 words; NULL with on = 1: the library's block */, int on);
+int hn_range_scope_end(void);
 int hn_range_check_collect(int32_t* block /* or NULL */, int32_t* dst /* device, 4 words */, void* stream);
 
 /* Kernel-form switches.  Older forms of some kernels stay in the library as bit-identity references for the tests and for

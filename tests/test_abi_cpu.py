@@ -152,3 +152,29 @@ def test_documents_cite_files_that_exist():
                 if not (root / "handnet-pipeline_amd" / tok.split(":")[0]).exists():
                     missing.append((doc, tok))
     assert not missing, missing
+
+
+def test_range_scope_is_host_thread_state():
+    """hn_range_scope_begin / _end (host-only): nesting restores the previous switch, another thread never sees this one's."""
+    import threading
+    from hn_amd import _lib
+    lib = _lib.load()
+    assert lib.hn_range_check_enabled() == 0
+    assert lib.hn_range_scope_end() != 0 and b"no open scope" in lib.hn_last_error()
+    assert lib.hn_range_scope_begin(None, 1) == 0 and lib.hn_range_check_enabled() == 1
+    assert lib.hn_range_scope_begin(None, 0) == 0 and lib.hn_range_check_enabled() == 0
+    other = []
+    t = threading.Thread(target=lambda: other.append(lib.hn_range_check_enabled()))
+    t.start(); t.join()
+    assert other == [0]
+    assert lib.hn_range_scope_end() == 0 and lib.hn_range_check_enabled() == 1
+    t = threading.Thread(target=lambda: other.append(lib.hn_range_check_enabled()))
+    t.start(); t.join()
+    assert other == [0, 0]
+    assert lib.hn_range_scope_end() == 0 and lib.hn_range_check_enabled() == 0
+    for _ in range(8):
+        assert lib.hn_range_scope_begin(None, 1) == 0
+    assert lib.hn_range_scope_begin(None, 1) != 0            # ninth level: refused, state unchanged
+    for _ in range(8):
+        assert lib.hn_range_scope_end() == 0
+    assert lib.hn_range_check_enabled() == 0

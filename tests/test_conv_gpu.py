@@ -484,6 +484,75 @@ def test_f16x3_range_contract_flags_overflow_instead_of_returning_inf():
         ops.range_check_enable(False)
 
 
+def test_nan_activations_are_flagged_and_stay_nan_behind_a_relu():
+    """a NaN that is BORN inside the network (here: an fp32 residual that carries one) must not be laundered to 0 by
+    the ReLU of the epilogue that meets it -- torch.relu(NaN) is NaN -- and the range note must see it: the magnitude maximum is
+    NaN-propagating (v_maximum3_f32), so word 0 of the flag block is set.  Also through the S32 max pooling."""
+    from hn_amd import ops
+    from hn_amd.weights import split_f16x3
+    x = _rand((1, 12, 12, 64), 81, 1.0).cuda()
+    wt = _rand((64, 3, 3, 64), 82, 0.05)
+    res = _rand((1, 12, 12, 64), 83, 1.0).cuda()
+    res[0, 5, 6, 9] = float("nan")
+    block = torch.zeros((4,), device="cuda", dtype=torch.int32)
+    with ops.range_scope(block):
+        xs = ops.to_split(x)
+        assert ops.range_check_collect(block).cpu().tolist() == [0, 0, 0, 0]
+        ys = ops.conv2d_nhwc(xs, wt.cuda(), None, pad=1, relu=True, residual=res, w16=split_f16x3(wt).cuda(), out_split=True)
+        words = ops.range_check_collect(block).cpu().tolist()
+        y = ops.from_split(ys)
+        assert words[0] == 1, words
+        assert torch.isnan(y[0, 5, 6, 9]) and int(torch.isnan(y).sum()) == 1          # NaN, not relu -> 0
+        pooled = ops.from_split(ops.maxpool3x3s2_nhwc(ys))
+        assert int(torch.isnan(pooled[..., 9]).sum()) >= 1 and torch.isfinite(pooled[..., :9]).all()
+    clean = ops.conv2d_nhwc(xs, wt.cuda(), None, pad=1, relu=True, residual=torch.nan_to_num(res), w16=split_f16x3(wt).cuda(),
+                            out_split=True)
+    ok = torch.ones_like(y, dtype=torch.bool)
+    ok[0, 5, 6, 9] = False
+    assert torch.equal(y[ok], ops.from_split(clean)[ok])
+
+
+def test_range_scopes_of_two_host_threads_do_not_mix():
+    """the switch and the bound flag block are state of the calling HOST THREAD.  While thread A holds a
+    scope on its block, thread B opens its own, overflows, and closes it: B's block is flagged, A's is not, A's scope is still
+    in force afterwards, and a thread without a scope notes nowhere."""
+    import threading
+    from hn_amd import ops
+    big = torch.full((1, 4, 4, 32), 1.0e5, device="cuda")
+    a_block = torch.zeros((4,), device="cuda", dtype=torch.int32)
+    b_block = torch.zeros((4,), device="cuda", dtype=torch.int32)
+    a_in, b_done = threading.Event(), threading.Event()
+    seen = {}
+
+    def thread_a():
+        with ops.range_scope(a_block):
+            a_in.set()
+            b_done.wait(30)
+            seen["a_enabled_after_b"] = ops._lib.load().hn_range_check_enabled()
+            ops.to_split(torch.ones((1, 4, 4, 32), device="cuda"))
+            seen["a_words_clean"] = ops.range_check_collect(a_block).cpu().tolist()
+            ops.to_split(big)
+            seen["a_words"] = ops.range_check_collect(a_block).cpu().tolist()
+        seen["a_enabled_outside"] = ops._lib.load().hn_range_check_enabled()
+
+    def thread_b():
+        a_in.wait(30)
+        seen["b_enabled_before"] = ops._lib.load().hn_range_check_enabled()
+        ops.to_split(big)                                  # no scope on this thread: noted nowhere
+        with ops.range_scope(b_block):
+            ops.to_split(big)
+            seen["b_words"] = ops.range_check_collect(b_block).cpu().tolist()
+        with ops.range_scope(b_block, on=False):           # an engine with noting off does not switch A off
+            ops.to_split(big)
+        seen["b_words_off"] = ops.range_check_collect(b_block).cpu().tolist()
+        b_done.set()
+
+    ta, tb = threading.Thread(target=thread_a), threading.Thread(target=thread_b)
+    ta.start(); tb.start(); ta.join(60); tb.join(60)
+    assert seen == {"b_enabled_before": 0, "b_words": [1, 0, 0, 0], "b_words_off": [0, 0, 0, 0], "a_enabled_after_b": 1,
+                    "a_words_clean": [0, 0, 0, 0], "a_words": [1, 0, 0, 0], "a_enabled_outside": 0}, seen
+
+
 def test_f16x3_wide_dynamic_range_keeps_precision():
     """Log-uniform magnitudes over nine decades (1e-6 .. 1e3) in activations and 1e-4 .. 1e1 in weights: error
     <= 2e-5 of the output scale against fp64 (the stored value's error is max(2^-22 |v|, 2^-25): tiny values lose

@@ -1,6 +1,7 @@
 """N > 1 path on CPU: two gloo ranks shard a batch, run the (CPU oracle) per-frame stage on
 their shard, all-gather the fixed-size records with hn_amd.dist.gather_results, and every
 rank must end up with exactly the single-process result in global frame order."""
+import json
 import os
 import socket
 import subprocess
@@ -140,18 +141,75 @@ def test_gather_is_one_collective_with_reused_buffers(monkeypatch):
     assert valid.tolist() == [True, True, True, False] * 2
 
 
+def _bench(args, env=None, timeout=600):
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "HN_BENCH_WORKER")}
+    base.update(env or {})
+    return subprocess.run([sys.executable, str(REPO / "bench.py")] + args, env=base, capture_output=True, text=True, timeout=timeout)
+
+
+STUB = ["--stub-engine", "--dist-backend", "gloo", "--steps", "3", "--warmup", "1", "--batch", "4", "--init-timeout", "60"]
+
+
+def test_bench_eight_ranks_through_its_own_main():
+    """the REAL world size of BASELINE config 5 through bench.py's own main() -- supervisor, eight fresh
+    workers, file:// rendezvous, device report, the per-step all-gather, per-rank times, ONE line from rank 0 -- with a CPU
+    stand-in for the engine (gloo; the one-GPU box's process guard cannot host eight GPU ranks)."""
+    r = _bench(["--gpus", "8"] + STUB)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 32 and d["config"]["rccl_ranks"] == 8
+    assert d["config"]["devices"] == [f"cpu-stub:{i}" for i in range(8)]
+    assert "attempt 1 of 2" in d["config"]["ipc_mode"] and "HSA_ENABLE_IPC_MODE_LEGACY=0" in d["config"]["ipc_mode"]
+    lo, med, hi = d["rank_ms"]["min_median_max"]
+    assert len(d["rank_ms"]["per_rank"]) == 8 and lo <= med <= hi
+    assert hi - lo > 2.0                 # the stub's rank 7 sleeps 3.5 ms longer than rank 0: a straggler is VISIBLE
+    assert abs(d["value"] - 32 * 3 / (d["ms_per_step"] * 3e-3)) < 0.02 * d["value"]
+
+
+def test_bench_launch_ladder_second_rung_after_an_injected_init_failure():
+    """One rank's process group "cannot start" on the first attempt (what a host with the other IPC-handle mode looks like):
+    the other ranks -- blocked in the rendezvous -- are stopped by pid, ONE fresh set starts with HSA_ENABLE_IPC_MODE_LEGACY
+    unset, and the line says which mode ran and why.  A failure on BOTH rungs exits non-zero with the error text, no line."""
+    r = _bench(["--gpus", "4"] + STUB, env={"HN_BENCH_INJECT_INIT_FAILURE": "2:0"})
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    mode = d["config"]["ipc_mode"]
+    assert d["n_gpus"] == 4 and d["config"]["rccl_ranks"] == 4
+    assert "HSA_ENABLE_IPC_MODE_LEGACY unset" in mode and "attempt 2 of 2" in mode and "hipIpcGetMemHandle" in mode
+    assert "attempt 1 failed to initialise" in r.stderr
+    # under torchrun-style environments (one supervisor per rank, as the driver launches it): same ladder, shared directory
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = {k: v for k, v in os.environ.items() if k != "HN_BENCH_WORKER"}
+        env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HN_BENCH_INJECT_INIT_FAILURE="1:0")
+        procs.append(subprocess.Popen([sys.executable, str(REPO / "bench.py"), "--gpus", "2"] + STUB, env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    lines = [l for o, _ in outs for l in o.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    assert "unset" in json.loads(lines[0])["config"]["ipc_mode"]
+    # both rungs fail
+    both = _bench(["--gpus", "2"] + STUB, env={"HN_BENCH_INJECT_INIT_FAILURE": "0:*"})
+    assert both.returncode != 0, both.stdout + both.stderr
+    assert "attempt 2 failed to initialise" in both.stderr and not any(l.startswith("{") for l in both.stdout.splitlines())
+
+
 def test_bench_fails_loudly_when_the_process_group_cannot_start():
-    """`--gpus 2` under a torchrun-style environment whose rendezvous cannot complete (nobody listens for rank 1's peer):
-    bench.py must exit non-zero with the backend's error text -- never fall back to a single-rank run, never re-exec."""
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
-    env.update(RANK="1", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
-               TORCH_DIST_INIT_BARRIER="0")
-    # rank 1 of 2 with no rank 0: the TCP store client cannot connect -> init_process_group raises after its timeout
-    code = ("import sys, datetime, torch.distributed as d; sys.argv = ['bench.py', '--gpus', '2', '--share-gpu', "
-            "'--dist-backend', 'gloo', '--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--no-roofline'];"
-            "orig = d.init_process_group;"
-            "d.init_process_group = lambda *a, **k: orig(*a, timeout=datetime.timedelta(seconds=5), **k);"
-            f"import runpy; runpy.run_path({str(REPO / 'bench.py')!r}, run_name='__main__')")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    """`--gpus 2` under a torchrun-style environment whose rendezvous cannot complete (rank 1 of 2 with no rank 0): both rungs
+    of the ladder time out (--init-timeout), bench.py exits non-zero with the backend's error text -- never a single-rank run,
+    never a re-exec, no JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "HN_BENCH_WORKER")}
+    env.update(RANK="1", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--stub-engine", "--dist-backend", "gloo",
+                        "--steps", "1", "--warmup", "0", "--init-timeout", "5"], env=env, capture_output=True, text=True,
+                       timeout=300)
     assert r.returncode != 0
     assert "failed to initialise" in (r.stdout + r.stderr) and not any(l.startswith("{") for l in r.stdout.splitlines())
+    assert "attempt 2 of 2" in r.stderr

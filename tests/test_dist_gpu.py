@@ -104,7 +104,7 @@ def test_bench_line_contract():
     assert len(lines) == 1
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "dropin", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "other_configs", "dropin", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["vs_baseline"] is None
     assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
@@ -121,6 +121,12 @@ def test_bench_line_contract():
     assert roof["traffic"] is None and any(why in roof["traffic_source"] for why in
                                            ("launches/step", "another revision", "dominant kernel"))
     assert set(roof["stages"]) >= {"resnet34_body", "fpn", "towers", "head_outputs", "a2j_trunk", "a2j_heads"}
+    oc = d["other_configs"]
+    assert set(oc) == {"a2j_b64", "fcos_b16", "pipeline_b1"}
+    for name, unit in (("a2j_b64", "crops/s"), ("fcos_b16", "frames/s"), ("pipeline_b1", "frames/s")):
+        assert oc[name]["unit"] == unit and oc[name]["value"] > 0 and oc[name]["ms_per_step"] > 0
+        assert 0 < oc[name]["frac"] < 1 and "conv_igemm" in oc[name]["kernel"]
+    assert oc["pipeline_b1"]["hipgraph"] is True and oc["pipeline_b1"]["ms_per_step"] < 10.0
     dr = d["dropin"]
     assert dr["batch1"]["frames_per_s"] > 0 and dr["batch2"]["frames_per_s"] > 0 and "HandNet.forward" in dr["call"]
     cpu = d["cpu_baseline"]
@@ -157,21 +163,50 @@ def test_four_ranks_equal_single_process_batch(tmp_path, fcos_sd, a2j_sd):
     assert (kp - ref.keypoints.cpu()).abs().max().item() <= 1e-4
 
 
-def test_bench_four_rank_rehearsal():
+def test_bench_four_rank_rehearsal_with_a_failed_first_attempt():
     """`bench.py --gpus 4 --share-gpu --dist-backend gloo --batch 8`: the self-launch path at a world size > 2 (global
-    batch 32 as 4 x 8), one JSON line from rank 0.  FOUR is the largest world this box rehearses: its process guard allows
-    six processes with the device open, and this test process, bench.py's launching parent (torch.cuda.device_count() opens
-    the device node) and the ranks all count -- a five-rank run was killed by the guard (round 4)."""
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    batch 32 as 4 x 8) on the REAL engine, one JSON line from rank 0 -- with the launch ladder exercised: rank 3's process
+    group "cannot start" on the first attempt (injected: what a host with the other IPC-handle mode looks like), the three
+    ranks waiting in the rendezvous are stopped by pid, ONE fresh set runs with HSA_ENABLE_IPC_MODE_LEGACY unset and the line
+    says so.  N > 1 replays the step from a hipGraph by default and reports every rank's own time per step.
+    FOUR is the largest world this box rehearses: its process guard allows six processes with the device open (this test
+    process and the four workers; the supervisor never opens the device)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "HN_BENCH_WORKER")}
+    env["HN_BENCH_INJECT_INIT_FAILURE"] = "3:0"
     r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "4", "--share-gpu", "--dist-backend", "gloo",
                         "--steps", "2", "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--no-roofline"],
-                       env=env, capture_output=True, text=True, timeout=900)
+                       env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 4 and line["config"]["global_batch"] == 32 and line["config"]["rccl_ranks"] == 4
+    cfg = line["config"]
+    assert line["n_gpus"] == 4 and cfg["global_batch"] == 32 and cfg["rccl_ranks"] == 4
+    assert "HSA_ENABLE_IPC_MODE_LEGACY unset" in cfg["ipc_mode"] and "attempt 2 of 2" in cfg["ipc_mode"]
+    assert cfg["hipgraph"] is True
+    assert len(cfg["devices"]) == 4 and len(set(cfg["devices"])) == 1 and ":" in cfg["devices"][0]   # --share-gpu: one PCI bus id
+    lo, med, hi = line["rank_ms"]["min_median_max"]
+    assert len(line["rank_ms"]["per_rank"]) == 4 and 0 < lo <= med <= hi
 
+
+def test_bench_under_a_torchrun_style_environment():
+    """The driver's launch form: every rank is started with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* already set (here by
+    hand, two ranks sharing the GPU).  Each started process supervises the fresh worker of its own rank; the workers
+    rendezvous through the job's shared file:// store; rank 0 prints the line."""
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = {k: v for k, v in os.environ.items() if k != "HN_BENCH_WORKER"}
+        env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--share-gpu", "--dist-backend",
+                                       "gloo", "--steps", "2", "--warmup", "1", "--batch", "4", "--no-cpu-baseline",
+                                       "--no-roofline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=1200) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    lines = [l for o, _ in outs for l in o.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, outs
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["rccl_ranks"] == 2 and "attempt 1 of 2" in line["config"]["ipc_mode"]
 
 
 def test_stages_are_repeatable_next_to_a_second_process(fcos_sd, a2j_sd):

@@ -110,6 +110,31 @@ def test_a2j_forward_equals_python_engine_and_golden(native, a2j_sd, golden_dir)
     assert np.abs(native.a2j(x2).cpu().numpy() - g["keypoints"]).max() < 1e-3
 
 
+def test_a2j_forward_nan_crop_gives_nan_row_like_the_python_engine(native, a2j_sd):
+    """hn_a2j_forward keeps flags of its own, so a crop with a NaN / inf pixel returns a NaN row (what
+    a2j/a2j.py:243-250 returns for it) instead of finite numbers from laundered NaNs -- with and without the caller's `valid`,
+    on the multi-launch path (<= 4 crops) and the grouped one; rows of the other crops bit-identical to A2JEngine.forward."""
+    from hn_amd import synth
+    from hn_amd.a2j_engine import A2JEngine
+    eng = A2JEngine(a2j_sd, device="cuda")
+    for k in (3, 6):
+        x = synth.make_crops(k, 176, seed=3100 + k)
+        x[1, 0, 40, 99] = float("nan")
+        x[k - 1, 0, 0, 0] = float("inf")
+        x = x.cuda()
+        ref = eng.forward(x)
+        assert torch.isnan(ref[1]).all() and torch.isnan(ref[k - 1]).all() and torch.isfinite(ref[0]).all()
+        kp = native.a2j(x)
+        assert torch.equal(torch.nan_to_num(kp, nan=-7.0), torch.nan_to_num(ref, nan=-7.0))
+        valid = torch.ones((k,), device="cuda", dtype=torch.int32)
+        valid[0] = 0
+        kpv = native.a2j(x, valid)
+        assert valid.cpu().tolist() == [0] + [1] * (k - 1)                  # the caller's flags stay read-only
+        assert (kpv[0] == 0).all() and torch.isnan(kpv[1]).all() and torch.isnan(kpv[k - 1]).all()
+        if k > 3:
+            assert torch.equal(kpv[2], ref[2])
+
+
 def test_model_abi_errors_are_loud(a2j_sd):
     from hn_amd import _lib
     from hn_amd.native_model import NativeModel

@@ -436,6 +436,56 @@ def test_nan_depth_pixels_give_nan_keypoints_like_the_reference(fcos_sd, a2j_sd)
         m.close()
 
 
+def test_nan_frame_does_not_switch_the_range_contract_off_for_the_other_frames(fcos_sd, a2j_sd, monkeypatch):
+    """ADVICE r04 (low x2): one NaN depth pixel in one frame of a batch (normal for 32FC1 cameras) must not hide an overflow in
+    another frame of the same call: frame 0 holds a NaN pixel inside its crop, frame 1's depth is finite but far outside the
+    fp16 range -> ops.RangeError (it used to return silently).  And the sparse path reports has_hand == 2 like the dense one."""
+    from hn_amd import ops, synth
+    from oracle import handnet_ref
+    net = _dropin(fcos_sd, a2j_sd)
+    rgb, depth = synth.make_rgb(2, seed=1000), synth.make_depth(2, seed=2000)
+    clean = handnet_ref.handnet_forward(list(rgb), depth, fcos_sd, a2j_sd, 3)
+    x1, y1, x2, y2 = clean[2][0].tolist()
+    depth[0, 0, (y1 + y2) // 2, (x1 + x2) // 2] = float("nan")
+    with torch.inference_mode():
+        kp, _db, _crops = net([r.cuda() for r in rgb], depth_images=depth.cuda())       # NaN alone: no error
+        assert torch.isnan(kp[0]).all() and torch.isfinite(kp[1]).all()
+        bad = depth.clone()
+        bad[1] *= 1.0e6
+        with pytest.raises(ops.RangeError, match="also saw non-finite"):
+            net([r.cuda() for r in rgb], depth_images=bad.cuda())
+    # sparse batch: 8 frames, a hand in 2 of them (the crop stage is patched as in test_sparse_stream_compacts_a2j), one of the two
+    # with a NaN pixel in its crop: the compacted A2J call must report has_hand == 2 for it like the dense path does
+    from hn_amd import pipeline
+    eng = net.engine()
+    rgb8, dep8 = synth.make_rgb(8, seed=1000).cuda(), synth.make_depth(8, seed=2000).cuda()
+    bx = eng.forward_device(rgb8, dep8).crop_box[2].cpu().tolist()
+    dep8[2, 0, (bx[1] + bx[3]) // 2, (bx[0] + bx[2]) // 2] = float("nan")
+    keep = torch.zeros((8,), dtype=torch.int32, device="cuda")
+    keep[[2, 5]] = 1
+    real_crop = ops.crop_resize
+
+    def sparse_crop(*a, **k):
+        box, has, crops = real_crop(*a, **k)
+        return box * keep[:, None].to(box.dtype), has * keep, crops * keep[:, None, None, None].to(crops.dtype)
+    monkeypatch.setattr(pipeline.ops, "crop_resize", sparse_crop)
+    dense = eng.forward_device(rgb8, dep8)
+    assert dense.has_hand.cpu().tolist() == [0, 0, 2, 0, 0, 1, 0, 0]
+    eng._sparse_hint, eng._hand_stat = True, None
+    calls = []
+    real_fwd = eng.a2j.forward_nhwc
+
+    def spy(x, valid=None, **k):
+        calls.append(x.shape[0])
+        return real_fwd(x, valid=valid, **k)
+    monkeypatch.setattr(eng.a2j, "forward_nhwc", spy)
+    out = eng.forward_device(rgb8, dep8)
+    assert calls == [2], calls
+    assert out.has_hand.cpu().tolist() == [0, 0, 2, 0, 0, 1, 0, 0]
+    assert torch.isnan(out.keypoints[2]).all() and torch.isfinite(out.keypoints[5]).all()
+    assert (out.keypoints[5] - dense.keypoints[5]).abs().max().item() < 1e-4
+
+
 def test_a2j_dropin_nan_crop_gives_nan_row(a2j_sd):
     """a2j.a2j.A2JModel (a2j_infer.py:25,59) on crops of which one holds a NaN pixel: NaN keypoints for that crop, like the
     reference's plain torch forward; the other crops are untouched."""
