@@ -41,7 +41,9 @@ Extra objects in the line:
                 head outputs / A2J trunk / A2J heads): ms per step, algorithmic TFLOP/s and fraction of the peak.
   dropin        the same batch through the reference's own callable -- handnet_pipeline.HandNet.forward as
                 ros_demo.py:270-273 calls it (list of [3,H,W] images + depth_images, keypoints copied to the
-                CPU) -- at the bench batch and at batch 1 (the only batch size the reference's caller uses).
+                CPU) -- at the bench batch and at batch 1 (the only batch size the reference's caller uses); and
+                `batch*_host`: the PCIe-inclusive figures, the same calls with the frames starting in pinned host
+                memory -- as converted fp32 tensors, and as the raw bgr8 + 16UC1 buffers through HandNet.forward_raw.
   cpu_baseline  the oracle (CPU restatement, kind "port") timed on this box's host cores on a
                 bounded sample of the same workload (rank 0, N == 1 only); the same frames go
                 through the HIP engine and the agreement is reported as `parity`.
@@ -345,6 +347,37 @@ def dropin_leg(args, sds, dev, batch):
             dt = time.perf_counter() - t0
         assert kp.device.type == "cpu" and tuple(kp.shape) == (b, 21, 3)
         out[f"batch{b}"] = {"frames_per_s": round(b * steps / dt, 2), "ms_per_call": round(1e3 * dt / steps, 3), "calls": steps}
+        # PCIe-INCLUSIVE: the same call when the frames start in (pinned) HOST memory, as they do for the reference's caller
+        # (ros_demo.py:227-231,266-267).  fp32 feed: the host has already converted (4.9 MB per frame cross PCIe as
+        # `.cuda()` copies); raw feed: HandNet.forward_raw on the cv_bridge 'bgr8' + 16UC1 buffers (1.5 MB per frame, the
+        # conversion runs in the ingest kernel, which reads the pinned buffers itself).
+        import numpy as np
+        rng = np.random.default_rng(1000)
+        bgr = torch.from_numpy(rng.integers(0, 256, size=(b, 480, 640, 3), dtype=np.uint8)).pin_memory()
+        mm = torch.from_numpy(rng.integers(300, 1500, size=(b, 480, 640)).astype(np.uint16)).pin_memory()
+        rgb_h = (bgr.flip(-1).permute(0, 3, 1, 2).float() / 255.0).contiguous().pin_memory()
+        dep_h = (mm.float() / 1000.0).unsqueeze(1).contiguous().pin_memory()
+        legs = {}
+        with torch.inference_mode():
+            def fp32_feed():
+                return net([rgb_h[i].to(dev, non_blocking=True) for i in range(b)], depth_images=dep_h.to(dev, non_blocking=True))
+
+            def raw_feed():
+                return net.forward_raw(bgr, mm)
+            for name, call in (("fp32_feed", fp32_feed), ("raw_feed", raw_feed)):
+                for _ in range(6):
+                    call()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    kp, _db, _crops = call()
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                legs[name] = {"frames_per_s": round(b * steps / dt, 2), "ms_per_call": round(1e3 * dt / steps, 3)}
+        legs["bytes_over_pcie_per_frame"] = {"fp32_feed": 4 * 480 * 640 * 4, "raw_feed": 480 * 640 * 5}
+        legs["what"] = ("the call of batch%d with its inputs starting in pinned host memory: host -> device transfer inside the "
+                        "timed region (value of the line: inputs resident in HBM)" % b)
+        out[f"batch{b}_host"] = legs
     del net
     return out
 

@@ -78,12 +78,14 @@ class HandNet(EngineOwner):
         return self._engine
 
     # forward() switches ITSELF to hipGraph replay once the same input shapes have come in a few times in a row -- the live
-    # caller's case (ros_demo.py:270-273: one 640x480 frame per call, ~200 dependent launches whose host cost is 8 % of the
-    # call; at batch 32 the replay saves the ~0.3 ms the GPU idles while Python issues the first launches after the sync).  forward() hands out fresh tensors (keypoints on the CPU, indexed copies of the crops), so replaying
-    # into captured buffers is invisible to the caller; enable_graph(False) turns it off, enable_graph(True) forces it from the
-    # first call and also for forward_device().
+    # caller's case (ros_demo.py:270-273: one 640x480 frame per call, ~150 dependent launches whose host cost is 8 % of the
+    # call; at batch 32 the replay saves the ~0.3 ms the GPU idles while Python issues the first launches after the sync).
+    # forward() hands out fresh tensors (keypoints on the CPU, copies of the crops), so replaying into captured buffers is
+    # invisible to the caller; enable_graph(False) turns it off, enable_graph(True) forces it from the first call and also for
+    # forward_device().
     AUTO_GRAPH_CALLS = 3        # same-shape calls in a row before forward() captures
-    AUTO_GRAPH_MAX_SHAPES = 4   # distinct input shapes captured automatically (each holds its own static buffers)
+    AUTO_GRAPH_MAX_SHAPES = 4   # captured steps kept at a time (each holds its own static activation pool): one more input
+    #                             shape EVICTS the least recently used capture (a batch-size-sweeping caller stays bounded)
     # HN_AUTO_GRAPH=0 in the environment keeps forward() eager; a capture that FAILS (no memory for the static pool, a
     # capture-unsafe call from another thread of the host) is not an error of the call: forward() runs that call eagerly and
     # never tries again (self._auto_graph_allowed = False), see _forward_auto.
@@ -101,32 +103,31 @@ class HandNet(EngineOwner):
             self._auto_graph_allowed = True
         return self
 
-    def _auto_graph(self, batch, depth) -> bool:
+    def _auto_graph(self, image_shape, depth_shape, on_gpu=True) -> bool:
         """Whether this call of forward() should run as a graph replay (capturing first if need be)."""
         eng = self.engine()
-        if (not self._auto_graph_allowed or eng.check_range or getattr(self, "_last_sparse", False)
-                or not (batch.is_cuda and depth.is_cuda)):
+        if not self._auto_graph_allowed or eng.check_range or getattr(self, "_last_sparse", False) or not on_gpu:
             return False
-        if eng.has_graph(batch.shape, depth.shape):
+        if eng.has_graph(image_shape, depth_shape, to_host=True):
             return True
-        key = (tuple(batch.shape), tuple(depth.shape))
+        key = (tuple(image_shape), tuple(depth_shape))
         if key == getattr(self, "_streak_key", None):
             self._streak += 1
         else:
             self._streak_key, self._streak = key, 1
-        return self._streak > self.AUTO_GRAPH_CALLS and eng.graph_count() < self.AUTO_GRAPH_MAX_SHAPES
+        return self._streak > self.AUTO_GRAPH_CALLS
 
-    def forward_device(self, images, depth_images, _graph=None):
+    def forward_device(self, images, depth_images, _graph=None, _to_host=False):
         """Sync-free variant: returns hn_amd.pipeline.HandNetOutput with everything on the GPU."""
         batch = images if torch.is_tensor(images) else torch.stack([i.float() for i in images])
         if getattr(self, "use_graph", None) if _graph is None else _graph:
             batch, depth = batch.float().contiguous(), depth_images.float().contiguous()
-            run, s_img, s_dep, out = self.engine().graphed(batch, depth)
+            run, s_img, s_dep, out = self.engine().graphed(batch, depth, to_host=_to_host, limit=self.AUTO_GRAPH_MAX_SHAPES)
             s_img.copy_(batch)
             s_dep.copy_(depth)
             run()
             return out
-        return self.engine().forward_device(batch, depth_images)
+        return self.engine().forward_device(batch, depth_images, to_host=_to_host)
 
     def _forward_auto(self, images, depth_images, n):
         """forward() in its default mode: replay when a captured step fits, capture when the shapes have repeated, else eager."""
@@ -134,22 +135,25 @@ class HandNet(EngineOwner):
         if (self._auto_graph_allowed and not torch.is_tensor(images) and n and depth_images.is_cuda
                 and depth_images.dtype == torch.float32 and all(i.dtype == torch.float32 and i.is_cuda for i in images)
                 and not eng.check_range and not getattr(self, "_last_sparse", False)):
-            out = eng.replay_frames(images, depth_images)
+            out = eng.replay_frames(images, depth_images, to_host=True)
             if out is not None:
                 return out
         batch = images if torch.is_tensor(images) else torch.stack([i.float() for i in images])
-        if self._auto_graph(batch, depth_images):
+        if self._auto_graph(batch.shape, depth_images.shape, batch.is_cuda and depth_images.is_cuda):
             try:
-                return self.forward_device(batch, depth_images, _graph=True)
+                return self.forward_device(batch, depth_images, _graph=True, _to_host=True)
             except ops.RangeError:
                 raise
             except Exception as e:  # noqa: BLE001 -- whatever made the capture fail, this call would succeed eagerly
-                import warnings
-                self._auto_graph_allowed = False
-                torch.cuda.synchronize()
-                warnings.warn(f"HandNet: automatic hipGraph capture failed ({type(e).__name__}: {e}); "
-                              "staying eager from now on (enable_graph(True) forces a new attempt)")
-        return self.forward_device(batch, depth_images, _graph=False)
+                self._capture_failed(e)
+        return self.forward_device(batch, depth_images, _graph=False, _to_host=True)
+
+    def _capture_failed(self, e):
+        import warnings
+        self._auto_graph_allowed = False
+        torch.cuda.synchronize()
+        warnings.warn(f"HandNet: automatic hipGraph capture failed ({type(e).__name__}: {e}); "
+                      "staying eager from now on (enable_graph(True) forces a new attempt)")
 
     def forward(self, images, depth_images=None, is_3D: bool = False, is_detect: bool = False):
         if is_detect or is_3D:
@@ -158,37 +162,76 @@ class HandNet(EngineOwner):
             raise ValueError("depth_images is required for the ensemble inference branch")
         n = len(images)
         mode = getattr(self, "use_graph", None)
-        out = None
         if mode is None and torch.is_tensor(depth_images):
             out = self._forward_auto(images, depth_images, n)
         else:
-            out = self.forward_device(images, depth_images)
-        # ONE device -> host copy (and sync) per call: the keypoints with the has-hand flags and the step's range-contract
-        # words as extra columns
-        kp = out.keypoints
-        j3 = kp.shape[1] * kp.shape[2]
-        # (as int32 words: the flags need no conversion kernels, the keypoints are reinterpreted back on the host)
-        cols = [kp.contiguous().reshape(n, j3).view(torch.int32), out.has_hand.reshape(n, 1)]
-        if out.range_flags is not None:
-            cols.append(out.range_flags[:3].reshape(1, 3).expand(n, 3))
-        flat = torch.cat(cols, dim=1).cpu()
-        final_results = flat[:, :j3].contiguous().view(torch.float32).reshape(kp.shape)   # the reference returns keypoints on the CPU
-        mask_cpu = flat[:, j3] != 0
-        self._last_sparse = n >= 8 and int(mask_cpu.sum()) * 2 < n      # (the engine's own threshold for compaction)
+            out = self.forward_device(images, depth_images, _to_host=True)
+        return self._finish(out, n, depth_images)
+
+    def forward_raw(self, bgr_u8, depth_raw, is_3D: bool = False, is_detect: bool = False):
+        """The reference caller's ingest AND its network call in one (ros_demo.py:227-231,266-273): bgr_u8 = the cv_bridge
+        'bgr8' frames, uint8 [N,H,W,3] (or one [H,W,3] frame); depth_raw = 16UC1 millimetres as uint16 [N,H,W] or 32FC1 metres
+        as float32 -- numpy arrays or torch tensors, on the host (pinned memory is read in place over PCIe, pageable memory is
+        staged once) or on the GPU.  One kernel does `astype(float32) / 255.0`, BGR -> RGB, HWC -> CHW and `/ 1000.0` (bit-identical
+        to the host arithmetic; 1.5 MB per frame cross PCIe instead of 4.9 MB) and the step runs exactly as forward() runs it.
+        Returns forward()'s tuple; its no-hand placeholder `zeros_like(depth_images)` has the fp32 [N,1|4,H,W] shape forward()
+        would have been given."""
+        if is_detect or is_3D:
+            return None
+        bgr = torch.as_tensor(bgr_u8)
+        dep = torch.as_tensor(depth_raw)
+        if bgr.dim() == 3:
+            bgr = bgr.unsqueeze(0)
+        if dep.dim() == 2:
+            dep = dep.unsqueeze(0)
+        if dep.dim() == 4 and dep.shape[1] == 1:
+            dep = dep[:, 0]
+        n, h, w = bgr.shape[0], bgr.shape[1], bgr.shape[2]
+        eng = self.engine()
+        shapes = ((n, 3, h, w), (n, 4 if self.RGBD else 1, h, w))
+        mode = getattr(self, "use_graph", None)
+        graph = bool(mode) if mode is not None else self._auto_graph(*shapes)
+        out = None
+        if graph:
+            try:
+                out = eng.forward_raw(bgr, dep, to_host=True, use_graph=True, limit=self.AUTO_GRAPH_MAX_SHAPES)
+            except (ops.RangeError, TypeError, ValueError):
+                raise
+            except Exception as e:  # noqa: BLE001
+                if mode:
+                    raise
+                self._capture_failed(e)
+        if out is None:
+            out = eng.forward_raw(bgr, dep, to_host=True)
+        return self._finish(out, n, None, placeholder_shape=shapes[1])
+
+    def _finish(self, out, n, depth_images, placeholder_shape=None):
+        """The reference's return tuple from a step's device results: ONE device -> host copy (and sync) per call -- the
+        step's record buffer (keypoints, has-hand flags, crop boxes, range-contract words), which the step has already enqueued
+        into pinned memory."""
+        from hn_amd.pipeline import read_host_record
+        # the usual case -- every frame has a hand -- needs fresh copies of the crop boxes and the depth crops; they are
+        # enqueued BEFORE the sync (hidden behind the step instead of trailing it) and thrown away in the other cases
+        # (.contiguous() of the permuted / sliced view is a copy: the caller never holds a view of a captured buffer)
+        sel = out.crops_nhwc
+        crops_all = out.crop_box.clone()
+        depth_all = (sel.permute(0, 3, 1, 2) if self.RGBD else sel[..., 0].unsqueeze(1)).contiguous()
+        torch.cuda.current_stream(out.keypoints.device).synchronize()
+        final_results, has, _box, words = read_host_record(out.host_record, n, out.keypoints.shape[1])
+        mask_cpu = has != 0
+        hands = int(mask_cpu.sum())
+        self._last_sparse = n >= 8 and hands * 2 < n      # (the engine's own threshold for compaction)
         # the f16x3 range contract, decided on what has just been copied (hn_amd.pipeline.check_range_contract): overflow raises,
         # non-finite depth pixels give NaN rows like the reference
-        check_range_contract(final_results, flat[0, j3 + 1:].tolist() if out.range_flags is not None else None, depth_images,
-                             has_hand=flat[:, j3])
-        if not bool(mask_cpu.any()):  # handnet_pipeline.py:107-108: the crops placeholder is a CPU float tensor
-            return torch.zeros((n, 21, 3)), torch.zeros_like(depth_images), torch.zeros((n, 4))
-        if bool(mask_cpu.all()):      # the usual case: no gather (a boolean-mask index would synchronise once more)
-            sel, crops = out.crops_nhwc, out.crop_box.clone()
-        else:
-            idx = mask_cpu.nonzero().flatten().to(out.crop_box.device)
-            sel, crops = out.crops_nhwc.index_select(0, idx), out.crop_box.index_select(0, idx)
-        # (.contiguous() of the permuted / sliced view is a copy: the caller never holds a view of a captured buffer)
-        depth_batch = (sel.permute(0, 3, 1, 2) if self.RGBD else sel[..., 0].unsqueeze(1)).contiguous()
-        return final_results, depth_batch, crops
+        check_range_contract(final_results, words if out.range_flags is not None else None, depth_images, has_hand=has)
+        if hands == 0:  # handnet_pipeline.py:107-108: the crops placeholder is a CPU float tensor
+            zeros = torch.zeros_like(depth_images) if depth_images is not None else torch.zeros(
+                placeholder_shape, device=out.keypoints.device)
+            return torch.zeros((n, 21, 3)), zeros, torch.zeros((n, 4))
+        if hands == n:
+            return final_results, depth_all, crops_all
+        idx = mask_cpu.nonzero().flatten().to(out.crop_box.device)
+        return final_results, depth_all.index_select(0, idx), crops_all.index_select(0, idx)
 
 
 HandNetPipeline = HandNet

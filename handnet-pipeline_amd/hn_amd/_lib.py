@@ -104,6 +104,7 @@ SIGNATURES = {
     "hn_conv2d_nhwc_f16x3_multi": (C.c_int, [C.POINTER(ConvMulti), VP, C.c_int64, VP]),
     "hn_conv2d_f16x3_multi_fuses": (C.c_int, [C.POINTER(ConvMulti), C.c_int64]),
     "hn_device_pci_bus_id": (C.c_int, [C.c_char_p, C.c_int]),
+    "hn_ingest_u8bgr_u16mm": (C.c_int, [VP, VP, C.c_int, VP, VP, VP, C.c_int, C.c_int, C.c_int, VP]),
     "hn_range_check_enable": (C.c_int, [C.c_int]),
     "hn_range_check_fetch": (C.c_int, [c_i32p, C.c_int, VP]),
     "hn_range_check_enabled": (C.c_int, []),

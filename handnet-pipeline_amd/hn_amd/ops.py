@@ -789,6 +789,57 @@ def to_split_levels(xs, affines, relu=True):
     return outs
 
 
+def _device_readable(t: torch.Tensor, name: str):
+    """A raw input buffer of ingest_raw: device memory of the current GPU, or PINNED host memory (the kernel reads it over
+    PCIe itself).  Pageable host memory is not readable by the device: the caller stages it (HandNet.forward_raw does)."""
+    if t.is_cuda:
+        _check_device(t, name)
+    elif not t.is_pinned():
+        raise RuntimeError(f"{name}: host memory must be pinned (tensor.pin_memory()) to be read by the ingest kernel")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t
+
+
+def ingest_raw(bgr_u8, depth=None, device=None, out_rgb=None, out_depth=None, out_rgbd=None, want_rgbd=False):
+    """The reference caller's host-side conversions as ONE kernel (hn_ingest_u8bgr_u16mm; ros_demo.py:227-231,266-269):
+    bgr_u8 uint8 [N,H,W,3] (cv_bridge 'bgr8' frames), depth [N,H,W] uint16 / int16 millimetres (16UC1) or float32 metres
+    (32FC1), each on the GPU or in PINNED host memory -> (rgb fp32 [N,3,H,W] in 0..1, depth fp32 [N,1,H,W] metres or None,
+    rgbd fp32 [N,4,H,W] or None) on the GPU; bit-identical to `astype(float32) / 255.0` and `/ 1000.0`."""
+    if bgr_u8.dtype != torch.uint8 or bgr_u8.dim() != 4 or bgr_u8.shape[3] != 3:
+        raise TypeError(f"bgr_u8: expected uint8 [N,H,W,3], got {bgr_u8.dtype} {tuple(bgr_u8.shape)}")
+    _device_readable(bgr_u8, "bgr_u8")
+    n, h, w, _ = bgr_u8.shape
+    kind = 0
+    if depth is not None:
+        if depth.dtype in (torch.uint16, torch.int16):
+            kind = 1        # (int16: the same bits; 16UC1 is unsigned and the kernel reads it so)
+        elif depth.dtype == torch.float32:
+            kind = 2
+        else:
+            raise TypeError(f"depth: expected uint16 / int16 millimetres or float32 metres, got {depth.dtype}")
+        if tuple(depth.shape) not in ((n, h, w), (n, 1, h, w)):
+            raise ValueError(f"depth: expected [N,H,W] matching the frames, got {tuple(depth.shape)}")
+        _device_readable(depth, "depth")
+    if device is None:
+        device = bgr_u8.device if bgr_u8.is_cuda else torch.device("cuda", _cur_device() if _cur_device else 0)
+    if out_rgb is None:
+        out_rgb = torch.empty((n, 3, h, w), device=device, dtype=torch.float32)
+    if kind and out_depth is None:
+        out_depth = torch.empty((n, 1, h, w), device=device, dtype=torch.float32)
+    if want_rgbd and out_rgbd is None:
+        if not kind:
+            raise ValueError("the RGB-D tensor needs a depth input")
+        out_rgbd = torch.empty((n, 4, h, w), device=device, dtype=torch.float32)
+    for t, nm in ((out_rgb, "out_rgb"), (out_depth, "out_depth"), (out_rgbd, "out_rgbd")):
+        if t is not None:
+            _req(t, name=nm)
+    check(_lib.load().hn_ingest_u8bgr_u16mm(bgr_u8.data_ptr(), depth.data_ptr() if kind else None, kind, ptr(out_rgb),
+                                            ptr(out_depth) if kind else None, ptr(out_rgbd), n, h, w, _stream()),
+          "hn_ingest_u8bgr_u16mm")
+    return out_rgb, (out_depth if kind else None), out_rgbd
+
+
 def fcos_preprocess(images, oh, ow, ph, pw, mean, std, out=None):
     """images [N,3,H,W] fp32 (0..1) -> [N,ph,pw,4] normalized / resized / padded NHWC."""
     lib = _lib.load()

@@ -8,6 +8,7 @@ step has a static launch sequence and can be captured into a hipGraph.
 """
 from __future__ import annotations
 
+import collections
 from dataclasses import dataclass
 
 import os
@@ -30,6 +31,25 @@ class HandNetOutput:
     detections: ops.Detections
     candidates: ops.Candidates   # rows at or beyond count[i] are undefined (never zero-filled)
     range_flags: torch.Tensor = None   # [4] int32 device: the step's f16x3 range-contract words (ops.range_bits), or None
+    host_record: torch.Tensor = None   # to_host steps: PINNED uint8 [N+1, 296] the step copies its results into (device -> host
+    #                                    copy enqueued by the step itself; valid after the stream is synchronised): rows 0..N-1 =
+    #                                    hn_pack_records rows (crop box 32 B | has_hand | 1 | keypoints), row N = the range words
+
+
+RECORD_BYTES = 296      # hn_amd.dist's per-frame record (box 32 + flags 8 + 21 x 3 fp32 keypoints, padded to 8)
+
+
+def read_host_record(rec: torch.Tensor, n: int, joints: int = 21):
+    """A synchronised host_record -> (keypoints [n,J,3] fp32, has_hand [n] int32, crop_box [n,4] int64, range words [4] list);
+    all fresh CPU tensors (the pinned buffer is overwritten by the engine's next step).  numpy slicing: a handful of torch
+    ops on 300-byte tensors would cost more host time than the copy itself (batch 1: the call is 2.3 ms in all)."""
+    import numpy as np
+    a = rec.numpy()
+    j3 = joints * 3
+    kp = torch.from_numpy(np.ascontiguousarray(a[:n, 40:40 + 4 * j3]).view(np.float32).reshape(n, joints, 3))
+    has = torch.from_numpy(np.ascontiguousarray(a[:n, 32:36]).view(np.int32).reshape(n))
+    box = torch.from_numpy(np.ascontiguousarray(a[:n, :32]).view(np.int64).reshape(n, 4))
+    return kp, has, box, a[n, :16].view(np.int32).tolist()
 
 
 def range_message(bits: int) -> str:
@@ -94,7 +114,10 @@ class HandNetEngine:
             raise ValueError(f"detector on {fcos.device} but A2J on {a2j.device}")
         self.fcos, self.a2j, self.num_classes = fcos, a2j, num_classes
         self.device = fcos.device
-        self._graphs = {}
+        # captured steps, least recently used first: key -> (graph, static images, static depth, static HandNetOutput)
+        self._graphs = collections.OrderedDict()
+        self._host_records = {}     # eager to_host steps: batch -> (pinned record, device record)
+        self._raw_staging = {}      # forward_raw from pageable host memory: (shape, dtype) -> pinned staging buffer
         # f16x3 range contract.  Always on (HN_CHECK_RANGE=0 turns it off for A/B timing): every split producer of a step
         # notes values outside the fp16 range into this engine's flag block and the step ends with ONE tiny launch that
         # hands the words over as HandNetOutput.range_flags -- no sync; the drop-in HandNet.forward reads them with the
@@ -112,9 +135,11 @@ class HandNetEngine:
         self._sparse_hint = False
 
     @ops.device_guarded
-    def forward_device(self, images, depth: torch.Tensor) -> HandNetOutput:
+    def forward_device(self, images, depth: torch.Tensor, to_host: bool = False, _record=None) -> HandNetOutput:
         """images [N,3,H,W] 0..1 (or a list of [3,h_i,w_i] tensors of different sizes), depth [N,1,H,W] metres
-        (RGBD model: [N,4,H,W] = RGB + depth), fp32 on the GPU."""
+        (RGBD model: [N,4,H,W] = RGB + depth), fp32 on the GPU.  to_host: the step also packs its per-frame results and the
+        range words into one record buffer and enqueues ONE device -> host copy of it into pinned memory
+        (HandNetOutput.host_record; the reference returns its keypoints on the CPU, a2j/a2j.py:229) -- no sync here."""
         want_c = 4 if self.a2j.rgbd else 1
         if depth.dim() != 4 or depth.shape[1] != want_c or depth.shape[0] != len(images):
             raise ValueError(f"depth_images must be [N,{want_c},H,W] matching images"
@@ -130,13 +155,21 @@ class HandNetEngine:
             kp = self._a2j_sparse(crops, has_hand) if self._use_compaction(len(images)) else None
             if kp is None:
                 kp = self.a2j.forward_nhwc(crops, valid=has_hand)
-            flags = ops.range_check_collect(self._range_block) if noting else None
+            host_rec = None
+            if to_host or _record is not None:
+                n = len(images)
+                host_rec, dev_rec = _record if _record is not None else self._host_record_buffers(n)
+                ops.pack_records(kp, crop_box, has_hand, n + 1, RECORD_BYTES, out=dev_rec)       # (row n: zeros)
+                flags = ops.range_check_collect(self._range_block, out=dev_rec[n, :16].view(torch.int32)) if noting else None
+                host_rec.copy_(dev_rec, non_blocking=True)
+            else:
+                flags = ops.range_check_collect(self._range_block) if noting else None
         self._note_hand_count(has_hand, len(images))
         if self.check_range:
             bits = ops.range_bits(flags.cpu().tolist())
             if bits:
                 raise ops.RangeError(range_message(bits))
-        return HandNetOutput(kp, crops, crop_box, has_hand, det, cand, flags)
+        return HandNetOutput(kp, crops, crop_box, has_hand, det, cand, flags, host_rec)
 
     # -------------------------------------------------------------------------------
     # sparse streams: A2J on the frames with a hand only
@@ -178,54 +211,125 @@ class HandNetEngine:
     # -------------------------------------------------------------------------------
     # hipGraph replay for a fixed batch shape (launch-bound at small batch)
     # -------------------------------------------------------------------------------
+    def _host_record_buffers(self, n):
+        buf = self._host_records.get(n)
+        if buf is None:
+            with torch.inference_mode(False):   # ordinary tensors: written in place by later calls in any mode
+                buf = self._host_records[n] = (torch.zeros((n + 1, RECORD_BYTES), dtype=torch.uint8, pin_memory=True),
+                                               torch.zeros((n + 1, RECORD_BYTES), dtype=torch.uint8, device=self.device))
+        return buf
+
     @ops.device_guarded
-    def graphed(self, images: torch.Tensor, depth: torch.Tensor):
+    def graphed(self, images: torch.Tensor, depth: torch.Tensor, to_host: bool = False, limit: int | None = None):
         """Returns (run, static_images, static_depth, static_output): copy new inputs into the
-        static tensors and call run() to replay the captured step."""
-        key = (tuple(images.shape), tuple(depth.shape))
+        static tensors and call run() to replay the captured step.  to_host: the captured step ends with the record pack and
+        the device -> host copy of forward_device(to_host=True) (static_output.host_record).  limit: at most that many
+        captured steps are kept -- capturing one more evicts the least recently used (its static activation pool is freed)."""
+        key = (tuple(images.shape), tuple(depth.shape), bool(to_host))
         if key not in self._graphs:
+            while limit is not None and len(self._graphs) >= max(1, limit):
+                self._graphs.popitem(last=False)
             with torch.inference_mode(False), torch.no_grad():
-                return self._capture(key, images, depth)
+                return self._capture(key, images, depth, to_host)
+        self._graphs.move_to_end(key)
         g, s_img, s_dep, out = self._graphs[key]
         return g.replay, s_img, s_dep, out
 
-    def has_graph(self, image_shape, depth_shape) -> bool:
-        return (tuple(image_shape), tuple(depth_shape)) in self._graphs
+    def has_graph(self, image_shape, depth_shape, to_host: bool = False) -> bool:
+        return (tuple(image_shape), tuple(depth_shape), bool(to_host)) in self._graphs
 
     def graph_count(self) -> int:
         return len(self._graphs)
 
-    def replay_frames(self, frames, depth):
+    def captured(self, image_shape, depth_shape, to_host: bool = False):
+        """(graph, static images, static depth, static output) of a captured step for these shapes, or None; a hit counts as a
+        use for the eviction order.  The caller fills the static inputs and calls graph.replay()."""
+        key = (tuple(image_shape), tuple(depth_shape), bool(to_host))
+        hit = self._graphs.get(key)
+        if hit is not None:
+            self._graphs.move_to_end(key)
+        return hit
+
+    def replay_frames(self, frames, depth, to_host: bool = False):
         """Steady state of the live caller (ros_demo.py:270: a list of equally sized frames per call): when a captured
         step for these shapes exists, stack the frames straight into its input buffer (one kernel instead of stack + copy),
         copy the depth map and replay.  Returns the step's static HandNetOutput, or None when nothing is captured for
         these shapes (or the frames differ in shape / dtype)."""
         first = frames[0]
-        hit = self._graphs.get(((len(frames),) + tuple(first.shape), tuple(depth.shape)))
+        hit = self.captured((len(frames),) + tuple(first.shape), depth.shape, to_host)
         if hit is None or any(f.shape != first.shape for f in frames):
             return None
         g, s_img, s_dep, out = hit
-        torch.stack(list(frames), out=s_img)
+        if len(frames) == 1:
+            s_img[0].copy_(first)
+        else:
+            torch.stack(list(frames), out=s_img)
         s_dep.copy_(depth)
         g.replay()
         return out
 
-    def _capture(self, key, images, depth):
+    # -------------------------------------------------------------------------------
+    # raw camera frames: the reference caller's host-side conversions as one kernel (ros_demo.py:227-231,266-269)
+    # -------------------------------------------------------------------------------
+    def _device_readable(self, t: torch.Tensor):
+        """GPU tensors and pinned host tensors as they are; pageable host memory through a pinned staging buffer of the
+        engine (one host memcpy; the ingest kernel then reads the pinned buffer over PCIe itself)."""
+        if t.is_cuda or t.is_pinned():
+            return t.contiguous()
+        key = (tuple(t.shape), t.dtype)
+        buf = self._raw_staging.get(key)
+        if buf is None:
+            with torch.inference_mode(False):
+                buf = self._raw_staging[key] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        buf.copy_(t)
+        return buf
+
+    @ops.device_guarded
+    def forward_raw(self, bgr_u8, depth_raw, to_host: bool = False, use_graph: bool = False, limit: int | None = None):
+        """bgr_u8 uint8 [N,H,W,3] (cv_bridge 'bgr8'), depth_raw [N,H,W] uint16 millimetres (16UC1) or float32 metres (32FC1);
+        torch tensors on the GPU or on the host (pinned: read in place; pageable: staged once).  ONE ingest kernel writes the
+        fp32 RGB batch and the metres depth map (RGB-D model: the 4-channel tensor) -- straight into the input buffers of the
+        captured step when use_graph / a capture for these shapes exists -- then the step runs as forward_device does."""
+        bgr, dep = self._device_readable(bgr_u8), self._device_readable(depth_raw)
+        n, h, w, _ = bgr.shape
+        dshape = (n, 4 if self.a2j.rgbd else 1, h, w)
+        hit = self.captured((n, 3, h, w), dshape, to_host)
+        if hit is None and use_graph and not torch.cuda.is_current_stream_capturing():
+            rgb, d1, d4 = ops.ingest_raw(bgr, dep, device=self.device, want_rgbd=self.a2j.rgbd)
+            self.graphed(rgb, d4 if self.a2j.rgbd else d1, to_host=to_host, limit=limit)
+            hit = self.captured((n, 3, h, w), dshape, to_host)
+        if hit is not None:
+            g, s_img, s_dep, out = hit
+            if self.a2j.rgbd:
+                ops.ingest_raw(bgr, dep, out_rgb=s_img, out_rgbd=s_dep)
+            else:
+                ops.ingest_raw(bgr, dep, out_rgb=s_img, out_depth=s_dep)
+            g.replay()
+            return out
+        rgb, d1, d4 = ops.ingest_raw(bgr, dep, device=self.device, want_rgbd=self.a2j.rgbd)
+        return self.forward_device(rgb, d4 if self.a2j.rgbd else d1, to_host=to_host)
+
+    def _capture(self, key, images, depth, to_host=False):
         # static buffers are ordinary (non-inference) tensors so that later copy_() works in any mode
         s_img, s_dep = torch.empty_like(images), torch.empty_like(depth)
         s_img.copy_(images)
         s_dep.copy_(depth)
+        record = None
+        if to_host:     # the capture's own record buffers (addresses are baked into the graph)
+            n = images.shape[0]
+            record = (torch.zeros((n + 1, RECORD_BYTES), dtype=torch.uint8, pin_memory=True),
+                      torch.zeros((n + 1, RECORD_BYTES), dtype=torch.uint8, device=self.device))
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with ops.launch_cost_hidden():
             with torch.cuda.stream(side):
                 for _ in range(2):  # warm-up (allocator, lazy module load) outside capture
-                    self.forward_device(s_img, s_dep)
+                    self.forward_device(s_img, s_dep, _record=record)
             torch.cuda.current_stream().wait_stream(side)
             g = torch.cuda.CUDAGraph()
             # thread_local: GPU work another thread of the host process issues meanwhile (a ROS node's other callbacks)
             # does not invalidate the capture
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                out = self.forward_device(s_img, s_dep)
+                out = self.forward_device(s_img, s_dep, _record=record)
         self._graphs[key] = (g, s_img, s_dep, out)
         return g.replay, s_img, s_dep, out

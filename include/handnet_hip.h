@@ -341,6 +341,19 @@ int hn_conv3x3_thin_affine_f16x3_levels(const hn_thin_levels* lv, const hn_thin_
                                         const void* w16, const float* bias, int relu_cols, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Caller-side ingest, fused: what ros_demo.py:227-231,266-269 does on the host before it calls the network --
+ *   bgr8 HWC uint8 -> cv2.COLOR_BGR2RGB -> transpose(2,0,1) -> float32 / 255.0        -> rgb    [n][3][h][w]
+ *   16UC1 depth in millimetres -> float32 / 1000.0 (32FC1 metres: passed through)      -> depth_m [n][1][h][w]
+ *   RGB-D model: torch.cat([rgb, depth], dim=1)                                        -> rgbd   [n][4][h][w]
+ * bgr [n][h][w][3] uint8 and depth [n][h][w] (depth_kind 1: uint16 mm, 2: float32 m, 0: none / NULL) only have to be
+ * READABLE by the device: device memory, or pinned host memory read over PCIe by the kernel itself (1.5 MB per 640x480
+ * frame instead of the 4.9 MB of the fp32 feed).  rgb / depth_m / rgbd are device tensors; any of them may be NULL if
+ * not wanted (rgbd needs a depth input).  IEEE float32 divisions: bit-identical to the reference's numpy arithmetic.
+ * ------------------------------------------------------------------------------------ */
+int hn_ingest_u8bgr_u16mm(const uint8_t* bgr, const void* depth, int depth_kind, float* rgb, float* depth_m,
+                          float* rgbd, int n, int h, int w, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * FCOS pre-processing: normalize + bilinear resize (align_corners=False, scale =
  * in/out as with recompute_scale_factor=True) + zero pad, NCHW fp32 in -> NHWC(4) out.
  * Replaces torchvision GeneralizedRCNNTransform called at fcos_utils/fcos.py:709.

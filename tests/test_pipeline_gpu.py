@@ -629,3 +629,102 @@ def test_pipeline_is_deterministic_over_many_steps(fcos_sd, a2j_sd):
             out = eng.forward_device(rgb, depth)
             bad += (out.keypoints != kp0).sum() + (out.crop_box != box0).sum() + (out.has_hand != has0).sum()
         assert int(bad) == 0
+
+
+# ---- raw camera frames: the reference caller's ingest (ros_demo.py:227-231,266-269) as one kernel ----
+def _raw_frames(n, h=480, w=640, seed=7):
+    rng = np.random.default_rng(seed)
+    bgr = rng.integers(0, 256, size=(n, h, w, 3), dtype=np.uint8)
+    mm = rng.integers(300, 1500, size=(n, h, w)).astype(np.uint16)
+    return bgr, mm
+
+
+def _host_ingest(bgr, mm):
+    """What ros_demo.py:230-231,266 compute on the host (cv2.COLOR_BGR2RGB = channel reversal)."""
+    rgb = np.ascontiguousarray(bgr[..., ::-1]).transpose(0, 3, 1, 2).astype(np.float32) / 255.0
+    depth = mm.astype(np.float32)
+    depth /= 1000.0
+    return torch.from_numpy(np.ascontiguousarray(rgb)), torch.from_numpy(depth).unsqueeze(1)
+
+
+@pytest.mark.parametrize("shape", [(2, 480, 640), (1, 37, 53), (3, 30, 44)])
+def test_ingest_raw_is_bit_identical_to_the_host_arithmetic(shape):
+    """hn_ingest_u8bgr_u16mm from device memory and straight from PINNED host memory: uint8 / 255.0 and uint16 / 1000.0 are IEEE
+    divisions of exact integers, so the fp32 tensors must equal numpy's bit for bit -- the vector path (H*W % 4 == 0) and
+    the per-pixel path; 32FC1 depth passes through; the RGB-D tensor is cat([rgb, depth])."""
+    from hn_amd import ops
+    n, h, w = shape
+    bgr, mm = _raw_frames(n, h, w)
+    ref_rgb, ref_d = _host_ingest(bgr, mm)
+    tb, td = torch.from_numpy(bgr), torch.from_numpy(mm)
+    for src_b, src_d in ((tb.cuda(), td.cuda()), (tb.pin_memory(), td.pin_memory())):
+        rgb, d, rgbd = ops.ingest_raw(src_b, src_d, want_rgbd=True)
+        assert torch.equal(rgb.cpu(), ref_rgb) and torch.equal(d.cpu(), ref_d)
+        assert torch.equal(rgbd.cpu(), torch.cat([ref_rgb, ref_d], dim=1))
+    f32 = ref_d[:, 0].contiguous()
+    f32[0, 0, 0] = float("nan")                                   # 32FC1 marks invalid pixels so: passed through untouched
+    rgb, d, _ = ops.ingest_raw(tb.cuda(), f32.cuda())
+    assert torch.equal(torch.nan_to_num(d.cpu(), nan=-1.0), torch.nan_to_num(f32.unsqueeze(1), nan=-1.0))
+    rgb_only, none_d, _ = ops.ingest_raw(tb.cuda())
+    assert none_d is None and torch.equal(rgb_only.cpu(), ref_rgb)
+    with pytest.raises(RuntimeError, match="pinned"):
+        ops.ingest_raw(tb, td.cuda())
+    with pytest.raises(TypeError):
+        ops.ingest_raw(tb.cuda().float(), td.cuda())
+
+
+def test_forward_raw_equals_forward_on_the_host_converted_frames(fcos_sd, a2j_sd):
+    """HandNet.forward_raw(bgr8 frames, 16UC1 depth) == HandNet.forward(the frames converted on the host exactly as
+    ros_demo.py:230-231,266 converts them): same kernels behind one ingest launch, so every returned tensor is bit-identical --
+    from numpy arrays (pageable host memory), pinned tensors and device tensors, eagerly and through the captured step."""
+    net = _dropin(fcos_sd, a2j_sd)
+    ref_net = _dropin(fcos_sd, a2j_sd).enable_graph(False)
+    frames = [_raw_frames(2, seed=11 + i) for i in range(3)]
+    with torch.inference_mode():
+        for call in range(7):                                   # calls 1-4 eager, then captured + replayed
+            bgr, mm = frames[call % 3]
+            rgb, depth = _host_ingest(bgr, mm)
+            want = ref_net([r.cuda() for r in rgb], depth_images=depth.cuda())
+            if call % 3 == 0:
+                got = net.forward_raw(bgr, mm)                                          # numpy, pageable
+            elif call % 3 == 1:
+                got = net.forward_raw(torch.from_numpy(bgr).pin_memory(), torch.from_numpy(mm).pin_memory())
+            else:
+                got = net.forward_raw(torch.from_numpy(bgr).cuda(), torch.from_numpy(mm).cuda())
+            assert got[0].device.type == "cpu" and got[1].is_cuda and got[2].dtype == torch.int64
+            for a, b in zip(got, want):
+                assert torch.equal(a.cpu(), b.cpu()), call
+        assert net.engine().graph_count() == 1
+        one = net.forward_raw(frames[0][0][0], frames[0][1][0])                      # a single [H,W,3] frame + [H,W] depth
+        assert tuple(one[0].shape) == (1, 21, 3)
+        # nothing detected: the placeholder tuple of handnet_pipeline.py:107-108 with the fp32 depth shape
+        black = net.forward_raw(np.zeros((2, 480, 640, 3), np.uint8), frames[0][1])
+        if float(black[2].abs().max()) == 0.0:
+            assert tuple(black[0].shape) == (2, 21, 3) and tuple(black[1].shape) == (2, 1, 480, 640) and tuple(black[2].shape) == (2, 4)
+
+
+def test_auto_captured_graphs_are_evicted_least_recently_used(fcos_sd, a2j_sd):
+    """a caller that sweeps input shapes keeps at most AUTO_GRAPH_MAX_SHAPES captured steps (each owns a
+    static activation pool); one more shape evicts the least recently used capture instead of refusing to capture."""
+    from hn_amd import synth
+    net = _dropin(fcos_sd, a2j_sd)
+    net.AUTO_GRAPH_MAX_SHAPES = 2
+    net.AUTO_GRAPH_CALLS = 1
+    eng = net.engine()
+
+    def run(h, w, times=3):
+        rgb, depth = synth.make_rgb(1, seed=1000)[:, :, :h, :w].contiguous().cuda(), synth.make_depth(1, seed=2000)[:, :, :h, :w].contiguous().cuda()
+        with torch.inference_mode():
+            for _ in range(times):
+                out = net([rgb[0]], depth_images=depth)
+        return out
+    a = run(480, 640)
+    run(448, 640)
+    assert eng.graph_count() == 2 and eng.has_graph((1, 3, 480, 640), (1, 1, 480, 640), to_host=True)
+    run(480, 640, times=1)                                     # a use: 448 x 640 is now the least recently used
+    run(416, 640)
+    assert eng.graph_count() == 2
+    assert eng.has_graph((1, 3, 480, 640), (1, 1, 480, 640), to_host=True) and not eng.has_graph((1, 3, 448, 640), (1, 1, 448, 640), to_host=True)
+    b = run(480, 640, times=1)
+    for x, y in zip(a, b):
+        assert torch.equal(x.cpu(), y.cpu())
