@@ -1489,6 +1489,10 @@ extern "C" int hn_conv2d_f16x3_uses_halo(const hn_conv_desc* d, int has_residual
   return d && hn::conv3x3_halo_applies(d, false, false, has_residual ? (const void*)d : nullptr) ? 1 : 0;
 }
 
+extern "C" int hn_conv2d_f16x3_uses_stream(const hn_conv_desc* d) {
+  return d && hn::conv1x1_stream_applies(d, false, false) ? 1 : 0;
+}
+
 extern "C" int hn_conv2d_f16x3_uses_rs(const hn_conv_desc* d) {
   if (!d || d->w <= 0 || d->cin <= 0) return 0;
   if (hn::conv3x3_halo_applies(d, false, false, d->res_mode ? (const void*)d : nullptr)) return 0;
@@ -1631,6 +1635,11 @@ static int conv16_run(const hn_conv_desc* d, const void* x16, const void* w16, c
   if (d->terms != 1 && hn::conv3x3_halo_applies(d, gn_partial != nullptr, group != nullptr, residual) &&
       hn::conv3x3_halo_operands_ok(d, x16, w16, bias, residual, y))
     return hn::conv3x3_halo(d, x16, w16, bias, residual, y, (hipStream_t)stream);
+  // short-k 1x1 layers with 256 k output channels on many pixels (the FPN P3 lateral, the A2J 64 -> 256 / 128 -> 512 expansions
+  // at batch >= ~32): filter bank in registers, activations streamed once (conv1x1_stream.hip; same k order, bit-identical)
+  if (hn::conv1x1_stream_applies(d, gn_partial != nullptr, group != nullptr) &&
+      hn::conv1x1_stream_operands_ok(d, x16, w16, bias, residual, y))
+    return hn::conv1x1_stream(d, x16, w16, bias, residual, y, (hipStream_t)stream);
 
   hn_conv_desc tile_desc = *d;  // what the tile heuristic sees: for a group, all members' rows together
   if (group) {
@@ -1746,6 +1755,9 @@ static bool multi_plan(const hn_conv_multi* mm, void* workspace, int64_t workspa
       return false;
     if (p.terms != 3 || (hn::conv3x3_halo_applies(d, false, false, mm->residual[g]) &&
                          hn::conv3x3_halo_operands_ok(d, mm->x16[g], mm->w16[g], mm->bias[g], mm->residual[g], mm->y[g])))
+      return false;
+    if (hn::conv1x1_stream_applies(d, false, false) &&
+        hn::conv1x1_stream_operands_ok(d, mm->x16[g], mm->w16[g], mm->bias[g], mm->residual[g], mm->y[g]))
       return false;
     const int t = hn_conv2d_f16x3_pick_tile(d);
     if (tile >= 0 && t != tile) return false;

@@ -121,6 +121,7 @@ SIGNATURES = {
     "hn_unsplit_f32": (C.c_int, [VP] + [C.c_int] * 4 + [VP, C.c_int, VP]),
     "hn_maxpool3x3s2_s32": (C.c_int, [VP, VP] + [C.c_int] * 6 + [VP]),
     "hn_conv2d_f16x3_pick_tile": (C.c_int, [C.POINTER(ConvDesc)]),
+    "hn_conv2d_f16x3_uses_stream": (C.c_int, [C.POINTER(ConvDesc)]),
     "hn_conv2d_f16x3_uses_rs": (C.c_int, [C.POINTER(ConvDesc)]),
     "hn_conv2d_f16x3_uses_halo": (C.c_int, [C.POINTER(ConvDesc), C.c_int]),
     "hn_maxpool3x3s2_nhwc_f32": (C.c_int, [VP, VP] + [C.c_int] * 6 + [VP]),

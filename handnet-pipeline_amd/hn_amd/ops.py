@@ -188,12 +188,15 @@ TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x64", 4: "128x32", 5: "256x128", 
 TILE_RS = 0x100  # profile records: tile id | TILE_RS when the launch ran the row-shared-A instantiation of that tile
 TILE_HALO = 0x200  # ... | TILE_HALO when it was routed to the halo-patch kernel (conv3x3_halo_kernel)
 TILE_MULTI = 0x400  # ... | TILE_MULTI for a heterogeneous launch (conv_igemm_f16x3_multi_kernel): several convolutions, one record
+TILE_STREAM = 0x800  # ... | TILE_STREAM when it was routed to the streaming 1x1 kernel (conv1x1_stream_kernel)
 
 
 def tile_name(tile) -> str:
     """'128x128' / '128x128+rs' (the row-shared-A kernels are separate instantiations, i.e. separate profiler rows)."""
     if isinstance(tile, int) and tile & TILE_HALO:
         return "halo16x16"
+    if isinstance(tile, int) and tile & TILE_STREAM:
+        return "stream1x1"
     base = TILE_NAMES.get(tile & 0xFF, str(tile & 0xFF)) if isinstance(tile, int) else str(tile)
     return base + ("+rs" if isinstance(tile, int) and tile & TILE_RS else "") + \
         ("+multi" if isinstance(tile, int) and tile & TILE_MULTI else "")
@@ -399,7 +402,8 @@ def conv2d_nhwc(x, w, bias=None, *, stride=1, pad=0, dil=1, relu=False, relu_col
         macs = n * d.oh * d.ow * cout * r * s * (algo_cin or cin)
         if use16:
             flags = TILE_HALO if lib.hn_conv2d_f16x3_uses_halo(C.byref(d), 1 if residual is not None else 0) else \
-                (TILE_RS if lib.hn_conv2d_f16x3_uses_rs(C.byref(d)) else 0)
+                (TILE_STREAM if lib.hn_conv2d_f16x3_uses_stream(C.byref(d)) else
+                 TILE_RS if lib.hn_conv2d_f16x3_uses_rs(C.byref(d)) else 0)
             kind = ("f16x3", lib.hn_conv2d_f16x3_pick_tile(C.byref(d)) | flags)
         else:
             kind = ("f32", lib.hn_conv2d_pick_tile(C.byref(d)))

@@ -88,7 +88,8 @@ int hn_range_check_collect(int32_t* block /* or NULL */, int32_t* dst /* device,
 
 /* Kernel-form switches.  Older forms of some kernels stay in the library as bit-identity references for the tests and for
  * same-box A/B timing ("conv_no_rs", "conv_no_rs32", "split_generic", "stem_pool_generic", "conv_no_halo", "preprocess_generic",
- * "conv_no_multi", "no_fuse_last_gn", "no_thin_outputs", "thin_form_tap", "thin_form_flat", "halo_stamps", "splitk_fill512"; results unchanged
+ * "conv_no_multi", "no_fuse_last_gn", "no_thin_outputs", "thin_form_tap", "thin_form_flat", "halo_stamps", "splitk_fill512",
+ * "conv_no_stream"; results unchanged
  * unless a test says otherwise).  The library NEVER reads them from the environment: a development host sets them by name
  * (bench.py and tools/ translate their HN_* variables through hn_amd/forms.py); a product process leaves them alone. */
 int hn_set_form(const char* name, int value);
@@ -182,6 +183,12 @@ int hn_conv2d_f16x3_uses_rs(const hn_conv_desc* d);
  * turns it off): a workgroup stages the 18 x 18 input patch of a 32-channel block once and reads all nine taps from it.
  * Same k order as the implicit-GEMM kernel: bit-identical results (ResNet-34 layer1, fcos_utils/fcos.py:737). */
 int hn_conv2d_f16x3_uses_halo(const hn_conv_desc* d, int has_residual);
+/* 1 when hn_conv2d_nhwc_f16x3(_ws) routes this descriptor to the streaming kernel for short-k 1x1 layers (1x1 / stride 1 / pad 0,
+ * cin 64 or 128, cout % 256 == 0, dense S32 input, ReLU on all columns or none, at least 65536 output pixels; "conv_no_stream"
+ * turns it off): a wave keeps the filter fragments of its 32 output channels in registers for the whole launch and the
+ * activations are streamed through LDS once.  Same k order and epilogue arithmetic as the implicit-GEMM kernel: bit-identical
+ * results (the FPN P3 lateral via fcos_utils/fcos.py:737, the bottleneck expansions of a2j/resnet.py:78-96 at batch >= ~32). */
+int hn_conv2d_f16x3_uses_stream(const hn_conv_desc* d);
 
 /* ---- S32 split activation format: fp16 [N][H][W][C/32][2][32] (hi[32] | lo[32] per block) ----
  * hn_affine_split_f32: fp32 NHWC -> S32; with scale/shift [n][c] it first applies

@@ -951,3 +951,74 @@ def test_halo_shape_with_unaligned_operands_takes_the_implicit_gemm():
     y0 = ops.conv2d_nhwc(x, wt.cuda(), bias_aligned, pad=1, relu=True, w16=w16, out_split=True)
     y1 = ops.conv2d_nhwc(x, wt.cuda(), bias_unaligned, pad=1, relu=True, w16=w16, out_split=True)
     assert torch.equal(y0, y1)
+
+
+@pytest.mark.parametrize("case", [
+    # (n, h, w, cin, cout, residual kind, out_split, relu)
+    (5, 100, 136, 128, 256, "up_s32", True, False),     # the FPN P3 lateral: top-down add read at (h/2, w/2) (res_mode 2), S32 in / out
+    (34, 44, 44, 64, 256, "same_s32", True, True),      # A2J layer1 expansion + identity + ReLU; 65 824 pixels: a ragged last tile
+    (140, 22, 22, 128, 512, None, False, False),        # two 256-channel column groups, fp32 output, no residual
+    (36, 44, 44, 64, 256, "same_f32", True, True),      # fp32 residual
+])
+def test_streaming_1x1_kernel_is_bit_identical_to_the_implicit_gemm(case):
+    """conv1x1_stream_kernel (1x1 / stride 1, Cin 64 or 128, Cout % 256 == 0, >= 65 536 pixels) against the
+    implicit-GEMM kernel it replaces for that shape (form "conv_no_stream"): same k order, same term order, same epilogue
+    arithmetic -- same bits; and against an fp64 convolution."""
+    from hn_amd import ops
+    from hn_amd.weights import split_f16x3
+    from oracle import ops_ref
+    n, h, w, cin, cout, res, osplit, relu = case
+    x = _rand((n, h, w, cin), 91)
+    wt = _rand((cout, 1, 1, cin), 92, scale=(2.0 / cin) ** 0.5)
+    b = _rand((cout,), 93, 0.1)
+    r = None
+    if res == "up_s32":
+        r = _rand((n, h // 2, w // 2, cout), 94)
+    elif res is not None:
+        r = _rand((n, h, w, cout), 94)
+    xs, w16 = ops.to_split(x.cuda()), split_f16x3(wt).cuda()
+    rdev = None if r is None else (r.cuda() if res == "same_f32" else ops.to_split(r.cuda()))
+    d = ops.make_conv_desc(n, h, w, cin, cout, 1, 1, 1, 0, 1, cout if relu else 0, 0 if res is None else (2 if res == "up_s32" else 1))
+    d.out_split = 1 if osplit else 0
+    assert ops._lib.load().hn_conv2d_f16x3_uses_stream(d) == 1
+    kw = dict(pad=0, relu=relu, w16=w16, out_split=osplit, residual=rdev, res_upsample=res == "up_s32")
+    block = torch.zeros((4,), device="cuda", dtype=torch.int32)
+    with ops.range_scope(block):
+        y_stream = ops.conv2d_nhwc(xs, wt.cuda(), b.cuda(), **kw)
+        assert ops.range_check_collect(block).cpu().tolist() == [0, 0, 0, 0]
+    ops.set_form("conv_no_stream", True)
+    try:
+        assert ops._lib.load().hn_conv2d_f16x3_uses_stream(d) == 0
+        y_gemm = ops.conv2d_nhwc(xs, wt.cuda(), b.cuda(), **kw)
+    finally:
+        ops.set_form("conv_no_stream", False)
+    assert y_stream.shape == y_gemm.shape and torch.equal(y_stream, y_gemm)
+    ref = ops_ref.conv2d_nhwc(x.double(), wt.double(), b.double(), 1, 0, 1, relu_cols=0)
+    if res == "up_s32":
+        ref = ref + r.double().repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+    elif res is not None:
+        ref = ref + r.double()
+    ref = (torch.relu(ref) if relu else ref).float()
+    got = (ops.from_split(y_stream) if osplit else y_stream).cpu()
+    assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    # the range contract rides along: an overflowing S32 output is flagged
+    if osplit:
+        big = wt * 3.0e4
+        with ops.range_scope(block):
+            ops.conv2d_nhwc(xs, big.cuda(), b.cuda(), **dict(kw, w16=split_f16x3(big).cuda()))
+            assert ops.range_check_collect(block).cpu().tolist() == [1, 0, 0, 0]
+
+
+def test_streaming_1x1_kernel_leaves_small_and_odd_shapes_to_the_implicit_gemm():
+    from hn_amd import ops
+    lib = ops._lib.load()
+
+    def uses(n, h, w, cin, cout, r=1, stride=1, relu_cols=0):
+        d = ops.make_conv_desc(n, h, w, cin, cout, r, r, stride, r // 2, 1, relu_cols, 0)
+        return lib.hn_conv2d_f16x3_uses_stream(d)
+    assert uses(32, 100, 136, 128, 256) == 1 and uses(64, 44, 44, 64, 256) == 1
+    assert uses(1, 100, 136, 128, 256) == 0          # batch 1: 13 600 pixels do not fill the chip with 128-pixel tiles
+    assert uses(32, 100, 136, 256, 256) == 0         # k too long for register-resident filters
+    assert uses(32, 100, 136, 128, 128) == 0         # not a whole 256-channel column group
+    assert uses(32, 100, 136, 128, 256, r=3) == 0 and uses(32, 100, 136, 128, 256, stride=2) == 0
+    assert uses(32, 100, 136, 128, 256, relu_cols=100) == 0
