@@ -93,6 +93,7 @@ struct ConvParams16 {
   float* split_ws;
   int64_t split_ws_bytes;
   int tiles_m, tiles_n, nblocks;
+  int small_mask;     // mixed grouped launch: bit g set = member g runs the 64-row per-tap form (see conv_igemm_f16x3_mixed_kernel)
   int* range_flag;    // f16x3 range contract (hn_range_check_enable): set to 1 when an S32 output value cannot be split
   // v6 operand addressing (BUF kernels): both operands are fetched through buffer descriptors, so a DMA's address is
   // <descriptor base> + <per-lane 32-bit offset, loop-invariant> + <wave-uniform SGPR offset of the k tile>, and a
@@ -309,7 +310,7 @@ constexpr int kPoolRows = 15, kPoolCols = 17, kPoolPR = 7, kPoolPC = 8;
 // The kernel's body as a device function of (parameter block, workgroup coordinates): conv_igemm_f16x3_kernel passes its own
 // kernel argument and blockIdx; conv_igemm_f16x3_multi_kernel (heterogeneous launches, below) the member's block and the
 // member-local coordinates.  Always inlined: the single-problem kernel compiles to what it was.
-template <int BM, int BN, int WM, int WN, int NBUF, bool BUF, bool RS = false, bool POOL = false, int TERMS = 3>
+template <int BM, int BN, int WM, int WN, int NBUF, bool BUF, bool RS = false, bool POOL = false, int TERMS = 3, bool DYN = false>
 __device__ __forceinline__ void conv_igemm_f16x3_body(const ConvParams16& p, const int blk_x, const int blk_y, const int blk_z) {
   static_assert(TERMS == 3 || TERMS == 1, "three terms (fp32-grade) or the hi*hi term alone");
   static_assert(NBUF >= 2 && NBUF <= 6, "2..6 LDS stages");
@@ -375,8 +376,9 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(const ConvParams16& p, con
   constexpr int A_BUF = A_ROWS * ROWH, B_BUF = BN * ROWH;  // halfs per buffer
   // the RS stages exceed the 64 KB a static array may have: dynamic LDS there (launch16_impl sets the size)
   extern __shared__ __attribute__((aligned(1024))) _Float16 smem_dyn[];
-  __shared__ __attribute__((aligned(1024))) _Float16 smem_static[RS ? 8 : NBUF * (A_BUF + B_BUF)];
-  _Float16* smem = RS ? smem_dyn : smem_static;
+  // (DYN: a per-tap form that shares its kernel -- and the dynamic LDS block -- with a row-shared form: the mixed grouped kernel)
+  __shared__ __attribute__((aligned(1024))) _Float16 smem_static[(RS || DYN) ? 8 : NBUF * (A_BUF + B_BUF)];
+  _Float16* smem = (RS || DYN) ? smem_dyn : smem_static;
   _Float16* As = smem;                 // [stage][A_ROWS][64]
   _Float16* Bs = smem + NBUF * A_BUF;  // [stage][BN][64]
 
@@ -1156,6 +1158,23 @@ void conv_igemm_f16x3_kernel(const ConvParams16 p) {
   conv_igemm_f16x3_body<BM, BN, WM, WN, NBUF, BUF, RS, POOL, TERMS>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
 }
 
+// ---- grouped launch whose members carry their own tile shape (round 5).  The FCOS tower layers at small batch are ONE grouped
+// launch over (tower, FPN level) members of very different sizes -- at batch 1: 214 + 54 + 14 tiles of 128 x 128 per tower, 564
+// in all on the chip's 512 slots: one full round and a second one that is 10 % full, i.e. the layer takes the time of three
+// tiles per CU where 2.2 would do (MFMA-bound workgroups: a CU's two slots share its matrix pipes).  Equal tiles cannot be
+// packed better; HALF tiles at the END of the dispatch order can: the small members (the stride-16 / stride-32 levels, a
+// quarter of the rows) run the 64 x 128 per-tap form -- same k order, bit-identical results -- so that the last round is filled
+// with half-size workgroups.  Both bodies live in one kernel (256 threads, the row-shared form's dynamic LDS block);
+// blockIdx.z = member as in the plain grouped launch.
+__global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_mixed_kernel(const ConvParams16 p) {
+  typedef __attribute__((address_space(4))) const ConvParams16 KArgs;
+  KArgs* kp = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  if ((kp->small_mask >> blockIdx.z) & 1)
+    conv_igemm_f16x3_body<64, 128, 2, 2, 3, true, false, false, 3, true>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+  else
+    conv_igemm_f16x3_body<128, 128, 2, 2, 2, true, true, false, 3>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
 // ---- heterogeneous launches (hn_conv2d_nhwc_f16x3_multi): up to HN_CONV_MULTI_MAX INDEPENDENT convolutions of different shapes
 // (channels, filter, stride, residual, split-K plan: anything) in ONE grid.  The kernel argument is a table of complete
 // parameter blocks; a workgroup finds its member from the prefix sums of the members' workgroup counts, copies that member's
@@ -1296,6 +1315,28 @@ static bool rs_will_run(const ConvParams16& p, int bm, int bn, int waves, int nb
   return true;
 }
 
+// Mixed grouped launch (conv_igemm_f16x3_mixed_kernel): which members take the 64-row form.  Only where the last round of
+// 128 x 128 tiles would be at most a QUARTER full on a grid of at most three rounds (the FCOS towers / tower0 at batch 1 and 2:
+// 2.277 -> 2.247 ms and 3.153 -> 3.114 ms per step in the frame; with a fuller last round -- batch 3 and 4 -- the per-tap 64-row
+// form's lower efficiency costs more than the packing gains, +70 / +80 us, tools/probes/exp/mixed_tiles.sh): the members with at
+// most half the rows of the largest one.  0 = the plain grouped launch.
+static int mixed_small_mask(const ConvParams16& p, int tiles_n) {
+  if (p.groups <= 1 || p.terms != 3 || hn::env_flags().no_mixed) return 0;
+  const int slots = 512;
+  int64_t total = 0;
+  int max_m = 0;
+  for (int g = 0; g < p.groups; ++g) {
+    total += (int64_t)hn::cdiv(p.gM[g], 128) * tiles_n;
+    max_m = max_m > p.gM[g] ? max_m : p.gM[g];
+  }
+  const int64_t tail = total % slots;
+  if (total <= slots || total > 3 * slots || tail == 0 || tail > slots / 4) return 0;
+  int mask = 0;
+  for (int g = 0; g < p.groups; ++g)
+    if ((int64_t)p.gM[g] * 2 <= max_m) mask |= 1 << g;
+  return mask;
+}
+
 template <int BM, int BN, int WM, int WN, int NBUF, bool BUF, int TERMS = 3>
 int launch16_impl(const ConvParams16& p0, hipStream_t st) {
   ConvParams16 p = p0;
@@ -1334,6 +1375,29 @@ int launch16_impl(const ConvParams16& p0, hipStream_t st) {
   // here so that only the eligible tile forms instantiate the RS kernel)
   if constexpr (BUF && NBUF == 2 && (WM * WN == 4 || WM * WN == 8) && RS_LDS_BYTES <= (WM * WN == 4 ? 80 : 160) * 1024 - 2048) {
     rs = rs_will_run(p, BM, BN, WM * WN, NBUF, BUF);
+    if constexpr (BM == 128 && BN == 128 && WM == 2 && WN == 2 && TERMS == 3) {
+      const int mask = rs ? mixed_small_mask(p, p.tiles_n) : 0;
+      if (mask) {   // members with their own tile shape: the small ones as 64 x 128 per-tap tiles (see the kernel's comment)
+        p.small_mask = mask;
+        grid_x = 0;
+        for (int g = 0; g < p.groups; ++g) {
+          p.gnblocks[g] = hn::cdiv(p.gM[g], (mask >> g) & 1 ? 64 : 128) * p.tiles_n;
+          grid_x = grid_x > p.gnblocks[g] ? grid_x : p.gnblocks[g];
+        }
+        constexpr int LDS_MIXED = RS_LDS_BYTES > 3 * (64 + 128) * ROWH * 2 ? RS_LDS_BYTES : 3 * (64 + 128) * ROWH * 2;
+        static bool mixed_attr[64] = {};
+        int dev = 0;
+        HN_CHECK_HIP(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64 || !mixed_attr[dev]) {
+          HN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_igemm_f16x3_mixed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           LDS_MIXED));
+          if (dev >= 0 && dev < 64) mixed_attr[dev] = true;
+        }
+        hipLaunchKernelGGL(conv_igemm_f16x3_mixed_kernel, dim3(grid_x, 1, p.groups), dim3(256), LDS_MIXED, st, p);
+        HN_CHECK_LAUNCH("conv_igemm_f16x3_mixed_kernel");
+        return HN_OK;
+      }
+    }
     if (rs) {
       constexpr int LDS_BYTES = RS_LDS_BYTES;
       static bool attr_set[64] = {};  // per device: the attribute belongs to the function's image on the current device
@@ -1612,6 +1676,7 @@ static int fill_params16(const hn_conv_desc* d, const void* x16, const void* w16
               ((uintptr_t)y % 16 == 0) && (bias == nullptr || (uintptr_t)bias % 16 == 0) &&
               (residual == nullptr || (uintptr_t)residual % 16 == 0);
   p.tiles_m = p.tiles_n = p.nblocks = 0;
+  p.small_mask = 0;
   p.range_flag = hn::range_flag_ptr();
   p.gn_partial = gn_partial;
   p.split_ws = (float*)workspace;
@@ -1850,6 +1915,7 @@ static int stem16_run(const void* x16, int n, int ph, int pw, int pad, int r, in
   p.rs = 0;
   p.vec_epi = (cout % 8 == 0) && ((uintptr_t)y % 16 == 0) && (bias == nullptr || (uintptr_t)bias % 16 == 0);
   p.tiles_m = p.tiles_n = p.nblocks = 0;
+  p.small_mask = 0;
   p.rs_ok = 0;
   p.terms = terms == 1 ? 1 : 3;
   p.pool_ty = p.pool_tx = p.pool_oh = p.pool_ow = 0;

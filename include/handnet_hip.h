@@ -89,7 +89,7 @@ int hn_range_check_collect(int32_t* block /* or NULL */, int32_t* dst /* device,
 /* Kernel-form switches.  Older forms of some kernels stay in the library as bit-identity references for the tests and for
  * same-box A/B timing ("conv_no_rs", "conv_no_rs32", "split_generic", "stem_pool_generic", "conv_no_halo", "preprocess_generic",
  * "conv_no_multi", "no_fuse_last_gn", "no_thin_outputs", "thin_form_tap", "thin_form_flat", "halo_stamps", "splitk_fill512",
- * "conv_no_stream"; results unchanged
+ * "conv_no_stream", "conv_no_mixed"; results unchanged
  * unless a test says otherwise).  The library NEVER reads them from the environment: a development host sets them by name
  * (bench.py and tools/ translate their HN_* variables through hn_amd/forms.py); a product process leaves them alone. */
 int hn_set_form(const char* name, int value);

@@ -577,7 +577,7 @@ def test_f16x3_wide_dynamic_range_keeps_precision():
 
 
 _FORMS = ("conv_no_rs", "conv_no_rs32", "split_generic", "stem_pool_generic", "conv_no_halo", "preprocess_generic", "conv_no_multi",
-          "no_fuse_last_gn", "no_thin_outputs", "thin_form_tap", "thin_form_flat", "splitk_fill512")
+          "no_fuse_last_gn", "no_thin_outputs", "thin_form_tap", "thin_form_flat", "splitk_fill512", "conv_no_stream", "conv_no_mixed")
 
 
 @pytest.fixture(autouse=True)
@@ -1022,3 +1022,45 @@ def test_streaming_1x1_kernel_leaves_small_and_odd_shapes_to_the_implicit_gemm()
     assert uses(32, 100, 136, 128, 128) == 0         # not a whole 256-channel column group
     assert uses(32, 100, 136, 128, 256, r=3) == 0 and uses(32, 100, 136, 128, 256, stride=2) == 0
     assert uses(32, 100, 136, 128, 256, relu_cols=100) == 0
+
+
+@pytest.mark.parametrize("n", [1, 2])
+def test_mixed_tile_grouped_launch_is_bit_identical_to_one_tile_shape(n):
+    """conv_igemm_f16x3_mixed_kernel (round 5): a grouped launch over the FPN levels of both towers whose last round of 128 x 128
+    tiles would be nearly empty (batch 1: 564 tiles on 512 slots; batch 2: 1128 = 2.2 rounds) gives the stride-16 / stride-32
+    members 64 x 128 per-tap tiles while the stride-8 members keep the 128 x 128 row-shared form.  Same k order: outputs and the
+    GroupNorm partial sums of the stacked slab are bit-identical to the plain grouped launch (form "conv_no_mixed"), as S32
+    with ReLU and as fp32 with the GroupNorm sums (what the towers use)."""
+    from types import SimpleNamespace as NS
+    from hn_amd import ops
+    from hn_amd.weights import split_f16x3
+    g = torch.Generator().manual_seed(97)
+    dims = [(100, 136), (50, 68), (25, 34)]
+    L = len(dims)
+    xs = [ops.to_split(torch.randn((n, h, w, 512), generator=g).cuda()) for h, w in dims]
+    cws = []
+    for _ in range(2):
+        wt = torch.randn((256, 3, 3, 256), generator=g) * (2.0 / 2304) ** 0.5
+        cws.append(NS(w=wt.cuda(), bias=torch.randn((256,), generator=g).cuda(), w16=split_f16x3(wt).cuda()))
+    members = [x[:, :, :, :8] for x in xs] + [x[:, :, :, 8:] for x in xs]
+    weights = [cws[0]] * L + [cws[1]] * L
+
+    def run():
+        hw = [h * w for h, w in dims]
+        parts = [torch.full((ops.gn_rows32_scratch_floats(n * hw[l], 512),), float("nan"), device="cuda") for l in range(L)]
+        t = [torch.empty((n, h, w, 512), device="cuda") for h, w in dims]
+        ops.conv2d_nhwc_grouped(members, weights, pad=1, outs=t + t, out_channel_offsets=[0] * L + [256] * L,
+                                gn=[(parts[l], 0) for l in range(L)] + [(parts[l], 32) for l in range(L)], gn_units=64)
+        s = ops.conv2d_nhwc_grouped(members, weights, pad=1, relu=True, out_split=True)
+        return t, parts, s
+    t_mixed, p_mixed, s_mixed = run()
+    ops.set_form("conv_no_mixed", True)
+    try:
+        t_plain, p_plain, s_plain = run()
+    finally:
+        ops.set_form("conv_no_mixed", False)
+    for a, b in zip(t_mixed + p_mixed + s_mixed, t_plain + p_plain + s_plain):
+        assert not torch.isnan(a).any() and torch.equal(a, b)
+    # and the plain form on one member alone agrees (the grouped launch is not its own only reference)
+    ref = ops.conv2d_nhwc(members[1], cws[0].w, cws[0].bias, pad=1, relu=True, w16=cws[0].w16, out_split=True, splitk=False)
+    assert torch.equal(s_mixed[1], ref)
