@@ -282,7 +282,7 @@ def measured_traffic(kernel, gflop_per_launch, launches_per_step):
         return None, f"{f.name} ({rec.get('tag')}) carries no bench stamp"
     if rec.get("kernel_source_sha16") != kernel_source_sha16():
         return None, (f"{rec.get('tag')} (commit {rec.get('commit')}): collected for another revision of "
-                      "csrc/conv_igemm_f16x3.hip (data movement may differ)")
+                      "csrc/conv_igemm_f16x3_kernel.h (data movement may differ)")
     if stamp.get("kernel") != kernel:
         return None, f"{rec.get('tag')}: collected for {stamp.get('kernel')}, this run's dominant kernel is {kernel}"
     if (stamp.get("launches_per_step") != launches_per_step
@@ -298,10 +298,14 @@ def measured_traffic(kernel, gflop_per_launch, launches_per_step):
     for name, k in rec["kernels"].items():
         if needle not in name:
             continue
-        # template arguments <BM, BN, WM, WN, NBUF, BUF, RS, POOL, TERMS> (f16x3) / <BM, BN, SMALLC> (f32)
+        # template arguments <BM, BN, WM, WN, NBUF, BUF, RS, TERMS> (f16x3; rounds 1-4 had a POOL flag in front of TERMS) /
+        # <BM, BN, SMALLC> (f32)
         targs = [a.strip() for a in name.split("<", 1)[1].split(">", 1)[0].split(",")]
-        if prec == "f16x3" and (len(targs) < 9 or (targs[6] == "true") != rs or targs[7] != "false" or targs[8] != "3"):
-            continue
+        if prec == "f16x3":
+            if len(targs) == 9 and targs[7] == "false":
+                del targs[7]
+            if len(targs) != 8 or (targs[6] == "true") != rs or targs[7] != "3":
+                continue
         return k["hbm_bytes_per_launch"], f"profiles/{rec.get('tag')}_traffic.json (commit {rec.get('commit')})"
     return None, f"{rec.get('tag')}: no {needle} record"
 
@@ -309,7 +313,7 @@ def measured_traffic(kernel, gflop_per_launch, launches_per_step):
 def kernel_source_sha16():
     """Identity of the dominant kernel's source: the HBM-traffic figure of an older revision is never paired with a run."""
     import hashlib
-    return hashlib.sha256((REPO / "handnet-pipeline_amd" / "csrc" / "conv_igemm_f16x3.hip").read_bytes()).hexdigest()[:16]
+    return hashlib.sha256((REPO / "handnet-pipeline_amd" / "csrc" / "conv_igemm_f16x3_kernel.h").read_bytes()).hexdigest()[:16]
 
 
 def dropin_leg(args, sds, dev, batch):

@@ -42,6 +42,7 @@ struct StemParams {
   _Float16* y;         // pooled S32 [n][poh][pow][64/32][2][32]
   int n, hb, wb, oh, ow, poh, pow_, ty, tx;
   long plane;          // halfs between the hi and the lo plane
+  int terms;          // 3: the split-precision product; 1: hi*hi only (the f16x1 throughput mode)
   int* range_flag;
 };
 
@@ -129,14 +130,16 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool_direct_kernel(const Ste
       bl[j] = *reinterpret_cast<const f16x8*>(pb + b_off + j * (16 * 7 * 128) + ky * 128 + 64);
     }
     // same term order per accumulator as conv_igemm_f16x3_kernel (lo*hi, hi*lo, hi*hi); W fragment = srcA (lane = pixel)
+    if (p.terms == 3) {   // (wave-uniform; terms == 1 issues the hi*hi products alone, like the TERMS = 1 kernels)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool_direct_kernel(const Ste
 namespace hn {
 
 // hn_conv_stem_pool_f16x3 for the shape every ResNet stem of this path has (7x7 / stride 2 / pad 3, 64 output channels)
-int stem_pool_direct(const void* x16, int n, int ph, int pw, const void* w16, const float* bias, void* y, hipStream_t st) {
+int stem_pool_direct(const void* x16, int n, int ph, int pw, const void* w16, const float* bias, void* y, int terms, hipStream_t st) {
   const int hb = ph + 6, wb = pw + 6;
   StemParams p;
   p.x = (const _Float16*)x16; p.w = (const _Float16*)w16; p.bias = bias; p.y = (_Float16*)y;
@@ -224,6 +227,7 @@ int stem_pool_direct(const void* x16, int n, int ph, int pw, const void* w16, co
   p.poh = (p.oh + 2 - 3) / 2 + 1; p.pow_ = (p.ow + 2 - 3) / 2 + 1;
   p.ty = hn::cdiv(p.poh, kQR); p.tx = hn::cdiv(p.pow_, kQC);
   p.plane = (long)n * hb * wb * 4;
+  p.terms = terms == 1 ? 1 : 3;
   p.range_flag = hn::range_flag_ptr();
   HN_CHECK_ARG(wb % 2 == 0 && (uintptr_t)x16 % 16 == 0 && (uintptr_t)w16 % 16 == 0 && (uintptr_t)y % 16 == 0 &&
                    (uintptr_t)bias % 16 == 0, "stem image rows / tensors must be 16-byte aligned");

@@ -16,7 +16,7 @@ int fail(int code, const char* fmt, ...);
 int* range_flag_ptr();
 // Kernel-form switches (hn_set_form; all false in a product process: the library never reads the environment)
 struct EnvFlags {
-  bool no_rs, no_rs32, split_generic, stem_generic, no_halo, no_thin, thin_tap, thin_flat, no_fuse_last_gn, pre_generic, no_multi,
+  bool no_rs, no_rs32, split_generic, no_halo, no_thin, thin_tap, thin_flat, no_fuse_last_gn, pre_generic, no_multi,
       halo_stamps, splitk_fill512, no_stream, no_mixed;
 };
 const EnvFlags& env_flags();
@@ -32,7 +32,7 @@ bool conv3x3_halo_operands_ok(const hn_conv_desc* d, const void* x16, const void
                               const void* y);
 int conv3x3_halo(const hn_conv_desc* d, const void* x16, const void* w16, const float* bias, const void* residual, void* y,
                  hipStream_t st);
-int stem_pool_direct(const void* x16, int n, int ph, int pw, const void* w16, const float* bias, void* y, hipStream_t st);
+int stem_pool_direct(const void* x16, int n, int ph, int pw, const void* w16, const float* bias, void* y, int terms, hipStream_t st);
 // conv1x1_stream.hip: 1x1 / stride 1, Cin 64 or 128, Cout % 256 == 0 on many pixels: filter bank in registers, activations streamed
 bool conv1x1_stream_applies(const hn_conv_desc* d, bool has_gn, bool has_group);
 bool conv1x1_stream_operands_ok(const hn_conv_desc* d, const void* x16, const void* w16, const float* bias, const void* residual,

@@ -86,7 +86,6 @@ extern "C" int hn_set_form(const char* name, int value) {
       {"conv_no_rs", &hn::EnvFlags::no_rs},                 // per-tap form of the 3x3 / stride-1 convolutions
       {"conv_no_rs32", &hn::EnvFlags::no_rs32},             // ... of the 128x32 tile only
       {"split_generic", &hn::EnvFlags::split_generic},      // generic GroupNorm-apply kernel
-      {"stem_pool_generic", &hn::EnvFlags::stem_generic},   // implicit-GEMM form of the fused stem + pooling
       {"conv_no_halo", &hn::EnvFlags::no_halo},             // implicit-GEMM form of the 64-channel 3x3 layers
       {"preprocess_generic", &hn::EnvFlags::pre_generic},   // per-pixel preprocess kernel
       {"conv_no_multi", &hn::EnvFlags::no_multi},           // hn_conv2d_nhwc_f16x3_multi: members one after the other

@@ -14,7 +14,7 @@ from . import build as _build
 
 ABI_VERSION = 32
 
-TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, TILE_256x128, TILE_64x128 = range(7)
+TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, _TILE_RETIRED_5, TILE_64x128 = range(7)
 HN_FCOS_MAX_LEVELS = 5
 
 c_f32p = C.POINTER(C.c_float)

@@ -27,7 +27,7 @@ ACTIVE = dict(ENGINE_DEFAULTS)
 # HN_* variable -> (library form, value that turns the form ON)
 _LIB_ENV = {
     "HN_CONV_NO_RS": ("conv_no_rs", None), "HN_CONV_NO_RS32": ("conv_no_rs32", None),
-    "HN_SPLIT_GENERIC": ("split_generic", None), "HN_STEM_POOL_GENERIC": ("stem_pool_generic", None),
+    "HN_SPLIT_GENERIC": ("split_generic", None),
     "HN_CONV_NO_HALO": ("conv_no_halo", None), "HN_PREPROCESS_GENERIC": ("preprocess_generic", None),
     "HN_CONV_NO_MULTI": ("conv_no_multi", None), "HN_HALO_STAMPS": ("halo_stamps", None),
     "HN_SPLITK_FILL512": ("splitk_fill512", None), "HN_CONV_NO_STREAM": ("conv_no_stream", None),

@@ -87,7 +87,7 @@ int hn_range_scope_end(void);
 int hn_range_check_collect(int32_t* block /* or NULL */, int32_t* dst /* device, 4 words */, void* stream);
 
 /* Kernel-form switches.  Older forms of some kernels stay in the library as bit-identity references for the tests and for
- * same-box A/B timing ("conv_no_rs", "conv_no_rs32", "split_generic", "stem_pool_generic", "conv_no_halo", "preprocess_generic",
+ * same-box A/B timing ("conv_no_rs", "conv_no_rs32", "split_generic", "conv_no_halo", "preprocess_generic",
  * "conv_no_multi", "no_fuse_last_gn", "no_thin_outputs", "thin_form_tap", "thin_form_flat", "halo_stamps", "splitk_fill512",
  * "conv_no_stream", "conv_no_mixed"; results unchanged
  * unless a test says otherwise).  The library NEVER reads them from the environment: a development host sets them by name
@@ -142,15 +142,11 @@ typedef struct hn_conv_desc {
 #define HN_TILE_128x64 2
 #define HN_TILE_64x64 3
 #define HN_TILE_128x32 4
-#define HN_TILE_256x128 5   /* f16x3 only: 4 waves with 128x64 wave tiles; slower than two 128x128 workgroups per CU, kept for sweeps */
+/* 5 (256x128), 9 (256x128 with 8 waves), 10 (256x64 with 8 waves), 11 (128x256 with 8 waves): sweep-only forms of rounds 1-4,
+ * retired in round 5 (measured and not taken: profiles/r04_tile_128x256.txt, profiles/NOTEBOOK.md); the ids stay reserved */
 #define HN_TILE_64x128 6
 #define HN_TILE_32x64 7   /* f16x3 only: 2-wave workgroups for small-M layers */
 #define HN_TILE_256x64 8  /* f16x3 only: Cout <= 64 layers with 64x64 wave tiles (4 waves stacked along M) */
-#define HN_TILE_256x128_W8 9 /* f16x3 only: 256x128 with 8 waves (64x64 wave tiles), one workgroup per CU */
-#define HN_TILE_256x64_W8 10 /* f16x3 only: 256x64 with 8 waves (64x32 wave tiles), one workgroup per CU: the form in which the
-                              * row-shared A operand fits for Cout <= 64 (W tile shared by 256 rows) */
-#define HN_TILE_128x256_W8 11 /* f16x3 only: 128x256 with 8 waves (64x64 wave tiles), one workgroup per CU: the A operand of a
-                               * Cout = 256 layer is fetched once instead of once per 128-column tile (sweeps / A-B) */
 
 int hn_conv2d_nhwc_f32(const hn_conv_desc* d, const float* x, const float* w,
                        const float* bias /* [cout] or NULL */,
@@ -392,7 +388,8 @@ int hn_conv_stem_f16x3(const void* x16, int n, int ph, int pw, int pad, int r, i
 /* The stem with the ResNet's 3x3 / stride-2 / pad-1 max pooling fused into its epilogue (conv1 -> bn1 -> relu -> maxpool of
  * torchvision resnet34, fcos_utils/fcos.py:737): cout = 64, ReLU on, y = the POOLED S32 map [n][(oh+1)/2][(ow+1)/2][64].
  * Bit-identical to hn_conv_stem_f16x3 followed by hn_maxpool3x3s2_s32; the half-resolution conv map (1.8 GB at batch
- * 32) never reaches HBM. */
+ * 32) never reaches HBM.  Written for the 7x7 / stride-2 / pad-3 ResNet stem (r = 7, stride = 2, pad = 3), the only stem of this
+ * path: other filter geometries are refused (run hn_conv_stem_f16x3 + hn_maxpool3x3s2_s32). */
 int hn_conv_stem_pool_f16x3(const void* x16, int n, int ph, int pw, int pad, int r, int stride, int cout,
                             const void* w16, const float* bias, void* y, void* stream);
 /* hn_conv_stem_pool_f16x3 with the term count of hn_conv_desc.terms (1 = the f16x1 throughput mode). */

@@ -124,8 +124,10 @@ def test_hand_scheduled_kernels_do_not_spill():
             if any(k in name for k in build.NO_SPILL_KERNELS):
                 seen += 1
                 assert " vgpr_spill 0 " in rest + " " and " scratch 0 " in rest, line
-                assert rest.strip().endswith("sgpr_spill 0") or "thin_flat" in name, line   # (plain loads only: lane spills are safe)
-    assert seen >= 30    # 31 instantiations of the implicit GEMM + halo + stem + the two thin-N kernels
+                # SGPR spills go to VGPR lanes, not to memory: tolerated in the P-form head kernel (plain loads only) and in the
+                # mixed grouped kernel (two bodies' scalar preambles in one kernel); never a VGPR spill or scratch anywhere
+                assert rest.strip().endswith("sgpr_spill 0") or "thin_flat" in name or "mixed_kernel" in name, line
+    assert seen >= 30    # the instantiations of the implicit GEMM (single, mixed, multi) + halo + stem + the two thin-N kernels
 
 
 def test_documents_cite_files_that_exist():

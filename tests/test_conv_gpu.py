@@ -138,7 +138,7 @@ F16X3_CASES = [
 
 
 @pytest.mark.parametrize("case", F16X3_CASES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 11])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 6, 7, 8])
 def test_conv_f16x3_matches_fp64_reference(case, tile):
     """Error budget: operands carry 22 bits (hi+lo), products exact, fp32 accumulate =>
     same 1e-4*scale bar as the exact-f32 kernel, checked against an fp64 convolution."""
@@ -576,7 +576,7 @@ def test_f16x3_wide_dynamic_range_keeps_precision():
     assert float((y.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
 
 
-_FORMS = ("conv_no_rs", "conv_no_rs32", "split_generic", "stem_pool_generic", "conv_no_halo", "preprocess_generic", "conv_no_multi",
+_FORMS = ("conv_no_rs", "conv_no_rs32", "split_generic", "conv_no_halo", "preprocess_generic", "conv_no_multi",
           "no_fuse_last_gn", "no_thin_outputs", "thin_form_tap", "thin_form_flat", "splitk_fill512", "conv_no_stream", "conv_no_mixed")
 
 

@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 bash $R/tools/pmc_conv.sh ${tag}_pmc f16x3 1 32 100 136 256 256 3 1 1 30 0 1
 out=$R/gpurun_out/${tag}_pmc_tower_conv.txt
 python3 $R/tools/pmc_summary.py $R/gpurun_out/${tag}_pmc > $out
-sha=$(sha256sum $R/handnet-pipeline_amd/csrc/conv_igemm_f16x3.hip | cut -c1-16)
+sha=$(sha256sum $R/handnet-pipeline_amd/csrc/conv_igemm_f16x3_kernel.h | cut -c1-16)
 echo "# collected by tools/collect_pmc.sh $tag: bash tools/pmc_conv.sh ${tag}_pmc f16x3 1 32 100 136 256 256 3 1 1 30 0 1" >> $out
-echo "# kernel_source_sha16 $sha (sha256 of handnet-pipeline_amd/csrc/conv_igemm_f16x3.hip, first 16 hex digits)" >> $out
+echo "# kernel_source_sha16 $sha (sha256 of handnet-pipeline_amd/csrc/conv_igemm_f16x3_kernel.h, first 16 hex digits)" >> $out
 cat $out

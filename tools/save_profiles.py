@@ -50,7 +50,7 @@ if len(sys.argv) >= 5:
         payload["commit"] = None
     import hashlib
     payload["kernel_source_sha16"] = hashlib.sha256(
-        (R / "handnet-pipeline_amd" / "csrc" / "conv_igemm_f16x3.hip").read_bytes()).hexdigest()[:16]
+        (R / "handnet-pipeline_amd" / "csrc" / "conv_igemm_f16x3_kernel.h").read_bytes()).hexdigest()[:16]
     if len(sys.argv) >= 6:
         line = [l for l in open(sys.argv[5]).read().splitlines() if l.startswith("{")][-1]
         roof = json.loads(line)["roofline"]
