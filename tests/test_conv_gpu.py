@@ -603,7 +603,7 @@ RS_CASES = [
 
 
 @pytest.mark.parametrize("case", RS_CASES)
-@pytest.mark.parametrize("tile", [1, 2, 4, 9, 10, 11])
+@pytest.mark.parametrize("tile", [1, 2, 4])
 def test_conv_f16x3_row_shared_a_is_bit_identical_to_per_tap_form(case, tile, monkeypatch):
     """Same k order and same operands => the row-shared kernel must reproduce the per-tap kernel bit for bit (S32 and fp32
     outputs, residual + ReLU), and both are fp32-grade against an fp64 convolution.  ops.set_form("conv_no_rs") selects the per-tap
