@@ -201,6 +201,24 @@ def test_bench_launch_ladder_second_rung_after_an_injected_init_failure():
     assert "attempt 2 failed to initialise" in both.stderr and not any(l.startswith("{") for l in both.stdout.splitlines())
 
 
+def test_bench_under_real_torchrun_with_a_failed_first_attempt():
+    """The driver's exact launch form -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` -- with the stub engine on gloo: every rank torchrun starts supervises the fresh worker
+    of its own rank (the job directory is derived from the elastic agent's pid), the ladder's second rung runs after an injected
+    first-attempt failure at rank 3, and exactly one line comes out."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "HN_BENCH_WORKER")}
+    env["HN_BENCH_INJECT_INIT_FAILURE"] = "3:0"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr",
+                        "127.0.0.1", "--master-port", str(_free_port()), str(REPO / "bench.py"), "--gpus", "4"] + STUB,
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["config"]["rccl_ranks"] == 4 and len(d["rank_ms"]["per_rank"]) == 4
+    assert "unset" in d["config"]["ipc_mode"] and "attempt 2 of 2" in d["config"]["ipc_mode"]
+
+
 def test_bench_fails_loudly_when_the_process_group_cannot_start():
     """`--gpus 2` under a torchrun-style environment whose rendezvous cannot complete (rank 1 of 2 with no rank 0): both rungs
     of the ladder time out (--init-timeout), bench.py exits non-zero with the backend's error text -- never a single-rank run,

@@ -189,24 +189,22 @@ def test_bench_four_rank_rehearsal_with_a_failed_first_attempt():
     assert len(line["rank_ms"]["per_rank"]) == 4 and 0 < lo <= med <= hi
 
 
-def test_bench_under_a_torchrun_style_environment():
-    """The driver's launch form: every rank is started with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* already set (here by
-    hand, two ranks sharing the GPU).  Each started process supervises the fresh worker of its own rank; the workers
-    rendezvous through the job's shared file:// store; rank 0 prints the line."""
-    port = _free_port()
-    procs = []
-    for rank in range(2):
-        env = {k: v for k, v in os.environ.items() if k != "HN_BENCH_WORKER"}
-        env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--share-gpu", "--dist-backend",
-                                       "gloo", "--steps", "2", "--warmup", "1", "--batch", "4", "--no-cpu-baseline",
-                                       "--no-roofline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    outs = [p.communicate(timeout=1200) for p in procs]
-    assert all(p.returncode == 0 for p in procs), outs
-    lines = [l for o, _ in outs for l in o.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, outs
+def test_bench_under_real_torchrun():
+    """The driver's launch form on the REAL engine: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr
+    127.0.0.1 --master-port P bench.py --gpus 2 ...` (two ranks sharing the GPU, gloo).  Each process torchrun starts
+    supervises the fresh worker of its own rank; the workers rendezvous through the job's shared file:// store; rank 0
+    prints the line.  (GPU-touching processes: this test, two workers.)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "HN_BENCH_WORKER")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(_free_port()), str(REPO / "bench.py"), "--gpus", "2", "--share-gpu",
+                        "--dist-backend", "gloo", "--steps", "2", "--warmup", "1", "--batch", "4", "--no-cpu-baseline",
+                        "--no-roofline"], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout + r.stderr
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["rccl_ranks"] == 2 and "attempt 1 of 2" in line["config"]["ipc_mode"]
+    assert line["config"]["hipgraph"] is True and len(line["rank_ms"]["per_rank"]) == 2
 
 
 def test_stages_are_repeatable_next_to_a_second_process(fcos_sd, a2j_sd):
