@@ -594,9 +594,9 @@ def device_identity(args, local, rank):
 
 def other_configs_leg(args, info, dev):
     """BASELINE.json's other single-GPU configurations on the engines this run has already built (5 timed steps each, inputs
-    resident in HBM): config 2 (A2J-only, batch 64; a2j_infer.py:58-60), config 3 (FCOS-only, batch 16;
-    trainval_net_fcos.py:124-130,173) and the full pipeline at batch 1 (the reference caller's own batch, ros_demo.py:270;
-    hipGraph replay, as the drop-in runs it).  Each: value, ms_per_step, and the dominant kernel's roofline fraction from
+    resident in HBM, hipGraph replay): config 2 (A2J-only, batch 64; a2j_infer.py:58-60), config 3 (FCOS-only, batch 16;
+    trainval_net_fcos.py:124-130,173) and the full pipeline at batch 1 (the reference caller's own batch, ros_demo.py:270,
+    as the drop-in runs it).  Each: value, ms_per_step, and the dominant kernel's roofline fraction from
     HIP-event-instrumented eager steps."""
     from hn_amd import synth
     eng = info["engine"]
@@ -621,18 +621,37 @@ def other_configs_leg(args, info, dev):
         return {"kernel": r["kernel"], "frac": r["frac"], "achieved_tflops": r["achieved"], "avg_launch_us": r["avg_launch_us"],
                 "launches_per_step": r["launches_per_step"], "all_conv_tflops": r["all_conv_achieved"]}
 
+    def captured(fn):
+        """hipGraph replay of fn (static launch sequence by construction): the timed figure is the engine's, not the Python
+        host's -- the first run on a fresh box has a slow host (image paging in), and five eager steps of ~80 launches each
+        measured that instead (16.8 ms per A2J step on one box against 3.1 ms on every other)."""
+        from hn_amd import ops
+        with torch.inference_mode(False), torch.no_grad(), ops.launch_cost_hidden():
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    fn()
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                keep = fn()
+        return g, keep
+
     crops = synth.make_crops(64, 176, seed=3000).to(dev)
-    rec = timed(lambda: eng.a2j.forward(crops), 64)
-    rec.update(unit="crops/s", workload="A2J-only inference, batch 64 176x176 depth crops (BASELINE config 2)",
+    g, keep = captured(lambda: eng.a2j.forward(crops))
+    rec = timed(g.replay, 64)
+    rec.update(unit="crops/s", hipgraph=True, workload="A2J-only inference, batch 64 176x176 depth crops (BASELINE config 2)",
                gflop_per_unit=round(2 * eng.a2j.macs_per_crop() / 1e9, 3), **roof_of(lambda: eng.a2j.forward(crops), rec["ms_per_step"]))
     out["a2j_b64"] = rec
-    del crops
+    del crops, g, keep
     rgb16 = synth.make_rgb(16, seed=1000).to(dev)
-    rec = timed(lambda: eng.fcos.detect(rgb16), 16)
-    rec.update(unit="frames/s", workload="FCOS ResNet34-FPN detector, batch 16 640x480 RGB (BASELINE config 3)",
+    g, keep = captured(lambda: eng.fcos.detect(rgb16))
+    rec = timed(g.replay, 16)
+    rec.update(unit="frames/s", hipgraph=True, workload="FCOS ResNet34-FPN detector, batch 16 640x480 RGB (BASELINE config 3)",
                gflop_per_unit=round(2 * eng.fcos.macs_per_frame() / 1e9, 3), **roof_of(lambda: eng.fcos.detect(rgb16), rec["ms_per_step"]))
     out["fcos_b16"] = rec
-    del rgb16
+    del rgb16, g, keep
     rgb1, dep1 = synth.make_rgb(1, seed=1000).to(dev), synth.make_depth(1, seed=2000).to(dev)
     run, _, _, _ = eng.graphed(rgb1, dep1)
     rec = timed(run, 1, steps=max(5, 50), warm=5)
