@@ -79,6 +79,44 @@ int launch16_impl(const ConvParams16& p0, hipStream_t st) {
   return HN_OK;
 }
 
+// deep-k forms (conv_igemm_f16x3_deepk_kernel): three terms, descriptor form only -- anything else takes the parent tile
+template <int BM, int BN, int WM, int WN, int NST, int KK>
+int launch16_deepk(const ConvParams16& p0, hipStream_t st) {
+  ConvParams16 p = p0;
+  p.tiles_m = hn::cdiv(p.M, BM);
+  p.tiles_n = hn::cdiv(p.Cout, BN);
+  p.nblocks = p.tiles_m * p.tiles_n;
+  plan_splits(p, BM, BN, KK);
+  int grid_x = p.nblocks;
+  if (p.groups > 1) {
+    grid_x = 0;
+    for (int g = 0; g < p.groups; ++g) {
+      p.gnblocks[g] = hn::cdiv(p.gM[g], BM) * p.tiles_n;
+      grid_x = grid_x > p.gnblocks[g] ? grid_x : p.gnblocks[g];
+    }
+  }
+  constexpr int LDS_BYTES = NST * KK * (BM + BN) * ROWH * 2;
+  static_assert(LDS_BYTES <= 160 * 1024, "deep-k ring exceeds the LDS");
+  static bool attr_set[64] = {};
+  int dev = 0;
+  HN_CHECK_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    HN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_igemm_f16x3_deepk_kernel<BM, BN, WM, WN, NST, KK>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL((conv_igemm_f16x3_deepk_kernel<BM, BN, WM, WN, NST, KK>), dim3(grid_x, p.splits, p.groups > 1 ? p.groups : 1),
+                     dim3(WM * WN * 64), LDS_BYTES, st, p);
+  HN_CHECK_LAUNCH("conv_igemm_f16x3_deepk_kernel");
+  if (p.splits > 1) {
+    const long total = (long)p.M * (p.Cout >> 3);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, p);
+    HN_CHECK_LAUNCH("splitk_reduce_kernel");
+  }
+  return HN_OK;
+}
+
 template <int BM, int BN, int WM, int WN, int NBUF, bool ALLOW_F16X1 = true>
 int launch16(const ConvParams16& p0, hipStream_t st) {
   ConvParams16 p = p0;
@@ -95,9 +133,15 @@ int launch16(const ConvParams16& p0, hipStream_t st) {
 
 }  // namespace
 
+static int deepk_of(const hn_conv_desc* d, int tile);
+static int pick_tile_base(const hn_conv_desc* d);
 extern "C" int hn_conv2d_f16x3_pick_tile(const hn_conv_desc* d) {
   if (!d) return HN_TILE_64x64;
   if (d->tile != HN_TILE_AUTO) return d->tile;
+  return deepk_of(d, pick_tile_base(d));
+}
+
+static int pick_tile_base(const hn_conv_desc* d) {
   // From tools/tile_sweep.py (every distinct conv shape of the pipeline, batch 1 and 32, clocks kept hot):
   // within 0.3 % (batch 32) / 2 % (batch 1) of the best tile per shape.
   if (d->cout <= 32) return nblocks16(d, 128, 32) < 64 ? HN_TILE_32x64 : HN_TILE_128x32;
@@ -114,6 +158,19 @@ extern "C" int hn_conv2d_f16x3_pick_tile(const hn_conv_desc* d) {
   // batch-1 frame the rule costs 15 us, 2.327 -> 2.342 ms over three same-box pairs: not taken.)
   if (nblocks16(d, 64, 64) < 128) return HN_TILE_32x64;
   return HN_TILE_64x64;
+}
+
+// the deep-k form of the 64x64 tile where the grid leaves every CU at most one workgroup and the k loop is long enough
+// (ResNet-34 layer3 at batch 1: 28.9 -> 25.8 us per layer, 2.243 -> 2.215 ms per frame)
+static int deepk_of(const hn_conv_desc* d, int tile) {
+  if (hn::env_flags().no_deepk || d->terms == 1) return tile;
+  const int ktiles = d->r * d->s * d->cin / 32;
+  if (ktiles < 8) return tile;
+  // (the 64x128 and 32x64 tiles were measured with the same loop and LOSE in the batch-1 frame -- ResNet-34 layer2 22.5 -> 23.2 us,
+  // layer4's split-K members 26.5 -> 29.1 us --, and so do deeper or wider rings for this one: profiles/r05_deepk_ab.txt,
+  // r05_deepk_variants.txt)
+  if (tile == HN_TILE_64x64 && nblocks16(d, 64, 64) <= 256) return HN_TILE_64x64_K2;
+  return tile;
 }
 
 // Does a launch of this descriptor run the row-shared-A kernel?  Evaluates the SAME functions as the launcher (tile pick,
@@ -152,7 +209,7 @@ extern "C" int hn_conv2d_f16x3_uses_rs(const hn_conv_desc* d) {
   TileForm f = tile_form(tile, tile == HN_TILE_128x32 && rs32_preferred(d));
   if (f.bm == 0) return 0;
   p.nblocks = hn::cdiv(p.M, f.bm) * hn::cdiv(p.Cout, f.bn);
-  plan_splits(p, f.bm, f.bn);
+  plan_splits(p, f.bm, f.bn, f.kk);
   if (tile == HN_TILE_128x32 && f.nbuf == 2 && !rs_will_run(p, f.bm, f.bn, f.waves, 2, true)) return 0;
   return rs_will_run(p, f.bm, f.bn, f.waves, f.nbuf, true) ? 1 : 0;
 }
@@ -256,7 +313,8 @@ int hn_igemm_conv16_run(const hn_conv_desc* d, const void* x16, const void* w16,
     HN_CHECK_ARG(d->oh * d->ow >= 32, "GroupNorm statistics in the epilogue need OH*OW >= 32");
   }
   hipStream_t st = (hipStream_t)stream;
-  switch (hn_conv2d_f16x3_pick_tile(&tile_desc)) {
+  int picked = hn_conv2d_f16x3_pick_tile(&tile_desc);
+  switch (picked) {
     case HN_TILE_128x128: return launch16<128, 128, 2, 2, 2>(p, st);
     // LDS stage counts from an in-pipeline sweep (round-1 commit 5dc48dd): extra stages only pay
     // where they do not cost occupancy
@@ -281,6 +339,12 @@ int hn_igemm_conv16_run(const hn_conv_desc* d, const void* x16, const void* w16,
     }
     case HN_TILE_64x128: return launch16<64, 128, 2, 2, 3>(p, st);
     case HN_TILE_32x64: return launch16<32, 64, 1, 2, 4>(p, st);
+    // deep-k forms: only the three-term descriptor form exists; f16x1 / oversized operands take the parent tile
+    case HN_TILE_64x64_K2: {
+      ConvParams16 q = p;
+      if (p.terms == 3 && finish_params16(q)) return launch16_deepk<64, 64, 2, 2, 3, 2>(q, st);
+      return launch16<64, 64, 2, 2, 3>(p, st);
+    }
     // (the row-shared A form does not fit two 256-row workgroups on a CU, and 128x64 with it -- 442 us on ResNet-34 layer1 --
     // loses to 256x64 without: 421 us)
     case HN_TILE_256x64: return launch16<256, 64, 4, 1, 2>(p, st);

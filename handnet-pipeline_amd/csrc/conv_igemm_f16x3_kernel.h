@@ -306,11 +306,20 @@ struct HalfSched {
 // The kernel's body as a device function of (parameter block, workgroup coordinates): conv_igemm_f16x3_kernel passes its own
 // kernel argument and blockIdx; conv_igemm_f16x3_multi_kernel (heterogeneous launches, below) the member's block and the
 // member-local coordinates.  Always inlined: the single-problem kernel compiles to what it was.
-template <int BM, int BN, int WM, int WN, int NBUF, bool BUF, bool RS = false, int TERMS = 3, bool DYN = false>
+// KK > 1 ("deep k", round 5; the small grids of batch 1): a stage of the ring holds KK consecutive k tiles and the loop has ONE
+// barrier per stage instead of one per tile.  A lone 4-wave workgroup per CU spends ~500 cycles per 32-deep step for ~190
+// cycles of MFMA issue (profiles/NOTEBOOK.md, round 4 stamps): the rest is the per-step rendezvous -- counted DMA wait, LDS read
+// latency in front of the barrier, the barrier itself -- which no number of stages in flight shortens, but fewer rendezvous
+// per MFMA do.  The deep loop is compiler-scheduled (plain LDS reads and builtin MFMAs between the barriers: both tiles of a
+// stage have landed, so the next tile's fragment reads overlap this tile's MFMAs without any hand-counted wait); the DMA
+// geometry, the k order, the term order and the epilogue are the pinned loop's: results are BIT-IDENTICAL to KK = 1.
+template <int BM, int BN, int WM, int WN, int NBUF, bool BUF, bool RS = false, int TERMS = 3, bool DYN = false, int KK = 1>
 __device__ __forceinline__ void conv_igemm_f16x3_body(const ConvParams16& p, const int blk_x, const int blk_y, const int blk_z) {
   static_assert(TERMS == 3 || TERMS == 1, "three terms (fp32-grade) or the hi*hi term alone");
   static_assert(NBUF >= 2 && NBUF <= 6, "2..6 LDS stages");
   static_assert(!RS || (BUF && NBUF == 2), "row-shared A needs the descriptor form and the 2-stage pipeline");
+  static_assert(KK == 1 || (BUF && !RS && DYN && TERMS == 3), "the deep-k loop: descriptor form, per-tap, dynamic LDS, three terms");
+  constexpr int NSLOT = NBUF * KK;   // k-tile slots in LDS (KK per stage)
   // Grouped launch: workgroup z works on member z -- its own tensors and, for FPN levels, its own spatial size.
   // Only these fields differ per member; they live in a small local struct `o` (picked with constant-index
   // selects: a dynamic index into the kernel-argument arrays would send the whole parameter block through
@@ -372,10 +381,10 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(const ConvParams16& p, con
   // the RS stages exceed the 64 KB a static array may have: dynamic LDS there (launch16_impl sets the size)
   extern __shared__ __attribute__((aligned(1024))) _Float16 smem_dyn[];
   // (DYN: a per-tap form that shares its kernel -- and the dynamic LDS block -- with a row-shared form: the mixed grouped kernel)
-  __shared__ __attribute__((aligned(1024))) _Float16 smem_static[(RS || DYN) ? 8 : NBUF * (A_BUF + B_BUF)];
+  __shared__ __attribute__((aligned(1024))) _Float16 smem_static[(RS || DYN) ? 8 : NSLOT * (A_BUF + B_BUF)];
   _Float16* smem = (RS || DYN) ? smem_dyn : smem_static;
   _Float16* As = smem;                 // [stage][A_ROWS][64]
-  _Float16* Bs = smem + NBUF * A_BUF;  // [stage][BN][64]
+  _Float16* Bs = smem + NSLOT * A_BUF;  // [slot][BN][64]
 
   int lid;
   {
@@ -836,6 +845,56 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(const ConvParams16& p, con
       cs ^= 1;
       aq ^= 1;
     }
+  } else if constexpr (KK > 1) {
+    // ---- deep-k loop: stage g = slots g*KK .. g*KK+KK-1; stages 0 .. NBUF-2 are put in flight, then per stage:
+    //   counted wait (the NBUF-2 younger stages stay in flight) -> barrier (stage st has landed for every wave, and nobody reads
+    //   stage st-1 any more) -> refill stage st-1's slots with the tiles of stage st+NBUF-1 -> the MFMAs of stage st's tiles.
+    // Past the end of k the loader re-loads the last tile (saturating cursor) into slots whose MFMAs are skipped.
+    static_assert((NBUF - 2) * KK * (A_IT + B_IT) <= 63, "vmcnt is a 6-bit counter");
+    for (int s0 = 0; s0 < (NBUF - 1) * KK; ++s0) dma_tile(s0);
+    const int nstages = (T + KK - 1) / KK;
+    int grp = 0;
+    for (int st = 0; st < nstages; ++st) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * KK * DPT) : "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const int refill = grp == 0 ? NBUF - 1 : grp - 1;
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) dma_tile(refill * KK + kk);
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        if (st * KK + kk < T) {   // (wave-uniform: the ragged last stage)
+          const int slot = grp * KK + kk;
+          const _Float16* Ab = As + slot * A_BUF;
+          const _Float16* Bb = Bs + slot * B_BUF;
+          f16x8 fah[TM], fal[TM], fbh[TN], fbl[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            fah[i] = *reinterpret_cast<const f16x8*>(Ab + a_rd[i][0]);
+            fal[i] = *reinterpret_cast<const f16x8*>(Ab + a_rd[i][1]);
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            fbh[j] = *reinterpret_cast<const f16x8*>(Bb + b_rd[j][0]);
+            fbl[j] = *reinterpret_cast<const f16x8*>(Bb + b_rd[j][1]);
+          }
+          // the pinned loop's term order per accumulator: lo*hi, hi*lo, hi*hi (W fragment = srcA)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbh[j], fal[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbl[j], fah[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbh[j], fah[i], acc[i][j], 0, 0, 0);
+        }
+      }
+      grp = grp + 1 == NBUF ? 0 : grp + 1;
+    }
   } else {
   // prologue: tile 0 -> stage 0 (waited for); tiles 1..NBUF-1 are put in flight behind it
   dma_tile(0);
@@ -1066,6 +1125,13 @@ void conv_igemm_f16x3_kernel(const ConvParams16 p) {
   conv_igemm_f16x3_body<BM, BN, WM, WN, NBUF, BUF, RS, TERMS>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
 }
 
+// the deep-k forms (KK k tiles per stage, NST stages; dynamic LDS, one workgroup per CU at most two)
+template <int BM, int BN, int WM, int WN, int NST, int KK>
+__global__ __launch_bounds__(WM* WN * 64, 2)
+void conv_igemm_f16x3_deepk_kernel(const ConvParams16 p) {
+  conv_igemm_f16x3_body<BM, BN, WM, WN, NST, true, false, 3, true, KK>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
 #ifdef HN_IGEMM_MAIN_TU
 // ---- grouped launch whose members carry their own tile shape (round 5).  The FCOS tower layers at small batch are ONE grouped
 // launch over (tower, FPN level) members of very different sizes -- at batch 1: 214 + 54 + 14 tiles of 128 x 128 per tower, 564
@@ -1113,7 +1179,7 @@ __device__ __forceinline__ void load_member16(const MultiParams16& unused_by_val
 }
 
 #ifdef HN_IGEMM_MULTI_TU
-template <int BM, int BN, int WM, int WN, int NBUF>
+template <int BM, int BN, int WM, int WN, int NBUF, int KK = 1>
 __global__ __launch_bounds__(WM* WN * 64, (BM * BN / (WM * WN) > 64 * 64 ? 1 : 2))
 void conv_igemm_f16x3_multi_kernel(const MultiParams16 mp) {
   typedef __attribute__((address_space(4))) const MultiParams16 KM;
@@ -1130,7 +1196,7 @@ void conv_igemm_f16x3_multi_kernel(const MultiParams16 mp) {
     local -= p.nblocks;
     ++by;
   }
-  conv_igemm_f16x3_body<BM, BN, WM, WN, NBUF, true, false, 3>(p, local, by, 0);
+  conv_igemm_f16x3_body<BM, BN, WM, WN, NBUF, true, false, 3, (KK > 1), KK>(p, local, by, 0);
 }
 
 // the reductions of a multi launch's split-K members as ONE launch: gridDim.y = member

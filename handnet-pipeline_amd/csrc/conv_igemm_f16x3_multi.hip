@@ -6,7 +6,7 @@
 // ---------------------------------------------------------------------------------------------------------------------
 // Heterogeneous launch (include/handnet_hip.h: hn_conv2d_nhwc_f16x3_multi)
 // ---------------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int NBUF>
+template <int BM, int BN, int WM, int WN, int NBUF, int KK = 1>
 static int launch_multi(MultiParams16& mp, hipStream_t st) {
   int total = 0, any_split = 0, red_grid = 1;
   for (int g = 0; g < mp.count; ++g) {
@@ -21,7 +21,18 @@ static int launch_multi(MultiParams16& mp, hipStream_t st) {
     }
   }
   for (int g = mp.count; g <= kMultiMax; ++g) mp.start[g] = total;
-  hipLaunchKernelGGL((conv_igemm_f16x3_multi_kernel<BM, BN, WM, WN, NBUF>), dim3(total), dim3(WM * WN * 64), 0, st, mp);
+  constexpr int LDS_BYTES = KK > 1 ? NBUF * KK * (BM + BN) * ROWH * 2 : 0;   // deep-k members: the ring lives in dynamic LDS
+  if constexpr (KK > 1) {
+    static bool attr_set[64] = {};
+    int dev = 0;
+    HN_CHECK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+      HN_CHECK_HIP(hipFuncSetAttribute((const void*)conv_igemm_f16x3_multi_kernel<BM, BN, WM, WN, NBUF, KK>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+      if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+  }
+  hipLaunchKernelGGL((conv_igemm_f16x3_multi_kernel<BM, BN, WM, WN, NBUF, KK>), dim3(total), dim3(WM * WN * 64), LDS_BYTES, st, mp);
   HN_CHECK_LAUNCH("conv_igemm_f16x3_multi_kernel");
   if (any_split) {
     hipLaunchKernelGGL(splitk_reduce_multi_kernel, dim3(red_grid, mp.count), dim3(256), 0, st, mp);
@@ -48,16 +59,20 @@ static bool multi_plan(const hn_conv_multi* mm, void* workspace, int64_t workspa
     if (hn::conv1x1_stream_applies(d, false, false) &&
         hn::conv1x1_stream_operands_ok(d, mm->x16[g], mm->w16[g], mm->bias[g], mm->residual[g], mm->y[g]))
       return false;
+    // members of one PARENT tile share a grid: a deep-k member (HN_TILE_*_K2) and a member of the same tile whose k loop is too
+    // short for the deep form on its own run together in the deep-k kernel (it handles any tile count, bit-identically);
+    // each member keeps the split-K plan of the form it would take alone
     const int t = hn_conv2d_f16x3_pick_tile(d);
-    if (tile >= 0 && t != tile) return false;
-    tile = t;
+    auto parent = [](int id) { return id == HN_TILE_64x64_K2 ? HN_TILE_64x64 : id; };
+    if (tile >= 0 && parent(t) != parent(tile)) return false;
+    tile = (tile >= 0 && tile != parent(tile)) ? tile : t;   // once a deep-k member is seen, the launch is the deep-k form
     TileForm f = tile_form(t, false);
     if (t == HN_TILE_128x32 || f.bm == 0) return false;   // (its stage count depends on the row-shared form: not worth a table)
     if (!finish_params16(p)) return false;
     p.tiles_m = hn::cdiv(p.M, f.bm);
     p.tiles_n = hn::cdiv(p.Cout, f.bn);
     p.nblocks = p.tiles_m * p.tiles_n;
-    plan_splits(p, f.bm, f.bn);
+    plan_splits(p, f.bm, f.bn, f.kk);
     p.rs_ok = 0;
     if (p.splits > 1) {   // the member's partial planes: its own slice of the workspace
       const int64_t bytes = (int64_t)p.splits * p.M * p.Cout * 4;
@@ -93,6 +108,7 @@ extern "C" int hn_conv2d_nhwc_f16x3_multi(const hn_conv_multi* mm, void* workspa
     case HN_TILE_64x64: return launch_multi<64, 64, 2, 2, 3>(mp, st);
     case HN_TILE_64x128: return launch_multi<64, 128, 2, 2, 3>(mp, st);
     case HN_TILE_32x64: return launch_multi<32, 64, 1, 2, 4>(mp, st);
+    case HN_TILE_64x64_K2: return launch_multi<64, 64, 2, 2, 3, 2>(mp, st);
     default: break;
   }
   for (int g = 0; g < mm->count; ++g)
@@ -108,5 +124,6 @@ extern "C" int hn_conv2d_f16x3_multi_fuses(const hn_conv_multi* mm, int64_t work
   mp.count = mm->count;
   int tile = -1;
   if (!multi_plan(mm, reinterpret_cast<void*>(256), workspace_bytes, mp, tile)) return 0;
-  return tile == HN_TILE_128x128 || tile == HN_TILE_128x64 || tile == HN_TILE_64x64 || tile == HN_TILE_64x128 || tile == HN_TILE_32x64;
+  return tile == HN_TILE_128x128 || tile == HN_TILE_128x64 || tile == HN_TILE_64x64 || tile == HN_TILE_64x128 || tile == HN_TILE_32x64 ||
+         tile == HN_TILE_64x64_K2;
 }

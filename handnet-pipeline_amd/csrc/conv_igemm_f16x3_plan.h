@@ -19,8 +19,9 @@ namespace {
 // epilogue) and time per k tile, from pairs of sweep rows (the 4-wave tiles spend 12-16 us outside their k loop at these grid
 // sizes, which is why halving a 36-tile loop does not pay for a reduction; the 2-wave 32x64 tile 3 us).
 struct SplitModel { int slots; double t_fix, t_k; };
-static SplitModel split_model(int bm, int bn) {
+static SplitModel split_model(int bm, int bn, int kk = 1) {
   const int cus = 256;
+  if (kk > 1) return {1 * cus, 12.0, 0.10};   // the 64x64 deep-k form: one workgroup per CU (96 KB of LDS), a shorter time per k tile
   if (bm == 32 && bn == 64) return {3 * cus, 3.0, 0.27};
   if (bm == 64 && bn == 64) return {3 * cus, 12.0, 0.12};
   if (bm == 64 && bn == 128) return {2 * cus, 16.0, 0.12};
@@ -28,7 +29,7 @@ static SplitModel split_model(int bm, int bn) {
   if (bm == 128 && bn == 32) return {2 * cus, 12.0, 0.15};
   return {2 * cus, 20.0, 0.40};   // 128x128 and the 256-row tiles
 }
-static void plan_splits(ConvParams16& p, int bm, int bn) {   // needs p.nblocks; sets p.splits / p.kt_per
+static void plan_splits(ConvParams16& p, int bm, int bn, int kk = 1) {   // needs p.nblocks; sets p.splits / p.kt_per
   p.splits = 1;
   p.kt_per = p.ktiles;
   if (p.groups > 1) return;  // grouped problems never split (the grid is already groups x larger)
@@ -48,7 +49,7 @@ static void plan_splits(ConvParams16& p, int bm, int bn) {   // needs p.nblocks;
     // eager callers that pay for the second launch on the host (desc.splitk = 0) split long loops only
     const int min_tiles = p.splitk_mode > 0 ? 8 : 128, min_per = p.splitk_mode > 0 ? 4 : 16;
     if (p.ktiles < min_tiles) return;
-    SplitModel sm = split_model(bm, bn);
+    SplitModel sm = split_model(bm, bn, kk);
     const hn::Tuning& tn = hn::tuning();   // development: scale factors of the model's constants (hn_set_tuning; all 1.0)
     sm.t_fix *= tn.splitk_fix;
     sm.t_k *= tn.splitk_tk;
@@ -175,20 +176,21 @@ int64_t nblocks16(const hn_conv_desc* d, int bm, int bn) {
 }
 
 // The tile forms behind the HN_TILE_* ids: {BM, BN, waves, LDS stages}; conv16_run's switch instantiates exactly these.
-struct TileForm { int bm, bn, waves, nbuf; };
+struct TileForm { int bm, bn, waves, nbuf, kk; };   // kk: k tiles per ring stage (1 = the pinned loop)
 static bool rs32_preferred(const hn_conv_desc* d) {
   return d->r == 3 && d->s == 3 && d->stride == 1 && d->dil == 1 && d->pad == 1 && !hn::env_flags().no_rs && !hn::env_flags().no_rs32;
 }
 static TileForm tile_form(int tile, bool rs32) {
   switch (tile) {
-    case HN_TILE_128x128: return {128, 128, 4, 2};
-    case HN_TILE_128x64: return {128, 64, 4, 2};
-    case HN_TILE_64x64: return {64, 64, 4, 3};
-    case HN_TILE_128x32: return {128, 32, 4, rs32 ? 2 : 3};   // 2 stages only when the row-shared form will run
-    case HN_TILE_64x128: return {64, 128, 4, 3};
-    case HN_TILE_32x64: return {32, 64, 2, 4};
-    case HN_TILE_256x64: return {256, 64, 4, 2};
-    default: return {0, 0, 0, 0};
+    case HN_TILE_128x128: return {128, 128, 4, 2, 1};
+    case HN_TILE_128x64: return {128, 64, 4, 2, 1};
+    case HN_TILE_64x64: return {64, 64, 4, 3, 1};
+    case HN_TILE_128x32: return {128, 32, 4, rs32 ? 2 : 3, 1};   // 2 stages only when the row-shared form will run
+    case HN_TILE_64x128: return {64, 128, 4, 3, 1};
+    case HN_TILE_32x64: return {32, 64, 2, 4, 1};
+    case HN_TILE_256x64: return {256, 64, 4, 2, 1};
+    case HN_TILE_64x64_K2: return {64, 64, 4, 3, 2};
+    default: return {0, 0, 0, 0, 1};
   }
 }
 

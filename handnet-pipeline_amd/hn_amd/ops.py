@@ -184,7 +184,7 @@ CONV_PROFILE = None
 # which stage of the hot path the engines are in (bench.py's roofline.stages): "resnet34_body", "fpn", "towers",
 # "head_outputs", "a2j_trunk", "a2j_heads"; recorded with every profiled conv launch
 PROFILE_STAGE = None
-TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x64", 4: "128x32", 6: "64x128", 7: "32x64", 8: "256x64"}   # (5, 9-11: retired sweep forms)
+TILE_NAMES = {1: "128x128", 2: "128x64", 3: "64x64", 4: "128x32", 6: "64x128", 7: "32x64", 8: "256x64", 12: "64x64k2"}   # (5, 9-11: retired sweep forms)
 TILE_RS = 0x100  # profile records: tile id | TILE_RS when the launch ran the row-shared-A instantiation of that tile
 TILE_HALO = 0x200  # ... | TILE_HALO when it was routed to the halo-patch kernel (conv3x3_halo_kernel)
 TILE_MULTI = 0x400  # ... | TILE_MULTI for a heterogeneous launch (conv_igemm_f16x3_multi_kernel): several convolutions, one record

@@ -89,7 +89,7 @@ int hn_range_check_collect(int32_t* block /* or NULL */, int32_t* dst /* device,
 /* Kernel-form switches.  Older forms of some kernels stay in the library as bit-identity references for the tests and for
  * same-box A/B timing ("conv_no_rs", "conv_no_rs32", "split_generic", "conv_no_halo", "preprocess_generic",
  * "conv_no_multi", "no_fuse_last_gn", "no_thin_outputs", "thin_form_tap", "thin_form_flat", "halo_stamps", "splitk_fill512",
- * "conv_no_stream", "conv_no_mixed"; results unchanged
+ * "conv_no_stream", "conv_no_mixed", "conv_no_deepk"; results unchanged
  * unless a test says otherwise).  The library NEVER reads them from the environment: a development host sets them by name
  * (bench.py and tools/ translate their HN_* variables through hn_amd/forms.py); a product process leaves them alone. */
 int hn_set_form(const char* name, int value);
@@ -147,6 +147,11 @@ typedef struct hn_conv_desc {
 #define HN_TILE_64x128 6
 #define HN_TILE_32x64 7   /* f16x3 only: 2-wave workgroups for small-M layers */
 #define HN_TILE_256x64 8  /* f16x3 only: Cout <= 64 layers with 64x64 wave tiles (4 waves stacked along M) */
+/* f16x3 only, round 5: the "deep k" form of the 64x64 tile for grids of at most one workgroup per CU (ResNet-34 layer3 at batch
+ * 1): a ring stage holds TWO k tiles and the loop has one barrier per stage instead of one per tile; bit-identical to
+ * HN_TILE_64x64; the auto heuristic picks it for such grids with at least 8 k tiles ("conv_no_deepk" turns that off).  Members of
+ * a heterogeneous launch whose tile is 64x64 share its kernel. */
+#define HN_TILE_64x64_K2 12
 
 int hn_conv2d_nhwc_f32(const hn_conv_desc* d, const float* x, const float* w,
                        const float* bias /* [cout] or NULL */,

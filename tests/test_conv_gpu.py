@@ -577,7 +577,7 @@ def test_f16x3_wide_dynamic_range_keeps_precision():
 
 
 _FORMS = ("conv_no_rs", "conv_no_rs32", "split_generic", "conv_no_halo", "preprocess_generic", "conv_no_multi",
-          "no_fuse_last_gn", "no_thin_outputs", "thin_form_tap", "thin_form_flat", "splitk_fill512", "conv_no_stream", "conv_no_mixed")
+          "no_fuse_last_gn", "no_thin_outputs", "thin_form_tap", "thin_form_flat", "splitk_fill512", "conv_no_stream", "conv_no_mixed", "conv_no_deepk")
 
 
 @pytest.fixture(autouse=True)
@@ -1064,3 +1064,81 @@ def test_mixed_tile_grouped_launch_is_bit_identical_to_one_tile_shape(n):
     # and the plain form on one member alone agrees (the grouped launch is not its own only reference)
     ref = ops.conv2d_nhwc(members[1], cws[0].w, cws[0].bias, pad=1, relu=True, w16=cws[0].w16, out_split=True, splitk=False)
     assert torch.equal(s_mixed[1], ref)
+
+
+DEEPK_CASES = [
+    # n, h, w, cin, cout, r, stride, pad, dil
+    (1, 50, 68, 256, 256, 3, 1, 1, 1),      # ResNet-34 layer3 at batch 1: 72 k tiles
+    (1, 100, 136, 128, 128, 3, 1, 1, 1),    # layer2
+    (1, 25, 34, 512, 512, 3, 1, 1, 1),      # layer4 (split-K in the auto plan)
+    (1, 11, 11, 512, 512, 3, 1, 2, 2),      # A2J layer4, dilation 2
+    (2, 11, 11, 1024, 256, 1, 1, 0, 1),     # 1x1, 32 k tiles
+    (1, 44, 44, 128, 128, 3, 2, 1, 1),      # stride 2
+    (3, 13, 17, 32, 48, 3, 1, 1, 1),        # 9 k tiles: a ragged last stage; ragged rows and columns
+    (1, 9, 9, 32, 64, 1, 1, 0, 1),          # ONE k tile: fewer tiles than a stage holds
+    (2, 22, 22, 96, 80, 3, 1, 1, 1),        # 27 k tiles
+]
+
+
+@pytest.mark.parametrize("case", DEEPK_CASES)
+@pytest.mark.parametrize("tiles", [(3, 12)])
+def test_deep_k_forms_are_bit_identical_to_their_parent_tiles(case, tiles):
+    """The deep-k loop (two k tiles per ring stage, one barrier per stage, compiler-scheduled; HN_TILE_64x64_K2) keeps the pinned
+    loop's DMA geometry, k order and term order: S32 / fp32 outputs, residual + ReLU, with and without split-K, equal the parent
+    tile's bit for bit -- including k loops with an odd tile count and with fewer tiles than one stage."""
+    from hn_amd import ops
+    from hn_amd.weights import split_f16x3
+    n, h, w, cin, cout, r, stride, pad, dil = case
+    parent, deep = tiles
+    x = _rand((n, h, w, cin), 101)
+    wt = _rand((cout, r, r, cin), 102, scale=(2.0 / (cin * r * r)) ** 0.5)
+    b = _rand((cout,), 103, 0.1)
+    oh, ow = ops.conv_out_size(h, w, r, r, stride, pad, dil)
+    res = _rand((n, oh, ow, cout), 104)
+    xs, w16 = ops.to_split(x.cuda()), split_f16x3(wt).cuda()
+    outs = {}
+    for tile in (parent, deep):
+        kw = dict(stride=stride, pad=pad, dil=dil, relu=True, tile=tile, w16=w16)
+        got = [ops.conv2d_nhwc(xs, wt.cuda(), b.cuda(), splitk=False, **kw)]
+        if cout % 32 == 0:
+            got.append(ops.conv2d_nhwc(xs, wt.cuda(), b.cuda(), residual=ops.to_split(res.cuda()), out_split=True, splitk=False, **kw))
+        if cout % 8 == 0 and r * r * cin // 32 >= 4:
+            got.append(ops.conv2d_nhwc(xs, wt.cuda(), b.cuda(), force_splits=2, **kw))
+            got.append(ops.conv2d_nhwc(xs, wt.cuda(), b.cuda(), force_splits=3, **kw))
+        outs[tile] = got
+    for a, c in zip(outs[parent], outs[deep]):
+        assert a.shape == c.shape and torch.equal(a, c), (case, tiles)
+
+
+def test_deep_k_tile_pick_and_multi_launch():
+    """The auto heuristic picks the deep-k form of the 64x64 tile for grids of at most one workgroup per CU with >= 8 k tiles
+    (ResNet-34 layer3 at batch 1), never at batch 32 and never with "conv_no_deepk"; a heterogeneous launch whose members take the
+    64x64 tile -- deep-k ones and one whose k loop is too short for it on its own -- is one launch, bit-identical to separate ones."""
+    from types import SimpleNamespace as NS
+    from hn_amd import ops
+    from hn_amd.weights import split_f16x3
+    lib = ops._lib.load()
+
+    def pick(n, h, w, cin, cout, r, stride=1):
+        return lib.hn_conv2d_f16x3_pick_tile(ops.make_conv_desc(n, h, w, cin, cout, r, r, stride, r // 2, 1, cout, 0))
+    assert pick(1, 50, 68, 256, 256, 3) == 12 and pick(1, 50, 68, 256, 256, 1) == 12
+    assert pick(1, 100, 136, 128, 128, 3) == 6 and pick(1, 11, 11, 512, 512, 3) == 7       # the other small tiles keep the pinned loop
+    assert pick(32, 50, 68, 256, 256, 3) == 1 and pick(1, 50, 68, 128, 256, 1) == 3       # batch 32; 4 k tiles only
+    ops.set_form("conv_no_deepk", True)
+    try:
+        assert pick(1, 50, 68, 256, 256, 3) == 3
+    finally:
+        ops.set_form("conv_no_deepk", False)
+    g = torch.Generator().manual_seed(105)
+    items = []
+    for cin, cout, r in ((256, 256, 3), (256, 256, 1), (128, 256, 1)):
+        x = ops.to_split(torch.randn((1, 50, 68, cin), generator=g).cuda())
+        wt = torch.randn((cout, r, r, cin), generator=g) * (2.0 / (cin * r * r)) ** 0.5
+        cw = NS(w=wt.cuda(), bias=torch.randn((cout,), generator=g).cuda(), w16=split_f16x3(wt).cuda(), stride=1, pad=r // 2, dil=1)
+        items.append((x, cw, dict(relu=r == 3, residual=None, out_split=True)))
+    alone = [ops.conv2d_nhwc(xi, cw.w, cw.bias, stride=cw.stride, pad=cw.pad, dil=cw.dil, w16=cw.w16, **o) for xi, cw, o in items]
+    flag = []
+    fused = ops.conv2d_nhwc_multi(items, fused=flag)
+    assert flag[0]
+    for a, c in zip(fused, alone):
+        assert torch.equal(a, c)
