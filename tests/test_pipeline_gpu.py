@@ -728,3 +728,34 @@ def test_auto_captured_graphs_are_evicted_least_recently_used(fcos_sd, a2j_sd):
     b = run(480, 640, times=1)
     for x, y in zip(a, b):
         assert torch.equal(x.cpu(), y.cpu())
+
+
+@pytest.mark.parametrize("n", [1, 6])
+def test_round5_kernel_forms_are_bit_identical_end_to_end(fcos_sd, a2j_sd, n):
+    """The three kernel routes added in round 5 -- the streaming 1x1 kernel (FPN P3 lateral from batch 5 on), the mixed-tile grouped
+    launch (tower layers at batch 1-2) and the deep-k form of the 64x64 tile (ResNet-34 layer3 at batch 1) -- keep every k order:
+    the whole pipeline's outputs (detections, crop boxes, keypoints) are bit-identical with the routes switched off by name."""
+    from hn_amd import ops, synth
+    from hn_amd.a2j_engine import A2JEngine
+    from hn_amd.fcos_engine import FCOSEngine
+    from hn_amd.pipeline import HandNetEngine
+    rgb, depth = synth.make_rgb(n, seed=1000).cuda(), synth.make_depth(n, seed=2000).cuda()
+    eng = HandNetEngine(FCOSEngine(fcos_sd, 3, device="cuda"), A2JEngine(a2j_sd, device="cuda"), 3)
+    ops.clear_plan_caches()
+    new = eng.forward_device(rgb, depth)
+    forms = ("conv_no_stream", "conv_no_mixed", "conv_no_deepk")
+    for f in forms:
+        ops.set_form(f, True)
+    try:
+        ops.clear_plan_caches()
+        old = eng.forward_device(rgb, depth)
+    finally:
+        for f in forms:
+            ops.set_form(f, False)
+        ops.clear_plan_caches()
+    assert torch.equal(new.keypoints.view(torch.int32), old.keypoints.view(torch.int32))
+    assert torch.equal(new.crop_box, old.crop_box) and torch.equal(new.has_hand, old.has_hand)
+    assert torch.equal(new.detections.count, old.detections.count)
+    for i, k in enumerate(new.detections.count.cpu().tolist()):      # (rows at or beyond count[i] are undefined)
+        assert torch.equal(new.detections.boxes[i, :k], old.detections.boxes[i, :k])
+        assert torch.equal(new.detections.scores[i, :k], old.detections.scores[i, :k])
