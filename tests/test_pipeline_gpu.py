@@ -759,3 +759,23 @@ def test_round5_kernel_forms_are_bit_identical_end_to_end(fcos_sd, a2j_sd, n):
     for i, k in enumerate(new.detections.count.cpu().tolist()):      # (rows at or beyond count[i] are undefined)
         assert torch.equal(new.detections.boxes[i, :k], old.detections.boxes[i, :k])
         assert torch.equal(new.detections.scores[i, :k], old.detections.scores[i, :k])
+
+
+def test_engine_forward_raw_rgbd_equals_forward_device(fcos_sd, a2j_rgbd_sd):
+    """The RGB-D model through the raw-frame entry: the ingest kernel writes the 4-channel tensor `cat([rgb, depth], 1)` that
+    ros_demo.py:268-270 builds on the host; keypoints, crop boxes and the 4-channel crops (channel order [2,1,0,3],
+    handnet_pipeline.py:102) equal forward_device on the host-converted inputs bit for bit, eagerly and through a captured step."""
+    from hn_amd.a2j_engine import A2JEngine
+    from hn_amd.fcos_engine import FCOSEngine
+    from hn_amd.pipeline import HandNetEngine
+    eng = HandNetEngine(FCOSEngine(fcos_sd, 3, device="cuda"), A2JEngine(a2j_rgbd_sd, rgbd=True, device="cuda"), 3)
+    bgr, mm = _raw_frames(2, seed=21)
+    rgb, depth = _host_ingest(bgr, mm)
+    want = eng.forward_device(rgb.cuda(), torch.cat([rgb, depth], dim=1).cuda())
+    tb, td = torch.from_numpy(bgr), torch.from_numpy(mm)
+    for use_graph in (False, True, True):
+        got = eng.forward_raw(tb, td, use_graph=use_graph)
+        torch.cuda.synchronize()
+        assert torch.equal(got.keypoints.view(torch.int32), want.keypoints.view(torch.int32))
+        assert torch.equal(got.crop_box, want.crop_box) and torch.equal(got.crops_nhwc, want.crops_nhwc)
+    assert eng.graph_count() == 1
