@@ -86,7 +86,7 @@ def parse():
                          "beside the parity mode: misses the 1e-3 contract, reported with its error figures, never the headline")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (the default for --gpus > 1)")
     ap.add_argument("--eager", action="store_true", help="--gpus > 1: issue the step's launches from Python instead of replaying a graph")
-    ap.add_argument("--init-timeout", type=float, default=300.0,
+    ap.add_argument("--init-timeout", type=float, default=180.0,
                     help="--gpus > 1: seconds the process group may take to start (rendezvous + first collective) per attempt")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the other single-GPU BASELINE configurations (a2j_b64, fcos_b16, pipeline_b1) of the default run")
