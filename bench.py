@@ -550,8 +550,10 @@ def supervise(args):
             break
         status = max((c.returncode for c in children), key=abs)
         break
-    if not under_torchrun:
+    if not under_torchrun or (status == 0 and any(r == 0 for r, _ in ranks)):
         import shutil
+        if under_torchrun:
+            time.sleep(1.0)    # (the other ranks' supervisors only look at the directory while their worker runs)
         shutil.rmtree(job_dir, ignore_errors=True)
     return status
 

@@ -274,8 +274,10 @@ class HandNetEngine:
     def _device_readable(self, t: torch.Tensor):
         """GPU tensors and pinned host tensors as they are; pageable host memory through a pinned staging buffer of the
         engine (one host memcpy; the ingest kernel then reads the pinned buffer over PCIe itself)."""
-        if t.is_cuda or t.is_pinned():
+        if t.is_cuda:
             return t.contiguous()
+        if t.is_pinned() and t.is_contiguous():
+            return t
         key = (tuple(t.shape), t.dtype)
         buf = self._raw_staging.get(key)
         if buf is None:
