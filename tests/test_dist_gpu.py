@@ -244,3 +244,18 @@ def test_stages_are_repeatable_next_to_a_second_process(fcos_sd, a2j_sd):
     finally:
         load.kill()
         load.wait()
+
+
+def test_bench_ladder_with_a_real_rccl_initialisation_failure():
+    """A REAL (not injected) RCCL failure: two ranks on the SAME GPU with the nccl backend -- RCCL refuses duplicate devices when
+    the communicator is created.  Both rungs of the ladder must run and fail on the backend's own error, bench.py must exit
+    non-zero with that error text and without a JSON line: never a gloo fallback, never a single-rank result."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "HN_BENCH_WORKER")}
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--share-gpu", "--dist-backend", "nccl",
+                        "--steps", "1", "--warmup", "0", "--batch", "2", "--no-cpu-baseline", "--no-roofline", "--init-timeout", "60"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    out = r.stdout + r.stderr
+    assert r.returncode != 0, out
+    assert not any(l.startswith("{") for l in r.stdout.splitlines()), r.stdout
+    assert "attempt 1 failed to initialise" in r.stderr and "attempt 2 failed to initialise" in r.stderr, out
+    assert "HSA_ENABLE_IPC_MODE_LEGACY unset" in r.stderr
