@@ -779,3 +779,20 @@ def test_engine_forward_raw_rgbd_equals_forward_device(fcos_sd, a2j_rgbd_sd):
         assert torch.equal(got.keypoints.view(torch.int32), want.keypoints.view(torch.int32))
         assert torch.equal(got.crop_box, want.crop_box) and torch.equal(got.crops_nhwc, want.crops_nhwc)
     assert eng.graph_count() == 1
+
+
+def test_exact_f32_mode_propagates_nan_crops_like_torch(a2j_sd):
+    """precision="f32" has no stem image to mark a crop on: a NaN pixel travels through the network itself.  With NaN-propagating
+    ReLU and max pooling (round 5; torch.relu / max_pool2d keep NaN, v_max_f32 would not) every joint of that crop comes out NaN,
+    as the reference's plain torch forward returns it, and the other crops are untouched."""
+    from hn_amd import synth
+    from hn_amd.a2j_engine import A2JEngine
+    from oracle import a2j_ref
+    eng = A2JEngine(a2j_sd, device="cuda", precision="f32")
+    x = synth.make_crops(3, seed=3200)
+    clean = eng.forward(x.cuda()).cpu()
+    x[1, 0, 90, 40] = float("nan")
+    ref = a2j_ref.a2j_forward(x, a2j_sd)
+    got = eng.forward(x.cuda()).cpu()
+    assert torch.isnan(ref[1]).all() and torch.isnan(got[1]).all()
+    assert torch.equal(got[[0, 2]], clean[[0, 2]]) and (got[[0, 2]] - ref[[0, 2]]).abs().max().item() < 1e-3
