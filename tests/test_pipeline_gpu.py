@@ -796,3 +796,20 @@ def test_exact_f32_mode_propagates_nan_crops_like_torch(a2j_sd):
     got = eng.forward(x.cuda()).cpu()
     assert torch.isnan(ref[1]).all() and torch.isnan(got[1]).all()
     assert torch.equal(got[[0, 2]], clean[[0, 2]]) and (got[[0, 2]] - ref[[0, 2]]).abs().max().item() < 1e-3
+
+
+def test_nonfinite_rgb_pixels_raise_instead_of_giving_undefined_detections(fcos_sd, a2j_sd):
+    """A NaN RGB pixel (not a camera's case: frames arrive as uint8) would make the reference's detector return nothing for that
+    frame; the split-precision detector cannot promise that, so the drop-in is LOUD: the NaN travels through the NaN-propagating
+    ReLUs into the activations, the range contract flags it, HandNet.forward raises ops.RangeError naming the cause (DESIGN section
+    2; a documented deviation) -- never silently undefined detections."""
+    from hn_amd import ops, synth
+    net = _dropin(fcos_sd, a2j_sd)
+    rgb, depth = synth.make_rgb(2, seed=1000), synth.make_depth(2, seed=2000)
+    rgb[1, 0, 200, 300] = float("nan")
+    with torch.inference_mode():
+        with pytest.raises(ops.RangeError, match="non-finite RGB"):
+            net([r.cuda() for r in rgb], depth_images=depth.cuda())
+        rgb[1, 0, 200, 300] = 0.5
+        kp, _, _ = net([r.cuda() for r in rgb], depth_images=depth.cuda())       # the flags are per step
+        assert torch.isfinite(kp).all()
