@@ -536,7 +536,13 @@ def supervise(args):
                             pass
             if failed.exists():
                 init_failed = True
-            if init_failed or all(c is not None for c in codes):
+            # a worker that fails AFTER the group was up (a refused configuration, a crash in the run) ends the job: its peers
+            # would otherwise wait in their next collective until the group's timeout
+            run_failed = any(code not in (None, 0) and (job_dir / f"attempt{attempt}.rank{rank}.ready").exists()
+                             for (rank, _), code in zip(ranks, codes))
+            if init_failed or run_failed or all(c is not None for c in codes):
+                if run_failed and not init_failed:
+                    stop_children()
                 break
             time.sleep(0.1)
         if init_failed:
@@ -548,7 +554,9 @@ def supervise(args):
                 continue
             status = EXIT_INIT_FAILED
             break
-        status = max((c.returncode for c in children), key=abs)
+        status = max((c.returncode for c in children if c.returncode is not None), key=abs, default=1)
+        if status == 0 and any(c.returncode != 0 for c in children):
+            status = 1
         break
     if not under_torchrun or (status == 0 and any(r == 0 for r, _ in ranks)):
         import shutil
@@ -715,6 +723,8 @@ def worker(args):
             except OSError:
                 pass
         sys.exit(EXIT_INIT_FAILED)
+    if multi and os.environ.get("HN_BENCH_INJECT_RUN_FAILURE") == str(rank_env):
+        raise SystemExit("[bench] injected for the supervisor test: a failure after the process group was up")
     if multi and not args.share_gpu and not args.stub_engine and len(set(devices)) != world:
         raise SystemExit(f"[bench] {world} ranks but only {len(set(devices))} distinct devices: {devices}")
     dev = torch.device("cpu") if args.stub_engine else torch.device("cuda", local)

@@ -219,6 +219,18 @@ def test_bench_under_real_torchrun_with_a_failed_first_attempt():
     assert "unset" in d["config"]["ipc_mode"] and "attempt 2 of 2" in d["config"]["ipc_mode"]
 
 
+def test_bench_stops_the_peers_when_a_worker_fails_after_the_group_was_up():
+    """A worker that fails AFTER the first collective (a refused configuration, a crash in the run) is not an initialisation
+    failure: no second rung; the supervisor stops its peers at once -- they would otherwise sit in their next collective until
+    the group's timeout -- and exits non-zero without a line."""
+    import time
+    t0 = time.time()
+    r = _bench(["--gpus", "4"] + STUB, env={"HN_BENCH_INJECT_RUN_FAILURE": "2"})
+    assert r.returncode != 0 and not any(l.startswith("{") for l in r.stdout.splitlines()), r.stdout + r.stderr
+    assert "attempt 2 of 2" not in r.stderr and "injected for the supervisor test" in r.stderr
+    assert time.time() - t0 < 45.0          # (the STUB runs use a 60 s group timeout: the peers were stopped, not timed out)
+
+
 def test_bench_fails_loudly_when_the_process_group_cannot_start():
     """`--gpus 2` under a torchrun-style environment whose rendezvous cannot complete (rank 1 of 2 with no rank 0): both rungs
     of the ladder time out (--init-timeout), bench.py exits non-zero with the backend's error text -- never a single-rank run,
