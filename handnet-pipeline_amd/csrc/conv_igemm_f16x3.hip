@@ -13,6 +13,8 @@ int launch16_impl(const ConvParams16& p0, hipStream_t st) {
   p.tiles_n = hn::cdiv(p.Cout, BN);
   p.nblocks = p.tiles_m * p.tiles_n;
   plan_splits(p, BM, BN);
+  int taken = 0;
+  assign_tickets(p, BM, BN, WM * WN, p.split_ws, taken);
   int grid_x = p.nblocks;
   if (p.groups > 1) {
     grid_x = 0;
@@ -70,7 +72,7 @@ int launch16_impl(const ConvParams16& p0, hipStream_t st) {
     hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, NBUF, BUF, false, TERMS>),
                        dim3(grid_x, p.splits, p.groups > 1 ? p.groups : 1), dim3(WM * WN * 64), 0, st, p);
   HN_CHECK_LAUNCH("conv_igemm_f16x3_kernel");
-  if (p.splits > 1) {
+  if (p.splits > 1 && p.ticket_base < 0) {
     const long total = (long)p.M * (p.Cout >> 3);
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, p);
@@ -87,6 +89,8 @@ int launch16_deepk(const ConvParams16& p0, hipStream_t st) {
   p.tiles_n = hn::cdiv(p.Cout, BN);
   p.nblocks = p.tiles_m * p.tiles_n;
   plan_splits(p, BM, BN, KK);
+  int taken = 0;
+  assign_tickets(p, BM, BN, WM * WN, p.split_ws, taken);
   int grid_x = p.nblocks;
   if (p.groups > 1) {
     grid_x = 0;
@@ -108,7 +112,7 @@ int launch16_deepk(const ConvParams16& p0, hipStream_t st) {
   hipLaunchKernelGGL((conv_igemm_f16x3_deepk_kernel<BM, BN, WM, WN, NST, KK>), dim3(grid_x, p.splits, p.groups > 1 ? p.groups : 1),
                      dim3(WM * WN * 64), LDS_BYTES, st, p);
   HN_CHECK_LAUNCH("conv_igemm_f16x3_deepk_kernel");
-  if (p.splits > 1) {
+  if (p.splits > 1 && p.ticket_base < 0) {
     const long total = (long)p.M * (p.Cout >> 3);
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, p);
@@ -221,8 +225,8 @@ extern "C" int hn_conv2d_nhwc_f16x3(const hn_conv_desc* d, const void* x16, cons
 }
 
 // The same convolution with a caller-provided fp32 workspace, which lets small grids use split-K
-// (deterministic: partial tiles are summed in a fixed order by a second kernel).  The workspace is only
-// touched between this call's two launches, so one buffer per stream serves every convolution.
+// (deterministic: partial tiles are summed in a fixed order, by the last workgroup of a tile or by a second kernel -- see
+// assign_tickets).  The workspace is only touched between this call's launches, so one buffer per stream serves every convolution.
 extern "C" int hn_conv2d_nhwc_f16x3_ws(const hn_conv_desc* d, const void* x16, const void* w16, const float* bias,
                                        const void* residual, void* y, void* workspace, int64_t workspace_bytes,
                                        void* stream) {

@@ -58,11 +58,25 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
 
 // 256 bytes of zeros: source of every out-of-image tap
 __device__ __attribute__((aligned(256))) _Float16 g_zero_page16[128];
+
+// Split-K tickets (round 5): one counter per (output tile, wave) of a split launch whose LAST workgroup does the reduction itself
+// (ConvParams16::ticket_base >= 0).  Zero at rest: the reducing workgroup puts its tile's counter back.  A launch owns the
+// kTicketsPerSlot counters of the slot its workspace is registered under (split_ticket_slot in the plan header): two launches
+// that are in flight together use different workspaces (they would race on the partial planes otherwise), hence different
+// counters.  (One array per translation unit that includes this header: launches of both use the same slot numbers on their own
+// arrays, which is fine for the same reason.)
+constexpr int kTicketSlots = 128, kTicketsPerSlot = 4096;
+// tile forms whose kernels hold the in-kernel reduction: the 32- and 64-row tiles, i.e. every split layer of the batch-1 frame.
+// (The 128x128 / 256x64 forms sit at 128 + 128 registers and spill VGPRs with it, the 128x64 form two SGPRs; they split at
+// batch 32 only, where a reduction launch is 1 % of the layer.)
+constexpr bool fused_reduce_form(int bm, int bn) { return bm <= 64 && bn <= 128; }
+__device__ int g_split_tickets[kTicketSlots * kTicketsPerSlot];
 
 struct ConvParams16 {
   const _Float16* x;  // S32 activations
@@ -94,6 +108,7 @@ struct ConvParams16 {
   int gM[HN_CONV_MAX_GROUP], gnblocks[HN_CONV_MAX_GROUP];   // members may differ in spatial size (FPN levels)
   int gn_units;       // 8-channel units per row group in the GroupNorm slab (Cout/8 unless members share a slab)
   int splits, kt_per, splitk_mode;
+  int ticket_base;    // >= 0: the last workgroup of a tile reduces (index of the launch's first counter in g_split_tickets); -1: splitk_reduce_kernel does
   float* split_ws;
   int64_t split_ws_bytes;
   int tiles_m, tiles_n, nblocks;
@@ -314,7 +329,8 @@ struct HalfSched {
 // stage have landed, so the next tile's fragment reads overlap this tile's MFMAs without any hand-counted wait); the DMA
 // geometry, the k order, the term order and the epilogue are the pinned loop's: results are BIT-IDENTICAL to KK = 1.
 template <int BM, int BN, int WM, int WN, int NBUF, bool BUF, bool RS = false, int TERMS = 3, bool DYN = false, int KK = 1>
-__device__ __forceinline__ void conv_igemm_f16x3_body(const ConvParams16& p, const int blk_x, const int blk_y, const int blk_z) {
+__device__ __forceinline__ void conv_igemm_f16x3_body(const ConvParams16& p, const int blk_x, const int blk_y, const int blk_z,
+                                                      const unsigned karg_off = 0 /* byte offset of `p` in the kernel-argument segment */) {
   static_assert(TERMS == 3 || TERMS == 1, "three terms (fp32-grade) or the hi*hi term alone");
   static_assert(NBUF >= 2 && NBUF <= 6, "2..6 LDS stages");
   static_assert(!RS || (BUF && NBUF == 2), "row-shared A needs the descriptor form and the 2-stage pipeline");
@@ -968,6 +984,19 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(const ConvParams16& p, con
       y[r] = __uint_as_float(s[1]);
     }
   };
+  // split-K whose last workgroup reduces (below): the partial planes are addressed through a buffer descriptor with the
+  // device-coherent cache policy
+  constexpr bool FUSED_REDUCE = !RS && TERMS == 3 && fused_reduce_form(BM, BN);
+  const bool tickets = FUSED_REDUCE && p.splits > 1 && p.ticket_base >= 0;
+  __amdgpu_buffer_rsrc_t rsrc_ws = __builtin_amdgcn_make_buffer_rsrc((void*)p.split_ws, 0, 0, 0x00020000);
+  int plane_off = 0;
+  if constexpr (FUSED_REDUCE) {
+    if (tickets) {
+      const int plane_bytes = o.M * p.Cout * 4;   // (splits * plane < 2 GB: assign_tickets)
+      rsrc_ws = __builtin_amdgcn_make_buffer_rsrc((void*)p.split_ws, 0, plane_bytes * p.splits, 0x00020000);
+      plane_off = blk_y * plane_bytes;
+    }
+  }
   if (p.vec_epi) {
     constexpr int NP = TN / 2;        // column-tile pairs per wave
     f32x4 bias0[NP], bias1[NP];
@@ -1046,6 +1075,16 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(const ConvParams16& p, con
             gsum[jp][2] += second ? s1 : 0.f;
             gsum[jp][3] += second ? s2 : 0.f;
           }
+          if constexpr (FUSED_REDUCE) {
+            if (tickets) {   // (wave-uniform) the raw partial tile, written THROUGH this XCD's L2: see the reduction below
+              const u32x4 d0 = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+              const u32x4 d1 = {__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])};
+              const int voff = (m * p.Cout + n) * 4;
+              __builtin_amdgcn_raw_buffer_store_b128(d0, rsrc_ws, voff, plane_off, 16 /* sc1 */);
+              __builtin_amdgcn_raw_buffer_store_b128(d1, rsrc_ws, voff + 16, plane_off, 16);
+              continue;
+            }
+          }
           if constexpr (PREF) {
             if (use_pre) epi_finish8(q, m, n, v, ohow, &rpre_h[(i + ii) * NP + jp], &rpre_l[(i + ii) * NP + jp]);
             else epi_finish8(q, m, n, v, ohow);
@@ -1067,6 +1106,93 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(const ConvParams16& p, con
             f32x4 o4 = {gsum[jp][0], gsum[jp][1], gsum[jp][2], gsum[jp][3]};
             *reinterpret_cast<f32x4*>(q.gn_partial + ((long)(m_grp >> 5) * p.gn_units + (n >> 3)) * 4) = o4;
           }
+        }
+      }
+    }
+    // Split-K without the second launch (round 5; batch 1 spends 33 launches of ~5 us each on reductions that move a few hundred
+    // KB): every wave takes a ticket once its part of the partial tile has been written; the one that draws the last ticket adds
+    // the planes IN z ORDER -- the arithmetic of splitk_reduce_body, whichever workgroup arrives last: bit-identical to the
+    // separate reduction -- and finishes its part of the tile.  The XCDs' L2s are not coherent with each other, and a device-scope fence
+    // (write back this L2, invalidate it) costs ~30 us per launch (measured: the batch-1 frame 2.23 -> 3.00 ms): the partial tiles
+    // are written and read with the device-coherent cache policy (sc1) instead, so the only ordering needed is "my stores have
+    // been acknowledged" (vmcnt(0)) before the ticket is drawn.  (The row-shared form never splits; the f16x1 throughput mode
+    // and the 128-row tiles keep the separate launch.)
+    if constexpr (FUSED_REDUCE) {
+      if (tickets) {
+        // The real epilogue's parameters are read from the kernel-argument segment HERE (under the wait for the stores),
+        // through an address the compiler cannot identify with the one it loaded `p` from: kept live from the prologue they
+        // cost every split-capable kernel ~11 SGPRs it does not have (spills in the 128x64 form).
+        typedef __attribute__((address_space(4))) const unsigned KW;
+        KW* kw = (KW*)((__attribute__((address_space(4))) const char*)__builtin_amdgcn_kernarg_segment_ptr() + karg_off);
+        asm volatile("" : "+s"(kw));
+        ConvParams16 f;
+        {
+          unsigned* dst = reinterpret_cast<unsigned*>(&f);
+#pragma unroll
+          for (int w = 0; w < (int)(sizeof(ConvParams16) / 4); ++w) dst[w] = kw[w];
+        }
+        // One ticket per (tile, wave): wave w of every workgroup of a tile owns the same rows and columns of it, so the waves
+        // need no rendezvous with their siblings -- each draws on its own counter as soon as ITS stores are in memory.
+        int* ticket = g_split_tickets + p.ticket_base + lid * (WM * WN) + __builtin_amdgcn_readfirstlane(wave);
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's part of the partial tile is in memory
+        int drawn = 0;
+        if (lane == 0) drawn = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        drawn = __builtin_amdgcn_readfirstlane(drawn);
+        if (drawn != f.splits - 1) return;
+        if (lane == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero at rest
+        const int plane_bytes = f.M * f.Cout * 4;
+        const int f_ohow = f.OH * f.OW;
+        // all of this lane's 8-channel units at once, the planes ZC at a time: the loads of a chunk are in flight together
+        // (a rolled loop waits a memory latency per plane); each element still adds its planes in z order
+        constexpr int NU = TM * NP, ZC = NU <= 2 ? 4 : 2;
+        float v[NU][8];
+        int voff[NU];
+        bool live[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          const int m = m0 + wm * (BM / WM) + (u / NP) * 16 + px, n = n_wave + (u % NP) * 32 + nsub;
+          live[u] = m < f.M && n < f.Cout;
+          voff[u] = live[u] ? (m * f.Cout + n) * 4 : 0;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[u][e] = 0.f;
+        }
+        for (int z0 = 0; z0 < f.splits; z0 += ZC) {
+          u32x4 ld[ZC][NU][2];
+#pragma unroll
+          for (int zz = 0; zz < ZC; ++zz) {
+            const int z = z0 + zz < f.splits ? z0 + zz : f.splits - 1;   // (a clamped plane is read and not added)
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+              ld[zz][u][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_ws, voff[u], z * plane_bytes, 16 /* sc1 */);
+              ld[zz][u][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_ws, voff[u] + 16, z * plane_bytes, 16);
+            }
+          }
+#pragma unroll
+          for (int zz = 0; zz < ZC; ++zz) {
+            if (z0 + zz < f.splits) {
+#pragma unroll
+              for (int u = 0; u < NU; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  v[u][e] += __uint_as_float(ld[zz][u][0][e]);
+                  v[u][4 + e] += __uint_as_float(ld[zz][u][1][e]);
+                }
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          if (!live[u]) continue;
+          const int m = m0 + wm * (BM / WM) + (u / NP) * 16 + px, n = n_wave + (u % NP) * 32 + nsub;
+          if (f.bias) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(f.bias + n), b1 = *reinterpret_cast<const f32x4*>(f.bias + n + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[u][e] += b0[e];
+              v[u][4 + e] += b1[e];
+            }
+          }
+          epi_finish8(f, m, n, v[u], f_ohow);
         }
       }
     }
@@ -1196,14 +1322,15 @@ void conv_igemm_f16x3_multi_kernel(const MultiParams16 mp) {
     local -= p.nblocks;
     ++by;
   }
-  conv_igemm_f16x3_body<BM, BN, WM, WN, NBUF, true, false, 3, (KK > 1), KK>(p, local, by, 0);
+  conv_igemm_f16x3_body<BM, BN, WM, WN, NBUF, true, false, 3, (KK > 1), KK>(
+      p, local, by, 0, (unsigned)(offsetof(MultiParams16, m) + (size_t)g * sizeof(ConvParams16)));
 }
 
 // the reductions of a multi launch's split-K members as ONE launch: gridDim.y = member
 __global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(const MultiParams16 mp) {
   ConvParams16 p;
   load_member16(mp, (int)blockIdx.y, p);
-  if (p.splits <= 1) return;
+  if (p.splits <= 1 || p.ticket_base >= 0) return;   // (members with tickets reduced in their own last workgroups)
   splitk_reduce_body(p);
 }
 #endif

@@ -13,7 +13,7 @@ static int launch_multi(MultiParams16& mp, hipStream_t st) {
     ConvParams16& p = mp.m[g];
     mp.start[g] = total;
     total += p.nblocks * p.splits;
-    if (p.splits > 1) {
+    if (p.splits > 1 && p.ticket_base < 0) {
       any_split = 1;
       const long units = (long)p.M * (p.Cout >> 3);
       const int grid = (int)((units + 255) / 256 < 4096 ? (units + 255) / 256 : 4096);
@@ -44,9 +44,10 @@ static int launch_multi(MultiParams16& mp, hipStream_t st) {
 // Would these convolutions run as ONE multi launch?  They do when every member, launched alone through
 // hn_conv2d_nhwc_f16x3_ws, would take the implicit-GEMM kernel of one and the same tile form in its descriptor form; the
 // members then keep their own split-K plans (the plan a member would get alone: its result does not depend on the grouping).
-static bool multi_plan(const hn_conv_multi* mm, void* workspace, int64_t workspace_bytes, MultiParams16& mp, int& tile) {
+static bool multi_plan(const hn_conv_multi* mm, void* workspace, int64_t workspace_bytes, MultiParams16& mp, int& tile, bool query = false) {
   tile = -1;
   int64_t ws_off = 0;
+  int taken = 0;
   for (int g = 0; g < mm->count; ++g) {
     const hn_conv_desc* d = &mm->desc[g];
     ConvParams16& p = mp.m[g];
@@ -79,6 +80,7 @@ static bool multi_plan(const hn_conv_multi* mm, void* workspace, int64_t workspa
       if (ws_off + bytes > workspace_bytes) return false;
       p.split_ws = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ws_off);
       ws_off += (bytes + 255) & ~(int64_t)255;
+      if (!query) assign_tickets(p, f.bm, f.bn, f.waves, workspace, taken);   // the members' counters: consecutive ranges of the workspace's slot
     }
   }
   return true;
@@ -123,7 +125,7 @@ extern "C" int hn_conv2d_f16x3_multi_fuses(const hn_conv_multi* mm, int64_t work
   MultiParams16 mp;
   mp.count = mm->count;
   int tile = -1;
-  if (!multi_plan(mm, reinterpret_cast<void*>(256), workspace_bytes, mp, tile)) return 0;
+  if (!multi_plan(mm, reinterpret_cast<void*>(256), workspace_bytes, mp, tile, true)) return 0;
   return tile == HN_TILE_128x128 || tile == HN_TILE_128x64 || tile == HN_TILE_64x64 || tile == HN_TILE_64x128 || tile == HN_TILE_32x64 ||
          tile == HN_TILE_64x64_K2;
 }

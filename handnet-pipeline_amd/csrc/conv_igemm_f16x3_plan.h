@@ -3,6 +3,7 @@
 // parameter block -- ONE definition of each decision, shared by the launchers (conv_igemm_f16x3.hip), the heterogeneous launch
 // (conv_igemm_f16x3_multi.hip) and the host-only queries (hn_conv2d_f16x3_uses_rs, ...).
 #pragma once
+#include <mutex>
 #include "conv_igemm_f16x3_kernel.h"
 
 namespace {
@@ -32,6 +33,7 @@ static SplitModel split_model(int bm, int bn, int kk = 1) {
 static void plan_splits(ConvParams16& p, int bm, int bn, int kk = 1) {   // needs p.nblocks; sets p.splits / p.kt_per
   p.splits = 1;
   p.kt_per = p.ktiles;
+  p.ticket_base = -1;   // (assign_tickets, once the plan stands)
   if (p.groups > 1) return;  // grouped problems never split (the grid is already groups x larger)
   if (!(p.split_ws && p.splitk_mode >= 0 && p.vec_epi && !p.gn_partial)) return;
   const int64_t plane_bytes = (int64_t)p.M * p.Cout * 4;
@@ -72,6 +74,32 @@ static void plan_splits(ConvParams16& p, int bm, int bn, int kk = 1) {   // need
     p.kt_per = hn::cdiv(p.ktiles, want);
     p.splits = hn::cdiv(p.ktiles, p.kt_per);  // every split has at least one tile
   }
+}
+
+// The ticket slot of a workspace (g_split_tickets in the kernel header): the first kTicketSlots distinct workspace addresses a
+// process splits with get one each, for good -- a captured graph keeps the slot number of its launches, so a slot is never
+// handed to another address; later workspaces take the separate reduction launch (same results).  -1: none.
+static int split_ticket_slot(const void* workspace) {
+  static std::mutex mu;
+  static const void* keys[kTicketSlots];
+  static int used = 0;
+  std::lock_guard<std::mutex> lock(mu);
+  for (int i = 0; i < used; ++i)
+    if (keys[i] == workspace) return i;
+  if (used == kTicketSlots) return -1;
+  keys[used] = workspace;
+  return used++;
+}
+// After plan_splits: the split launch reduces in its own last workgroups when it can have counters -- `taken` of the slot's
+// counters already belong to earlier members of the same launch (heterogeneous launches; 0 otherwise).
+static void assign_tickets(ConvParams16& p, int bm, int bn, int waves, const void* workspace, int& taken) {
+  p.ticket_base = -1;
+  if (p.splits <= 1 || !fused_reduce_form(bm, bn) || p.terms != 3 || !workspace || hn::env_flags().no_fused_reduce || taken + p.nblocks * waves > kTicketsPerSlot ||
+      (int64_t)p.splits * p.M * p.Cout * 4 >= ((int64_t)1 << 31)) return;   // (the planes sit behind one buffer descriptor)
+  const int slot = split_ticket_slot(workspace);
+  if (slot < 0) return;
+  p.ticket_base = slot * kTicketsPerSlot + taken;
+  taken += p.nblocks * waves;   // one counter per (tile, wave)
 }
 
 // Row-shared A operand: 3x3 / stride 1 / pad 1 / dilation 1 on a dense-row tensor, single pass (no split-K), a tile form

@@ -98,6 +98,7 @@ extern "C" int hn_set_form(const char* name, int value) {
       {"conv_no_stream", &hn::EnvFlags::no_stream},         // implicit-GEMM form of the short-k 1x1 layers (conv1x1_stream.hip)
       {"conv_no_mixed", &hn::EnvFlags::no_mixed},           // grouped launches: one tile shape for every member
       {"conv_no_deepk", &hn::EnvFlags::no_deepk},           // small grids: the pinned one-tile-per-barrier loop
+      {"conv_no_fused_reduce", &hn::EnvFlags::no_fused_reduce},   // split-K: the separate reduction launch
   };
   for (const Entry& e : table)
     if (strcmp(e.name, name) == 0) {

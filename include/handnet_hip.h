@@ -89,7 +89,7 @@ int hn_range_check_collect(int32_t* block /* or NULL */, int32_t* dst /* device,
 /* Kernel-form switches.  Older forms of some kernels stay in the library as bit-identity references for the tests and for
  * same-box A/B timing ("conv_no_rs", "conv_no_rs32", "split_generic", "conv_no_halo", "preprocess_generic",
  * "conv_no_multi", "no_fuse_last_gn", "no_thin_outputs", "thin_form_tap", "thin_form_flat", "halo_stamps", "splitk_fill512",
- * "conv_no_stream", "conv_no_mixed", "conv_no_deepk"; results unchanged
+ * "conv_no_stream", "conv_no_mixed", "conv_no_deepk", "conv_no_fused_reduce"; results unchanged
  * unless a test says otherwise).  The library NEVER reads them from the environment: a development host sets them by name
  * (bench.py and tools/ translate their HN_* variables through hn_amd/forms.py); a product process leaves them alone. */
 int hn_set_form(const char* name, int value);
@@ -224,7 +224,10 @@ int hn_groupnorm_affine_f32(const float* x /* [n][hw][c] */, const float* gamma,
 /* hn_conv2d_nhwc_f16x3 with a caller-provided workspace (fp32 scratch, 16-byte aligned, any size; only used
  * between this call's own launches, so one buffer per stream serves all convolutions).  With it, layers
  * whose output grid would leave most CUs idle (n*oh*ow small: the 11x11 A2J maps, everything at batch 1)
- * run split-K: up to 16 workgroups share an output tile, partial tiles are summed in a fixed order. */
+ * run split-K: up to 16 workgroups share an output tile, partial tiles are summed in a fixed order -- for the 32- / 64-row
+ * tiles by the workgroup that finishes a tile last (a ticket per tile in library-owned device memory, keyed by the workspace
+ * ADDRESS: as before, launches that may be in flight together must not share a workspace), otherwise by a second launch;
+ * the results are bit-identical either way ("conv_no_fused_reduce" forces the second launch). */
 int hn_conv2d_nhwc_f16x3_ws(const hn_conv_desc* desc, const void* x16, const void* w16,
                             const float* bias, const void* residual, void* y,
                             void* workspace, int64_t workspace_bytes, void* stream);

@@ -577,7 +577,7 @@ def test_f16x3_wide_dynamic_range_keeps_precision():
 
 
 _FORMS = ("conv_no_rs", "conv_no_rs32", "split_generic", "conv_no_halo", "preprocess_generic", "conv_no_multi",
-          "no_fuse_last_gn", "no_thin_outputs", "thin_form_tap", "thin_form_flat", "splitk_fill512", "conv_no_stream", "conv_no_mixed", "conv_no_deepk")
+          "no_fuse_last_gn", "no_thin_outputs", "thin_form_tap", "thin_form_flat", "splitk_fill512", "conv_no_stream", "conv_no_mixed", "conv_no_deepk", "conv_no_fused_reduce")
 
 
 @pytest.fixture(autouse=True)
@@ -1142,3 +1142,67 @@ def test_deep_k_tile_pick_and_multi_launch():
     assert flag[0]
     for a, c in zip(fused, alone):
         assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize("case,tile,splits", [
+    ((1, 25, 34, 512, 512, 3, 1, 1, 1), 7, 3), ((1, 25, 34, 512, 512, 3, 1, 1, 1), 7, 16), ((1, 11, 11, 512, 512, 3, 1, 1, 1), 7, 5),
+    ((1, 11, 11, 2048, 512, 3, 1, 1, 1), 7, 8), ((1, 11, 11, 1024, 256, 1, 1, 0, 1), 7, 2), ((1, 50, 68, 256, 256, 3, 1, 1, 1), 3, 2),
+    ((1, 50, 68, 256, 256, 3, 1, 1, 1), 12, 3), ((1, 100, 136, 128, 128, 3, 1, 1, 1), 6, 2), ((2, 23, 19, 160, 72, 3, 2, 1, 1), 3, 3),
+    ((1, 11, 11, 512, 512, 3, 1, 2, 2), 6, 4), ((32, 11, 11, 512, 512, 3, 1, 1, 1), 6, 12)])
+def test_split_k_reduction_in_the_last_workgroup_is_bit_identical(case, tile, splits):
+    """Round 5: a split-K launch of the 32- / 64-row tiles reduces in the workgroup that finishes a tile LAST (a ticket per tile and
+    wave, zero at rest) instead of in a second launch.  The planes are added in z order whoever arrives last, so fp32 and S32 outputs,
+    with residual and ReLU, equal the separate reduction ("conv_no_fused_reduce") bit for bit -- on every one of many repeats
+    (which workgroup reduces differs from run to run), and the tickets are zero again for the next launch."""
+    from hn_amd import ops
+    from hn_amd.weights import split_f16x3
+    n, h, w, cin, cout, r, stride, pad, dil = case
+    x = _rand((n, h, w, cin), 111)
+    wt = _rand((cout, r, r, cin), 112, scale=(2.0 / (cin * r * r)) ** 0.5)
+    b = _rand((cout,), 113, 0.1)
+    oh, ow = ops.conv_out_size(h, w, r, r, stride, pad, dil)
+    res = ops.to_split(_rand((n, oh, ow, cout), 114).cuda()) if cout % 32 == 0 else None
+    xs, w16 = ops.to_split(x.cuda()), split_f16x3(wt).cuda()
+    kw = dict(stride=stride, pad=pad, dil=dil, relu=True, tile=tile, w16=w16, force_splits=splits)
+
+    def run():
+        out = [ops.conv2d_nhwc(xs, wt.cuda(), b.cuda(), **kw)]
+        if cout % 32 == 0:
+            out.append(ops.conv2d_nhwc(xs, wt.cuda(), b.cuda(), residual=res, out_split=True, **kw))
+        return out
+    ops.set_form("conv_no_fused_reduce", True)
+    try:
+        ref = run()
+    finally:
+        ops.set_form("conv_no_fused_reduce", False)
+    for rep in range(60 if splits == 16 else 12):   # (the 16-way split of 112 tiles: 1792 workgroups racing for 448 wave tickets)
+        for a, c in zip(ref, run()):
+            assert torch.equal(a, c), (case, tile, splits, rep)
+
+
+def test_split_k_in_kernel_reduction_of_a_heterogeneous_launch():
+    """Members of one multi launch that split keep their own ticket ranges: two 11 x 11 layers of the 32x64 tile (both split by
+    the plan) beside each other equal their separate-reduction results bit for bit, repeatedly."""
+    from types import SimpleNamespace as NS
+    from hn_amd import ops
+    from hn_amd.weights import split_f16x3
+    g = torch.Generator().manual_seed(115)
+    items = []
+    for cin, cout, r in ((512, 512, 3), (1024, 512, 3), (2048, 256, 1)):
+        x = ops.to_split(torch.randn((1, 11, 11, cin), generator=g).cuda())
+        wt = torch.randn((cout, r, r, cin), generator=g) * (2.0 / (cin * r * r)) ** 0.5
+        cw = NS(w=wt.cuda(), bias=torch.randn((cout,), generator=g).cuda(), w16=split_f16x3(wt).cuda(), stride=1, pad=r // 2, dil=1)
+        items.append((x, cw, dict(relu=True, residual=None, out_split=True)))
+    ops.set_form("conv_no_fused_reduce", True)
+    try:
+        flag = []
+        ref = ops.conv2d_nhwc_multi(items, fused=flag)
+    finally:
+        ops.set_form("conv_no_fused_reduce", False)
+    assert flag[0]
+    for rep in range(12):
+        flag = []
+        got = ops.conv2d_nhwc_multi(items, fused=flag)
+        assert flag[0]
+        for a, c in zip(ref, got):
+            assert torch.equal(a, c), rep

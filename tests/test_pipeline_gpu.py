@@ -733,7 +733,7 @@ def test_auto_captured_graphs_are_evicted_least_recently_used(fcos_sd, a2j_sd):
 @pytest.mark.parametrize("n", [1, 6])
 def test_round5_kernel_forms_are_bit_identical_end_to_end(fcos_sd, a2j_sd, n):
     """The three kernel routes added in round 5 -- the streaming 1x1 kernel (FPN P3 lateral from batch 5 on), the mixed-tile grouped
-    launch (tower layers at batch 1-2) and the deep-k form of the 64x64 tile (ResNet-34 layer3 at batch 1) -- keep every k order:
+    launch (tower layers at batch 1-2) the deep-k form of the 64x64 tile (ResNet-34 layer3 at batch 1) and the split-K reduction inside the last workgroup -- keep every k order:
     the whole pipeline's outputs (detections, crop boxes, keypoints) are bit-identical with the routes switched off by name."""
     from hn_amd import ops, synth
     from hn_amd.a2j_engine import A2JEngine
@@ -743,7 +743,7 @@ def test_round5_kernel_forms_are_bit_identical_end_to_end(fcos_sd, a2j_sd, n):
     eng = HandNetEngine(FCOSEngine(fcos_sd, 3, device="cuda"), A2JEngine(a2j_sd, device="cuda"), 3)
     ops.clear_plan_caches()
     new = eng.forward_device(rgb, depth)
-    forms = ("conv_no_stream", "conv_no_mixed", "conv_no_deepk")
+    forms = ("conv_no_stream", "conv_no_mixed", "conv_no_deepk", "conv_no_fused_reduce")
     for f in forms:
         ops.set_form(f, True)
     try:
