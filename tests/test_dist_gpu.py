@@ -126,6 +126,7 @@ def test_bench_line_contract():
     for name, unit in (("a2j_b64", "crops/s"), ("fcos_b16", "frames/s"), ("pipeline_b1", "frames/s")):
         assert oc[name]["unit"] == unit and oc[name]["value"] > 0 and oc[name]["ms_per_step"] > 0
         assert 0 < oc[name]["frac"] < 1 and "conv_igemm" in oc[name]["kernel"]
+        assert "median" in oc[name]["timing"] and oc[name]["ms_per_step_worst_group"] >= oc[name]["ms_per_step"]
     assert all(oc[k]["hipgraph"] is True for k in oc) and oc["pipeline_b1"]["ms_per_step"] < 10.0
     dr = d["dropin"]
     assert dr["batch1"]["frames_per_s"] > 0 and dr["batch2"]["frames_per_s"] > 0 and "HandNet.forward" in dr["call"]
