@@ -404,6 +404,8 @@ class FCOSEngine:
         list of [3,h_i,w_i] tensors of different sizes (each resized on its own, boxes rescaled per image)."""
         cls_lr, reg_ctr, strides, (oh, ow, ph, pw) = self.forward_heads(images)
         cand = ops.fcos_candidates(cls_lr, reg_ctr, strides, self.num_classes, SCORE_THRESH, out=cand)
+        if det is None:   # (rows at or beyond count[i] stay undefined: nobody downstream reads them)
+            det = ops.alloc_detections(cand.scores.shape[0], cand.scores.shape[1], cand.scores.device, zero=False)
         # resize_boxes (fcos.py:770-783): fp32 tensor / fp32 tensor
         if not torch.is_tensor(images):
             hs = torch.tensor([float(i.shape[1]) for i in images]) / torch.tensor([float(v) for v in oh])

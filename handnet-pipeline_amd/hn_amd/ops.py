@@ -1012,8 +1012,10 @@ def alloc_candidates(n, cap, device) -> Candidates:
     return Candidates(b, s, l.view(i32), sd.view(i32), lv.view(i32), cnt.view(i32), pt.view(i32))
 
 
-def alloc_detections(n, cap, device) -> Detections:
-    b, s, l, sd, lv, kp, cnt = _zero_fields(n, cap, device, [4, 1, 1, 1, 1, 1])
+def alloc_detections(n, cap, device, zero=True) -> Detections:
+    """zero=False: no fill launch -- rows at or beyond count[i] are then undefined (hn_fcos_nms writes every count and the
+    rows below it; the engines, which only ever read those, allocate this way: one launch fewer per detector pass)."""
+    b, s, l, sd, lv, kp, cnt = _zero_fields(n, cap, device, [4, 1, 1, 1, 1, 1], zero=zero)
     i32 = torch.int32
     return Detections(b, s, l.view(i32), sd.view(i32), lv.view(i32), kp.view(i32), cnt.view(i32))
 
