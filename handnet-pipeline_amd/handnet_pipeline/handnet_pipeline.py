@@ -69,6 +69,13 @@ class HandNet(EngineOwner):
         self._auto_graph_allowed = os.environ.get("HN_AUTO_GRAPH", "1") != "0"
 
     def engine(self) -> HandNetEngine:
+        # the per-call path: the engines stand and belong to the sub-modules' CURRENT state -- load_state_dict() and every
+        # device / dtype move (nn.Module._apply) reset a sub-module's engine (hn_amd/state.py), which this test sees.  (Walking
+        # the three parameter trees for their device on every call was 20 us of the ~90 us the call costs beyond its GPU time.)
+        eng = self._engine
+        if (eng is not None and getattr(self.detector, "_engine", None) is eng.fcos
+                and getattr(self.a2j, "_engine", None) is eng.a2j):
+            return eng
         self._require_gpu()
         fcos, a2j = self.detector.engine(), self.a2j.engine()
         # the sub-modules rebuild their engines when THEIR weights change (net.detector.load_state_dict(...)):
