@@ -1206,3 +1206,15 @@ def test_split_k_in_kernel_reduction_of_a_heterogeneous_launch():
         assert flag[0]
         for a, c in zip(ref, got):
             assert torch.equal(a, c), rep
+
+
+def test_split_k_tickets_with_more_workspaces_than_slots():
+    """The library keeps one ticket slot per workspace ADDRESS (128 of them, never re-assigned); a process that splits with more
+    addresses than that gets the separate reduction launch for the later ones -- same bits (tests/ticket_registry_worker.py, in
+    its own process: it uses the registry up)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    r = subprocess.run([sys.executable, str(Path(__file__).with_name("ticket_registry_worker.py"))], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "mismatching launches: 0" in r.stdout, r.stdout + r.stderr
