@@ -528,7 +528,10 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(const ConvParams16& p, con
     lds_void* dst = (lds_void*)(Ad + (it * ROWS_PASS + grp_row) * ROWH);
     if constexpr (BUF) {
       const unsigned voff = ((a_inv[it] << sh) & 0x80000000u) | a_off[it];
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, dst, 16, (int)voff, (int)uoff, 0, 0);
+      // (deep-k form: with its scalar registers used up the compiler keeps the walk's counters in VECTOR registers and would
+      // wrap every DMA in a waterfall loop over the "divergent" offset; the value is wave-uniform by construction)
+      const int so = KK > 1 ? __builtin_amdgcn_readfirstlane((int)uoff) : (int)uoff;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, dst, 16, (int)voff, so, 0, 0);
     } else {
       const bool ok = (unsigned)(a_ih0[it] + dr) < (unsigned)o.H && (unsigned)(a_iw0[it] + ds) < (unsigned)o.W;
       const _Float16* src = ok ? a_row[it] + uoff : g_zero_page16 + a_cc[it];  // padding taps read zeros
@@ -538,7 +541,8 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(const ConvParams16& p, con
   auto dma_b_piece = [&](int it, _Float16* Bd, long boff) {
     lds_void* dst = (lds_void*)(Bd + (it * ROWS_PASS + grp_row) * ROWH);
     if constexpr (BUF)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, dst, 16, (int)b_off[it], (int)boff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, dst, 16, (int)b_off[it],
+                                               KK > 1 ? __builtin_amdgcn_readfirstlane((int)boff) : (int)boff, 0, 0);
     else
       __builtin_amdgcn_global_load_lds((gbl_void*)(b_ptr[it] + boff), dst, 16, 0, 0);
   };
@@ -870,46 +874,64 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(const ConvParams16& p, con
     for (int s0 = 0; s0 < (NBUF - 1) * KK; ++s0) dma_tile(s0);
     const int nstages = (T + KK - 1) / KK;
     int grp = 0;
-    for (int st = 0; st < nstages; ++st) {
+    // Order inside a stage (round 5, second half; PMC of the first version: the matrix pipe busy 22 % of the time, 4 scalar
+    // instructions per MFMA): the fragment reads of the stage's FIRST tile go out right after the barrier, the refill's address
+    // arithmetic + DMA issue (~75 scalar instructions that used to sit between the barrier and the first MFMA with the matrix
+    // pipe idle) runs under their latency, the second tile's reads follow, and only then the MFMAs -- tile 0's with tile 1's
+    // fragments already on their way.  Same tiles, same k order, same term order per accumulator: bit-identical.
+    static_assert(KK == 2, "the stage schedule below is written for two tiles per stage");
+    auto read_frags = [&](int slot, f16x8 (&fah)[TM], f16x8 (&fal)[TM], f16x8 (&fbh)[TN], f16x8 (&fbl)[TN]) {
+      const _Float16* Ab = As + slot * A_BUF;
+      const _Float16* Bb = Bs + slot * B_BUF;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        fah[i] = *reinterpret_cast<const f16x8*>(Ab + a_rd[i][0]);
+        fal[i] = *reinterpret_cast<const f16x8*>(Ab + a_rd[i][1]);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        fbh[j] = *reinterpret_cast<const f16x8*>(Bb + b_rd[j][0]);
+        fbl[j] = *reinterpret_cast<const f16x8*>(Bb + b_rd[j][1]);
+      }
+    };
+    auto mfma_tile = [&](const f16x8 (&fah)[TM], const f16x8 (&fal)[TM], const f16x8 (&fbh)[TN], const f16x8 (&fbl)[TN]) {
+      // the pinned loop's term order per accumulator: lo*hi, hi*lo, hi*hi (W fragment = srcA)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbh[j], fal[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbl[j], fah[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbh[j], fah[i], acc[i][j], 0, 0, 0);
+    };
+    (void)nstages;
+    const int full = T / KK;   // stages with both tiles: ONE basic block each (no branch between the two tiles' MFMAs)
+    for (int st = 0; st < full; ++st) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * KK * DPT) : "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      f16x8 a0h[TM], a0l[TM], b0h[TN], b0l[TN], a1h[TM], a1l[TM], b1h[TN], b1l[TN];
+      read_frags(grp * KK, a0h, a0l, b0h, b0l);
       const int refill = grp == 0 ? NBUF - 1 : grp - 1;
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk) dma_tile(refill * KK + kk);
-#pragma unroll
-      for (int kk = 0; kk < KK; ++kk) {
-        if (st * KK + kk < T) {   // (wave-uniform: the ragged last stage)
-          const int slot = grp * KK + kk;
-          const _Float16* Ab = As + slot * A_BUF;
-          const _Float16* Bb = Bs + slot * B_BUF;
-          f16x8 fah[TM], fal[TM], fbh[TN], fbl[TN];
-#pragma unroll
-          for (int i = 0; i < TM; ++i) {
-            fah[i] = *reinterpret_cast<const f16x8*>(Ab + a_rd[i][0]);
-            fal[i] = *reinterpret_cast<const f16x8*>(Ab + a_rd[i][1]);
-          }
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            fbh[j] = *reinterpret_cast<const f16x8*>(Bb + b_rd[j][0]);
-            fbl[j] = *reinterpret_cast<const f16x8*>(Bb + b_rd[j][1]);
-          }
-          // the pinned loop's term order per accumulator: lo*hi, hi*lo, hi*hi (W fragment = srcA)
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbh[j], fal[i], acc[i][j], 0, 0, 0);
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbl[j], fah[i], acc[i][j], 0, 0, 0);
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbh[j], fah[i], acc[i][j], 0, 0, 0);
-        }
-      }
+      read_frags(grp * KK + 1, a1h, a1l, b1h, b1l);
+      mfma_tile(a0h, a0l, b0h, b0l);
+      mfma_tile(a1h, a1l, b1h, b1l);
       grp = grp + 1 == NBUF ? 0 : grp + 1;
+    }
+    if (T & 1) {   // the ragged last stage: one tile, nothing left to refill
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * KK * DPT) : "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      f16x8 a0h[TM], a0l[TM], b0h[TN], b0l[TN];
+      read_frags(grp * KK, a0h, a0l, b0h, b0l);
+      mfma_tile(a0h, a0l, b0h, b0l);
     }
   } else {
   // prologue: tile 0 -> stage 0 (waited for); tiles 1..NBUF-1 are put in flight behind it
