@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kThreads, 4) void conv1x1_stream_kernel(const Strea
   const unsigned src_off = (unsigned)((tid / CHUNKS) * PIX_BYTES + (((tid % CHUNKS) ^ ((tid / CHUNKS) & 15)) << 4));
   const int wave_base = __builtin_amdgcn_readfirstlane(wave) * 64 * 16;
   auto dma_tile = [&](int t, int stage) {
-    // a tile past the tensor's end (the look-ahead, the ragged last tile) is zero-filled by the descriptor's range check
+    // the part of the ragged last tile past the tensor's end is zero-filled by the descriptor's range check
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(smem + stage * TILE_BYTES + ps * kThreads * 16 + wave_base), 16,
@@ -110,7 +110,8 @@ __global__ __launch_bounds__(kThreads, 4) void conv1x1_stream_kernel(const Strea
   for (int t = t0; t < p.tiles; t += dt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // tile t has landed for every wave, and nobody reads the other stage (tile t - dt) any more
-    dma_tile(t + dt, stage ^ 1);
+    if (t + dt < p.tiles) dma_tile(t + dt, stage ^ 1);   // (wave-uniform; no look-ahead past the tensor: nothing rests on the
+    //                                                       range check of an offset beyond num_records)
 #pragma unroll
     for (int pt = 0; pt < kTilePix / 16; ++pt) {
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;

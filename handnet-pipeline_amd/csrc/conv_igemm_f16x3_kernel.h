@@ -912,7 +912,9 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(const ConvParams16& p, con
     (void)nstages;
     const int full = T / KK;   // stages with both tiles: ONE basic block each (no branch between the two tiles' MFMAs)
     for (int st = 0; st < full; ++st) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * KK * DPT) : "memory");
+      // lgkmcnt(0): this wave's fragment reads of the stage consumed last (compiler-scheduled ds_reads) have RETURNED before
+      // it passes the barrier behind which that stage is refilled -- stated, not left to the MFMAs' implicit waits
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NBUF - 2) * KK * DPT) : "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       f16x8 a0h[TM], a0l[TM], b0h[TN], b0l[TN], a1h[TM], a1l[TM], b1h[TN], b1l[TN];

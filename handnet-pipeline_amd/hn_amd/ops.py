@@ -805,11 +805,12 @@ def _device_readable(t: torch.Tensor, name: str):
     return t
 
 
-def ingest_raw(bgr_u8, depth=None, device=None, out_rgb=None, out_depth=None, out_rgbd=None, want_rgbd=False):
+def ingest_raw(bgr_u8, depth=None, device=None, out_rgb=None, out_depth=None, out_rgbd=None, want_rgbd=False, want_depth=True):
     """The reference caller's host-side conversions as ONE kernel (hn_ingest_u8bgr_u16mm; ros_demo.py:227-231,266-269):
     bgr_u8 uint8 [N,H,W,3] (cv_bridge 'bgr8' frames), depth [N,H,W] uint16 / int16 millimetres (16UC1) or float32 metres
     (32FC1), each on the GPU or in PINNED host memory -> (rgb fp32 [N,3,H,W] in 0..1, depth fp32 [N,1,H,W] metres or None,
-    rgbd fp32 [N,4,H,W] or None) on the GPU; bit-identical to `astype(float32) / 255.0` and `/ 1000.0`."""
+    rgbd fp32 [N,4,H,W] or None) on the GPU; bit-identical to `astype(float32) / 255.0` and `/ 1000.0`.
+    want_depth=False (with an RGB-D output): the separate depth map is neither allocated nor written."""
     if bgr_u8.dtype != torch.uint8 or bgr_u8.dim() != 4 or bgr_u8.shape[3] != 3:
         raise TypeError(f"bgr_u8: expected uint8 [N,H,W,3], got {bgr_u8.dtype} {tuple(bgr_u8.shape)}")
     _device_readable(bgr_u8, "bgr_u8")
@@ -829,17 +830,18 @@ def ingest_raw(bgr_u8, depth=None, device=None, out_rgb=None, out_depth=None, ou
         device = bgr_u8.device if bgr_u8.is_cuda else torch.device("cuda", _cur_device() if _cur_device else 0)
     if out_rgb is None:
         out_rgb = torch.empty((n, 3, h, w), device=device, dtype=torch.float32)
-    if kind and out_depth is None:
-        out_depth = torch.empty((n, 1, h, w), device=device, dtype=torch.float32)
     if want_rgbd and out_rgbd is None:
         if not kind:
             raise ValueError("the RGB-D tensor needs a depth input")
         out_rgbd = torch.empty((n, 4, h, w), device=device, dtype=torch.float32)
+    if kind and out_depth is None and (want_depth or out_rgbd is None):
+        out_depth = torch.empty((n, 1, h, w), device=device, dtype=torch.float32)
     for t, nm in ((out_rgb, "out_rgb"), (out_depth, "out_depth"), (out_rgbd, "out_rgbd")):
         if t is not None:
             _req(t, name=nm)
     check(_lib.load().hn_ingest_u8bgr_u16mm(bgr_u8.data_ptr(), depth.data_ptr() if kind else None, kind, ptr(out_rgb),
-                                            ptr(out_depth) if kind else None, ptr(out_rgbd), n, h, w, _stream()),
+                                            ptr(out_depth) if (kind and out_depth is not None) else None, ptr(out_rgbd),
+                                            n, h, w, _stream()),
           "hn_ingest_u8bgr_u16mm")
     return out_rgb, (out_depth if kind else None), out_rgbd
 

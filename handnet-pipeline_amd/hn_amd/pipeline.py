@@ -117,7 +117,7 @@ class HandNetEngine:
         # captured steps, least recently used first: key -> (graph, static images, static depth, static HandNetOutput)
         self._graphs = collections.OrderedDict()
         self._host_records = {}     # eager to_host steps: batch -> (pinned record, device record)
-        self._raw_staging = {}      # forward_raw from pageable host memory: (shape, dtype) -> pinned staging buffer
+        self._raw_staging = {}      # forward_raw from pageable host memory: (shape, dtype) -> two rotating pinned buffers + their events
         # f16x3 range contract.  Always on (HN_CHECK_RANGE=0 turns it off for A/B timing): every split producer of a step
         # notes values outside the fp16 range into this engine's flag block and the step ends with ONE tiny launch that
         # hands the words over as HandNetOutput.range_flags -- no sync; the drop-in HandNet.forward reads them with the
@@ -271,20 +271,38 @@ class HandNetEngine:
     # -------------------------------------------------------------------------------
     # raw camera frames: the reference caller's host-side conversions as one kernel (ros_demo.py:227-231,266-269)
     # -------------------------------------------------------------------------------
-    def _device_readable(self, t: torch.Tensor):
+    def _device_readable(self, t: torch.Tensor, used: list):
         """GPU tensors and pinned host tensors as they are; pageable host memory through a pinned staging buffer of the
-        engine (one host memcpy; the ingest kernel then reads the pinned buffer over PCIe itself)."""
+        engine (one host memcpy; the ingest kernel then reads the pinned buffer over PCIe itself).  The ingest kernel reads the
+        staging buffer ASYNCHRONOUSLY, so a buffer is only written again once the event recorded behind the ingest launch
+        that read it has passed (_staged_done); two buffers per (shape, dtype) rotate, so that a pipelined caller -- call k + 1
+        issued while step k still runs -- only ever waits for the ingest of call k - 1."""
         if t.is_cuda:
             return t.contiguous()
         if t.is_pinned() and t.is_contiguous():
             return t
         key = (tuple(t.shape), t.dtype)
-        buf = self._raw_staging.get(key)
-        if buf is None:
+        ring = self._raw_staging.get(key)
+        if ring is None:
             with torch.inference_mode(False):
-                buf = self._raw_staging[key] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-        buf.copy_(t)
-        return buf
+                ring = self._raw_staging[key] = {"slots": [[torch.empty(t.shape, dtype=t.dtype, pin_memory=True), None]
+                                                           for _ in range(2)], "next": 0}
+        slot = ring["slots"][ring["next"]]
+        ring["next"] ^= 1
+        if slot[1] is not None:
+            slot[1].synchronize()       # the ingest launch that last read this buffer has finished
+            slot[1] = None
+        slot[0].copy_(t)
+        used.append(slot)
+        return slot[0]
+
+    @staticmethod
+    def _staged_done(used: list):
+        """Record, behind the ingest launch, the event that frees the staging buffers it reads."""
+        for slot in used:
+            ev = torch.cuda.Event()
+            ev.record()
+            slot[1] = ev
 
     @ops.device_guarded
     def forward_raw(self, bgr_u8, depth_raw, to_host: bool = False, use_graph: bool = False, limit: int | None = None):
@@ -292,23 +310,28 @@ class HandNetEngine:
         torch tensors on the GPU or on the host (pinned: read in place; pageable: staged once).  ONE ingest kernel writes the
         fp32 RGB batch and the metres depth map (RGB-D model: the 4-channel tensor) -- straight into the input buffers of the
         captured step when use_graph / a capture for these shapes exists -- then the step runs as forward_device does."""
-        bgr, dep = self._device_readable(bgr_u8), self._device_readable(depth_raw)
+        staged = []
+        bgr, dep = self._device_readable(bgr_u8, staged), self._device_readable(depth_raw, staged)
         n, h, w, _ = bgr.shape
         dshape = (n, 4 if self.a2j.rgbd else 1, h, w)
         hit = self.captured((n, 3, h, w), dshape, to_host)
         if hit is None and use_graph and not torch.cuda.is_current_stream_capturing():
-            rgb, d1, d4 = ops.ingest_raw(bgr, dep, device=self.device, want_rgbd=self.a2j.rgbd)
+            rgb, d1, d4 = ops.ingest_raw(bgr, dep, device=self.device, want_rgbd=self.a2j.rgbd, want_depth=not self.a2j.rgbd)
+            self._staged_done(staged)
+            staged = []
             self.graphed(rgb, d4 if self.a2j.rgbd else d1, to_host=to_host, limit=limit)
             hit = self.captured((n, 3, h, w), dshape, to_host)
         if hit is not None:
             g, s_img, s_dep, out = hit
-            if self.a2j.rgbd:
-                ops.ingest_raw(bgr, dep, out_rgb=s_img, out_rgbd=s_dep)
+            if self.a2j.rgbd:     # (the 4-channel tensor only: no separate depth map is written or allocated)
+                ops.ingest_raw(bgr, dep, out_rgb=s_img, out_rgbd=s_dep, want_depth=False)
             else:
                 ops.ingest_raw(bgr, dep, out_rgb=s_img, out_depth=s_dep)
+            self._staged_done(staged)
             g.replay()
             return out
-        rgb, d1, d4 = ops.ingest_raw(bgr, dep, device=self.device, want_rgbd=self.a2j.rgbd)
+        rgb, d1, d4 = ops.ingest_raw(bgr, dep, device=self.device, want_rgbd=self.a2j.rgbd, want_depth=not self.a2j.rgbd)
+        self._staged_done(staged)
         return self.forward_device(rgb, d4 if self.a2j.rgbd else d1, to_host=to_host)
 
     def _capture(self, key, images, depth, to_host=False):

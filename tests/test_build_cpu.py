@@ -47,3 +47,35 @@ def test_library_objects_hold_no_such_instruction():
         pytest.skip("library not built yet")
     for o in objs:
         build._check_packed_opsel(o, objdir)
+
+
+def test_every_kernel_with_counted_waits_is_spill_guarded():
+    """A register spill inside a kernel that requests operands with LDS-DMA / asm loads and retires them with hand-counted
+    `s_waitcnt vmcnt(n)` stores garbage (scratch traffic shares vmcnt).  Every __global__ kernel of a source file that issues
+    such loads must be matched by build.NO_SPILL_KERNELS, and the recorded resource usage of every matched kernel of the built
+    library must show no VGPR spill and no scratch."""
+    import re
+    pat = re.compile(r"buffer_load_lds|global_load_lds|s_waitcnt vmcnt")
+    unguarded = []
+    for src in sorted(build.CSRC.glob("*.hip")) + sorted(build.CSRC.glob("*.h")):
+        text = src.read_text()
+        if not pat.search(text):
+            continue
+        for m in re.finditer(r"__global__[^;{]*?\bvoid\s+(\w+)\s*\(", text, flags=re.S):
+            name = m.group(1)
+            if name.startswith("splitk_reduce"):      # plain compiler-scheduled loads
+                continue
+            if not any(k in name for k in build.NO_SPILL_KERNELS):
+                unguarded.append(f"{src.name}:{name}")
+    assert not unguarded, f"kernels with counted waits outside NO_SPILL_KERNELS: {unguarded}"
+    res = sorted((build.CSRC / "build").glob("*.resources.txt"))
+    if not res:
+        pytest.skip("library not built yet")
+    seen = 0
+    for f in res:
+        for line in f.read_text().splitlines():
+            if any(k in line for k in build.NO_SPILL_KERNELS):
+                seen += 1
+                assert " vgpr_spill 0 " in line and " scratch 0 " in line, line
+    assert seen >= 10
+    assert any("deepk" in l for f in res for l in f.read_text().splitlines() if any(k in l for k in build.NO_SPILL_KERNELS))
