@@ -24,9 +24,13 @@ off); every rank reports its device (`config.devices`: PCI bus ids, asserted dis
 beside the max-over-ranks wall time that `value` is computed from).
 
 Extra objects in the line:
-  other_configs the other single-GPU configurations of BASELINE.json, 5 timed steps each (default N = 1 run only): a2j_b64
-                (config 2), fcos_b16 (config 3), pipeline_b1 (the reference caller's own batch, ros_demo.py:270; hipGraph
-                replay) -- value, ms_per_step and the dominant kernel's roofline fraction of each.
+  other_configs the other single-GPU configurations of BASELINE.json (default N = 1 run only): a2j_b64 (config 2), fcos_b16
+                (config 3), pipeline_b1 (the reference caller's own batch, ros_demo.py:270) -- hipGraph replay, median of five
+                groups of steps; value, ms_per_step and the dominant kernel's roofline fraction of each -- and pipeline_b32_f32:
+                config 4 on the exact-f32 engines (the reference's own arithmetic; 3 timed steps, fraction of the f32-MFMA
+                peak).  a2j_b64.parity ("EPE vs CPU ref": max |d(u,v,d)| and mm EPE of 16 of the 64 crops vs the oracle) and
+                fcos_b16.parity ("box IoU vs torchvision ref": survivor-index equality, labels, mean / min IoU of matched
+                survivors on the 16 frames) compare the outputs of the TIMED steps; the oracle runs after every timed region.
   roofline      dominant kernel (the conv_igemm_f16x3_kernel instantiation with the largest share of
                 the step; conv_igemm_f32_kernel with --precision f32): ALGORITHMIC FLOP per launch /
                 average launch duration, both measured live with HIP events on the launch stream
@@ -44,9 +48,10 @@ Extra objects in the line:
                 CPU) -- at the bench batch and at batch 1 (the only batch size the reference's caller uses); and
                 `batch*_host`: the PCIe-inclusive figures, the same calls with the frames starting in pinned host
                 memory -- as converted fp32 tensors, and as the raw bgr8 + 16UC1 buffers through HandNet.forward_raw.
-  cpu_baseline  the oracle (CPU restatement, kind "port") timed on this box's host cores on a
-                bounded sample of the same workload (rank 0, N == 1 only); the same frames go
-                through the HIP engine and the agreement is reported as `parity`.
+  cpu_baseline  the oracle (CPU restatement, kind "port") timed on this box's host cores on a bounded sample of the same
+                workload (rank 0, N == 1 only): ONE pass over --cpu-frames frames in batches of 8 (`value`), and `batch1`: the
+                median of 5 single-frame forwards after 2 warm-ups; `sample` says so.  The same frames go through the HIP
+                engine and the agreement is reported as `parity`.
 """
 from __future__ import annotations
 
@@ -386,7 +391,7 @@ def dropin_leg(args, sds, dev, batch):
     return out
 
 
-def cpu_baseline(args, sds, engine=None, dev=None):
+def cpu_baseline(args, sds, engine=None, dev=None, others=None, hip_outputs=None):
     """Oracle (CPU restatement of the reference path) on a bounded sample, all host cores.  For the pipeline the
     same frames also go through the HIP engine, and the difference is reported next to the timing ("parity")."""
     from hn_amd import synth
@@ -423,11 +428,12 @@ def cpu_baseline(args, sds, engine=None, dev=None):
     from hn_amd import ops
     from oracle import parity
     handnet_ref.handnet_forward([rgb[0]], depth[:1], fcos_sd, a2j_sd, 3)  # warm-up
-    stats, oracle_s, (g_kp, g_box, g_has, o_kp, o_box, o_has) = parity.pipeline_parity(
+    stats, oracle_s, (g_kp, g_box, g_has, o_kp, o_box, o_has, o_dets) = parity.pipeline_parity(
         engine, rgb, depth, fcos_sd, a2j_sd, 3, chunk=8)
     res = {"value": round(n / oracle_s, 3), "unit": "frames/s", "cores": threads, "kind": "port",
-           "sample": f"{n} frames (seeds 1000/2000) in batches of 8, full-pipeline oracle forward "
-                     "(torch CPU fp32, FCOS+crop+A2J)"}
+           "sample": f"ONE pass over {n} frames (seeds 1000/2000) in batches of 8 after one warm-up frame: full-pipeline oracle "
+                     f"forward (oracle.fcos_ref + handnet_ref.select_and_crop + a2j_ref, torch CPU fp32, {threads} threads); "
+                     "the bounded form of BASELINE.md section 3 (a median of 5 passes would be 80 s of CPU); batch 1: `batch1`"}
     eq = (g_box == o_box).all(dim=1) & g_has & o_has
     if bool(eq.any()):
         paras = (617.343, 617.343, 312.42, 241.42)   # SURVEY 8d intrinsics for the millimetre figure
@@ -436,6 +442,27 @@ def cpu_baseline(args, sds, engine=None, dev=None):
         xyz_ref = ops.convert_joints(o_kp.to(dev), o_box.to(dev), valid, paras).cpu()
         stats["mm_epe"] = float((xyz - xyz_ref)[eq].norm(dim=-1).mean())
     res["parity"] = stats
+    # batch 1, the reference caller's batch (ros_demo.py:270): 2 warm-ups, median of 5 single-frame oracle forwards
+    per = []
+    for i in range(7):
+        t0 = time.time()
+        handnet_ref.handnet_forward([rgb[i % n]], depth[i % n:i % n + 1], fcos_sd, a2j_sd, 3)
+        per.append(time.time() - t0)
+    med = sorted(per[2:])[2]
+    res["batch1"] = {"value": round(1.0 / med, 3), "unit": "frames/s", "ms_per_frame": round(1e3 * med, 1),
+                     "sample": "median of 5 single-frame full-pipeline oracle forwards after 2 warm-ups (frames 0..6 of the sample)"}
+    # BASELINE configs 2 and 3 in their own parity terms, against what their TIMED steps produced (other_configs_leg)
+    if others is not None and hip_outputs:
+        if "fcos_b16" in hip_outputs:
+            # frames 0..15 of the sample ARE the batch-16 detector run's frames (make_rgb streams one generator): the oracle's
+            # detections for them come from the pass above (a sample of fewer than 16 frames compares what it has)
+            m = min(16, n)
+            others["fcos_b16"]["parity"] = parity.fcos_parity(hip_outputs["fcos_b16"][:m], o_dets[:m])
+        if "a2j_b64" in hip_outputs:
+            hip_kp, crops = hip_outputs["a2j_b64"]
+            others["a2j_b64"]["parity"], a2j_s = parity.a2j_parity(hip_kp, crops, a2j_sd)
+            res["a2j_only"] = {"value": round(crops.shape[0] / a2j_s, 2), "unit": "crops/s",
+                               "sample": f"ONE batch-{crops.shape[0]} oracle.a2j_ref.a2j_forward (the parity run of other_configs.a2j_b64)"}
     return res
 
 
@@ -602,7 +629,10 @@ def device_identity(args, local, rank):
     return f"{buf.value.decode()} {p.name}" + (f" uuid={uuid}" if uuid is not None else "")
 
 
-def other_configs_leg(args, info, dev):
+PARITY_CROPS = 16    # crops of the batch-64 A2J step compared with the oracle (other_configs.a2j_b64.parity)
+
+
+def other_configs_leg(args, info, dev, sds=None, hip=None):
     """BASELINE.json's other single-GPU configurations on the engines this run has already built (10-50 timed steps each, inputs
     resident in HBM, hipGraph replay): config 2 (A2J-only, batch 64; a2j_infer.py:58-60), config 3 (FCOS-only, batch 16;
     trainval_net_fcos.py:124-130,173) and the full pipeline at batch 1 (the reference caller's own batch, ros_demo.py:270,
@@ -612,6 +642,7 @@ def other_configs_leg(args, info, dev):
     eng = info["engine"]
     terms = 1 if args.precision == "f16x1" else 3
     out = {}
+    hip = {} if hip is None else hip    # HIP outputs of the timed steps, for parity_legs()
 
     def timed(step, units, per_group=4, groups=5, warm=2):
         """`groups` groups of `per_group` steps, each group bracketed by a synchronize; the figure is the MEDIAN group (mean and
@@ -662,6 +693,8 @@ def other_configs_leg(args, info, dev):
     rec.update(unit="crops/s", hipgraph=True, workload="A2J-only inference, batch 64 176x176 depth crops (BASELINE config 2)",
                gflop_per_unit=round(2 * eng.a2j.macs_per_crop() / 1e9, 3), **roof_of(lambda: eng.a2j.forward(crops), rec["ms_per_step"]))
     out["a2j_b64"] = rec
+    # rows 0..15 of the timed batch-64 step's own output: compared with the oracle by parity_legs() AFTER every timed region
+    hip["a2j_b64"] = (keep[:PARITY_CROPS].cpu(), crops[:PARITY_CROPS].cpu())
     del crops, g, keep
     rgb16 = synth.make_rgb(16, seed=1000).to(dev)
     g, keep = captured(lambda: eng.fcos.detect(rgb16))
@@ -669,7 +702,11 @@ def other_configs_leg(args, info, dev):
     rec.update(unit="frames/s", hipgraph=True, workload="FCOS ResNet34-FPN detector, batch 16 640x480 RGB (BASELINE config 3)",
                gflop_per_unit=round(2 * eng.fcos.macs_per_frame() / 1e9, 3), **roof_of(lambda: eng.fcos.detect(rgb16), rec["ms_per_step"]))
     out["fcos_b16"] = rec
-    del rgb16, g, keep
+    det = keep[0]     # the timed batch-16 step's own detections (score-ordered survivors + their candidate indices)
+    cnt = det.count.cpu().tolist()
+    bx, sc, lb, kp_ = det.boxes.cpu(), det.scores.cpu(), det.labels.cpu(), det.keep.cpu()
+    hip["fcos_b16"] = [(bx[i, :k].clone(), sc[i, :k].clone(), lb[i, :k].clone(), kp_[i, :k].clone()) for i, k in enumerate(cnt)]
+    del rgb16, g, keep, det
     rgb1, dep1 = synth.make_rgb(1, seed=1000).to(dev), synth.make_depth(1, seed=2000).to(dev)
     run, _, _, _ = eng.graphed(rgb1, dep1)
     rec = timed(run, 1, per_group=10, warm=5)
@@ -677,6 +714,23 @@ def other_configs_leg(args, info, dev):
                workload="Full HandNet pipeline at batch 1 (the reference caller's batch, ros_demo.py:270), hipGraph replay",
                **roof_of(lambda: eng.forward_device(rgb1, dep1), rec["ms_per_step"]))
     out["pipeline_b1"] = rec
+    if args.precision == "f16x3" and sds is not None:
+        # the reference's own arithmetic -- IEEE fp32 operands on the f32 MFMA -- driver-timed beside the split-fp16 headline:
+        # the same step on engines built with precision="f32", eager, 3 timed steps; roofline against the f32-MFMA peak
+        from hn_amd.a2j_engine import A2JEngine
+        from hn_amd.fcos_engine import FCOSEngine
+        from hn_amd.pipeline import HandNetEngine
+        fcos_sd, a2j_sd = sds
+        e32 = HandNetEngine(FCOSEngine(fcos_sd, 3, device=dev, precision="f32"), A2JEngine(a2j_sd, device=dev, precision="f32"), 3)
+        rgb, depth = synth.make_rgb(32, seed=1000).to(dev), synth.make_depth(32, seed=2000).to(dev)
+        rec = timed(lambda: e32.forward_device(rgb, depth), 32, per_group=1, groups=3, warm=1)
+        rec.update(unit="frames/s", hipgraph=False, dtype="f32 (IEEE fp32 operands, f32 MFMA, fp32 accumulate)",
+                   workload="Full HandNet pipeline, batch 32, exact-f32 engines (precision='f32'): BASELINE config 4 in the "
+                            "reference's own arithmetic", peak_tflops=F32_MFMA_PEAK_TFLOPS,
+                   **roof_of(lambda: e32.forward_device(rgb, depth), rec["ms_per_step"]))
+        out["pipeline_b32_f32"] = rec
+        del e32, rgb, depth
+        torch.cuda.empty_cache()
     return out
 
 
@@ -825,12 +879,13 @@ def worker(args):
     dropin = None
     if single and args.workload == "pipeline" and not args.no_dropin and not args.native and not args.graph:
         dropin = dropin_leg(args, sds, dev, batch)
-    others = None
+    others, hip_outputs = None, None
     if single and args.workload == "pipeline" and not args.no_other_configs and not args.native and not args.graph:
-        others = other_configs_leg(args, info, dev)
+        hip_outputs = {}
+        others = other_configs_leg(args, info, dev, sds, hip_outputs)
     cpu = None
     if single and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args, sds, info.get("engine"), dev)
+        cpu = cpu_baseline(args, sds, info.get("engine"), dev, others, hip_outputs)
 
     if rank == 0:
         units = world * batch * args.steps

@@ -57,7 +57,8 @@ def range_message(bits: int) -> str:
     from ._lib import RANGE_ACTIVATION, RANGE_INPUT, RANGE_INPUT_NONFINITE
     if bits & RANGE_INPUT_NONFINITE:
         return ("the inputs hold non-finite values (NaN / inf pixels): frames whose depth crop holds one return NaN "
-                "keypoints, as the reference does; non-finite RGB pixels give undefined detections")
+                "keypoints, as the reference does; a non-finite RGB pixel raises RangeError (its NaN reaches the activation "
+                "flag through the NaN-propagating ReLUs)")
     if bits & RANGE_INPUT:
         return ("an input value lies outside the range of the f16x3 split format (|v| > 65504): RGB must be 0..1 and depth "
                 "METRES (ros_demo.py:230-231 divides 16UC1 millimetres by 1000); or build the engines with precision='f32'")

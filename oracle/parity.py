@@ -27,7 +27,8 @@ def _top_hand(boxes, scores, labels, hand_label):
 
 def pipeline_parity(engine, rgb, depth, fcos_sd, a2j_sd, num_classes=3, chunk=8, tolerance=1e-3):
     """rgb [N,3,H,W], depth [N,1,H,W] CPU tensors; engine: hn_amd.pipeline.HandNetEngine on the GPU.
-    Returns (stats dict, oracle seconds).  The oracle runs in chunks of `chunk` frames."""
+    Returns (stats dict, oracle seconds, (HIP keypoints / boxes / flags, oracle keypoints / boxes / flags, the oracle's
+    detection dicts per frame)).  The oracle runs in chunks of `chunk` frames."""
     n = rgb.shape[0]
     dev = engine.fcos.device
     hand = num_classes - 1
@@ -96,4 +97,75 @@ def pipeline_parity(engine, rgb, depth, fcos_sd, a2j_sd, num_classes=3, chunk=8,
              "crop_boxes_identical": bool(same.all()),
              "max_abs_keypoint_diff": kp_diff, "mean_abs_keypoint_diff": kp_mean, "tolerance": tolerance,
              "keypoints_within_tolerance": bool(kp_diff < tolerance), "flips": flips}
-    return stats, oracle_s, (g_kp, g_box, g_has, o_kp, o_box, o_has)
+    return stats, oracle_s, (g_kp, g_box, g_has, o_kp, o_box, o_has, o_dets)
+
+
+def _iou(a, b):
+    """row-wise IoU of two [k,4] (x1,y1,x2,y2) box lists, in float64"""
+    a, b = a.double(), b.double()
+    ix = (torch.minimum(a[:, 2], b[:, 2]) - torch.maximum(a[:, 0], b[:, 0])).clamp(min=0)
+    iy = (torch.minimum(a[:, 3], b[:, 3]) - torch.maximum(a[:, 1], b[:, 1])).clamp(min=0)
+    inter = ix * iy
+    union = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]) + (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]) - inter
+    return torch.where(union > 0, inter / union, torch.ones_like(union))
+
+
+def fcos_parity(hip_dets, oracle_dets):
+    """Detector agreement in the terms BASELINE.json config 3 names ("box IoU vs torchvision ref", SURVEY 8d: "+ survivor-index
+    equality"), per frame and over the batch.
+      hip_dets     per frame (boxes [k,4], scores [k], labels [k], keep [k]) CPU tensors from the HIP detector; keep = index of
+                   each survivor in the frame's anchor-ordered candidate list (fcos_utils/fcos.py:624-635), score-descending
+      oracle_dets  oracle.fcos_ref.fcos_forward's dicts for the same frames (they carry the same `keep`)
+    Survivors are matched BY THAT INDEX (the same anchor point); IoU / score / label figures are over matched survivors."""
+    frames = len(hip_dets)
+    list_equal = set_equal = 0
+    ious, dscore, label_eq, matched, total_o, total_h = [], 0.0, 0, 0, 0, 0
+    for (hb, hs, hl, hk), od in zip(hip_dets, oracle_dets):
+        hk = hk.to(torch.int64)
+        ok = od["keep"].to(torch.int64)
+        total_o += int(ok.numel())
+        total_h += int(hk.numel())
+        list_equal += int(hk.numel() == ok.numel() and bool((hk == ok).all()))
+        set_equal += int(set(hk.tolist()) == set(ok.tolist()))
+        pos = {int(v): i for i, v in enumerate(ok.tolist())}
+        hi = [i for i, v in enumerate(hk.tolist()) if int(v) in pos]
+        if not hi:
+            continue
+        oi = [pos[int(hk[i])] for i in hi]
+        hi, oi = torch.tensor(hi), torch.tensor(oi)
+        ious.append(_iou(hb[hi], od["boxes"][oi]))
+        dscore = max(dscore, float((hs[hi] - od["scores"][oi]).abs().max()))
+        label_eq += int((hl[hi].to(torch.int64) == od["labels"][oi].to(torch.int64)).sum())
+        matched += int(hi.numel())
+    iou = torch.cat(ious) if ious else torch.ones(0, dtype=torch.float64)
+    return {"frames": frames, "survivors_oracle": total_o, "survivors_hip": total_h, "matched_survivors": matched,
+            "survivor_index_list_equal_frames": list_equal, "survivor_index_list_equality_rate": round(list_equal / max(1, frames), 4),
+            "survivor_index_set_equal_frames": set_equal,
+            "label_equality_rate": round(label_eq / max(1, matched), 6),
+            "mean_box_iou": round(float(iou.mean()), 9) if iou.numel() else None,
+            "min_box_iou": round(float(iou.min()), 9) if iou.numel() else None,
+            "max_abs_score_diff": dscore,
+            "what": "HIP detector vs oracle.fcos_ref.fcos_forward on the same frames; survivors matched by their index in the "
+                    "anchor-ordered candidate list; a frame counts as list-equal when the score-ordered survivor indices are "
+                    "identical (near-tied scores may exchange places: DESIGN.md section 5)"}
+
+
+def a2j_parity(hip_kp, crops, a2j_sd, box=(224, 152, 400, 328), paras=(617.343, 617.343, 312.42, 241.42), tolerance=1e-3):
+    """A2J-only agreement in the terms BASELINE.json config 2 names ("EPE vs CPU ref"): hip_kp [k,21,3] (CPU) from the HIP
+    engine for crops [k,1,176,176] vs oracle.a2j_ref.a2j_forward on the same crops -- max / mean |d(u,v,d)| in crop units
+    and the end-point error in millimetres after convert_joints + uvd2xyz (a2j/a2j.py:17-43, a2jdataset.py:31-38) with ONE
+    nominal 176 x 176 crop box around the principal point (an A2J-only run has no detector boxes; SURVEY 8d's intrinsics)."""
+    import numpy as np
+    t0 = time.time()
+    o_kp = a2j_ref.a2j_forward(crops, a2j_sd)
+    oracle_s = time.time() - t0
+    d = (hip_kp - o_kp).abs()
+    epe = []
+    for i in range(hip_kp.shape[0]):
+        a = a2j_ref.convert_joints(hip_kp[i].numpy(), np.asarray(box), paras)
+        b = a2j_ref.convert_joints(o_kp[i].numpy(), np.asarray(box), paras)
+        epe.append(np.linalg.norm(a.astype(np.float64) - b.astype(np.float64), axis=1).mean())
+    return {"crops": int(hip_kp.shape[0]), "max_abs_uvd_diff": float(d.max()), "mean_abs_uvd_diff": float(d.mean()),
+            "mm_epe": float(np.mean(epe)), "max_crop_mm_epe": float(np.max(epe)), "tolerance": tolerance,
+            "keypoints_within_tolerance": bool(float(d.max()) < tolerance), "crop_box_for_mm": list(box), "paras": list(paras),
+            "what": "HIP A2J (rows of the batch-64 step) vs oracle.a2j_ref.a2j_forward (torch CPU fp32) on the same crops"}, oracle_s

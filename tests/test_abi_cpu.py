@@ -156,6 +156,19 @@ def test_documents_cite_files_that_exist():
     assert not missing, missing
 
 
+def test_documents_do_not_contradict_the_product():
+    """Statements that were once true and stayed in a document after the product changed: a non-finite
+    RGB pixel RAISES (it does not give "undefined detections"), and the batch-1 drop-in figures are the driver-timed ones."""
+    root = build.REPO_ROOT
+    integ = (root / "INTEGRATION.md").read_text()
+    design = (root / "DESIGN.md").read_text()
+    msg = (root / "handnet-pipeline_amd" / "hn_amd" / "pipeline.py").read_text()
+    assert "non-finite RGB pixels give undefined detections" not in integ
+    assert "non-finite RGB pixels give undefined detections" not in msg
+    assert "2.55–2.6 ms per call" not in integ
+    assert "2.32–2.36 ms per call at batch 1**" not in design
+
+
 def test_range_scope_is_host_thread_state():
     """hn_range_scope_begin / _end (host-only): nesting restores the previous switch, another thread never sees this one's."""
     import threading

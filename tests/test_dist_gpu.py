@@ -122,18 +122,30 @@ def test_bench_line_contract():
                                            ("launches/step", "another revision", "dominant kernel"))
     assert set(roof["stages"]) >= {"resnet34_body", "fpn", "towers", "head_outputs", "a2j_trunk", "a2j_heads"}
     oc = d["other_configs"]
-    assert set(oc) == {"a2j_b64", "fcos_b16", "pipeline_b1"}
-    for name, unit in (("a2j_b64", "crops/s"), ("fcos_b16", "frames/s"), ("pipeline_b1", "frames/s")):
+    assert set(oc) == {"a2j_b64", "fcos_b16", "pipeline_b1", "pipeline_b32_f32"}
+    for name, unit in (("a2j_b64", "crops/s"), ("fcos_b16", "frames/s"), ("pipeline_b1", "frames/s"), ("pipeline_b32_f32", "frames/s")):
         assert oc[name]["unit"] == unit and oc[name]["value"] > 0 and oc[name]["ms_per_step"] > 0
         assert 0 < oc[name]["frac"] < 1 and "conv_igemm" in oc[name]["kernel"]
         assert "median" in oc[name]["timing"] and oc[name]["ms_per_step_worst_group"] >= oc[name]["ms_per_step"]
-    assert all(oc[k]["hipgraph"] is True for k in oc) and oc["pipeline_b1"]["ms_per_step"] < 200.0   # (2.2 ms alone; 28 ms next to a load process)
+    assert all(oc[k]["hipgraph"] is True for k in oc if k != "pipeline_b32_f32")
+    assert oc["pipeline_b1"]["ms_per_step"] < 200.0   # (2.2 ms alone; 28 ms next to a load process)
+    # the exact-f32 leg: the reference's own arithmetic beside the split-fp16 headline, priced against the f32-MFMA peak
+    f32 = oc["pipeline_b32_f32"]
+    assert "conv_igemm_f32" in f32["kernel"] and f32["peak_tflops"] == 157.3 and f32["dtype"].startswith("f32")
+    assert abs(f32["frac"] - f32["achieved_tflops"] / 157.3) < 1e-3
+    # BASELINE config 2 / 3 in their own parity terms, taken on the outputs of the timed steps
+    pa = oc["a2j_b64"]["parity"]
+    assert pa["crops"] == 16 and pa["keypoints_within_tolerance"] is True and pa["max_abs_uvd_diff"] < 1e-3 and pa["mm_epe"] < 0.05
+    pf = oc["fcos_b16"]["parity"]
+    assert pf["frames"] == 2 and pf["matched_survivors"] > 0 and pf["label_equality_rate"] == 1.0
+    assert pf["survivor_index_set_equal_frames"] == 2 and pf["min_box_iou"] > 0.999
     dr = d["dropin"]
     assert dr["batch1"]["frames_per_s"] > 0 and dr["batch2"]["frames_per_s"] > 0 and "HandNet.forward" in dr["call"]
     cpu = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample", "parity"):
         assert k in cpu, k
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["parity"]["frames"] == 2
+    assert "ONE pass" in cpu["sample"] and cpu["batch1"]["value"] > 0 and "median of 5" in cpu["batch1"]["sample"]
     assert cpu["parity"]["keypoints_within_tolerance"] is True
 
 
