@@ -179,6 +179,7 @@ def build_workload(args, dev, rank):
     info.update(unit="frames/s", gflop_per_unit=2 * (fcos.macs_per_frame() + a2j.macs_per_crop()) / 1e9,
                 name="Full HandNet pipeline (FCOS -> crop -> A2J), 640x480 RGB-D (BASELINE config 4)", engine=eng)
     info["eager_step"] = lambda: eng.forward_device(rgb, depth)  # noqa: E731 -- (the roofline leg instruments eager launches)
+    info["inputs"] = (rgb, depth)
     if args.native:
         from hn_amd.native_model import NativeModel
         from hn_amd.pipeline import HandNetOutput
@@ -486,6 +487,28 @@ def _ladder_envs():
     return [first, second]
 
 
+def visible_gpus():
+    """GPUs of this host without touching the HIP / amdsmi runtimes (torch.cuda.device_count() goes through amdsmi and falls
+    back to hipGetDeviceCount when that fails -- the one process that must never initialise the GPU before it spawns its
+    workers might): KFD topology nodes with a non-zero simd_count are GPUs (CPUs have 0), narrowed by an index list in
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES.  None when the topology is not readable: the pre-check is then skipped (the
+    workers' distinct-PCI-id assertion catches a short host anyway)."""
+    nodes = Path("/sys/class/kfd/kfd/topology/nodes")
+    try:
+        count = 0
+        for node in nodes.iterdir():
+            props = dict(l.split(None, 1) for l in (node / "properties").read_text().splitlines() if " " in l)
+            if int(props.get("simd_count", "0")) > 0:
+                count += 1
+    except (OSError, ValueError):
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            count = min(count, len([x for x in v.split(",") if x.strip() != ""]))
+    return count
+
+
 def supervise(args):
     """N > 1: this process never initialises HIP.  It owns the workers of one or more ranks (all N when started by hand, its
     own rank when torchrun started it), relays their output (inherited stdout / stderr) and walks the launch ladder: a worker
@@ -511,8 +534,8 @@ def supervise(args):
         job_dir.mkdir(exist_ok=True)
     else:
         if not args.stub_engine and not args.share_gpu:
-            have = torch.cuda.device_count()          # does not initialise the GPU on this image
-            if have < args.gpus:
+            have = visible_gpus()                     # (sysfs: the supervisor never opens the GPU runtime)
+            if have is not None and have < args.gpus:
                 raise SystemExit(f"--gpus {args.gpus} but only {have} GPU(s) are visible "
                                  "(--share-gpu --dist-backend gloo rehearses the plumbing on one)")
         world = args.gpus
@@ -596,6 +619,18 @@ def supervise(args):
 class _StubOutput:
     def __init__(self, keypoints, crop_box, has_hand):
         self.keypoints, self.crop_box, self.has_hand = keypoints, crop_box, has_hand
+        self.crops_nhwc = torch.zeros((keypoints.shape[0], 176, 176, 4))
+        self.range_flags = torch.zeros((4,), dtype=torch.int32)
+
+
+class _StubNet:
+    """what hn_amd.dist.ShardedHandNet drives in the --stub-engine runs"""
+
+    def __init__(self, step):
+        self.step = step
+
+    def forward_device(self, images, depth):
+        return self.step()
 
 
 def stub_workload(args, rank):
@@ -810,20 +845,37 @@ def worker(args):
 
     gathered = {"rows": None}
     ev = {"pairs": [], "on": False}
+    sharded = None
+    if world > 1 and args.workload == "pipeline":
+        # the product's N > 1 callable (hn_amd.dist.ShardedHandNet): this rank's resident frames as its shard of the global
+        # batch; the step AND the all-gather of the per-frame records replay from ONE hipGraph when RCCL lets itself be
+        # captured (config.gather says which)
+        if args.stub_engine:
+            sharded = hdist.ShardedHandNet(_StubNet(step), use_graph=False)
+            shard_in = (torch.zeros((batch, 3, 2, 2)), torch.zeros((batch, 1, 2, 2)))
+        elif not args.native:
+            sharded = hdist.ShardedHandNet(info["engine"], use_graph=bool(args.graph))
+            shard_in = info["inputs"]
+            if args.graph:
+                sharded.prepare(*shard_in, global_batch=world * batch)
 
     def full_step():
         if ev["on"] and on_gpu:     # HIP events (torch's current stream = the launch stream) around THIS rank's engine work
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
         t_a = time.perf_counter()
-        out = step()
+        if sharded is not None:
+            out = sharded.forward_device(*shard_in, global_batch=world * batch)
+            gathered["rows"] = out.valid
+        else:
+            out = step()
         if ev["on"]:
             if on_gpu:
                 b.record()
                 ev["pairs"].append((a, b))
             else:
                 ev["pairs"].append(time.perf_counter() - t_a)
-        if world > 1 and args.workload == "pipeline":
+        if sharded is None and world > 1 and args.workload == "pipeline":
             if args.dist_backend == "gloo" and on_gpu:  # rehearsal only: gloo gathers host tensors
                 g = hdist.gather_results(out.keypoints.cpu(), out.crop_box.cpu(), out.has_hand.cpu(), per_rank=batch)
             else:
@@ -856,14 +908,35 @@ def worker(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # every rank's own engine time per step (HIP events; without the gather and without waiting for the others)
-        mine = (sum(a.elapsed_time(b) for a, b in ev["pairs"]) if on_gpu else 1e3 * sum(ev["pairs"])) / max(1, args.steps)
+        if sharded is not None:
+            # the product callable's step holds the collective (inside its hipGraph when RCCL allows), i.e. every rank's step
+            # waits for the slowest: a straggler is only visible in the engine-only step, timed here AFTER the timed region
+            k = max(1, min(args.steps, 5))
+            if on_gpu:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                step()
+                torch.cuda.synchronize()
+                a.record()
+                for _ in range(k):
+                    step()
+                b.record()
+                torch.cuda.synchronize()
+                mine = a.elapsed_time(b) / k
+            else:
+                t_a = time.perf_counter()
+                for _ in range(k):
+                    step()
+                mine = 1e3 * (time.perf_counter() - t_a) / k
+        else:
+            mine = (sum(a.elapsed_time(b) for a, b in ev["pairs"]) if on_gpu else 1e3 * sum(ev["pairs"])) / max(1, args.steps)
         per_rank = [None] * world
         dist.all_gather_object(per_rank, float(mine))
         srt = sorted(per_rank)
         rank_ms = {"min_median_max": [round(srt[0], 3), round(srt[len(srt) // 2] if len(srt) % 2 else
                                       0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2]), 3), round(srt[-1], 3)],
                    "per_rank": [round(v, 3) for v in per_rank],
-                   "what": "engine launches of one step on each rank's own stream (HIP events), without the all-gather"}
+                   "what": "engine launches of one step on each rank's own stream (HIP events), without the all-gather"
+                           + (" (timed after the timed region: the product callable's step holds the collective)" if sharded is not None else "")}
 
     # what the collective really spanned: ranks seen by an actual all_gather_into_tensor (not the --gpus flag)
     rccl_ranks = world
@@ -911,6 +984,8 @@ def worker(args):
                        "frame": {"a2j": "176x176 depth crop", "pose2mesh": "21 x 2-D joints"}.get(args.workload, "640x480 RGB-D"),
                        "parallelism": f"frames sharded over {world} GPU(s), one all-gather of per-frame records per step",
                        "collective_backend": (dist.get_backend() if world > 1 else None), "rccl_ranks": rccl_ranks,
+                       "gather": (sharded.capture_note if sharded is not None and args.graph and on_gpu else
+                                  "eager all-gather behind the step" if world > 1 else None),
                        "devices": devices, "ipc_mode": ipc_mode,
                        "gflop_per_unit": round(info["gflop_per_unit"], 3), "hipgraph": bool(args.graph),
                        "host": "STUB" if args.stub_engine else "C++ layer graph (model-level C ABI)" if args.native

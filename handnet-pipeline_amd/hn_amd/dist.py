@@ -121,3 +121,280 @@ def gather_results(keypoints: torch.Tensor, crop_box: torch.Tensor, has_hand: to
 def compact_gathered(kp, crop_box, has_hand, valid):
     """Drop the padding rows of gather_results -> tensors over the real global batch."""
     return kp[valid], crop_box[valid], has_hand[valid]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# BASELINE.json config 5 as a product callable: shard -> step -> all-gather -> the reference's tuple, on every rank
+# ---------------------------------------------------------------------------------------------------------------------------
+CROP = 176
+
+
+class ShardedOutput:
+    """One sharded step's results over the GLOBAL batch, every tensor on the rank's own device (no host sync yet):
+    keypoints [N,J,3] fp32, crop_box [N,4] int64, has_hand [N] int32 (0 none, 1 hand, 2 hand with a non-finite depth crop),
+    range_words [W,4] int32 (every rank's f16x3 range-contract words), depth_rows [N,C,176,176] fp32 (gather_depth; else
+    the [b,C,176,176] rows of this rank's own frames), host_record: pinned uint8 [W*(per_rank+1), 296] the step copies the gathered records into (valid after
+    the stream is synchronised), rows: global frame index -> row of the gathered buffers, valid [N] int32: the row-is-a-real-
+    frame word of each record AS IT CAME BACK through the collective (1 everywhere when every rank delivered its shard)."""
+
+    __slots__ = ("keypoints", "crop_box", "has_hand", "valid", "range_words", "depth_rows", "host_record", "rows", "n", "per_rank",
+                 "world")
+
+    def __init__(self, **kw):
+        for k in self.__slots__:
+            setattr(self, k, kw.get(k))
+
+
+class ShardedHandNet:
+    """`handnet_pipeline.HandNet` over the ranks of a process group (one process per GPU, full weight replica each; SURVEY 8e,
+    north_star: "batched frames shard naturally across the 8 GPUs of one node with RCCL all-gather of detections"):
+
+        net = HandNet(args, reload_detector=True, num_classes=3, reload_a2j=True).cuda().eval()
+        hn_amd.dist.init_from_env()                       # torchrun environment -> RCCL process group
+        sharded = ShardedHandNet(net, gather_depth=True)
+        keypoints, depth_batch, crops = sharded(images, depth_images=depth)      # the GLOBAL batch, on every rank
+
+    Every rank runs the step on its contiguous shard (shard_bounds), packs its per-frame results into the 296-byte records of
+    the single-GPU step (+ one record with its range-contract words), ONE all_gather_into_tensor moves them, and every rank
+    returns the reference's tuple over the global batch (handnet_pipeline.py:107-116): keypoints [N,21,3] on the CPU,
+    depth_batch [K,1|4,176,176] and crops [K,4] int64 on the rank's device, K = frames with a hand, global frame order.
+    gather_depth=True adds SURVEY 8e's optional second collective for the depth crops (123 904 B per frame); without it
+    depth_batch holds the crops of THIS rank's frames only.  A rank may also pass just its own shard
+    (`global_batch=<frames over all ranks>`): what bench.py does, where every rank's frames are already resident.
+    No collective touches the networks' data path.  The step AND its collectives are captured into one hipGraph once the
+    shapes repeat (use_graph); when the backend refuses the capture the step alone is replayed and the gather is issued
+    eagerly behind it (`gather_captured`, `capture_note` say which) -- never a restart, never a fallback backend.
+    `net`: the drop-in HandNet, a HandNetEngine, or (tests) any object with forward_device(images, depth) -> an object with
+    keypoints / crop_box / has_hand / crops_nhwc / range_flags; host tensors take the same path with torch ops (gloo)."""
+
+    GRAPH_AFTER = 2     # eager steps with one input shape before the step + gather is captured
+
+    def __init__(self, net, group=None, gather_depth: bool = False, use_graph: bool = True, rgbd: bool | None = None):
+        self.net, self.group, self.gather_depth, self.use_graph = net, group, bool(gather_depth), bool(use_graph)
+        self.rgbd = bool(getattr(net, "RGBD", False)) if rgbd is None else bool(rgbd)
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self._bufs = {}
+        self._graphs = {}
+        self._seen = {}
+        self.gather_captured = None     # True / False once a capture has been attempted
+        self.capture_note = "no capture attempted yet"
+
+    # -- the engine behind `net` -------------------------------------------------------------------------------------------
+    def _engine(self):
+        eng = self.net.engine() if hasattr(self.net, "engine") else self.net
+        return eng
+
+    def _stage_through_host(self, t: torch.Tensor) -> bool:
+        """gloo moves host memory: a rehearsal of the N-rank plumbing on GPU tensors (ranks sharing one card) stages the
+        records through the host.  Not a performance mode; RCCL ("nccl") gathers device memory in place."""
+        return t.is_cuda and dist.is_initialized() and dist.get_backend(self.group) == "gloo"
+
+    def _buffers(self, per_rank, channels, dev):
+        key = (per_rank, channels, str(dev))
+        b = self._bufs.get(key)
+        if b is None:
+            rows, w = per_rank + 1, self.world
+            with torch.inference_mode(False):
+                b = {"send": torch.zeros((rows, 296), dtype=torch.uint8, device=dev),
+                     "recv": torch.zeros((w * rows, 296), dtype=torch.uint8, device=dev),
+                     "host": torch.zeros((w * rows, 296), dtype=torch.uint8, pin_memory=dev.type == "cuda")}
+                # this rank's depth crops [per_rank,C,176,176]: the send buffer of the optional second collective, and what
+                # depth_batch is cut from when the crops are not gathered
+                b["send_d"] = torch.zeros((per_rank, channels, CROP, CROP), dtype=torch.float32, device=dev)
+                if self.gather_depth:
+                    b["recv_d"] = torch.zeros((w * per_rank, channels, CROP, CROP), dtype=torch.float32, device=dev)
+            self._bufs[key] = b
+        return b
+
+    def _all_gather(self, recv, send):
+        if not dist.is_initialized():
+            recv.copy_(send)
+            return
+        if self._stage_through_host(send):
+            r = torch.empty(recv.shape, dtype=recv.dtype)
+            dist.all_gather_into_tensor(r, send.cpu(), group=self.group)
+            recv.copy_(r)
+            return
+        dist.all_gather_into_tensor(recv, send, group=self.group)
+
+    # -- one step on this rank's shard + the collectives (static launch sequence: capturable) ---------------------------------
+    def _step(self, images, depth, per_rank, bufs):
+        eng = self._engine()
+        out = eng.forward_device(images, depth)
+        b = out.keypoints.shape[0]
+        send, recv = bufs["send"], bufs["recv"]
+        if send.is_cuda:
+            from . import ops
+            with ops.on_device(send.device):
+                ops.pack_records(out.keypoints, out.crop_box, out.has_hand, per_rank + 1, 296, out=send)     # (rows >= b: zeros)
+                if getattr(out, "range_flags", None) is not None:
+                    send[per_rank, :16].view(torch.int32).copy_(out.range_flags)
+        else:
+            send.zero_()
+            send[:b, :32] = out.crop_box.to(torch.int64).contiguous().view(torch.uint8).reshape(b, 32)
+            fl = torch.stack([out.has_hand.to(torch.int32), torch.ones((b,), dtype=torch.int32)], dim=1)
+            send[:b, 32:_HEAD] = fl.contiguous().view(torch.uint8).reshape(b, 8)
+            j3 = out.keypoints.shape[1] * 3
+            send[:b, _HEAD:_HEAD + 4 * j3] = out.keypoints.to(torch.float32).reshape(b, j3).contiguous().view(torch.uint8)
+            if getattr(out, "range_flags", None) is not None:
+                send[per_rank, :16] = out.range_flags.to(torch.int32).contiguous().view(torch.uint8)
+        self._all_gather(recv, send)
+        sd = bufs["send_d"]
+        crops = out.crops_nhwc                      # [b,176,176,4]: channel 0 = depth (RGB-D: the four reordered channels)
+        sd[:b].copy_(crops.permute(0, 3, 1, 2) if self.rgbd else crops[..., 0].unsqueeze(1))
+        if self.gather_depth:
+            if b < per_rank:
+                sd[b:].zero_()
+            self._all_gather(bufs["recv_d"], sd)
+        bufs["host"].copy_(recv, non_blocking=True)
+        return out
+
+    def forward_device(self, images, depth_images, global_batch: int | None = None) -> ShardedOutput:
+        """The sync-free form: runs the step + the collectives and returns ShardedOutput (device tensors over the global batch;
+        its host_record is valid after the stream is synchronised)."""
+        n_in = len(images)
+        if global_batch is None:
+            total = n_in
+            lo, hi = shard_bounds(total, self.rank, self.world)
+            images = images[lo:hi] if torch.is_tensor(images) else list(images)[lo:hi]
+            depth_images = depth_images[lo:hi]
+        else:
+            total = int(global_batch)
+            lo, hi = shard_bounds(total, self.rank, self.world)
+            if n_in != hi - lo:
+                raise ValueError(f"rank {self.rank} of {self.world} holds frames [{lo}, {hi}) of a {total}-frame batch, "
+                                 f"got {n_in} frames")
+        per_rank = -(-total // self.world)
+        if hi == lo:
+            raise ValueError(f"a {total}-frame batch leaves rank {self.rank} of {self.world} without a frame")
+        batch = images if torch.is_tensor(images) else torch.stack([i.float() for i in images])
+        dev = batch.device
+        channels = 4 if self.rgbd else 1
+        bufs = self._buffers(per_rank, channels, dev)
+        key = (tuple(batch.shape), tuple(depth_images.shape), per_rank)
+        if dev.type == "cuda" and self.use_graph and not self._stage_through_host(batch):
+            hit = self._graphs.get(key)
+            if hit is None:
+                self._seen[key] = self._seen.get(key, 0) + 1
+                if self._seen[key] > self.GRAPH_AFTER and self.gather_captured is not False:
+                    hit = self._capture(key, batch, depth_images, per_rank, bufs)
+            if hit is not None:
+                g, s_img, s_dep = hit
+                s_img.copy_(batch)
+                s_dep.copy_(depth_images)
+                g.replay()
+                return self._gathered(total, per_rank, bufs)
+        self._step(batch, depth_images, per_rank, bufs)
+        return self._gathered(total, per_rank, bufs)
+
+    def prepare(self, images, depth_images, global_batch: int | None = None):
+        """Capture the step + collectives for these shapes NOW (instead of after GRAPH_AFTER eager steps): a caller that
+        times its steps (bench.py) calls this before its warm-up.  Returns self.gather_captured."""
+        for _ in range(self.GRAPH_AFTER + 1):
+            self.forward_device(images, depth_images, global_batch)
+        return self.gather_captured
+
+    def _capture(self, key, batch, depth, per_rank, bufs):
+        """The step and its collectives as ONE hipGraph.  The warm-up steps run the collectives eagerly first (communicator
+        and buffers exist before the capture starts).  A backend that refuses to be captured leaves gather_captured = False:
+        forward_device then stays eager for the collectives (the engine's own captured step still serves the launches)."""
+        from . import ops
+        with torch.inference_mode(False), torch.no_grad():
+            s_img, s_dep = torch.empty_like(batch), torch.empty_like(depth)
+            s_img.copy_(batch)
+            s_dep.copy_(depth)
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with ops.launch_cost_hidden():
+                    with torch.cuda.stream(side):
+                        for _ in range(2):
+                            self._step(s_img, s_dep, per_rank, bufs)
+                    torch.cuda.current_stream().wait_stream(side)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        self._step(s_img, s_dep, per_rank, bufs)
+            except Exception as e:  # noqa: BLE001 -- the backend (or a capture-unsafe call elsewhere in the process) refused
+                torch.cuda.synchronize()
+                self.gather_captured = False
+                self.capture_note = (f"capture of step + all-gather refused ({type(e).__name__}: {str(e)[:200]}); the gather is "
+                                     "issued eagerly behind the step")
+                return None
+        self.gather_captured = True
+        self.capture_note = ("step + all-gather" + (" + depth all-gather" if self.gather_depth else "")
+                             + " + record copy to the host captured in ONE hipGraph")
+        self._graphs[key] = (g, s_img, s_dep)
+        return self._graphs[key]
+
+    def _gathered(self, total, per_rank, bufs) -> ShardedOutput:
+        """Views / unpacked tensors of the gathered buffers (device side; no sync)."""
+        recv = bufs["recv"]
+        w, rows_per = self.world, per_rank + 1
+        # row of the gathered buffers for global frame f: rank r's block starts at r * (per_rank + 1)
+        rows, rows_d = [], []
+        for r in range(w):
+            lo, hi = shard_bounds(total, r, w)
+            rows += [r * rows_per + i for i in range(hi - lo)]
+            rows_d += [r * per_rank + i for i in range(hi - lo)]
+        idx = torch.tensor(rows, dtype=torch.int64, device=recv.device)
+        if recv.is_cuda:
+            from . import ops
+            with ops.on_device(recv.device):
+                kp, box, has, valid = ops.unpack_records(recv, 21)
+        else:
+            n_rows = recv.shape[0]
+            box = recv[:, :32].contiguous().view(torch.int64).reshape(n_rows, 4)
+            has = recv[:, 32:36].contiguous().view(torch.int32).reshape(n_rows)
+            valid = recv[:, 36:40].contiguous().view(torch.int32).reshape(n_rows)
+            kp = recv[:, _HEAD:_HEAD + 252].contiguous().view(torch.float32).reshape(n_rows, 21, 3)
+        words = recv.view(w, rows_per, 296)[:, per_rank, :16].contiguous().view(torch.int32).reshape(w, 4)
+        if self.gather_depth:   # rows of the GLOBAL batch
+            depth_rows = bufs["recv_d"].index_select(0, torch.tensor(rows_d, dtype=torch.int64, device=recv.device))
+        else:                   # rows of THIS rank's frames only
+            lo, hi = shard_bounds(total, self.rank, w)
+            depth_rows = bufs["send_d"][:hi - lo]
+        return ShardedOutput(keypoints=kp.index_select(0, idx), crop_box=box.index_select(0, idx),
+                             has_hand=has.index_select(0, idx), valid=valid.index_select(0, idx), range_words=words,
+                             depth_rows=depth_rows,
+                             host_record=bufs["host"], rows=rows, n=total, per_rank=per_rank, world=w)
+
+    # -- the reference's tuple ---------------------------------------------------------------------------------------------
+    def forward(self, images, depth_images=None, is_3D: bool = False, is_detect: bool = False, global_batch: int | None = None):
+        if is_detect or is_3D:
+            return None
+        if depth_images is None:
+            raise ValueError("depth_images is required for the ensemble inference branch")
+        out = self.forward_device(images, depth_images, global_batch)
+        dev = out.keypoints.device
+        if dev.type == "cuda":
+            torch.cuda.current_stream(dev).synchronize()
+        import numpy as np
+        a = out.host_record.numpy()
+        rows = np.asarray(out.rows)
+        n = out.n
+        kp = torch.from_numpy(np.ascontiguousarray(a[rows, _HEAD:_HEAD + 252]).view(np.float32).reshape(n, 21, 3))
+        has = torch.from_numpy(np.ascontiguousarray(a[rows, 32:36]).view(np.int32).reshape(n))
+        # the f16x3 range contract over EVERY rank's words (all ranks see the same words: all raise, or none does)
+        words = np.ascontiguousarray(a.reshape(out.world, out.per_rank + 1, 296)[:, out.per_rank, :16]).view(np.int32)
+        words = words.reshape(out.world, 4).max(axis=0).tolist()
+        noted = any(getattr(self._engine(), k, False) for k in ("note_range", "check_range"))
+        if noted:
+            from .pipeline import check_range_contract
+            check_range_contract(kp, words, None, has_hand=has)
+        mask = has != 0
+        hands = int(mask.sum())
+        if hands == 0:    # handnet_pipeline.py:107-108 (the placeholder has the GLOBAL batch's shape)
+            shape = (n,) + tuple(depth_images.shape[1:])
+            return torch.zeros((n, 21, 3)), torch.zeros(shape, dtype=depth_images.dtype, device=depth_images.device), torch.zeros((n, 4))
+        idx = mask.nonzero().flatten().to(dev)
+        crops = out.crop_box.index_select(0, idx)
+        if self.gather_depth:
+            depth_batch = out.depth_rows.index_select(0, idx)
+        else:   # this rank's frames only: the rows of its own shard that hold a hand
+            lo, hi = shard_bounds(n, self.rank, self.world)
+            mine = (mask[lo:hi]).nonzero().flatten().to(dev)
+            depth_batch = out.depth_rows.index_select(0, mine)
+        return kp, depth_batch, crops
+
+    __call__ = forward

@@ -3,7 +3,7 @@
 Launched with a torchrun-style environment (RANK / WORLD_SIZE / MASTER_*).  Every rank builds the engines from the
 seeded synthetic checkpoints, takes its contiguous shard of the seeded global batch, runs forward_device and
 all-gathers the per-frame records with hn_amd.dist.gather_results; rank 0 saves what it gathered.
-usage: dist_worker.py <total_frames> <backend: gloo|nccl> <out.pt>   (gloo: every rank uses cuda:0, records
+usage: dist_worker.py <total_frames> <backend: gloo|nccl> <out.pt> [sharded]   (gloo: every rank uses cuda:0, records
 travel through host memory -- the rehearsal mode of bench.py --share-gpu)"""
 import os
 import sys
@@ -39,6 +39,21 @@ def main():
     eng = HandNetEngine(FCOSEngine(synth.make_fcos_state_dict(0, 3), 3, device=dev),
                         A2JEngine(synth.make_a2j_state_dict(0), device=dev), 3)
     rgb, depth = synth.make_rgb(total, seed=1000), synth.make_depth(total, seed=2000)
+    if len(sys.argv) > 4 and sys.argv[4] == "sharded":
+        # the product's N > 1 callable around the engine: the GLOBAL batch in, the reference's tuple out on every rank
+        # (five calls: the third captures step + collectives into one hipGraph where the backend allows it)
+        net = hdist.ShardedHandNet(eng, gather_depth=True)
+        images = [rgb[i].to(dev) for i in range(total)]
+        d = depth.to(dev)
+        outs = [net(images, depth_images=d) for _ in range(5)]
+        for o in outs[1:]:
+            assert all(torch.equal(a, b) for a, b in zip(o, outs[0])), "replayed steps differ from the eager ones"
+        kp, depth_batch, crops = outs[-1]
+        assert kp.device.type == "cpu" and depth_batch.is_cuda and crops.is_cuda and crops.dtype == torch.int64
+        torch.save((kp, depth_batch.cpu(), crops.cpu(), world, net.gather_captured, net.capture_note), out_path + f".rank{rank}")
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     lo, hi = hdist.shard_bounds(total, rank, world)
     per_rank = -(-total // world)
     out = eng.forward_device(rgb[lo:hi].to(dev), depth[lo:hi].to(dev))

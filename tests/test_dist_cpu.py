@@ -243,3 +243,138 @@ def test_bench_fails_loudly_when_the_process_group_cannot_start():
     assert r.returncode != 0
     assert "failed to initialise" in (r.stdout + r.stderr) and not any(l.startswith("{") for l in r.stdout.splitlines())
     assert "attempt 2 of 2" in r.stderr
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# ShardedHandNet (BASELINE config 5 as a product callable): the reference's tuple over the GLOBAL batch on every rank
+# ---------------------------------------------------------------------------------------------------------------------------
+class _StubNet:
+    """CPU stand-in for the drop-in HandNet / its engine: per-frame results are a pure function of the frame (frames are
+    independent), including frames without a hand and the depth crops."""
+    RGBD = False
+    note_range = True
+
+    def forward_device(self, images, depth):
+        import types
+        n = images.shape[0]
+        key = images.reshape(n, -1)[:, :4]
+        kp = torch.stack([torch.arange(63, dtype=torch.float32).reshape(21, 3) * 0.01 + key[i].sum() for i in range(n)])
+        box = torch.stack([torch.tensor([int(key[i, 0] * 100), 2, 30 + int(key[i, 1] * 50), 40], dtype=torch.int64) for i in range(n)])
+        has = (key[:, 0] > 0.2).to(torch.int32)
+        kp = kp * (has != 0).reshape(n, 1, 1)                      # zero rows for frames without a hand, as the engine writes
+        crops = torch.zeros((n, 176, 176, 4))
+        crops[..., 0] = depth[:, 0, :176, :176] * 2.0              # "the crop" = a function of the frame's depth map
+        return types.SimpleNamespace(keypoints=kp, crop_box=box, has_hand=has, crops_nhwc=crops,
+                                     range_flags=torch.zeros(4, dtype=torch.int32))
+
+
+def _single_process_tuple(images, depth):
+    """What handnet_pipeline.HandNet.forward returns for the whole batch (handnet_pipeline.py:107-116)."""
+    out = _StubNet().forward_device(images, depth)
+    mask = out.has_hand != 0
+    if int(mask.sum()) == 0:
+        return torch.zeros((len(images), 21, 3)), torch.zeros_like(depth), torch.zeros((len(images), 4))
+    return out.keypoints, out.crops_nhwc[..., 0].unsqueeze(1)[mask], out.crop_box[mask]
+
+
+def _sharded_inputs(total, no_hand=False):
+    g = torch.Generator().manual_seed(321)
+    images = torch.rand((total, 3, 8, 8), generator=g)
+    images[:, 0, 0, 0] = 0.25 + 0.5 * images[:, 0, 0, 0]      # a hand ...
+    images[1::3, 0, 0, 0] = 0.1                                  # ... except in frames 1, 4, 7, ...
+    if no_hand:
+        images[:, 0, 0, 0] = 0.1
+    depth = torch.rand((total, 1, 180, 200), generator=g)
+    return images, depth
+
+
+def _sharded_worker(rank, world, port, total, out_dir, gather_depth, local_shards, no_hand):
+    for p in (str(REPO), str(REPO / "handnet-pipeline_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from hn_amd import dist as hdist
+    hdist.init_from_env("gloo")
+    images, depth = _sharded_inputs(total, no_hand)
+    net = hdist.ShardedHandNet(_StubNet(), gather_depth=gather_depth)
+    outs = []
+    for _ in range(2):      # (twice: the buffers are reused from step to step)
+        if local_shards:
+            lo, hi = hdist.shard_bounds(total, rank, world)
+            outs.append(net(images[lo:hi], depth_images=depth[lo:hi], global_batch=total))
+        else:
+            outs.append(net(images, depth_images=depth))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    torch.save(outs[-1], os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,total,local_shards", [(2, 8, False), (2, 7, True), (8, 27, False), (8, 27, True)])
+def test_sharded_handnet_returns_the_single_process_tuple_on_every_rank(tmp_path, world, total, local_shards):
+    """Every rank of a 2- and an 8-rank group (27 frames: ragged shards of 4 and 3) gets the tuple the single-process call
+    returns for the global batch -- keypoints (CPU, zero rows for frames without a hand), depth_batch and crops of the K
+    frames with a hand in global order -- whether it passed the global batch or just its own shard."""
+    mp.spawn(_sharded_worker, args=(world, _free_port(), total, str(tmp_path), True, local_shards, False), nprocs=world, join=True)
+    kp, depth_batch, crops = _single_process_tuple(*_sharded_inputs(total))
+    assert 0 < crops.shape[0] < total            # (the case holds frames with and without a hand)
+    for rank in range(world):
+        g_kp, g_depth, g_crops = torch.load(tmp_path / f"rank{rank}.pt")
+        assert torch.equal(g_kp, kp) and g_kp.dtype == torch.float32
+        assert torch.equal(g_crops, crops) and g_crops.dtype == torch.int64
+        assert torch.equal(g_depth, depth_batch) and tuple(g_depth.shape[1:]) == (1, 176, 176)
+
+
+def test_sharded_handnet_without_depth_gather_and_without_hands(tmp_path):
+    """gather_depth=False: ONE collective; depth_batch holds the crops of the rank's OWN frames with a hand.  A batch without
+    any hand returns the reference's placeholder triple over the global batch (handnet_pipeline.py:107-108)."""
+    from hn_amd.dist import shard_bounds
+    world, total = 2, 7
+    mp.spawn(_sharded_worker, args=(world, _free_port(), total, str(tmp_path), False, False, False), nprocs=world, join=True)
+    images, depth = _sharded_inputs(total)
+    kp, depth_batch, crops = _single_process_tuple(images, depth)
+    has = _StubNet().forward_device(images, depth).has_hand != 0
+    for rank in range(world):
+        g_kp, g_depth, g_crops = torch.load(tmp_path / f"rank{rank}.pt")
+        lo, hi = shard_bounds(total, rank, world)
+        before, mine = int(has[:lo].sum()), int(has[lo:hi].sum())
+        assert torch.equal(g_kp, kp) and torch.equal(g_crops, crops)
+        assert torch.equal(g_depth, depth_batch[before:before + mine])
+    mp.spawn(_sharded_worker, args=(world, _free_port(), total, str(tmp_path), True, True, True), nprocs=world, join=True)
+    for rank in range(world):
+        g_kp, g_depth, g_crops = torch.load(tmp_path / f"rank{rank}.pt")
+        assert tuple(g_kp.shape) == (total, 21, 3) and not g_kp.any()
+        assert tuple(g_depth.shape) == (total, 1, 180, 200) and not g_depth.any()
+        assert tuple(g_crops.shape) == (total, 4) and g_crops.dtype == torch.float32 and not g_crops.any()
+
+
+def test_sharded_handnet_single_process_and_collective_count(monkeypatch):
+    """Without a process group the callable is the single-process call; with one it issues exactly one collective per step
+    (two with gather_depth) and reuses its buffers."""
+    import torch.distributed as dist
+    from hn_amd import dist as hdist
+    images, depth = _sharded_inputs(5)
+    want = _single_process_tuple(images, depth)
+    got = hdist.ShardedHandNet(_StubNet(), gather_depth=True)(images, depth_images=depth)
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+    assert hdist.ShardedHandNet(_StubNet())(images, depth_images=depth, is_detect=True) is None
+    calls = []
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_world_size", lambda group=None: 1)
+    monkeypatch.setattr(dist, "get_rank", lambda group=None: 0)
+    monkeypatch.setattr(dist, "get_backend", lambda group=None: "gloo")
+
+    def fake_gather(out, inp, group=None):
+        calls.append((out.data_ptr(), inp.data_ptr()))
+        out.copy_(inp)
+    monkeypatch.setattr(dist, "all_gather_into_tensor", fake_gather)
+    for gather_depth, per_step in ((False, 1), (True, 2)):
+        calls.clear()
+        net = hdist.ShardedHandNet(_StubNet(), gather_depth=gather_depth)
+        for _ in range(3):
+            got = net(images, depth_images=depth)
+        assert len(calls) == 3 * per_step and len(set(calls)) == per_step
+        assert torch.equal(got[0], want[0]) and torch.equal(got[2], want[2])
+    with pytest.raises(ValueError, match="holds frames"):
+        hdist.ShardedHandNet(_StubNet())(images, depth_images=depth, global_batch=9)

@@ -272,3 +272,61 @@ def test_bench_ladder_with_a_real_rccl_initialisation_failure():
     assert not any(l.startswith("{") for l in r.stdout.splitlines()), r.stdout
     assert "attempt 1 failed to initialise" in r.stderr and "attempt 2 failed to initialise" in r.stderr, out
     assert "HSA_ENABLE_IPC_MODE_LEGACY unset" in r.stderr
+
+
+def _reference_tuple(eng, total):
+    """handnet_pipeline.HandNet.forward's tuple for the whole batch from ONE single-process step of the same engines."""
+    from hn_amd import synth
+    out = eng.forward_device(synth.make_rgb(total, seed=1000).cuda(), synth.make_depth(total, seed=2000).cuda())
+    mask = out.has_hand != 0
+    return out.keypoints.cpu(), out.crops_nhwc[..., 0].unsqueeze(1)[mask].cpu(), out.crop_box[mask].cpu()
+
+
+def test_sharded_handnet_two_ranks_sharing_the_card(tmp_path, fcos_sd, a2j_sd):
+    """hn_amd.dist.ShardedHandNet (BASELINE config 5's callable) on the REAL engine: two ranks sharing cuda:0 (gloo: the
+    records travel through the host) each return the reference's tuple over the GLOBAL batch -- crop boxes and depth crops
+    bit-for-bit the single-process step's, keypoints within the batch-size summation-order difference."""
+    from hn_amd.a2j_engine import A2JEngine
+    from hn_amd.fcos_engine import FCOSEngine
+    from hn_amd.pipeline import HandNetEngine
+    total, world = 16, 2
+    port = _free_port()
+    out_file = tmp_path / "sharded.pt"
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(REPO / "tests" / "dist_worker.py"), str(total), "gloo",
+                                       str(out_file), "sharded"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    eng = HandNetEngine(FCOSEngine(fcos_sd, 3, device="cuda"), A2JEngine(a2j_sd, device="cuda"), 3)
+    kp, depth_batch, crops = _reference_tuple(eng, total)
+    for rank in range(world):
+        g_kp, g_depth, g_crops, w, _cap, _note = torch.load(str(out_file) + f".rank{rank}")
+        assert w == world and tuple(g_kp.shape) == (total, 21, 3)
+        assert torch.equal(g_crops, crops) and torch.equal(g_depth, depth_batch)
+        assert (g_kp - kp).abs().max().item() <= 2.5e-4
+
+
+def test_sharded_handnet_rccl_single_rank_with_the_gather_in_the_graph(tmp_path, fcos_sd, a2j_sd):
+    """The RCCL leg on the one GPU of this box: a single-rank "nccl" group; from the third call on ShardedHandNet replays the
+    step AND both collectives (records, depth crops) from ONE hipGraph when RCCL lets itself be captured (the worker asserts
+    that replayed results equal the eager ones) -- or says why not and keeps the gather eager.  Results are the in-process
+    step's bit for bit either way."""
+    from hn_amd.a2j_engine import A2JEngine
+    from hn_amd.fcos_engine import FCOSEngine
+    from hn_amd.pipeline import HandNetEngine
+    total = 8
+    out_file = tmp_path / "sharded_rccl.pt"
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(REPO / "tests" / "dist_worker.py"), str(total), "nccl", str(out_file), "sharded"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout
+    g_kp, g_depth, g_crops, w, captured, note = torch.load(str(out_file) + ".rank0")
+    print("ShardedHandNet on a single-rank RCCL group:", note)
+    assert w == 1 and captured in (True, False) and note
+    eng = HandNetEngine(FCOSEngine(fcos_sd, 3, device="cuda"), A2JEngine(a2j_sd, device="cuda"), 3)
+    kp, depth_batch, crops = _reference_tuple(eng, total)
+    assert torch.equal(g_crops, crops) and torch.equal(g_depth, depth_batch) and torch.equal(g_kp, kp)
