@@ -332,12 +332,17 @@ class ShardedHandNet:
         recv = bufs["recv"]
         w, rows_per = self.world, per_rank + 1
         # row of the gathered buffers for global frame f: rank r's block starts at r * (per_rank + 1)
-        rows, rows_d = [], []
-        for r in range(w):
-            lo, hi = shard_bounds(total, r, w)
-            rows += [r * rows_per + i for i in range(hi - lo)]
-            rows_d += [r * per_rank + i for i in range(hi - lo)]
-        idx = torch.tensor(rows, dtype=torch.int64, device=recv.device)
+        cached = bufs.get(("rows", total))
+        if cached is None:      # (index tensors are built once per batch size: no host -> device copy on the stepping path)
+            rows, rows_d = [], []
+            for r in range(w):
+                lo, hi = shard_bounds(total, r, w)
+                rows += [r * rows_per + i for i in range(hi - lo)]
+                rows_d += [r * per_rank + i for i in range(hi - lo)]
+            with torch.inference_mode(False):
+                cached = bufs[("rows", total)] = (rows, torch.tensor(rows, dtype=torch.int64, device=recv.device),
+                                                  torch.tensor(rows_d, dtype=torch.int64, device=recv.device))
+        rows, idx, idx_d = cached
         if recv.is_cuda:
             from . import ops
             with ops.on_device(recv.device):
@@ -350,7 +355,7 @@ class ShardedHandNet:
             kp = recv[:, _HEAD:_HEAD + 252].contiguous().view(torch.float32).reshape(n_rows, 21, 3)
         words = recv.view(w, rows_per, 296)[:, per_rank, :16].contiguous().view(torch.int32).reshape(w, 4)
         if self.gather_depth:   # rows of the GLOBAL batch
-            depth_rows = bufs["recv_d"].index_select(0, torch.tensor(rows_d, dtype=torch.int64, device=recv.device))
+            depth_rows = bufs["recv_d"].index_select(0, idx_d)
         else:                   # rows of THIS rank's frames only
             lo, hi = shard_bounds(total, self.rank, w)
             depth_rows = bufs["send_d"][:hi - lo]
