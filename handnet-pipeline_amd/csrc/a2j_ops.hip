@@ -56,6 +56,51 @@ __global__ __launch_bounds__(256) void pack_depth_kernel(const float* __restrict
 // Pass 1: per-joint max of the logits (exact, order independent).
 // Pass 2: e = exp(x - max); partial sums of e, e*(anchor+offset), e*depth per (group, anchor, joint), then
 // combined through LDS in a fixed order (group-major, then anchor): bitwise reproducible, and independent of the joint split.
+// crop-(u,v,d) of one joint -> image (u,v,d) and / or camera xyz in millimetres (a2j/a2j.py:17-34 convert_joints +
+// datasets3d/a2jdataset.py:31-38 uvd2xyz).  ONE function for the stand-alone kernel and the aggregation's epilogue: the two are
+// bit-identical by construction.  (Every operation is a single rounding in the reference's order; nothing here can contract
+// into an fma: each product feeds a division.)
+struct ConvertSpec {
+  const long long* box;   // [n,4] padded crop boxes (x1,y1,x2,y2), or nullptr: no conversion
+  float crop_w, crop_h;
+  int has_paras;          // camera intrinsics given: xyz_mm is written
+  float fx, fy, cx, cy;
+  int clamp_kp;           // clamp the crop-(u,v,d) to [0, crop_w] first (ros_demo.py:283 clamps all three to [0, 176])
+  int clamp_h, clamp_w;   // > 0: clamp box x1,y1 to [0, clamp_h] and x2,y2 to [0, clamp_w] first (ros_demo.py:279-280, as written there)
+  float* image_uvd;       // [n,J,3] or nullptr
+  float* xyz_mm;          // [n,J,3] or nullptr
+};
+
+__device__ __forceinline__ void convert_one(const ConvertSpec& cs, int img, long joint_row, float ku, float kv, float kd) {
+  float x0 = (float)cs.box[img * 4 + 0], y0 = (float)cs.box[img * 4 + 1];
+  float x1 = (float)cs.box[img * 4 + 2], y1 = (float)cs.box[img * 4 + 3];
+  if (cs.clamp_h > 0) {
+    x0 = fminf(fmaxf(x0, 0.f), (float)cs.clamp_h);
+    y0 = fminf(fmaxf(y0, 0.f), (float)cs.clamp_h);
+    x1 = fminf(fmaxf(x1, 0.f), (float)cs.clamp_w);
+    y1 = fminf(fmaxf(y1, 0.f), (float)cs.clamp_w);
+  }
+  if (cs.clamp_kp) {   // torch.clamp keeps NaN; fminf / fmaxf would drop it
+    ku = ku != ku ? ku : fminf(fmaxf(ku, 0.f), cs.crop_w);
+    kv = kv != kv ? kv : fminf(fmaxf(kv, 0.f), cs.crop_w);
+    kd = kd != kd ? kd : fminf(fmaxf(kd, 0.f), cs.crop_w);
+  }
+  const float u = ku * (x1 - x0) / cs.crop_w + x0;
+  const float v = kv * (y1 - y0) / cs.crop_h + y0;
+  if (cs.image_uvd) {
+    float* o = cs.image_uvd + joint_row * 3;
+    o[0] = u;
+    o[1] = v;
+    o[2] = kd;
+  }
+  if (cs.xyz_mm && cs.has_paras) {
+    float* o = cs.xyz_mm + joint_row * 3;
+    o[0] = (u - cs.cx) * kd / cs.fx * 1000.f;
+    o[1] = (v - cs.cy) * kd / cs.fy * 1000.f;
+    o[2] = kd * 1000.f;
+  }
+}
+
 constexpr int kAnchorsPerCell = 16;
 constexpr int kMaxGroups = 9;   // (round 4: 3 -> 9 cell groups: on an 11 x 11 map a thread owns 14 cells = ONE batch of loads per pass
                                 // instead of three, 18 -> ~11 us at one crop; the group count fixes the summation order, so it is the
@@ -66,7 +111,8 @@ __global__ __launch_bounds__(1024) void a2j_aggregate_kernel(const float* __rest
                                                              const float* __restrict__ reg,
                                                              const float* __restrict__ dep,
                                                              const int* __restrict__ valid, int fh, int fw,
-                                                             int J, int Jw, int stride, int G, float* __restrict__ out) {
+                                                             int J, int Jw, int stride, int G, float* __restrict__ out,
+                                                             const ConvertSpec cs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [G][4][A*Jw]
   const int k = blockIdx.x;
   const int j0 = blockIdx.y * Jw;
@@ -80,8 +126,13 @@ __global__ __launch_bounds__(1024) void a2j_aggregate_kernel(const float* __rest
   const int c = a * J + j0 + jl;        // channel in memory
   if (valid && valid[k] != 1) {  // uniform per workgroup: 0 = no crop (zero row), 2 = non-finite crop (NaN row, as the
     // reference's network returns for it: every cell of the 11 x 11 maps sees every pixel of the crop)
-    if ((int)threadIdx.x < jn * 3)
-      out[((long)k * J + j0) * 3 + threadIdx.x] = valid[k] == 0 ? 0.f : __builtin_nanf("");
+    if ((int)threadIdx.x < jn * 3) {
+      const float fill = valid[k] == 0 ? 0.f : __builtin_nanf("");
+      const long at = ((long)k * J + j0) * 3 + threadIdx.x;
+      out[at] = fill;
+      if (cs.box && cs.image_uvd) cs.image_uvd[at] = fill;
+      if (cs.box && cs.xyz_mm && cs.has_paras) cs.xyz_mm[at] = fill;
+    }
     return;
   }
   const int cells = fh * fw;
@@ -170,41 +221,29 @@ __global__ __launch_bounds__(1024) void a2j_aggregate_kernel(const float* __rest
       td += lds[3 * AW + aa * Jw + jj];
     }
     float* o = out + ((long)k * J + j0 + jj) * 3;
-    o[0] = t0 / t;
-    o[1] = t1 / t;
-    o[2] = td / t;
+    const float ku = t0 / t, kv = t1 / t, kd = td / t;
+    o[0] = ku;
+    o[1] = kv;
+    o[2] = kd;
+    // convert_joints + uvd2xyz in the aggregation's epilogue (what every caller does next: ros_demo.py:289,
+    // 329-330, a2j/a2j.py:341-348) -- from the registers that hold the joint, no second launch
+    if (cs.box) convert_one(cs, k, (long)k * J + j0 + jj, ku, kv, kd);
   }
 }
 
-// crop-(u,v,d) -> image (u,v,d) -> camera xyz in millimetres (a2j/a2j.py:17-34 convert_joints +
-// datasets3d/a2jdataset.py:31-38 uvd2xyz), one thread per joint
-__global__ __launch_bounds__(256) void convert_joints_kernel(const float* __restrict__ kp,
-                                                             const long long* __restrict__ box,
-                                                             const int* __restrict__ valid, int n, int J,
-                                                             float crop_w, float crop_h, int has_paras, float fx,
-                                                             float fy, float cx, float cy, float* __restrict__ out) {
+// the stand-alone form (the reference form of the fused epilogue above), one thread per joint: out = camera xyz in mm when
+// intrinsics are given, else image (u,v,d)
+__global__ __launch_bounds__(256) void convert_joints_kernel(const float* __restrict__ kp, const int* __restrict__ valid, int n,
+                                                             int J, const ConvertSpec cs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * J) return;
   const int img = i / J;
-  float* o = out + (long)i * 3;
   if (valid && valid[img] == 0) {
+    float* o = (cs.has_paras ? cs.xyz_mm : cs.image_uvd) + (long)i * 3;
     o[0] = o[1] = o[2] = 0.f;
     return;
   }
-  const float x0 = (float)box[img * 4 + 0], y0 = (float)box[img * 4 + 1];
-  const float x1 = (float)box[img * 4 + 2], y1 = (float)box[img * 4 + 3];
-  const float u = kp[(long)i * 3 + 0] * (x1 - x0) / crop_w + x0;
-  const float v = kp[(long)i * 3 + 1] * (y1 - y0) / crop_h + y0;
-  const float d = kp[(long)i * 3 + 2];
-  if (has_paras) {
-    o[0] = (u - cx) * d / fx * 1000.f;
-    o[1] = (v - cy) * d / fy * 1000.f;
-    o[2] = d * 1000.f;
-  } else {
-    o[0] = u;
-    o[1] = v;
-    o[2] = d;
-  }
+  convert_one(cs, img, i, kp[(long)i * 3 + 0], kp[(long)i * 3 + 1], kp[(long)i * 3 + 2]);
 }
 
 }  // namespace
@@ -215,9 +254,18 @@ extern "C" int hn_convert_joints_f32(const float* kp, const int64_t* crop_box, c
   HN_CHECK_ARG(n >= 0 && joints > 0 && crop_w > 0.f && crop_h > 0.f, "bad dims");
   if (n == 0) return HN_OK;
   const int total = n * joints;
-  hipLaunchKernelGGL(convert_joints_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, kp,
-                     (const long long*)crop_box, valid, n, joints, crop_w, crop_h, paras ? 1 : 0, paras ? paras[0] : 1.f,
-                     paras ? paras[1] : 1.f, paras ? paras[2] : 0.f, paras ? paras[3] : 0.f, out);
+  ConvertSpec cs{};
+  cs.box = (const long long*)crop_box;
+  cs.crop_w = crop_w;
+  cs.crop_h = crop_h;
+  cs.has_paras = paras ? 1 : 0;
+  cs.fx = paras ? paras[0] : 1.f;
+  cs.fy = paras ? paras[1] : 1.f;
+  cs.cx = paras ? paras[2] : 0.f;
+  cs.cy = paras ? paras[3] : 0.f;
+  cs.image_uvd = paras ? nullptr : out;
+  cs.xyz_mm = paras ? out : nullptr;
+  hipLaunchKernelGGL(convert_joints_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, kp, valid, n, joints, cs);
   HN_CHECK_LAUNCH("convert_joints_kernel");
   return HN_OK;
 }
@@ -245,12 +293,8 @@ extern "C" int hn_pack_depth_nhwc(const float* src, float* dst, int n, int hw, i
   return HN_OK;
 }
 
-extern "C" int hn_a2j_aggregate_f32(const float* cls, const float* reg, const float* dep, const int32_t* valid,
-                                    int k, int fh, int fw, int joints, int stride, float* out, void* stream) {
-  HN_CHECK_ARG(cls && reg && dep && out, "hn_a2j_aggregate_f32: null pointer");
-  HN_CHECK_ARG(k >= 0 && fh > 0 && fw > 0 && stride > 0, "bad dims");
-  HN_CHECK_ARG(joints > 0 && joints * kAnchorsPerCell <= 1024, "joints must be in [1, 64]");
-  if (k == 0) return HN_OK;
+static int launch_aggregate(const float* cls, const float* reg, const float* dep, const int32_t* valid, int k, int fh, int fw,
+                            int joints, int stride, float* out, const ConvertSpec& cs, void* stream) {
   // the cell-group count depends on the joint count only (it fixes the summation order): min(9, 1024 / (16 * joints per workgroup))
   const int split = joints >= 2 * kJointSplit ? kJointSplit : 1;
   const int jw = (joints + split - 1) / split;
@@ -260,8 +304,92 @@ extern "C" int hn_a2j_aggregate_f32(const float* cls, const float* reg, const fl
   groups = groups < 1 ? 1 : groups;
   const int threads = ((groups * aw + 63) / 64) * 64;
   hipLaunchKernelGGL(a2j_aggregate_kernel, dim3(k, split), dim3(threads), groups * 4 * aw * sizeof(float),
-                     (hipStream_t)stream, cls, reg, dep, valid, fh, fw, joints, jw, stride, groups, out);
+                     (hipStream_t)stream, cls, reg, dep, valid, fh, fw, joints, jw, stride, groups, out, cs);
   HN_CHECK_LAUNCH("a2j_aggregate_kernel");
+  return HN_OK;
+}
+
+extern "C" int hn_a2j_aggregate_f32(const float* cls, const float* reg, const float* dep, const int32_t* valid,
+                                    int k, int fh, int fw, int joints, int stride, float* out, void* stream) {
+  HN_CHECK_ARG(cls && reg && dep && out, "hn_a2j_aggregate_f32: null pointer");
+  HN_CHECK_ARG(k >= 0 && fh > 0 && fw > 0 && stride > 0, "bad dims");
+  HN_CHECK_ARG(joints > 0 && joints * kAnchorsPerCell <= 1024, "joints must be in [1, 64]");
+  if (k == 0) return HN_OK;
+  return launch_aggregate(cls, reg, dep, valid, k, fh, fw, joints, stride, out, ConvertSpec{}, stream);
+}
+
+extern "C" int hn_a2j_aggregate_convert_f32(const float* cls, const float* reg, const float* dep, const int32_t* valid, int k,
+                                            int fh, int fw, int joints, int stride, const int64_t* crop_box, float crop_w,
+                                            float crop_h, const float* paras, const hn_convert_opts* opts, float* out_uvd,
+                                            float* out_image_uvd, float* out_xyz_mm, void* stream) {
+  HN_CHECK_ARG(cls && reg && dep && out_uvd && crop_box, "hn_a2j_aggregate_convert_f32: null pointer");
+  HN_CHECK_ARG(out_image_uvd || out_xyz_mm, "hn_a2j_aggregate_convert_f32: no converted output requested");
+  HN_CHECK_ARG(!out_xyz_mm || paras, "hn_a2j_aggregate_convert_f32: camera xyz needs the intrinsics (fx, fy, cx, cy)");
+  HN_CHECK_ARG(k >= 0 && fh > 0 && fw > 0 && stride > 0 && crop_w > 0.f && crop_h > 0.f, "bad dims");
+  HN_CHECK_ARG(joints > 0 && joints * kAnchorsPerCell <= 1024, "joints must be in [1, 64]");
+  if (k == 0) return HN_OK;
+  ConvertSpec cs{};
+  cs.box = (const long long*)crop_box;
+  cs.crop_w = crop_w;
+  cs.crop_h = crop_h;
+  cs.has_paras = paras ? 1 : 0;
+  cs.fx = paras ? paras[0] : 1.f;
+  cs.fy = paras ? paras[1] : 1.f;
+  cs.cx = paras ? paras[2] : 0.f;
+  cs.cy = paras ? paras[3] : 0.f;
+  cs.clamp_kp = opts ? opts->clamp_keypoints : 0;
+  cs.clamp_h = opts ? opts->clamp_box_h : 0;
+  cs.clamp_w = opts ? opts->clamp_box_w : 0;
+  HN_CHECK_ARG((cs.clamp_h > 0) == (cs.clamp_w > 0), "clamp_box_h and clamp_box_w are given together");
+  cs.image_uvd = out_image_uvd;
+  cs.xyz_mm = out_xyz_mm;
+  return launch_aggregate(cls, reg, dep, valid, k, fh, fw, joints, stride, out_uvd, cs, stream);
+}
+
+// ---------------------------------------------------------------------------------------
+// The lifter's input (include/handnet_hip.h): per frame and axis (x - mean) / std over the J joints, population std.
+// One wave per frame; sums in fp64 in joint order (numpy's pairwise fp32 / fp64 summation differs from ANY fixed order by
+// rounding only; the oracle restates the caller's whole chain in fp64).
+// ---------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(64) void joints2d_standardize_kernel(const float* __restrict__ uvd, const int* __restrict__ valid,
+                                                                  int J, float* __restrict__ out) {
+  const int img = blockIdx.x, lane = threadIdx.x;
+  float* o = out + (long)img * J * 2;
+  if (valid && valid[img] != 1) {
+    for (int i = lane; i < J * 2; i += 64) o[i] = 0.f;
+    return;
+  }
+  const float* p = uvd + (long)img * J * 3;
+  // every lane computes both axes' statistics itself (J <= 64 values each: 2 x 21 loads that hit the same cache line)
+  double m0 = 0.0, m1 = 0.0;
+  for (int j = 0; j < J; ++j) {
+    m0 += (double)p[j * 3 + 0];
+    m1 += (double)p[j * 3 + 1];
+  }
+  m0 /= J;
+  m1 /= J;
+  double v0 = 0.0, v1 = 0.0;
+  for (int j = 0; j < J; ++j) {
+    const double a = (double)p[j * 3 + 0] - m0, b = (double)p[j * 3 + 1] - m1;
+    v0 += a * a;
+    v1 += b * b;
+  }
+  const double s0 = sqrt(v0 / J), s1 = sqrt(v1 / J);
+  for (int j = lane; j < J; j += 64) {
+    o[j * 2 + 0] = (float)(((double)p[j * 3 + 0] - m0) / s0);
+    o[j * 2 + 1] = (float)(((double)p[j * 3 + 1] - m1) / s1);
+  }
+}
+}  // namespace
+
+extern "C" int hn_joints2d_standardize_f32(const float* image_uvd, const int32_t* valid, int n, int joints, float* out,
+                                           void* stream) {
+  HN_CHECK_ARG(image_uvd && out, "hn_joints2d_standardize_f32: null pointer");
+  HN_CHECK_ARG(n >= 0 && joints > 1, "bad dims");
+  if (n == 0) return HN_OK;
+  hipLaunchKernelGGL(joints2d_standardize_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, image_uvd, valid, joints, out);
+  HN_CHECK_LAUNCH("joints2d_standardize_kernel");
   return HN_OK;
 }
 
@@ -275,7 +403,8 @@ constexpr int kRecHead = 40;  // 4 x int64 box, int32 has_hand, int32 row flag
 // one thread per 4-byte word of a record
 __global__ __launch_bounds__(256) void pack_records_kernel(const float* __restrict__ kp, const long long* __restrict__ box,
                                                            const int* __restrict__ has, int n, int rows, int j3,
-                                                           int rec_words, unsigned* __restrict__ rec) {
+                                                           int rec_words, unsigned* __restrict__ rec,
+                                                           const float* __restrict__ e0, const float* __restrict__ e1) {
   const long total = (long)rows * rec_words;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int r = (int)(i / rec_words), w = (int)(i - (long)r * rec_words);
@@ -290,6 +419,10 @@ __global__ __launch_bounds__(256) void pack_records_kernel(const float* __restri
         v = 1u;
       } else if (w - 10 < j3) {
         v = __float_as_uint(kp[(long)r * j3 + (w - 10)]);
+      } else if (e0 && w - 10 < 2 * j3) {           // wide records: image (u,v,d) behind the crop (u,v,d) ...
+        v = __float_as_uint(e0[(long)r * j3 + (w - 10 - j3)]);
+      } else if (e1 && w - 10 < 3 * j3) {           // ... then camera xyz in mm
+        v = __float_as_uint(e1[(long)r * j3 + (w - 10 - 2 * j3)]);
       }
     }
     rec[i] = v;
@@ -328,18 +461,27 @@ __global__ __launch_bounds__(256) void nonfinite_count_kernel(const float* __res
 
 }  // namespace
 
-extern "C" int hn_pack_records(const float* keypoints, const int64_t* crop_box, const int32_t* has_hand, int n, int rows,
-                               int joints, int rec_bytes, void* records, void* stream) {
+extern "C" int hn_pack_records_ex(const float* keypoints, const int64_t* crop_box, const int32_t* has_hand, int n, int rows,
+                                  int joints, int rec_bytes, const float* extra0, const float* extra1, void* records,
+                                  void* stream) {
   HN_CHECK_ARG(records && (n == 0 || (keypoints && crop_box && has_hand)), "hn_pack_records: null pointer");
   HN_CHECK_ARG(n >= 0 && rows >= n && joints > 0, "bad dims");
-  HN_CHECK_ARG(rec_bytes >= kRecHead + 12 * joints && rec_bytes % 8 == 0, "rec_bytes must be a multiple of 8 >= 40 + 12*joints");
+  HN_CHECK_ARG(extra0 || !extra1, "hn_pack_records_ex: extra1 without extra0");
+  const int fields = 1 + (extra0 ? 1 : 0) + (extra1 ? 1 : 0);
+  HN_CHECK_ARG(rec_bytes >= kRecHead + 12 * joints * fields && rec_bytes % 8 == 0,
+               "rec_bytes must be a multiple of 8 >= 40 + 12*joints per keypoint field");
   if (rows == 0) return HN_OK;
   const long total = (long)rows * (rec_bytes / 4);
   const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
   hipLaunchKernelGGL(pack_records_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, keypoints, (const long long*)crop_box,
-                     has_hand, n, rows, joints * 3, rec_bytes / 4, (unsigned*)records);
+                     has_hand, n, rows, joints * 3, rec_bytes / 4, (unsigned*)records, extra0, extra1);
   HN_CHECK_LAUNCH("pack_records_kernel");
   return HN_OK;
+}
+
+extern "C" int hn_pack_records(const float* keypoints, const int64_t* crop_box, const int32_t* has_hand, int n, int rows,
+                               int joints, int rec_bytes, void* records, void* stream) {
+  return hn_pack_records_ex(keypoints, crop_box, has_hand, n, rows, joints, rec_bytes, nullptr, nullptr, records, stream);
 }
 
 extern "C" int hn_unpack_records(const void* records, int rows, int joints, int rec_bytes, float* keypoints,

@@ -328,6 +328,27 @@ inline void out_size(int h, int w, int r, int s, int stride, int pad, int dil, i
 // descriptor of the graph carries it (0 = f16x3; 1 = the f16x1 throughput mode)
 thread_local int t_terms = 0;
 
+// hn_handnet_forward_xyz: the conversion the aggregation's epilogue performs for the forward being enqueued on this thread
+// (null: plain hn_a2j_aggregate_f32)
+struct ConvertReq {
+  const int64_t* crop_box;
+  const float* paras;
+  const hn_convert_opts* opts;
+  float* image_uvd;
+  float* xyz_mm;
+};
+thread_local const ConvertReq* t_convert = nullptr;
+
+int aggregate(Ctx& cx, const T& cls, const T& reg, const T& dep, const int32_t* valid, int k, float* keypoints) {
+  hn_model* m = cx.m;
+  if (t_convert)
+    return hn_a2j_aggregate_convert_f32((const float*)cls.p, (const float*)reg.p, (const float*)dep.p, valid, k, cls.h, cls.w,
+                                        m->cfg.num_joints, 16, t_convert->crop_box, (float)kCrop, (float)kCrop, t_convert->paras,
+                                        t_convert->opts, keypoints, t_convert->image_uvd, t_convert->xyz_mm, cx.stream);
+  return hn_a2j_aggregate_f32((const float*)cls.p, (const float*)reg.p, (const float*)dep.p, valid, k, cls.h, cls.w,
+                              m->cfg.num_joints, 16, keypoints, cx.stream);
+}
+
 hn_conv_desc make_desc(const T& x, const ConvW& cw, int relu_cols) {
   hn_conv_desc d;
   memset(&d, 0, sizeof(d));
@@ -537,8 +558,7 @@ int a2j_graph_f32(Ctx& cx, const T& crops /* fp32 [k][176][176][4] */, const int
   HN_TRY(conv32(cx, r, m->a_reg_out, 0, nullptr, false, nullptr, nullptr, 0, reg));
   HN_TRY(conv32(cx, dd, m->a_dep_out, 0, nullptr, false, nullptr, nullptr, 0, dep));
   if (cx.dry) return HN_OK;
-  return hn_a2j_aggregate_f32((const float*)cls.p, (const float*)reg.p, (const float*)dep.p, valid, k, cls.h, cls.w,
-                              m->cfg.num_joints, 16, keypoints, cx.stream);
+  return aggregate(cx, cls, reg, dep, valid, k, keypoints);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -616,8 +636,7 @@ int a2j_tail_small(Ctx& cx, T x, const int32_t* valid, float* keypoints) {
   io[1].x = dd; io[1].w = &m->a_dep_out; io[1].relu = false; io[1].out_split = false;
   HN_TRY(conv_multi(cx, io, 2));
   if (cx.dry) return HN_OK;
-  return hn_a2j_aggregate_f32((const float*)cls.p, (const float*)io[0].y.p, (const float*)io[1].y.p, valid, k, cls.h, cls.w,
-                              m->cfg.num_joints, 16, keypoints, cx.stream);
+  return aggregate(cx, cls, io[0].y, io[1].y, valid, k, keypoints);
 }
 
 // valid_rw: the per-crop flags when they are the model's own to update (hn_handnet_forward's has_hand: a crop with non-finite
@@ -694,8 +713,7 @@ int a2j_graph(Ctx& cx, const T& crops /* fp32 [k][176][176][4] */, const int32_t
   }
   HN_TRY(conv16(cx, r, m->a_reg_out, false, false, nullptr, false, reg));
   if (cx.dry) return HN_OK;
-  return hn_a2j_aggregate_f32((const float*)cls.p, (const float*)reg.p, (const float*)dep.p, valid, k, c.h, c.w,
-                              m->cfg.num_joints, 16, keypoints, cx.stream);
+  return aggregate(cx, cls, reg, dep, valid, k, keypoints);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1417,6 +1435,18 @@ extern "C" int hn_handnet_forward(hn_model* m, const float* rgb, const float* de
                             m->cfg.rgbd ? 1 : 0, h, w, kCrop, 4, crop_box, has_hand, (float*)crops.p, cx.stream));
     return a2j_graph(cx, crops, has_hand, keypoints, has_hand);
   });
+}
+
+extern "C" int hn_handnet_forward_xyz(hn_model* m, const float* rgb, const float* depth, int n, int h, int w, const float* paras,
+                                      const hn_convert_opts* opts, float* keypoints, float* image_uvd, float* xyz_mm,
+                                      int64_t* crop_box, int32_t* has_hand, void* stream) {
+  HN_CHECK_ARG(image_uvd || xyz_mm, "hn_handnet_forward_xyz: no converted output requested (use hn_handnet_forward)");
+  HN_CHECK_ARG(!xyz_mm || paras, "hn_handnet_forward_xyz: camera xyz needs the intrinsics (fx, fy, cx, cy)");
+  const ConvertReq req{crop_box, paras, opts, image_uvd, xyz_mm};
+  t_convert = &req;     // (this host thread's forward; the aggregation's launch reads it)
+  const int rc = hn_handnet_forward(m, rgb, depth, n, h, w, keypoints, crop_box, has_hand, stream);
+  t_convert = nullptr;
+  return rc;
 }
 
 extern "C" int hn_destroy(hn_model* m) {

@@ -82,7 +82,20 @@ class HandNet(EngineOwner):
         # never keep running a holder of stale ones
         if self._engine is None or self._engine.fcos is not fcos or self._engine.a2j is not a2j:
             self._engine = HandNetEngine(fcos, a2j, self.num_classes)
+            if getattr(self, "_convert_cfg", None) is not None:
+                self._engine.set_convert(*self._convert_cfg)
         return self._engine
+
+    def set_convert(self, paras=None, clamp: bool = False, on: bool = True):
+        """What the reference's caller does with every result (ros_demo.py:279-290,329-330: clamp, convert_joints to image
+        (u,v,d), uvd2xyz to camera millimetres) as part of the step: the aggregation's own launch writes them and the call's one
+        device -> host record carries them.  After each forward(): `net.last_converted` = {"image_uvd": [N,21,3] CPU,
+        "xyz_mm": [N,21,3] CPU or None (no intrinsics)}; forward()'s tuple itself is unchanged.  paras = (fx, fy, cx, cy)."""
+        self._convert_cfg = (paras, bool(clamp)) if on else None
+        if self._engine is not None:
+            self._engine.set_convert(paras, clamp, on)
+        self.last_converted = None
+        return self
 
     # forward() switches ITSELF to hipGraph replay once the same input shapes have come in a few times in a row -- the live
     # caller's case (ros_demo.py:270-273: one 640x480 frame per call, ~150 dependent launches whose host cost is 8 % of the
@@ -224,7 +237,11 @@ class HandNet(EngineOwner):
         crops_all = out.crop_box.clone()
         depth_all = (sel.permute(0, 3, 1, 2) if self.RGBD else sel[..., 0].unsqueeze(1)).contiguous()
         torch.cuda.current_stream(out.keypoints.device).synchronize()
-        final_results, has, _box, words = read_host_record(out.host_record, n, out.keypoints.shape[1])
+        if out.image_uvd is not None:
+            final_results, has, _box, words, more = read_host_record(out.host_record, n, out.keypoints.shape[1], extras=True)
+            self.last_converted = {"image_uvd": more[0], "xyz_mm": more[1] if len(more) > 1 else None}
+        else:
+            final_results, has, _box, words = read_host_record(out.host_record, n, out.keypoints.shape[1])
         mask_cpu = has != 0
         hands = int(mask_cpu.sum())
         self._last_sparse = n >= 8 and hands * 2 < n      # (the engine's own threshold for compaction)

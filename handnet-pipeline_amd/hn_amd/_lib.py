@@ -12,7 +12,7 @@ from pathlib import Path
 
 from . import build as _build
 
-ABI_VERSION = 32
+ABI_VERSION = 33
 
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, _TILE_RETIRED_5, TILE_64x128 = range(7)
 HN_FCOS_MAX_LEVELS = 5
@@ -46,6 +46,10 @@ class ConvMulti(C.Structure):  # == struct hn_conv_multi
     _fields_ = [("count", C.c_int32), ("desc", ConvDesc * CONV_MULTI_MAX), ("x16", C.c_void_p * CONV_MULTI_MAX),
                 ("w16", C.c_void_p * CONV_MULTI_MAX), ("bias", C.c_void_p * CONV_MULTI_MAX),
                 ("residual", C.c_void_p * CONV_MULTI_MAX), ("y", C.c_void_p * CONV_MULTI_MAX)]
+
+
+class ConvertOpts(C.Structure):  # == struct hn_convert_opts
+    _fields_ = [("clamp_keypoints", C.c_int32), ("clamp_box_h", C.c_int32), ("clamp_box_w", C.c_int32)]
 
 
 class ModelConfig(C.Structure):  # == struct hn_model_config
@@ -171,6 +175,7 @@ SIGNATURES = {
     "hn_groupnorm_finalize_rows32_levels": (C.c_int, [C.POINTER(GnLevels), VP, VP, C.c_int, C.c_int, C.c_int, C.c_float, VP]),
     "hn_affine_split_f32_levels": (C.c_int, [C.POINTER(SplitLevels)] + [C.c_int] * 6 + [VP]),
     "hn_pack_records": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP]),
+    "hn_pack_records_ex": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP]),
     "hn_unpack_records": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, VP]),
     "hn_nonfinite_count_f32": (C.c_int, [VP, C.c_int64, VP, VP]),
     "hn_conv3x3_thin_f16x3_levels": (C.c_int, [C.POINTER(ThinLevels), C.c_int, C.c_int, C.c_int, VP, VP, C.c_int, C.c_int, VP]),
@@ -179,6 +184,11 @@ SIGNATURES = {
                                                       VP, VP, C.c_int, VP]),
     "hn_conv3x3_thin_uses_flat": (C.c_int, [C.POINTER(ThinLevels), C.c_int, C.c_int, C.c_int]),
     "hn_convert_joints_f32": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_float, C.c_float, c_f32p, VP, VP]),
+    "hn_a2j_aggregate_convert_f32": (C.c_int, [VP, VP, VP, VP] + [C.c_int] * 5 + [VP, C.c_float, C.c_float, c_f32p,
+                                               C.POINTER(ConvertOpts), VP, VP, VP, VP]),
+    "hn_joints2d_standardize_f32": (C.c_int, [VP, VP, C.c_int, C.c_int, VP, VP]),
+    "hn_handnet_forward_xyz": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_int, c_f32p, C.POINTER(ConvertOpts),
+                                         VP, VP, VP, VP, VP, VP]),
 }
 
 _lock = threading.Lock()

@@ -231,11 +231,13 @@ class A2JEngine:
         return cls, reg, dep
 
     @ops.device_guarded
-    def forward_nhwc(self, x, valid=None, return_heads=False):
+    def forward_nhwc(self, x, valid=None, return_heads=False, convert=None):
+        """convert (ops.a2j_aggregate's dict: crop_box, paras, clamps): the aggregation's epilogue also writes image (u,v,d)
+        and camera xyz in mm -> returns (crop_uvd, image_uvd, xyz_mm or None) instead of crop_uvd alone."""
         with ops.f16_terms(self.terms):
             x3, x4 = self.trunk(x, valid)
             cls, reg, dep = self.heads(x3, x4)
-        out = ops.a2j_aggregate(cls, reg, dep, joints=self.joints, stride=16, valid=valid)
+        out = ops.a2j_aggregate(cls, reg, dep, joints=self.joints, stride=16, valid=valid, convert=convert)
         if return_heads:
             if ops.is_split(x3):
                 x3, x4 = ops.from_split(x3), ops.from_split(x4)

@@ -1,0 +1,113 @@
+"""The live caller's whole chain as ONE captured step (ros_demo.py:270-290,329-337):
+
+    HandNet (FCOS -> crop -> A2J)                                  handnet_pipeline.py:58-116
+      -> clamp + convert_joints: image (u,v), camera xyz in mm     ros_demo.py:279-283,329-330 -- the aggregation's epilogue
+      -> the lifter's input (bbox / affine / standardisation)      ros_demo.py:148-157        -- hn_joints2d_standardize_f32
+      -> Pose2Mesh (PoseNet MLP + Chebyshev graph convolutions)    ros_demo.py:161, pose2mesh/lib/models/*
+      -> ONE device -> host copy: the wide per-frame records (crop box, flags, crop uvd, image uvd, xyz) + the mesh vertices
+
+Everything between the frame and the copy is a static launch sequence on the device: one hipGraph, no host round trip between
+the pose network and the lifter (the reference copies the keypoints to the CPU, converts them in numpy and uploads the
+normalised joints again, per frame).  What stays the caller's: the vertex permutation / camera offset of the final mesh
+(`pred_mesh[:, graph_perm_reverse[:V]]`, `mesh * 1000 + joints3d[0]`, ros_demo.py:162,332-337) -- the step hands over what
+`model(joint_img)` and `convert_joints` return.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+
+from . import ops
+from .pipeline import HandNetEngine, HandNetOutput, read_host_record, record_bytes
+from .pose2mesh_engine import Pose2MeshEngine
+
+
+@dataclass
+class LiveOutput:
+    hand: HandNetOutput          # the step's detector / pose results (image_uvd and xyz_mm included), on the device
+    pose2d: torch.Tensor         # [N,21,2] the lifter's standardised input
+    mesh: torch.Tensor           # [N,V0,3] Pose2Mesh vertices (finest level of the graph hierarchy, coarsening order)
+    pose3d: torch.Tensor         # [N,21,3] PoseNet's lifted joints (millimetre scale of the lifter's training set)
+    host: torch.Tensor           # pinned uint8: (N + 1) wide records, then the mesh as fp32 -- ONE copy, enqueued by the step
+    n: int = 0
+
+    def read(self):
+        """After the stream is synchronised: (keypoints, has_hand, crop_box, range words, [image_uvd, xyz_mm], mesh) as fresh CPU
+        tensors."""
+        rb = record_bytes(3)
+        n = self.n
+        rec = self.host[: (n + 1) * rb].view(n + 1, rb)
+        kp, has, box, words, more = read_host_record(rec, n, extras=True)
+        mesh = self.host[(n + 1) * rb:].view(torch.float32).reshape(n, -1, 3).clone()
+        return kp, has, box, words, more, mesh
+
+
+class LiveHandEngine:
+    def __init__(self, hand: HandNetEngine, lifter: Pose2MeshEngine, paras, clamp: bool = True):
+        """paras = (fx, fy, cx, cy) of the depth camera (ros_demo.py:191-196); clamp: the caller's clamps before the
+        conversion (ros_demo.py:279-283)."""
+        if hand.device != lifter.device:
+            raise ValueError(f"HandNet on {hand.device} but the lifter on {lifter.device}")
+        self.hand, self.lifter, self.device = hand, lifter, hand.device
+        hand.set_convert(paras=paras, clamp=clamp)
+        self._graphs = {}
+        self._buffers = {}
+
+    def _out_buffers(self, n, v0):
+        key = (n, v0)
+        b = self._buffers.get(key)
+        if b is None:
+            rb = record_bytes(3)
+            nbytes = (n + 1) * rb + n * v0 * 12
+            with torch.inference_mode(False):
+                b = self._buffers[key] = (torch.zeros((nbytes,), dtype=torch.uint8, device=self.device),
+                                          torch.zeros((nbytes,), dtype=torch.uint8, pin_memory=True))
+        return b
+
+    @ops.device_guarded
+    def forward_device(self, images, depth, _buffers=None) -> LiveOutput:
+        """images [N,3,H,W] 0..1 (or a list), depth [N,1,H,W] metres on the GPU -> LiveOutput (no sync)."""
+        out = self.hand.forward_device(images, depth)
+        n = out.keypoints.shape[0]
+        p2d = ops.joints2d_standardize(out.image_uvd, valid=out.has_hand)
+        mesh, pose3d = self.lifter.forward(p2d)
+        v0 = mesh.shape[1]
+        dev, host = _buffers if _buffers is not None else self._out_buffers(n, v0)
+        rb = record_bytes(3)
+        rec = dev[: (n + 1) * rb].view(n + 1, rb)
+        ops.pack_records(out.keypoints, out.crop_box, out.has_hand, n + 1, rb, out=rec, extras=(out.image_uvd, out.xyz_mm))
+        if out.range_flags is not None:
+            rec[n, :16].view(torch.int32).copy_(out.range_flags)
+        dev[(n + 1) * rb:].view(torch.float32).view(n, v0, 3).copy_(mesh)
+        host.copy_(dev, non_blocking=True)
+        return LiveOutput(out, p2d, mesh, pose3d, host, n)
+
+    @ops.device_guarded
+    def graphed(self, images: torch.Tensor, depth: torch.Tensor):
+        """(run, static images, static depth, static LiveOutput): copy new frames into the static inputs and call run()."""
+        key = (tuple(images.shape), tuple(depth.shape))
+        hit = self._graphs.get(key)
+        if hit is None:
+            with torch.inference_mode(False), torch.no_grad():
+                s_img, s_dep = torch.empty_like(images), torch.empty_like(depth)
+                s_img.copy_(images)
+                s_dep.copy_(depth)
+                n = images.shape[0]
+                v0 = self.lifter.graphs[0].v
+                nbytes = (n + 1) * record_bytes(3) + n * v0 * 12
+                bufs = (torch.zeros((nbytes,), dtype=torch.uint8, device=self.device),
+                        torch.zeros((nbytes,), dtype=torch.uint8, pin_memory=True))
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with ops.launch_cost_hidden():
+                    with torch.cuda.stream(side):
+                        for _ in range(2):
+                            self.forward_device(s_img, s_dep, _buffers=bufs)
+                    torch.cuda.current_stream().wait_stream(side)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        out = self.forward_device(s_img, s_dep, _buffers=bufs)
+            hit = self._graphs[key] = (g, s_img, s_dep, out)
+        g, s_img, s_dep, out = hit
+        return g.replay, s_img, s_dep, out

@@ -1179,8 +1179,13 @@ def pack_depth_nhwc(depth, cpad=4, out=None):
     return out
 
 
-def a2j_aggregate(cls, reg, dep, joints=21, stride=16, valid=None, out=None):
-    """cls/dep [K,fh,fw,16*J], reg [K,fh,fw,16*J*2] -> [K,J,3]."""
+def a2j_aggregate(cls, reg, dep, joints=21, stride=16, valid=None, out=None, convert=None):
+    """cls/dep [K,fh,fw,16*J], reg [K,fh,fw,16*J*2] -> [K,J,3].
+    convert: optional dict -- convert_joints + uvd2xyz in the SAME launch (hn_a2j_aggregate_convert_f32):
+      crop_box [K,4] int64 (the boxes the crops were cut with), paras = (fx, fy, cx, cy) or None, crop = 176,
+      clamp_keypoints / clamp_box = (H, W): the live caller's clamps (ros_demo.py:279-283),
+      image_uvd / xyz_mm: preallocated outputs (optional).
+    Then returns (crop_uvd, image_uvd [K,J,3], xyz_mm [K,J,3] or None), bit-identical to convert_joints() on crop_uvd."""
     lib = _lib.load()
     _req(cls, name="cls"); _req(reg, name="reg"); _req(dep, name="dep")
     k, fh, fw, aj = cls.shape
@@ -1192,8 +1197,44 @@ def a2j_aggregate(cls, reg, dep, joints=21, stride=16, valid=None, out=None):
         return out
     if valid is not None:
         _req(valid, torch.int32, "valid")
+    if convert is not None:
+        box = _req(convert["crop_box"], torch.int64, "crop_box")
+        if tuple(box.shape) != (k, 4):
+            raise ValueError("crop_box must be [K,4]")
+        paras = convert.get("paras")
+        img = convert.get("image_uvd")
+        xyz = convert.get("xyz_mm")
+        if img is None:
+            img = torch.empty((k, joints, 3), device=cls.device, dtype=torch.float32)
+        if xyz is None and paras is not None:
+            xyz = torch.empty((k, joints, 3), device=cls.device, dtype=torch.float32)
+        pp = (C.c_float * 4)(*[float(v) for v in paras]) if paras is not None else None
+        opts = None
+        cb = convert.get("clamp_box")
+        if convert.get("clamp_keypoints") or cb:
+            opts = _lib.ConvertOpts(1 if convert.get("clamp_keypoints") else 0, int(cb[0]) if cb else 0, int(cb[1]) if cb else 0)
+        crop = float(convert.get("crop", 176))
+        check(lib.hn_a2j_aggregate_convert_f32(ptr(cls), ptr(reg), ptr(dep), ptr(valid), k, fh, fw, joints, stride, ptr(box),
+                                               crop, crop, pp, C.byref(opts) if opts is not None else None, ptr(out), ptr(img),
+                                               ptr(xyz), _stream()), "hn_a2j_aggregate_convert_f32")
+        return out, img, xyz
     check(lib.hn_a2j_aggregate_f32(ptr(cls), ptr(reg), ptr(dep), ptr(valid), k, fh, fw, joints, stride, ptr(out),
                                    _stream()), "hn_a2j_aggregate_f32")
+    return out
+
+
+def joints2d_standardize(image_uvd, valid=None, out=None):
+    """image (u,v,d) joints [N,J,3] -> the lifter's input [N,J,2]: per frame and axis (x - mean) / std over the joints
+    (hn_joints2d_standardize_f32 = the live caller's bbox / affine / normalisation chain, ros_demo.py:148-157, which reduces
+    to exactly this when there is no rotation); rows with valid != 1 are zeros."""
+    _req(image_uvd, name="image_uvd")
+    n, j, _ = image_uvd.shape
+    if out is None:
+        out = torch.empty((n, j, 2), device=image_uvd.device, dtype=torch.float32)
+    if valid is not None:
+        _req(valid, torch.int32, "valid")
+    check(_lib.load().hn_joints2d_standardize_f32(ptr(image_uvd), ptr(valid), n, j, ptr(out), _stream()),
+          "hn_joints2d_standardize_f32")
     return out
 
 
@@ -1216,12 +1257,23 @@ def convert_joints(kp, crop_box, valid=None, paras=None, crop=176, out=None):
     return out
 
 
-def pack_records(kp, crop_box, has_hand, rows, rec_bytes, out=None):
-    """One step's per-frame results -> [rows, rec_bytes] uint8 records (rows >= frames: shard padding is zero rows)."""
+def pack_records(kp, crop_box, has_hand, rows, rec_bytes, out=None, extras=()):
+    """One step's per-frame results -> [rows, rec_bytes] uint8 records (rows >= frames: shard padding is zero rows).
+    extras: up to two more [N,J,3] fp32 fields behind the keypoints (image uvd, camera xyz: the wide record)."""
     _req(kp, name="keypoints"); _req(crop_box, torch.int64, "crop_box"); _req(has_hand, torch.int32, "has_hand")
     n, j = kp.shape[0], kp.shape[1]
     if out is None:
         out = torch.empty((rows, rec_bytes), device=kp.device, dtype=torch.uint8)
+    extras = [e for e in extras if e is not None]
+    if extras:
+        for e in extras:
+            _req(e, name="extra")
+            if e.shape != kp.shape:
+                raise ValueError("extra fields must have the keypoints' shape")
+        e0, e1 = extras[0], (extras[1] if len(extras) > 1 else None)
+        check(_lib.load().hn_pack_records_ex(ptr(kp), ptr(crop_box), ptr(has_hand), n, rows, j, rec_bytes, ptr(e0), ptr(e1),
+                                             ptr(out), _stream()), "hn_pack_records_ex")
+        return out
     check(_lib.load().hn_pack_records(ptr(kp), ptr(crop_box), ptr(has_hand), n, rows, j, rec_bytes, ptr(out), _stream()),
           "hn_pack_records")
     return out

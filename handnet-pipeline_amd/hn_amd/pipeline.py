@@ -31,25 +31,40 @@ class HandNetOutput:
     detections: ops.Detections
     candidates: ops.Candidates   # rows at or beyond count[i] are undefined (never zero-filled)
     range_flags: torch.Tensor = None   # [4] int32 device: the step's f16x3 range-contract words (ops.range_bits), or None
+    image_uvd: torch.Tensor = None     # [N,21,3] fp32 device, after HandNetEngine.set_convert(): image (u,v,d) per joint
+    xyz_mm: torch.Tensor = None        # [N,21,3] fp32 device, set_convert(paras=...): camera xyz in millimetres
     host_record: torch.Tensor = None   # to_host steps: PINNED uint8 [N+1, 296] the step copies its results into (device -> host
     #                                    copy enqueued by the step itself; valid after the stream is synchronised): rows 0..N-1 =
     #                                    hn_pack_records rows (crop box 32 B | has_hand | 1 | keypoints), row N = the range words
 
 
 RECORD_BYTES = 296      # hn_amd.dist's per-frame record (box 32 + flags 8 + 21 x 3 fp32 keypoints, padded to 8)
+RECORD_FIELD = 252      # one [21,3] fp32 field; the WIDE record of a converting step appends image (u,v,d) and camera xyz
 
 
-def read_host_record(rec: torch.Tensor, n: int, joints: int = 21):
+def record_bytes(fields: int = 1) -> int:
+    return (40 + RECORD_FIELD * fields + 7) // 8 * 8
+
+
+def read_host_record(rec: torch.Tensor, n: int, joints: int = 21, extras: bool = False):
     """A synchronised host_record -> (keypoints [n,J,3] fp32, has_hand [n] int32, crop_box [n,4] int64, range words [4] list);
     all fresh CPU tensors (the pinned buffer is overwritten by the engine's next step).  numpy slicing: a handful of torch
-    ops on 300-byte tensors would cost more host time than the copy itself (batch 1: the call is 2.3 ms in all)."""
+    ops on 300-byte tensors would cost more host time than the copy itself (batch 1: the call is 2.3 ms in all).
+    extras: also the further [n,J,3] fields of a wide record (image uvd, camera xyz) as a list, appended to the tuple."""
     import numpy as np
     a = rec.numpy()
     j3 = joints * 3
     kp = torch.from_numpy(np.ascontiguousarray(a[:n, 40:40 + 4 * j3]).view(np.float32).reshape(n, joints, 3))
     has = torch.from_numpy(np.ascontiguousarray(a[:n, 32:36]).view(np.int32).reshape(n))
     box = torch.from_numpy(np.ascontiguousarray(a[:n, :32]).view(np.int64).reshape(n, 4))
-    return kp, has, box, a[n, :16].view(np.int32).tolist()
+    words = a[n, :16].view(np.int32).tolist()
+    if not extras:
+        return kp, has, box, words
+    more = []
+    for f in range(1, (a.shape[1] - 40) // (4 * j3)):
+        lo = 40 + 4 * j3 * f
+        more.append(torch.from_numpy(np.ascontiguousarray(a[:n, lo:lo + 4 * j3]).view(np.float32).reshape(n, joints, 3)))
+    return kp, has, box, words, more
 
 
 def range_message(bits: int) -> str:
@@ -134,6 +149,31 @@ class HandNetEngine:
         self.compact_sparse = os.environ.get("HN_COMPACT_SPARSE", "1") != "0"
         self._hand_stat = None      # (event, pinned count tensor, frames) of the last eager step
         self._sparse_hint = False
+        self._convert = None        # set_convert(): the aggregation's epilogue also writes image (u,v,d) / camera xyz
+
+    def set_convert(self, paras=None, clamp: bool = False, on: bool = True):
+        """convert_joints + uvd2xyz as part of the step (a2j/a2j.py:17-43, what ros_demo.py:289,329-330 does with
+        every result): HandNetOutput.image_uvd, and .xyz_mm when the camera intrinsics paras = (fx, fy, cx, cy) are given, are
+        written by the aggregation's own launch, and to_host steps carry them in a wide record.  clamp: the live caller's
+        clamps before the conversion (keypoints to [0, 176], box to the frame: ros_demo.py:279-283).  Captured steps are
+        dropped (their launch sequence changes)."""
+        self._convert = None if not on else {"paras": None if paras is None else tuple(float(v) for v in paras), "clamp": bool(clamp)}
+        self._graphs.clear()
+        self._host_records.clear()
+        return self
+
+    def _convert_spec(self, crop_box, frame_hw):
+        c = self._convert
+        if c is None:
+            return None
+        spec = {"crop_box": crop_box, "paras": c["paras"], "crop": CROP}
+        if c["clamp"]:
+            spec.update(clamp_keypoints=True, clamp_box=frame_hw)
+        return spec
+
+    def _fields(self) -> int:
+        c = self._convert
+        return 1 if c is None else (3 if c["paras"] is not None else 2)
 
     @ops.device_guarded
     def forward_device(self, images, depth: torch.Tensor, to_host: bool = False, _record=None) -> HandNetOutput:
@@ -153,14 +193,18 @@ class HandNetEngine:
             det, cand = self.fcos.detect(images)
             crop_box, has_hand, crops = ops.crop_resize(det, self.num_classes - 1, depth.float().contiguous(), CROP, 4,
                                                         reorder_bgr=self.a2j.rgbd)
-            kp = self._a2j_sparse(crops, has_hand) if self._use_compaction(len(images)) else None
+            conv = self._convert_spec(crop_box, tuple(depth.shape[-2:]))
+            kp = self._a2j_sparse(crops, has_hand, conv) if self._use_compaction(len(images)) else None
             if kp is None:
-                kp = self.a2j.forward_nhwc(crops, valid=has_hand)
+                kp = self.a2j.forward_nhwc(crops, valid=has_hand, convert=conv)
+            img_uvd = xyz = None
+            if conv is not None:
+                kp, img_uvd, xyz = kp
             host_rec = None
             if to_host or _record is not None:
                 n = len(images)
                 host_rec, dev_rec = _record if _record is not None else self._host_record_buffers(n)
-                ops.pack_records(kp, crop_box, has_hand, n + 1, RECORD_BYTES, out=dev_rec)       # (row n: zeros)
+                ops.pack_records(kp, crop_box, has_hand, n + 1, dev_rec.shape[1], out=dev_rec, extras=(img_uvd, xyz))   # (row n: zeros)
                 flags = ops.range_check_collect(self._range_block, out=dev_rec[n, :16].view(torch.int32)) if noting else None
                 host_rec.copy_(dev_rec, non_blocking=True)
             else:
@@ -170,7 +214,7 @@ class HandNetEngine:
             bits = ops.range_bits(flags.cpu().tolist())
             if bits:
                 raise ops.RangeError(range_message(bits))
-        return HandNetOutput(kp, crops, crop_box, has_hand, det, cand, flags, host_rec)
+        return HandNetOutput(kp, crops, crop_box, has_hand, det, cand, flags, img_uvd, xyz, host_rec)
 
     # -------------------------------------------------------------------------------
     # sparse streams: A2J on the frames with a hand only
@@ -194,20 +238,27 @@ class HandNetEngine:
         ev.record()
         self._hand_stat = (ev, pinned, n)
 
-    def _a2j_sparse(self, crops, has_hand):
-        """A2J on the frames with a hand only (one device -> host sync for the count); None = not sparse after all."""
+    def _a2j_sparse(self, crops, has_hand, conv=None):
+        """A2J on the frames with a hand only (one device -> host sync for the count); None = not sparse after all.
+        conv: the step's conversion spec -> (crop uvd, image uvd, xyz or None), zero rows for the frames without a hand."""
         n = has_hand.shape[0]
         idx = torch.nonzero(has_hand, as_tuple=False).flatten()      # synchronises
         k = int(idx.numel())
         if k * 2 >= n:
             self._sparse_hint = False
             return None
-        kp = torch.zeros((n, self.a2j.joints, 3), device=crops.device, dtype=torch.float32)
+        fields = 1 if conv is None else (3 if conv["paras"] is not None else 2)
+        outs = [torch.zeros((n, self.a2j.joints, 3), device=crops.device, dtype=torch.float32) for _ in range(fields)]
         if k:
             v = has_hand[idx].contiguous()
-            kp[idx] = self.a2j.forward_nhwc(crops[idx].contiguous(), valid=v)
+            sub = None if conv is None else dict(conv, crop_box=conv["crop_box"][idx].contiguous())
+            res = self.a2j.forward_nhwc(crops[idx].contiguous(), valid=v, convert=sub)
+            for o, r in zip(outs, res if conv is not None else (res,)):
+                o[idx] = r
             has_hand[idx] = v       # (the stem raises a flag to 2 for a crop with non-finite pixels: report it like the dense path)
-        return kp
+        if conv is None:
+            return outs[0]
+        return outs[0], outs[1], (outs[2] if fields == 3 else None)
 
     # -------------------------------------------------------------------------------
     # hipGraph replay for a fixed batch shape (launch-bound at small batch)
@@ -216,8 +267,9 @@ class HandNetEngine:
         buf = self._host_records.get(n)
         if buf is None:
             with torch.inference_mode(False):   # ordinary tensors: written in place by later calls in any mode
-                buf = self._host_records[n] = (torch.zeros((n + 1, RECORD_BYTES), dtype=torch.uint8, pin_memory=True),
-                                               torch.zeros((n + 1, RECORD_BYTES), dtype=torch.uint8, device=self.device))
+                rb = record_bytes(self._fields())
+                buf = self._host_records[n] = (torch.zeros((n + 1, rb), dtype=torch.uint8, pin_memory=True),
+                                               torch.zeros((n + 1, rb), dtype=torch.uint8, device=self.device))
         return buf
 
     @ops.device_guarded
@@ -343,8 +395,9 @@ class HandNetEngine:
         record = None
         if to_host:     # the capture's own record buffers (addresses are baked into the graph)
             n = images.shape[0]
-            record = (torch.zeros((n + 1, RECORD_BYTES), dtype=torch.uint8, pin_memory=True),
-                      torch.zeros((n + 1, RECORD_BYTES), dtype=torch.uint8, device=self.device))
+            rb = record_bytes(self._fields())
+            record = (torch.zeros((n + 1, rb), dtype=torch.uint8, pin_memory=True),
+                      torch.zeros((n + 1, rb), dtype=torch.uint8, device=self.device))
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with ops.launch_cost_hidden():

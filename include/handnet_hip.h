@@ -33,7 +33,7 @@ extern "C" {
 #define HN_ERR_HIP 2
 
 /* ABI version; bumped whenever a struct below changes. */
-#define HN_ABI_VERSION 32
+#define HN_ABI_VERSION 33
 int hn_abi_version(void);
 const char* hn_last_error(void);
 
@@ -525,6 +525,33 @@ int hn_convert_joints_f32(const float* kp, const int64_t* crop_box, const int32_
                           int n, int joints, float crop_w, float crop_h,
                           const float* paras /* host, 4 floats, or NULL */, float* out, void* stream);
 
+/* The aggregation with convert_joints + uvd2xyz in its EPILOGUE: what hn_a2j_aggregate_f32 writes to out_uvd,
+ * plus -- from the registers that hold each joint, no second launch -- its image (u,v,d) (out_image_uvd, or NULL) and its
+ * camera xyz in millimetres (out_xyz_mm, or NULL; needs paras = host array (fx, fy, cx, cy)), each [k][J][3]: bit-identical
+ * to hn_convert_joints_f32 on out_uvd (one device function serves both).  crop_box [k][4] int64 = the padded crop boxes the
+ * crops were cut with (hn_crop_resize).  Rows with valid[k] == 0 are zeros in all outputs, rows with valid[k] == 2 NaN.
+ * opts (host, or NULL = none): the live caller's two clamps BEFORE the conversion, which it applies to the values it converts
+ * (ros_demo.py:279-283) -- they touch the converted outputs only, out_uvd stays what the network returned:
+ *   clamp_keypoints  1: the crop-(u,v,d) is clamped to [0, crop_w] (torch.clamp(keypoint_pred, 0, 176), all three columns)
+ *   clamp_box_h / _w > 0: box x1,y1 are clamped to [0, clamp_box_h] and x2,y2 to [0, clamp_box_w] (as written there:
+ *                    detection[:2] against the image HEIGHT, detection[2:] against the WIDTH) */
+typedef struct hn_convert_opts {
+  int32_t clamp_keypoints;
+  int32_t clamp_box_h, clamp_box_w;
+} hn_convert_opts;
+int hn_a2j_aggregate_convert_f32(const float* cls, const float* reg, const float* dep, const int32_t* valid, int k, int fh,
+                                 int fw, int joints, int stride, const int64_t* crop_box, float crop_w, float crop_h,
+                                 const float* paras /* host, 4 floats, or NULL */, const hn_convert_opts* opts /* host or NULL */,
+                                 float* out_uvd, float* out_image_uvd, float* out_xyz_mm, void* stream);
+
+/* The lifter's input from a step's image-(u,v) joints (the live caller's glue between the path and Pose2Mesh,
+ * ros_demo.py:148-157: get_bbox -> process_bbox -> j2d_processing (rot 0, no flip) -> / input_shape -> (x - mean) / std):
+ * with no rotation that chain is a per-axis POSITIVE affine map followed by a per-axis standardisation over the J joints,
+ * which cancels the map -- so the result is (x - mean_J(x)) / std_J(x) per frame and axis (population std, numpy's default).
+ * image_uvd [n][J][3] (columns 0, 1 are read) -> out [n][J][2] fp32; rows with valid[i] != 1 are zeros. */
+int hn_joints2d_standardize_f32(const float* image_uvd, const int32_t* valid /* or NULL */, int n, int joints, float* out,
+                                void* stream);
+
 /* Per-frame result records for the N > 1 all-gather (ONE collective of fixed-size records per step).
  * Record layout (rec_bytes >= 40 + 12*joints, multiple of 8): bytes 0..31 crop box 4 x int64, 32..35 has_hand,
  * 36..39 row-is-a-real-frame, 40.. keypoints joints*3 x fp32.  hn_pack_records writes rows [0, n) from the three
@@ -532,6 +559,12 @@ int hn_convert_joints_f32(const float* kp, const int64_t* crop_box, const int32_
  * (valid[r] = the row flag).  One launch each, so a step adds pack + collective + unpack to the engine's launches. */
 int hn_pack_records(const float* keypoints, const int64_t* crop_box, const int32_t* has_hand, int n, int rows,
                     int joints, int rec_bytes, void* records, void* stream);
+/* Wide records: up to two more [n][joints][3] fp32 fields behind the keypoints (the step's image (u,v,d) and camera xyz in mm,
+ * hn_a2j_aggregate_convert_f32): bytes 40 + 12*joints .. and 40 + 24*joints ..; rec_bytes >= 40 + 12*joints per field.
+ * hn_unpack_records reads the first field of records of any width. */
+int hn_pack_records_ex(const float* keypoints, const int64_t* crop_box, const int32_t* has_hand, int n, int rows, int joints,
+                       int rec_bytes, const float* extra0 /* or NULL */, const float* extra1 /* or NULL */, void* records,
+                       void* stream);
 int hn_unpack_records(const void* records, int rows, int joints, int rec_bytes, float* keypoints,
                       int64_t* crop_box, int32_t* has_hand, int32_t* valid, void* stream);
 
@@ -578,7 +611,7 @@ int hn_feat_interp_add_f32(const float* xin, const float* y, float* out, int64_t
  *                      det_level [n][cap], det_count [n]
  *   hn_a2j_forward     a2j/a2j.py:243-250: crops [k][1][h][w] fp32 metres -> keypoints [k][J][3] (u, v, d) on the
  *                      device (the reference's .cpu() is the caller's copy); rows with valid[i] == 0 are zeros
- *   hn_handnet_forward handnet_pipeline/handnet_pipeline.py:58-116: rgb [n][3][h][w] + depth [n][1][h][w] (RGB-D
+ *   hn_handnet_forward(_xyz) handnet_pipeline/handnet_pipeline.py:58-116: rgb [n][3][h][w] + depth [n][1][h][w] (RGB-D
  *                      model: [n][4][h][w]) -> keypoints [n][J][3], crop_box [n][4] int64 (padded, clamped
  *                      x1,y1,x2,y2), has_hand [n]; frames without a hand give zero rows (deviations)
  * All tensors are device pointers borrowed from the caller; work is enqueued on `stream`.  Activations live in one
@@ -634,6 +667,13 @@ int hn_a2j_forward(hn_model* m, const float* crops, int k, int h, int w, const i
                    float* keypoints, void* stream);
 int hn_handnet_forward(hn_model* m, const float* rgb, const float* depth, int n, int h, int w, float* keypoints,
                        int64_t* crop_box, int32_t* has_hand, void* stream);
+/* hn_handnet_forward + what the reference's caller computes from its results right away (ros_demo.py:289,329-330;
+ * a2j/a2j.py:17-43): image (u,v,d) and / or camera xyz in mm per joint, written by the aggregation's epilogue
+ * (hn_a2j_aggregate_convert_f32) -- same launches as hn_handnet_forward.  image_uvd / xyz_mm [n][J][3] device, either may be
+ * NULL (not both); paras (host: fx, fy, cx, cy) is needed for xyz_mm; opts as in hn_a2j_aggregate_convert_f32. */
+int hn_handnet_forward_xyz(hn_model* m, const float* rgb, const float* depth, int n, int h, int w, const float* paras,
+                           const hn_convert_opts* opts, float* keypoints, float* image_uvd, float* xyz_mm, int64_t* crop_box,
+                           int32_t* has_hand, void* stream);
 int hn_destroy(hn_model* m);
 
 #ifdef __cplusplus

@@ -108,3 +108,89 @@ def pose2mesh_forward(pose2d, sd, graphs):
         pose3d = posenet(pose2d.reshape(B, -1), sd).reshape(-1, J, 3)
         comb = torch.cat((pose2d, pose3d / 1000), dim=2)
         return meshnet(comb, sd, graphs), pose3d
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The live caller's glue between the pose network and the lifter (ros_demo.py:148-157), restated function by function.
+# cv2.getAffineTransform (absent from this image) is the exact solution of the three-point correspondence: numpy solves it.
+# ---------------------------------------------------------------------------------------------------------------------------
+INPUT_SHAPE = (384, 288)    # cfg.MODEL.input_shape, pose2mesh/lib/core/config.py:52
+
+
+def get_bbox(joint_img):
+    """pose2mesh/lib/coord_utils.py:21-40"""
+    import numpy as np
+    x_img, y_img = joint_img[:, 0], joint_img[:, 1]
+    xmin, ymin, xmax, ymax = min(x_img), min(y_img), max(x_img), max(y_img)
+    x_center = (xmin + xmax) / 2.
+    width = xmax - xmin
+    xmin, xmax = x_center - 0.5 * width, x_center + 0.5 * width
+    y_center = (ymin + ymax) / 2.
+    height = ymax - ymin
+    ymin, ymax = y_center - 0.5 * height, y_center + 0.5 * height
+    return np.array([xmin, ymin, xmax - xmin, ymax - ymin]).astype(np.float32)
+
+
+def process_bbox(bbox, aspect_ratio=None, scale=1.0):
+    """pose2mesh/lib/coord_utils.py:42-66"""
+    import numpy as np
+    x, y, w, h = bbox
+    x1, y1, x2, y2 = x, y, x + (w - 1), y + (h - 1)
+    if w * h > 0 and x2 >= x1 and y2 >= y1:
+        bbox = np.array([x1, y1, x2 - x1, y2 - y1])
+    else:
+        return None
+    w, h = bbox[2], bbox[3]
+    c_x, c_y = bbox[0] + w / 2., bbox[1] + h / 2.
+    if aspect_ratio is None:
+        aspect_ratio = INPUT_SHAPE[1] / INPUT_SHAPE[0]
+    if w > aspect_ratio * h:
+        h = w / aspect_ratio
+    elif w < aspect_ratio * h:
+        w = h * aspect_ratio
+    bbox[2], bbox[3] = w * scale, h * scale
+    bbox[0], bbox[1] = c_x - bbox[2] / 2., c_y - bbox[3] / 2.
+    return bbox
+
+
+def _affine_transform_rot0(center, scale, output_size):
+    """pose2mesh/lib/aug_utils.py:140-173 with rot = 0, shift = 0, inv = 0"""
+    import numpy as np
+    src_w, dst_w, dst_h = scale[0], output_size[0], output_size[1]
+    src_dir = [0.0, src_w * -0.5]                       # get_dir at rot_rad = 0 (:188-195)
+    dst_dir = np.array([0, dst_w * -0.5], np.float32)
+    src = np.zeros((3, 2), dtype=np.float32)
+    dst = np.zeros((3, 2), dtype=np.float32)
+    src[0, :] = center
+    src[1, :] = center + np.array(src_dir, dtype=np.float32)
+    dst[0, :] = [dst_w * 0.5, dst_h * 0.5]
+    dst[1, :] = np.array([dst_w * 0.5, dst_h * 0.5]) + dst_dir
+    third = lambda a, b: b + np.array([-(a - b)[1], (a - b)[0]], dtype=np.float32)     # get_3rd_point (:182-184)
+    src[2, :] = third(src[0, :], src[1, :])
+    dst[2, :] = third(dst[0, :], dst[1, :])
+    a = np.concatenate([src.astype(np.float64), np.ones((3, 1))], axis=1)             # [x y 1] T^t = [x' y']
+    return np.linalg.solve(a, dst.astype(np.float64)).T                                # 2 x 3, as cv2.getAffineTransform returns
+
+
+def lifter_input(joint_input):
+    """ros_demo.py:148-157 (predict_mesh up to the model call): image-(u,v) joints [J,2] -> the standardised [J,2] the lifter
+    is fed, or None when the caller would skip the frame (process_bbox rejects the box)."""
+    import numpy as np
+    joint_input = np.asarray(joint_input, dtype=np.float32)
+    bbox = get_bbox(joint_input)
+    bbox2 = process_bbox(bbox.copy())
+    if bbox2 is None:
+        return None
+    # j2d_processing(joint_input.copy(), (input_shape[1], input_shape[0]), bbox2, 0, 0, None)  (aug_utils.py:51-64)
+    center = np.zeros((2,), dtype=np.float32)                                          # get_center_scale (coord_utils.py:7-18)
+    center[0], center[1] = bbox2[0] + bbox2[2] * 0.5, bbox2[1] + bbox2[3] * 0.5
+    scale = np.array([bbox2[2] * 1.0, bbox2[3] * 1.0], dtype=np.float32)
+    trans = _affine_transform_rot0(center, scale, (INPUT_SHAPE[1], INPUT_SHAPE[0]))
+    kp = joint_input.copy()
+    for i in range(kp.shape[0]):
+        kp[i, :2] = np.dot(trans, np.array([kp[i, 0], kp[i, 1], 1.]).T)[:2]            # affine_transform (:176-179)
+    kp = kp.astype("float32")
+    joint_img = kp[:, :2]
+    joint_img /= np.array([[INPUT_SHAPE[1], INPUT_SHAPE[0]]])
+    mean, std = np.mean(joint_img, axis=0), np.std(joint_img, axis=0)
+    return ((joint_img.copy() - mean) / std).astype(np.float32)

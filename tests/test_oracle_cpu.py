@@ -278,3 +278,24 @@ def test_fpn_top_down_matches_hand_written_fp64_loops(fcos_sd):
     for i in range(3):
         assert got[i].shape == want[i].shape
         assert (got[i].double() - want[i]).abs().max().item() < 1e-4 * max(1.0, want[i].abs().max().item())
+
+
+def test_lifter_input_chain_is_a_per_axis_standardisation():
+    """oracle.pose2mesh_ref.lifter_input restates ros_demo.py:148-157 function by function (get_bbox, process_bbox,
+    j2d_processing's affine map at rot 0, / input_shape, (x - mean) / std).  With no rotation that chain is a per-axis positive
+    affine map followed by a per-axis standardisation, which cancels the map: it equals (x - mean) / std of the image joints
+    to the chain's own fp32 rounding -- what hn_joints2d_standardize_f32 computes on the device."""
+    import numpy as np
+    from oracle import pose2mesh_ref
+    rng = np.random.default_rng(0)
+    worst = 0.0
+    for _ in range(100):
+        j = (rng.uniform(50, 600, 2) + rng.normal(size=(21, 2)) * rng.uniform(5, 150, 2)).astype(np.float32)
+        a = pose2mesh_ref.lifter_input(j)
+        j64 = j.astype(np.float64)
+        worst = max(worst, float(np.abs(a - (j64 - j64.mean(0)) / j64.std(0)).max()))
+    assert worst < 3e-5
+    assert pose2mesh_ref.lifter_input(np.full((21, 2), 7.0, dtype=np.float32)) is None    # degenerate box: the caller skips the frame
+    # the affine map really is isotropic scale + translation (three-point solve, as cv2.getAffineTransform)
+    t = pose2mesh_ref._affine_transform_rot0(np.array([100.0, 50.0], np.float32), np.array([40.0, 30.0], np.float32), (288, 384))
+    assert abs(t[0, 1]) < 1e-9 and abs(t[1, 0]) < 1e-9 and abs(t[0, 0] - t[1, 1]) < 1e-9 and t[0, 0] > 0
