@@ -28,7 +28,8 @@ Extra objects in the line:
                 (config 3), pipeline_b1 (the reference caller's own batch, ros_demo.py:270) -- hipGraph replay, median of five
                 groups of steps; value, ms_per_step and the dominant kernel's roofline fraction of each -- and pipeline_b32_f32:
                 config 4 on the exact-f32 engines (the reference's own arithmetic; 3 timed steps, fraction of the f32-MFMA
-                peak).  a2j_b64.parity ("EPE vs CPU ref": max |d(u,v,d)| and mm EPE of 16 of the 64 crops vs the oracle) and
+                peak); pose2mesh_b1 / _b32: the lifter that follows the path alone; live_b1: HandNet + convert_joints
+                + lifter as ONE captured step with one device -> host copy (the live caller's chain, ros_demo.py:270-337).  a2j_b64.parity ("EPE vs CPU ref": max |d(u,v,d)| and mm EPE of 16 of the 64 crops vs the oracle) and
                 fcos_b16.parity ("box IoU vs torchvision ref": survivor-index equality, labels, mean / min IoU of matched
                 survivors on the 16 frames) compare the outputs of the TIMED steps; the oracle runs after every timed region.
   roofline      dominant kernel (the conv_igemm_f16x3_kernel instantiation with the largest share of
@@ -665,6 +666,51 @@ def device_identity(args, local, rank):
 
 
 PARITY_CROPS = 16    # crops of the batch-64 A2J step compared with the oracle (other_configs.a2j_b64.parity)
+LIVE_PARAS = (617.343, 617.343, 312.42, 241.42)   # SURVEY 8d's intrinsics
+
+
+def lifter_legs(eng, dev, timed):
+    """SURVEY 8f #4 and the live caller's chain (ros_demo.py:270-290,329-337): the Pose2Mesh lifter alone at batch 1 and 32
+    (hipGraph replay; 26 launches per forward), and `live_b1`: HandNet -> clamp + convert_joints in the aggregation's epilogue
+    -> lifter input -> Pose2Mesh -> ONE device -> host copy, all of it one captured step on one frame.  The graph hierarchy
+    is the data fixture of the lifter's golden test (synthetic topology with the reference's level sizes; the MANO files do
+    not travel), weights seeded like every other leg."""
+    import numpy as np
+    import scipy.sparse as sp
+    from hn_amd import synth
+    from hn_amd.live import LiveHandEngine
+    from hn_amd.pose2mesh_engine import Pose2MeshEngine
+    f = REPO / "tests" / "golden" / "pose2mesh_forward.npz"
+    if not f.exists():
+        return {}
+    g = np.load(f)
+    graphs = [sp.csr_matrix((g[f"L{i}_data"], g[f"L{i}_indices"], g[f"L{i}_indptr"]), shape=tuple(int(v) for v in g[f"L{i}_shape"]))
+              for i in range(int(g["num_levels"]))]
+    sd = synth.make_pose2mesh_state_dict(0, graph_sizes=[m.shape[0] for m in graphs])
+    lifter = Pose2MeshEngine(sd, graphs, device=dev)
+    out = {}
+    for b, per in ((1, 20), (32, 8)):
+        x = torch.randn((b, 21, 2), generator=torch.Generator().manual_seed(5000)).to(dev)
+        run, _, _ = lifter.graphed(x)
+        rec = timed(run, b, per_group=per, warm=5)
+        rec.update(unit="meshes/s", hipgraph=True, launches_per_step=26,
+                   workload=f"Pose2Mesh lifter alone, batch {b} (PoseNet MLP + 15 Chebyshev graph convolutions + fc; SURVEY 8f #4)")
+        out[f"pose2mesh_b{b}"] = rec
+    live = LiveHandEngine(eng, lifter, LIVE_PARAS, clamp=True)
+    try:
+        rgb1, dep1 = synth.make_rgb(1, seed=1000).to(dev), synth.make_depth(1, seed=2000).to(dev)
+        run, _, _, lo = live.graphed(rgb1, dep1)
+        rec = timed(run, 1, per_group=10, warm=5)
+        torch.cuda.synchronize()
+        kp, has, _box, _words, _more, mesh = lo.read()
+        rec.update(unit="frames/s", hipgraph=True,
+                   workload="the live caller's chain on one frame (ros_demo.py:270-290,329-337): HandNet -> clamp + convert_joints "
+                            "(aggregation epilogue) -> lifter input -> Pose2Mesh -> one device -> host copy, ONE captured step",
+                   host_bytes_per_frame=int(lo.host.numel()), mesh_vertices=int(mesh.shape[1]), frames_with_hand=int((has == 1).sum()))
+        out["live_b1"] = rec
+    finally:
+        eng.set_convert(on=False)     # (the run's engine goes back to the plain step: the later legs time that)
+    return out
 
 
 def other_configs_leg(args, info, dev, sds=None, hip=None):
@@ -749,6 +795,8 @@ def other_configs_leg(args, info, dev, sds=None, hip=None):
                workload="Full HandNet pipeline at batch 1 (the reference caller's batch, ros_demo.py:270), hipGraph replay",
                **roof_of(lambda: eng.forward_device(rgb1, dep1), rec["ms_per_step"]))
     out["pipeline_b1"] = rec
+    if args.precision == "f16x3":
+        out.update(lifter_legs(eng, dev, timed))
     if args.precision == "f16x3" and sds is not None:
         # the reference's own arithmetic -- IEEE fp32 operands on the f32 MFMA -- driver-timed beside the split-fp16 headline:
         # the same step on engines built with precision="f32", eager, 3 timed steps; roofline against the f32-MFMA peak

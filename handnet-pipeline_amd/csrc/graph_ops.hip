@@ -106,7 +106,259 @@ __global__ __launch_bounds__(256) void feat_interp_add_kernel(const float* __res
 
 int grid_for(long total) { return (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192); }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// One Chebyshev graph convolution (K = 3) as ONE kernel: basis -> Linear (+ folded BatchNorm) -> ReLU (-> block residual +
+// vertex up-sampling).  The lifter is launch-bound at the live caller's batch (76 launches of ~10 us for ~0.3 GFLOP), so the
+// three launches of a layer (spmm, basis, 1x1 convolution) and the residual pass behind a block become one:
+//   phase 1  a tile of 32 rows (row = sample * V + vertex) of the basis [x0 | L x0 | (2 L L - I) x0 | 0] is gathered from x
+//            (fp32, L2-resident: at most 1152 x 256 floats per sample) into LDS as fp16 hi / lo planes.  The second-order
+//            term uses the matrix 2 L L - I precomputed at load (fp64 product, ~19 entries per row instead of a second
+//            dependent gather over 7 x 7): the same polynomial as cheby_graph_conv.py:28-31, rounded once per coefficient.
+//   phase 2  [32 x K] x [K x Fout] on the f16 MFMA in the split form (lo*hi + hi*lo + hi*hi per k tile, fp32 accumulate), the
+//            filter fragments read straight from global memory (<= 768 x 256 values, L2-resident; each of the four waves
+//            owns every fourth 16-column tile), A fragments from LDS.
+//   epilogue bias, ReLU, optional residual = linear interpolation of the block input along the FEATURE axis
+//            (meshnet.py:105-113, ATen's align_corners = False source index), `up` copies of the row (nearest vertex
+//            up-sampling), fp32 or S32 stores.
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int kGcRows = 32;      // rows per workgroup (two 16-row MFMA tiles)
+constexpr int kGcPad = 8;        // halves of padding per LDS row: consecutive rows start 16 bytes further along the banks
+constexpr int kGcMaxNt = 4;      // 16-column tiles per wave (Fout <= 256)
+
+struct GraphConvParams {
+  const int* l_ptr; const int* l_idx; const float* l_val;       // L            (CSR, V rows)
+  const int* q_ptr; const int* q_idx; const float* q_val;       // 2 L L - I    (CSR, V rows)
+  const float* x;          // [rows][Fin] fp32
+  const _Float16* w16;     // [Fout][K / 32][2][32]
+  const float* bias;       // [Fout] or null
+  const float* xin;        // [rows][Fi] block input for the residual, or null
+  void* y;                 // fp32 [rows * up][Fout], or S32 [rows * up][Fout / 32][2][32]
+  int rows, V, Fin, Fout, K, Fi, relu, up, out_split;
+  int* range_flag;
+};
+
+__global__ __launch_bounds__(256) void graph_conv_fused_kernel(const GraphConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 gc_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ldk = p.K + kGcPad;
+  _Float16* hi_pl = gc_lds;
+  _Float16* lo_pl = gc_lds + kGcRows * ldk;
+  const int row0 = blockIdx.x * kGcRows;
+
+  // ---- phase 1: the basis rows of this tile ----
+  const int F4 = p.Fin >> 2;
+  for (int i = tid; i < kGcRows * F4; i += 256) {
+    const int r = i / F4, c = i - r * F4;
+    const int row = row0 + r;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
+    if (row < p.rows) {
+      const int b = row / p.V, v = row - b * p.V;
+      const float* xb = p.x + (long)b * p.V * p.Fin + c * 4;
+      a0 = *reinterpret_cast<const f32x4*>(xb + (long)v * p.Fin);
+      for (int e = p.l_ptr[v]; e < p.l_ptr[v + 1]; ++e) {
+        const float w = p.l_val[e];
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + (long)p.l_idx[e] * p.Fin);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a1[q] += w * xv[q];
+      }
+      for (int e = p.q_ptr[v]; e < p.q_ptr[v + 1]; ++e) {
+        const float w = p.q_val[e];
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + (long)p.q_idx[e] * p.Fin);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a2[q] += w * xv[q];
+      }
+    }
+    const f32x4* parts[3] = {&a0, &a1, &a2};
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      f16x4 h, l;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float val = (*parts[t])[q];
+        h[q] = (_Float16)val;
+        l[q] = (_Float16)(val - (float)h[q]);
+      }
+      const int k = t * p.Fin + c * 4;
+      *reinterpret_cast<f16x4*>(hi_pl + r * ldk + k) = h;
+      *reinterpret_cast<f16x4*>(lo_pl + r * ldk + k) = l;
+    }
+  }
+  const int padk = p.K - 3 * p.Fin;      // zero channels behind the basis (K is a multiple of 32)
+  for (int i = tid; i < kGcRows * (padk >> 2); i += 256) {
+    const int r = i / (padk >> 2), c = i - r * (padk >> 2);
+    const f16x4 z = {(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0};
+    *reinterpret_cast<f16x4*>(hi_pl + r * ldk + 3 * p.Fin + c * 4) = z;
+    *reinterpret_cast<f16x4*>(lo_pl + r * ldk + 3 * p.Fin + c * 4) = z;
+  }
+  __syncthreads();
+
+  // ---- phase 2: [32 x K] x [K x Fout] ----
+  const int nt_all = (p.Fout + 15) >> 4;
+  const int lr = lane & 15, lg = lane >> 4;
+  f32x4 acc[2][kGcMaxNt];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int j = 0; j < kGcMaxNt; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ktiles = p.K >> 5;
+  const f16x8 zero8 = {(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0};
+  if (wave < nt_all) {
+    for (int kt = 0; kt < ktiles; ++kt) {
+      f16x8 ah[2], al[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int off = (m * 16 + lr) * ldk + kt * 32 + lg * 8;
+        ah[m] = *reinterpret_cast<const f16x8*>(hi_pl + off);
+        al[m] = *reinterpret_cast<const f16x8*>(lo_pl + off);
+      }
+#pragma unroll
+      for (int j = 0; j < kGcMaxNt; ++j) {
+        const int nt = wave + 4 * j;
+        if (nt >= nt_all) break;
+        const int col = nt * 16 + lr;
+        f16x8 bh = zero8, bl = zero8;
+        if (col < p.Fout) {
+          const _Float16* q = p.w16 + (((long)col * ktiles + kt) * 2) * 32 + lg * 8;
+          bh = *reinterpret_cast<const f16x8*>(q);
+          bl = *reinterpret_cast<const f16x8*>(q + 32);
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh, acc[m][j], 0, 0, 0);
+          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl, acc[m][j], 0, 0, 0);
+          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh, acc[m][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: D[row = m * 16 + lg * 4 + r][col = nt * 16 + lr] ----
+  const float scale = p.xin ? (float)p.Fi / (float)p.Fout : 0.f;
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < kGcMaxNt; ++j) {
+    const int nt = wave + 4 * j;
+    if (nt >= nt_all) break;
+    const int col = nt * 16 + lr;
+    if (col >= p.Fout) continue;
+    const float bias = p.bias ? p.bias[col] : 0.f;
+    int i0 = 0, i1 = 0;
+    float w0 = 0.f, w1 = 0.f;
+    if (p.xin) {   // ATen area_pixel_compute_source_index, align_corners = False (as feat_interp_add_kernel)
+      float src = fmaf(scale, (float)col + 0.5f, -0.5f);
+      src = src < 0.f ? 0.f : src;
+      i0 = (int)src;
+      i1 = i0 + (i0 < p.Fi - 1 ? 1 : 0);
+      w1 = src - (float)i0;
+      w0 = 1.f - w1;
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + m * 16 + lg * 4 + r;
+        if (row >= p.rows) continue;
+        float v = acc[m][j][r] + bias;
+        if (p.relu) v = hn::relu(v);
+        if (p.xin) {
+          const float* xr = p.xin + (long)row * p.Fi;
+          v = v + (w0 * xr[i0] + w1 * xr[i1]);
+        }
+        for (int u = 0; u < p.up; ++u) {
+          const long orow = (long)row * p.up + u;
+          if (p.out_split) {
+            _Float16* o = (_Float16*)p.y + orow * 2 * p.Fout + (col >> 5) * 64 + (col & 31);
+            const _Float16 h = (_Float16)v;
+            o[0] = h;
+            o[32] = (_Float16)(v - (float)h);
+            bad |= hn::range_bad(v);
+          } else {
+            ((float*)p.y)[orow * p.Fout + col] = v;
+          }
+        }
+      }
+  }
+  if (bad && p.range_flag) *p.range_flag = 1;
+}
+
 }  // namespace
+
+extern "C" int hn_graph_conv_cheby3_f16x3(const hn_graph_csr* L, const hn_graph_csr* L2, const float* x, int batch, int fin,
+                                          const void* w16, const float* bias, int fout, int relu, const float* xin, int fi,
+                                          int up, void* y, int out_split, void* stream) {
+  HN_CHECK_ARG(L && L2 && x && w16 && y, "hn_graph_conv_cheby3_f16x3: null pointer");
+  HN_CHECK_ARG(L->indptr && L->indices && L->values && L2->indptr && L2->indices && L2->values, "null CSR arrays");
+  HN_CHECK_ARG(L->v > 0 && L2->v == L->v && batch > 0, "bad graph / batch");
+  HN_CHECK_ARG(fin >= 4 && fin % 4 == 0 && fin <= 256, "Fin must be a multiple of 4 in [4, 256]");
+  HN_CHECK_ARG(fout >= 1 && fout <= 16 * 4 * kGcMaxNt, "Fout must be in [1, 256]");
+  HN_CHECK_ARG(up >= 1 && up <= 4 && (!xin || fi > 0), "bad residual / up-sampling arguments");
+  HN_CHECK_ARG(!out_split || fout % 32 == 0, "the S32 output needs Fout % 32 == 0");
+  HN_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)w16 % 16 == 0, "unaligned operands");
+  GraphConvParams p;
+  p.l_ptr = L->indptr; p.l_idx = L->indices; p.l_val = L->values;
+  p.q_ptr = L2->indptr; p.q_idx = L2->indices; p.q_val = L2->values;
+  p.x = x; p.w16 = (const _Float16*)w16; p.bias = bias; p.xin = xin; p.y = y;
+  p.rows = batch * L->v; p.V = L->v; p.Fin = fin; p.Fout = fout; p.K = (3 * fin + 31) / 32 * 32; p.Fi = fi;
+  p.relu = relu ? 1 : 0; p.up = up; p.out_split = out_split ? 1 : 0;
+  p.range_flag = out_split ? hn::range_flag_ptr() : nullptr;
+  const size_t lds = (size_t)2 * kGcRows * (p.K + kGcPad) * sizeof(_Float16);
+  static bool attr_set = false;    // (> 64 KB of dynamic LDS needs the attribute once per process)
+  if (!attr_set) {
+    HN_CHECK_HIP(hipFuncSetAttribute((const void*)graph_conv_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(graph_conv_fused_kernel, dim3((p.rows + kGcRows - 1) / kGcRows), dim3(256), lds, (hipStream_t)stream, p);
+  HN_CHECK_LAUNCH("graph_conv_fused_kernel");
+  return HN_OK;
+}
+
+namespace {
+// fp32 rows [rows][f] -> S32 rows of cpad channels (zero padding behind f): the operand of the lifter's first Linear
+__global__ __launch_bounds__(256) void pad_split_rows_kernel(const float* __restrict__ x, _Float16* __restrict__ out16, long rows,
+                                                             int f, int cpad) {
+  const long total = rows * cpad;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cpad);
+    const long r = i / cpad;
+    const float v = c < f ? x[r * f + c] : 0.f;
+    const _Float16 h = (_Float16)v;
+    _Float16* o = out16 + r * 2 * cpad + (c >> 5) * 64 + (c & 31);
+    o[0] = h;
+    o[32] = (_Float16)(v - (float)h);
+  }
+}
+
+// pose_combine of pose2mesh_net.py:20: [pose2d | pose3d / 1000 | 0-pad] per joint, fp32 [rows][fpad] (fpad = 8: the padded
+// input of the first graph convolution)
+__global__ __launch_bounds__(256) void lifter_combine_kernel(const float* __restrict__ pose2d, const float* __restrict__ pose3d,
+                                                             float* __restrict__ out, long rows, int fpad) {
+  const long total = rows * fpad;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % fpad);
+    const long r = i / fpad;
+    out[i] = c < 2 ? pose2d[r * 2 + c] : (c < 5 ? pose3d[r * 3 + (c - 2)] / 1000.f : 0.f);
+  }
+}
+}  // namespace
+
+extern "C" int hn_pad_split_rows_f32(const float* x, int64_t rows, int f, int cpad, void* out16, void* stream) {
+  HN_CHECK_ARG(x && out16, "hn_pad_split_rows_f32: null pointer");
+  HN_CHECK_ARG(rows > 0 && f > 0 && cpad >= f && cpad % 32 == 0, "bad dims (cpad: a multiple of 32 >= f)");
+  hipLaunchKernelGGL(pad_split_rows_kernel, dim3(grid_for(rows * cpad)), dim3(256), 0, (hipStream_t)stream, x, (_Float16*)out16,
+                     (long)rows, f, cpad);
+  HN_CHECK_LAUNCH("pad_split_rows_kernel");
+  return HN_OK;
+}
+
+extern "C" int hn_lifter_combine_f32(const float* pose2d, const float* pose3d, int64_t rows, int fpad, float* out, void* stream) {
+  HN_CHECK_ARG(pose2d && pose3d && out, "hn_lifter_combine_f32: null pointer");
+  HN_CHECK_ARG(rows > 0 && fpad >= 5, "bad dims");
+  hipLaunchKernelGGL(lifter_combine_kernel, dim3(grid_for(rows * fpad)), dim3(256), 0, (hipStream_t)stream, pose2d, pose3d, out,
+                     (long)rows, fpad);
+  HN_CHECK_LAUNCH("lifter_combine_kernel");
+  return HN_OK;
+}
 
 extern "C" int hn_spmm_csr_f32(const int32_t* indptr, const int32_t* indices, const float* values, int v,
                                const float* x, float* y, int batch, int f, void* stream) {

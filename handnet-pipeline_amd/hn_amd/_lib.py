@@ -48,6 +48,10 @@ class ConvMulti(C.Structure):  # == struct hn_conv_multi
                 ("residual", C.c_void_p * CONV_MULTI_MAX), ("y", C.c_void_p * CONV_MULTI_MAX)]
 
 
+class GraphCsr(C.Structure):  # == struct hn_graph_csr
+    _fields_ = [("indptr", C.c_void_p), ("indices", C.c_void_p), ("values", C.c_void_p), ("v", C.c_int32)]
+
+
 class ConvertOpts(C.Structure):  # == struct hn_convert_opts
     _fields_ = [("clamp_keypoints", C.c_int32), ("clamp_box_h", C.c_int32), ("clamp_box_w", C.c_int32)]
 
@@ -138,6 +142,10 @@ SIGNATURES = {
     "hn_groupnorm_rows32_scratch_floats": (C.c_int64, [C.c_int64, C.c_int]),
     "hn_groupnorm_finalize_rows32": (C.c_int, [VP, VP, VP] + [C.c_int] * 4 + [C.c_float, VP, VP, VP]),
     "hn_spmm_csr_f32": (C.c_int, [VP, VP, VP, C.c_int, VP, VP, C.c_int, C.c_int, VP]),
+    "hn_graph_conv_cheby3_f16x3": (C.c_int, [C.POINTER(GraphCsr), C.POINTER(GraphCsr), VP, C.c_int, C.c_int, VP, VP, C.c_int,
+                                             C.c_int, VP, C.c_int, C.c_int, VP, C.c_int, VP]),
+    "hn_pad_split_rows_f32": (C.c_int, [VP, C.c_int64, C.c_int, C.c_int, VP, VP]),
+    "hn_lifter_combine_f32": (C.c_int, [VP, VP, C.c_int64, C.c_int, VP, VP]),
     "hn_cheby3_basis_split": (C.c_int, [VP, VP, VP, C.c_int, VP, VP, VP, C.c_int, C.c_int, C.c_int, VP]),
     "hn_feat_interp_add_f32": (C.c_int, [VP, VP, VP, C.c_int64, C.c_int, C.c_int, C.c_int, VP]),
     "hn_fcos_preprocess_split": (C.c_int, [VP, VP] + [C.c_int] * 8 + [c_f32p, c_f32p, VP]),

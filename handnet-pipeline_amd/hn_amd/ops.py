@@ -1432,6 +1432,61 @@ def csr_graph(L, device) -> CsrGraph:
                     torch.from_numpy(m.data.astype(np.float32)).to(device), m.shape[0])
 
 
+def cheby2_graph(L, device) -> CsrGraph:
+    """2 L L - I as a device CSR (the second-order Chebyshev polynomial of the graph convolution, formed in fp64 on the host)."""
+    import scipy.sparse as sp
+    m = L.tocsr().astype(np.float64)
+    q = (2.0 * (m @ m) - sp.identity(m.shape[0], dtype=np.float64, format="csr")).tocsr()
+    q.sum_duplicates()
+    return csr_graph(q, device)
+
+
+def _csr_struct(g: CsrGraph):
+    return _lib.GraphCsr(g.indptr.data_ptr(), g.indices.data_ptr(), g.values.data_ptr(), g.v)
+
+
+def graph_conv_cheby3(g: CsrGraph, g2: CsrGraph, x, cw, relu=True, xin=None, up=1, out_split=False):
+    """One Chebyshev graph convolution (K = 3) as ONE launch (hn_graph_conv_cheby3_f16x3): x fp32 [B,V,Fin] ->
+    act(Linear([x0 | L x0 | (2 L L - I) x0]) + bias) (+ feature-axis interpolation of xin [B,V,Fi], rows repeated `up` times);
+    cw: ConvW-like with .w [Fout,1,1,K], .w16, .bias over K = pad32(3 Fin) k-major channels.  -> fp32 [B,V*up,Fout] or, with
+    out_split, the S32 operand [B,V*up,1,Fout/32,2,32]."""
+    _req(x, name="x")
+    b, v, fin = x.shape
+    fout, _, _, k = cw.w.shape
+    if v != g.v or g2.v != g.v or k != (3 * fin + 31) // 32 * 32:
+        raise ValueError("graph / filter bank do not match the input")
+    if xin is not None:
+        _req(xin, name="xin")
+        if tuple(xin.shape[:2]) != (b, v):
+            raise ValueError("xin must be [B,V,Fi]")
+    if out_split:
+        y = torch.empty((b, v * up, 1, fout // 32, 2, 32), device=x.device, dtype=torch.float16)
+    else:
+        y = torch.empty((b, v * up, fout), device=x.device, dtype=torch.float32)
+    check(_lib.load().hn_graph_conv_cheby3_f16x3(C.byref(_csr_struct(g)), C.byref(_csr_struct(g2)), ptr(x), b, fin, ptr(cw.w16),
+                                                 ptr(cw.bias), fout, 1 if relu else 0, ptr(xin), xin.shape[2] if xin is not None else 0,
+                                                 up, ptr(y), 1 if out_split else 0, _stream()), "hn_graph_conv_cheby3_f16x3")
+    return y
+
+
+def pad_split_rows(x, cpad):
+    """fp32 [rows, f] -> S32 [rows,1,1,cpad/32,2,32], channels f.. zero (hn_pad_split_rows_f32)."""
+    _req(x, name="x")
+    rows, f = x.shape
+    out = torch.empty((rows, 1, 1, cpad // 32, 2, 32), device=x.device, dtype=torch.float16)
+    check(_lib.load().hn_pad_split_rows_f32(ptr(x), rows, f, cpad, ptr(out), _stream()), "hn_pad_split_rows_f32")
+    return out
+
+
+def lifter_combine(pose2d, pose3d, fpad=8):
+    """pose2d [B,J,2], pose3d [B,J,3] (or [B,3J]) fp32 -> [B,J,fpad] = [pose2d | pose3d / 1000 | 0] (pose2mesh_net.py:20)."""
+    _req(pose2d, name="pose2d"); _req(pose3d, name="pose3d")
+    b, j, _ = pose2d.shape
+    out = torch.empty((b, j, fpad), device=pose2d.device, dtype=torch.float32)
+    check(_lib.load().hn_lifter_combine_f32(ptr(pose2d), ptr(pose3d), b * j, fpad, ptr(out), _stream()), "hn_lifter_combine_f32")
+    return out
+
+
 def spmm_csr(g: CsrGraph, x):
     """x fp32 [B,V,F] -> L x."""
     _req(x, name="x")

@@ -588,6 +588,28 @@ int hn_nonfinite_count_f32(const float* x, int64_t count, int32_t* flag, void* s
  * ------------------------------------------------------------------------------------ */
 int hn_spmm_csr_f32(const int32_t* indptr, const int32_t* indices, const float* values, int v,
                     const float* x, float* y, int batch, int f, void* stream);
+/* One whole graph convolution of the 'mano' mesh net (K = 3; meshnet.py:95-100 = cheby_graph_conv.py:5-42 + F.relu) as ONE
+ * launch, optionally with the block's residual and vertex up-sampling (meshnet.py:105-113) in its epilogue -- the lifter is
+ * launch-bound at the live caller's batch:
+ *   y[r*up + u][:] = act(W [x0 | L x0 | L2 x0 | 0][r] + bias) (+ interp_linear(xin[r][:], fi -> fout)),  u < up
+ * L2 = 2 L L - I, precomputed by the host (the same second-order Chebyshev polynomial, one rounding per coefficient instead of
+ * a second dependent sparse product); x fp32 [batch][v][fin] (fin % 4 == 0, <= 256); w16 = the split filter bank
+ * [fout][K/32][2][32] over K = pad32(3*fin) k-major channels (as hn_cheby3_basis_split's operand); xin fp32 [batch][v][fi]
+ * or NULL; y fp32 [batch][v*up][fout], or S32 rows when out_split (fout % 32 == 0).  fout <= 256. */
+typedef struct hn_graph_csr {
+  const int32_t* indptr;   /* [v + 1] */
+  const int32_t* indices;  /* ascending per row */
+  const float* values;
+  int32_t v;
+} hn_graph_csr;
+int hn_graph_conv_cheby3_f16x3(const hn_graph_csr* L, const hn_graph_csr* L2, const float* x, int batch, int fin,
+                               const void* w16, const float* bias, int fout, int relu, const float* xin, int fi, int up,
+                               void* y, int out_split, void* stream);
+/* Glue of the lifter as single launches: fp32 rows [rows][f] -> S32 rows of cpad channels, zero padded (the operand of
+ * PoseNet's first Linear from the [batch][2J] joints); pose_combine (pose2mesh_net.py:20) = [pose2d | pose3d / 1000 | 0] per
+ * joint as fp32 [rows = batch*J][fpad] (the padded input of the first graph convolution). */
+int hn_pad_split_rows_f32(const float* x, int64_t rows, int f, int cpad, void* out16, void* stream);
+int hn_lifter_combine_f32(const float* pose2d, const float* pose3d, int64_t rows, int fpad, float* out, void* stream);
 int hn_cheby3_basis_split(const int32_t* indptr, const int32_t* indices, const float* values, int v,
                           const float* x0, const float* x1, void* out16, int batch, int f, int cpad,
                           void* stream);

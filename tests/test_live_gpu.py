@@ -52,7 +52,14 @@ def test_aggregate_epilogue_equals_convert_joints_bit_for_bit():
     # image uvd only (no intrinsics): no xyz
     uvd2, img2, xyz2 = ops.a2j_aggregate(cls, reg, dep, valid=valid, convert=dict(crop_box=box))
     assert xyz2 is None and torch.equal(img2[ok], want_img[ok]) and torch.equal(uvd2[ok], uvd[ok])
-    # the live caller's clamps (ros_demo.py:279-283): keypoints to [0, 176], box x1,y1 to [0, H], x2,y2 to [0, W]
+    # the live caller's clamps (ros_demo.py:279-283): keypoints to [0, 176], box x1,y1 to [0, H], x2,y2 to [0, W] -- on heads
+    # whose dominant anchors put joints outside the crop, and boxes beyond the frame
+    g = torch.Generator().manual_seed(5)
+    pred = torch.rand((k, 21, 3), generator=g) * torch.tensor([240.0, 240.0, 1.2]) - torch.tensor([30.0, 30.0, -0.3])
+    cls, reg, dep = _heads(k, 13, peaked=pred)
+    box = torch.tensor([[0, 200, 49, 266], [500, 0, 700, 46], [100, 50, 420, 430], [-5, -3, 640, 480], [7, 9, 8, 10], [500, 490, 660, 500]],
+                       dtype=torch.int64).cuda()
+    plain = ops.a2j_aggregate(cls, reg, dep, valid=valid)
     uvd3, img3, xyz3 = ops.a2j_aggregate(cls, reg, dep, valid=valid,
                                          convert=dict(crop_box=box, paras=PARAS, clamp_keypoints=True, clamp_box=(480, 640)))
     kp_c = torch.clamp(plain, min=0.0, max=176.0)
@@ -60,7 +67,7 @@ def test_aggregate_epilogue_equals_convert_joints_bit_for_bit():
     box_c[:, :2] = torch.clamp(box_c[:, :2], 0, 480)
     box_c[:, 2:] = torch.clamp(box_c[:, 2:], 0, 640)
     assert not torch.equal(kp_c[ok], plain[ok]) and not torch.equal(box_c, box)        # (the case exercises both clamps)
-    assert torch.equal(uvd3[ok], uvd[ok])                                             # the network's own output is untouched
+    assert torch.equal(uvd3[ok], plain[ok])                                           # the network's own output is untouched
     assert torch.equal(img3[ok], ops.convert_joints(kp_c, box_c, valid, None)[ok])
     assert torch.equal(xyz3[ok], ops.convert_joints(kp_c, box_c, valid, PARAS)[ok])
 

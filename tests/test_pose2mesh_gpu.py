@@ -82,3 +82,50 @@ def test_pose2mesh_dropin_matches_reference_golden(p2m):
     torch.cuda.synchronize()
     # (capture splits more k loops than eager mode does: equal to fp32 rounding, not bitwise)
     assert (g_mesh - e_mesh).abs().max().item() < 1e-4 and (g_pose - e_pose).abs().max().item() < 2e-3
+
+
+def test_fused_graph_conv_matches_the_layer_by_layer_form(p2m):
+    """hn_graph_conv_cheby3_f16x3 (basis gather, MFMA, bias / ReLU, block residual + vertex up-sampling in ONE launch) against
+    spmm -> basis -> 1x1 convolution -> feat_interp_add on every shape class of the mesh net: narrow input (8 features),
+    wide (256), the 3-channel output layer without ReLU, the S32 output in front of fc, batch 1 and 3 (a tile spanning
+    two samples), on the coarsest and the finest graph."""
+    from hn_amd import ops
+    from hn_amd.pose2mesh_engine import Pose2MeshEngine
+    _, graphs, sd = p2m
+    eng = Pose2MeshEngine(sd, graphs, device="cuda")
+    gen = torch.Generator().manual_seed(21)
+    # (layer index in eng.cl, graph level, residual?, up, out_split)
+    cases = [(0, -1, False, 1, False), (2, -1, False, 1, True), (4, -2, True, 2, False), (6, -3, True, 2, False),
+             (12, 0, True, 1, False), (13, 0, False, 1, False), (14, 0, False, 1, False)]
+    for b in (1, 3):
+        for li, lv, res, up, split in cases:
+            cw, fin_pad, relu = eng.cl[li]
+            g, g2 = eng.graphs[lv], eng.graphs2[lv]
+            x = torch.randn((b, g.v, fin_pad), generator=gen).cuda()
+            fi = 64 if fin_pad >= 64 else fin_pad
+            xin = torch.randn((b, g.v, fi), generator=gen).cuda() if res else None
+            got = ops.graph_conv_cheby3(g, g2, x, cw, relu=relu, xin=xin, up=up, out_split=split)
+            basis = ops.cheby3_basis_split(g, x, ops.spmm_csr(g, x))
+            want = ops.conv2d_nhwc(basis, cw.w, cw.bias, relu=relu, w16=cw.w16, splitk=False).view(b, g.v, -1)
+            if res:
+                want = ops.feat_interp_add(xin, want.contiguous(), up=up)
+            if split:
+                got = ops.from_split(got).view(b, g.v * up, -1)
+            assert got.shape == want.shape, (li, got.shape, want.shape)
+            scale = max(1.0, want.abs().max().item())
+            assert (got - want).abs().max().item() <= 3e-6 * scale, (b, li, (got - want).abs().max().item(), scale)
+
+
+def test_fused_lifter_matches_the_layer_by_layer_lifter(p2m):
+    """The 26-launch forward (fused=True) against the round-2 launch structure (fused=False) of the same weights: pose3d
+    (millimetres, |x| ~ 1e2) within 5e-3, mesh (|x| ~ 4) within 2e-4 -- summation order only (batch_norm2 folded into the
+    Linear in front of it, 2 L L - I formed on the host, no split-K in the fused graph convolutions)."""
+    from hn_amd.pose2mesh_engine import Pose2MeshEngine
+    g, graphs, sd = p2m
+    a = Pose2MeshEngine(sd, graphs, device="cuda", fused=True)
+    b = Pose2MeshEngine(sd, graphs, device="cuda", fused=False)
+    for n in (1, 5):
+        pose2d = torch.randn((n, 21, 2), generator=torch.Generator().manual_seed(31 + n)).cuda()
+        m1, p1 = a.forward(pose2d)
+        m2, p2 = b.forward(pose2d)
+        assert (p1 - p2).abs().max().item() < 5e-3 and (m1 - m2).abs().max().item() < 2e-4
