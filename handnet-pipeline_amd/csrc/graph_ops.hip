@@ -110,21 +110,24 @@ int grid_for(long total) { return (int)((total + 255) / 256 < 8192 ? (total + 25
 // One Chebyshev graph convolution (K = 3) as ONE kernel: basis -> Linear (+ folded BatchNorm) -> ReLU (-> block residual +
 // vertex up-sampling).  The lifter is launch-bound at the live caller's batch (76 launches of ~10 us for ~0.3 GFLOP), so the
 // three launches of a layer (spmm, basis, 1x1 convolution) and the residual pass behind a block become one:
-//   phase 1  a tile of 32 rows (row = sample * V + vertex) of the basis [x0 | L x0 | (2 L L - I) x0 | 0] is gathered from x
+//   phase 1  a tile of 16 rows (row = sample * V + vertex; 1024 threads: one (row, 4 features) item each at 256 features) of the basis [x0 | L x0 | (2 L L - I) x0 | 0] is gathered from x
 //            (fp32, L2-resident: at most 1152 x 256 floats per sample) into LDS as fp16 hi / lo planes.  The second-order
 //            term uses the matrix 2 L L - I precomputed at load (fp64 product, ~19 entries per row instead of a second
 //            dependent gather over 7 x 7): the same polynomial as cheby_graph_conv.py:28-31, rounded once per coefficient.
-//   phase 2  [32 x K] x [K x Fout] on the f16 MFMA in the split form (lo*hi + hi*lo + hi*hi per k tile, fp32 accumulate), the
-//            filter fragments read straight from global memory (<= 768 x 256 values, L2-resident; each of the four waves
-//            owns every fourth 16-column tile), A fragments from LDS.
+//   phase 2  [16 x K] x [K x Fout] on the f16 MFMA in the split form (lo*hi + hi*lo + hi*hi per k tile, fp32 accumulate), the
+//            filter fragments read straight from global memory, eight k tiles requested at a time (<= 768 x 256 values,
+//            L2-resident), A fragments from LDS.  The sixteen waves are (column tile, k slice) pairs: 16 column tiles x 1
+//            slice at 256 outputs, 4 x 4 at 64, 1 x 16 for the 3-channel output layer; slices are added in slice order.
 //   epilogue bias, ReLU, optional residual = linear interpolation of the block input along the FEATURE axis
 //            (meshnet.py:105-113, ATen's align_corners = False source index), `up` copies of the row (nearest vertex
 //            up-sampling), fp32 or S32 stores.
 // ---------------------------------------------------------------------------------------------------------------------------
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-constexpr int kGcRows = 32;      // rows per workgroup (two 16-row MFMA tiles)
+constexpr int kGcRows = 16;      // rows per workgroup (one 16-row MFMA tile)
 constexpr int kGcPad = 8;        // halves of padding per LDS row: consecutive rows start 16 bytes further along the banks
-constexpr int kGcMaxNt = 4;      // 16-column tiles per wave (Fout <= 256)
+constexpr int kGcWaves = 16;     // 1024 threads: one basis item per thread at Fin = 256, one (column tile, k slice) per wave
+constexpr int kGcChunk = 16;     // neighbours gathered per batch of independent loads
+constexpr int kGcKBatch = 8;     // k tiles whose filter fragments are requested before the first of them is used
 
 struct GraphConvParams {
   const int* l_ptr; const int* l_idx; const float* l_val;       // L            (CSR, V rows)
@@ -135,20 +138,50 @@ struct GraphConvParams {
   const float* xin;        // [rows][Fi] block input for the residual, or null
   void* y;                 // fp32 [rows * up][Fout], or S32 [rows * up][Fout / 32][2][32]
   int rows, V, Fin, Fout, K, Fi, relu, up, out_split;
+  int nt_pow2;             // column tiles rounded up to a power of two (<= 16); k slices = 16 / nt_pow2
   int* range_flag;
 };
 
-__global__ __launch_bounds__(256) void graph_conv_fused_kernel(const GraphConvParams p) {
+// sum_e val[e] * x[idx[e]][c4 .. c4 + 4) over one CSR row, in CSR order; the loads of kGcChunk neighbours are issued together
+// (written as load -> use per neighbour, every one of the ~26 gathers of a row waited for its own trip to the L2)
+__device__ __forceinline__ f32x4 gather_row(const int* __restrict__ ptr, const int* __restrict__ idx, const float* __restrict__ val,
+                                            int v, const float* __restrict__ xb, int fin) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int e1 = ptr[v + 1];
+  for (int e = ptr[v]; e < e1; e += kGcChunk) {
+    int id[kGcChunk];
+    float w[kGcChunk];
+#pragma unroll
+    for (int u = 0; u < kGcChunk; ++u) {
+      const bool in = e + u < e1;
+      id[u] = in ? idx[e + u] : v;
+      w[u] = in ? val[e + u] : 0.f;
+    }
+    f32x4 xv[kGcChunk];
+#pragma unroll
+    for (int u = 0; u < kGcChunk; ++u) xv[u] = *reinterpret_cast<const f32x4*>(xb + (long)id[u] * fin);
+#pragma unroll
+    for (int u = 0; u < kGcChunk; ++u)
+      if (e + u < e1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] += w[u] * xv[u][q];
+      }
+  }
+  return acc;
+}
+
+__global__ __launch_bounds__(kGcWaves * 64) void graph_conv_fused_kernel(const GraphConvParams p) {
   extern __shared__ __attribute__((aligned(16))) _Float16 gc_lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ldk = p.K + kGcPad;
   _Float16* hi_pl = gc_lds;
   _Float16* lo_pl = gc_lds + kGcRows * ldk;
+  float* red = reinterpret_cast<float*>(gc_lds + 2 * kGcRows * ldk);   // [16 waves][64 lanes][4]: k-slice partial tiles
   const int row0 = blockIdx.x * kGcRows;
 
   // ---- phase 1: the basis rows of this tile ----
   const int F4 = p.Fin >> 2;
-  for (int i = tid; i < kGcRows * F4; i += 256) {
+  for (int i = tid; i < kGcRows * F4; i += kGcWaves * 64) {
     const int r = i / F4, c = i - r * F4;
     const int row = row0 + r;
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
@@ -156,18 +189,8 @@ __global__ __launch_bounds__(256) void graph_conv_fused_kernel(const GraphConvPa
       const int b = row / p.V, v = row - b * p.V;
       const float* xb = p.x + (long)b * p.V * p.Fin + c * 4;
       a0 = *reinterpret_cast<const f32x4*>(xb + (long)v * p.Fin);
-      for (int e = p.l_ptr[v]; e < p.l_ptr[v + 1]; ++e) {
-        const float w = p.l_val[e];
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + (long)p.l_idx[e] * p.Fin);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) a1[q] += w * xv[q];
-      }
-      for (int e = p.q_ptr[v]; e < p.q_ptr[v + 1]; ++e) {
-        const float w = p.q_val[e];
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + (long)p.q_idx[e] * p.Fin);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) a2[q] += w * xv[q];
-      }
+      a1 = gather_row(p.l_ptr, p.l_idx, p.l_val, v, xb, p.Fin);
+      a2 = gather_row(p.q_ptr, p.q_idx, p.q_val, v, xb, p.Fin);
     }
     const f32x4* parts[3] = {&a0, &a1, &a2};
 #pragma unroll
@@ -185,7 +208,7 @@ __global__ __launch_bounds__(256) void graph_conv_fused_kernel(const GraphConvPa
     }
   }
   const int padk = p.K - 3 * p.Fin;      // zero channels behind the basis (K is a multiple of 32)
-  for (int i = tid; i < kGcRows * (padk >> 2); i += 256) {
+  for (int i = tid; i < kGcRows * (padk >> 2); i += kGcWaves * 64) {
     const int r = i / (padk >> 2), c = i - r * (padk >> 2);
     const f16x4 z = {(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0};
     *reinterpret_cast<f16x4*>(hi_pl + r * ldk + 3 * p.Fin + c * 4) = z;
@@ -193,91 +216,89 @@ __global__ __launch_bounds__(256) void graph_conv_fused_kernel(const GraphConvPa
   }
   __syncthreads();
 
-  // ---- phase 2: [32 x K] x [K x Fout] ----
+  // ---- phase 2: [16 x K] x [K x Fout]; wave = (column tile nt, k slice ks) ----
   const int nt_all = (p.Fout + 15) >> 4;
+  const int slices = kGcWaves / p.nt_pow2;
+  const int nt = wave & (p.nt_pow2 - 1), ks = wave / p.nt_pow2;
   const int lr = lane & 15, lg = lane >> 4;
-  f32x4 acc[2][kGcMaxNt];
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int j = 0; j < kGcMaxNt; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int ktiles = p.K >> 5;
+  const int per = (ktiles + slices - 1) / slices;
+  const int kt0 = ks * per, kt1 = min(ktiles, kt0 + per);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int col = nt * 16 + lr;
+  const bool live = nt < nt_all && col < p.Fout;
   const f16x8 zero8 = {(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0};
-  if (wave < nt_all) {
-    for (int kt = 0; kt < ktiles; ++kt) {
-      f16x8 ah[2], al[2];
+  if (nt < nt_all) {
+    const _Float16* wq = p.w16 + ((long)(live ? col : 0) * ktiles * 2) * 32 + lg * 8;
+    for (int kb = kt0; kb < kt1; kb += kGcKBatch) {
+      f16x8 bh[kGcKBatch], bl[kGcKBatch];
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const int off = (m * 16 + lr) * ldk + kt * 32 + lg * 8;
-        ah[m] = *reinterpret_cast<const f16x8*>(hi_pl + off);
-        al[m] = *reinterpret_cast<const f16x8*>(lo_pl + off);
+      for (int u = 0; u < kGcKBatch; ++u) {
+        const bool in = live && kb + u < kt1;
+        bh[u] = in ? *reinterpret_cast<const f16x8*>(wq + (long)(kb + u) * 64) : zero8;
+        bl[u] = in ? *reinterpret_cast<const f16x8*>(wq + (long)(kb + u) * 64 + 32) : zero8;
       }
 #pragma unroll
-      for (int j = 0; j < kGcMaxNt; ++j) {
-        const int nt = wave + 4 * j;
-        if (nt >= nt_all) break;
-        const int col = nt * 16 + lr;
-        f16x8 bh = zero8, bl = zero8;
-        if (col < p.Fout) {
-          const _Float16* q = p.w16 + (((long)col * ktiles + kt) * 2) * 32 + lg * 8;
-          bh = *reinterpret_cast<const f16x8*>(q);
-          bl = *reinterpret_cast<const f16x8*>(q + 32);
-        }
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh, acc[m][j], 0, 0, 0);
-          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl, acc[m][j], 0, 0, 0);
-          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh, acc[m][j], 0, 0, 0);
+      for (int u = 0; u < kGcKBatch; ++u) {
+        if (kb + u < kt1) {
+          const int off = lr * ldk + (kb + u) * 32 + lg * 8;
+          const f16x8 ah = *reinterpret_cast<const f16x8*>(hi_pl + off);
+          const f16x8 al = *reinterpret_cast<const f16x8*>(lo_pl + off);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[u], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[u], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[u], acc, 0, 0, 0);
         }
       }
     }
   }
+  if (slices > 1) {   // the k slices of a column tile are added in slice order by the wave of slice 0
+    *reinterpret_cast<f32x4*>(red + ((long)wave * 64 + lane) * 4) = acc;
+    __syncthreads();
+    if (ks == 0)
+      for (int s2 = 1; s2 < slices; ++s2) {
+        const f32x4 o = *reinterpret_cast<const f32x4*>(red + ((long)(s2 * p.nt_pow2 + nt) * 64 + lane) * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] += o[q];
+      }
+  }
+  if (ks != 0 || !live) return;
 
-  // ---- epilogue: D[row = m * 16 + lg * 4 + r][col = nt * 16 + lr] ----
-  const float scale = p.xin ? (float)p.Fi / (float)p.Fout : 0.f;
+  // ---- epilogue: D[row = lg * 4 + r][col] ----
+  const float bias = p.bias ? p.bias[col] : 0.f;
+  int i0 = 0, i1 = 0;
+  float w0 = 0.f, w1 = 0.f;
+  if (p.xin) {   // ATen area_pixel_compute_source_index, align_corners = False (as feat_interp_add_kernel)
+    const float scale = (float)p.Fi / (float)p.Fout;
+    float src = fmaf(scale, (float)col + 0.5f, -0.5f);
+    src = src < 0.f ? 0.f : src;
+    i0 = (int)src;
+    i1 = i0 + (i0 < p.Fi - 1 ? 1 : 0);
+    w1 = src - (float)i0;
+    w0 = 1.f - w1;
+  }
   bool bad = false;
 #pragma unroll
-  for (int j = 0; j < kGcMaxNt; ++j) {
-    const int nt = wave + 4 * j;
-    if (nt >= nt_all) break;
-    const int col = nt * 16 + lr;
-    if (col >= p.Fout) continue;
-    const float bias = p.bias ? p.bias[col] : 0.f;
-    int i0 = 0, i1 = 0;
-    float w0 = 0.f, w1 = 0.f;
-    if (p.xin) {   // ATen area_pixel_compute_source_index, align_corners = False (as feat_interp_add_kernel)
-      float src = fmaf(scale, (float)col + 0.5f, -0.5f);
-      src = src < 0.f ? 0.f : src;
-      i0 = (int)src;
-      i1 = i0 + (i0 < p.Fi - 1 ? 1 : 0);
-      w1 = src - (float)i0;
-      w0 = 1.f - w1;
+  for (int r = 0; r < 4; ++r) {
+    const int row = row0 + lg * 4 + r;
+    if (row >= p.rows) continue;
+    float v = acc[r] + bias;
+    if (p.relu) v = hn::relu(v);
+    if (p.xin) {
+      const float* xr = p.xin + (long)row * p.Fi;
+      v = v + (w0 * xr[i0] + w1 * xr[i1]);
     }
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = row0 + m * 16 + lg * 4 + r;
-        if (row >= p.rows) continue;
-        float v = acc[m][j][r] + bias;
-        if (p.relu) v = hn::relu(v);
-        if (p.xin) {
-          const float* xr = p.xin + (long)row * p.Fi;
-          v = v + (w0 * xr[i0] + w1 * xr[i1]);
-        }
-        for (int u = 0; u < p.up; ++u) {
-          const long orow = (long)row * p.up + u;
-          if (p.out_split) {
-            _Float16* o = (_Float16*)p.y + orow * 2 * p.Fout + (col >> 5) * 64 + (col & 31);
-            const _Float16 h = (_Float16)v;
-            o[0] = h;
-            o[32] = (_Float16)(v - (float)h);
-            bad |= hn::range_bad(v);
-          } else {
-            ((float*)p.y)[orow * p.Fout + col] = v;
-          }
-        }
+    for (int u = 0; u < p.up; ++u) {
+      const long orow = (long)row * p.up + u;
+      if (p.out_split) {
+        _Float16* o = (_Float16*)p.y + orow * 2 * p.Fout + (col >> 5) * 64 + (col & 31);
+        const _Float16 h = (_Float16)v;
+        o[0] = h;
+        o[32] = (_Float16)(v - (float)h);
+        bad |= hn::range_bad(v);
+      } else {
+        ((float*)p.y)[orow * p.Fout + col] = v;
       }
+    }
   }
   if (bad && p.range_flag) *p.range_flag = 1;
 }
@@ -291,7 +312,7 @@ extern "C" int hn_graph_conv_cheby3_f16x3(const hn_graph_csr* L, const hn_graph_
   HN_CHECK_ARG(L->indptr && L->indices && L->values && L2->indptr && L2->indices && L2->values, "null CSR arrays");
   HN_CHECK_ARG(L->v > 0 && L2->v == L->v && batch > 0, "bad graph / batch");
   HN_CHECK_ARG(fin >= 4 && fin % 4 == 0 && fin <= 256, "Fin must be a multiple of 4 in [4, 256]");
-  HN_CHECK_ARG(fout >= 1 && fout <= 16 * 4 * kGcMaxNt, "Fout must be in [1, 256]");
+  HN_CHECK_ARG(fout >= 1 && fout <= 16 * kGcWaves, "Fout must be in [1, 256]");
   HN_CHECK_ARG(up >= 1 && up <= 4 && (!xin || fi > 0), "bad residual / up-sampling arguments");
   HN_CHECK_ARG(!out_split || fout % 32 == 0, "the S32 output needs Fout % 32 == 0");
   HN_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)w16 % 16 == 0, "unaligned operands");
@@ -302,13 +323,15 @@ extern "C" int hn_graph_conv_cheby3_f16x3(const hn_graph_csr* L, const hn_graph_
   p.rows = batch * L->v; p.V = L->v; p.Fin = fin; p.Fout = fout; p.K = (3 * fin + 31) / 32 * 32; p.Fi = fi;
   p.relu = relu ? 1 : 0; p.up = up; p.out_split = out_split ? 1 : 0;
   p.range_flag = out_split ? hn::range_flag_ptr() : nullptr;
-  const size_t lds = (size_t)2 * kGcRows * (p.K + kGcPad) * sizeof(_Float16);
+  p.nt_pow2 = 1;
+  while (p.nt_pow2 * 16 < fout) p.nt_pow2 *= 2;
+  const size_t lds = (size_t)2 * kGcRows * (p.K + kGcPad) * sizeof(_Float16) + (size_t)kGcWaves * 64 * 4 * sizeof(float);
   static bool attr_set = false;    // (> 64 KB of dynamic LDS needs the attribute once per process)
   if (!attr_set) {
     HN_CHECK_HIP(hipFuncSetAttribute((const void*)graph_conv_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(graph_conv_fused_kernel, dim3((p.rows + kGcRows - 1) / kGcRows), dim3(256), lds, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(graph_conv_fused_kernel, dim3((p.rows + kGcRows - 1) / kGcRows), dim3(kGcWaves * 64), lds, (hipStream_t)stream, p);
   HN_CHECK_LAUNCH("graph_conv_fused_kernel");
   return HN_OK;
 }

@@ -101,6 +101,11 @@ class Pose2MeshEngine:
                 self.cl.append((_dense(wk.reshape(fout, CL_K * fin_pad), b, dev), fin_pad, not last))
                 idx += 1
 
+    # The one-launch graph convolution is a LATENCY design (16 rows per 1024-thread workgroup, every workgroup gathers its own
+    # basis rows): it wins where the forward is launch-bound.  Larger batches are throughput-bound and run the mesh net
+    # layer by layer (streaming spmm / basis passes + the tiled 1x1 convolution).
+    FUSED_MAX_BATCH = 4
+
     @staticmethod
     def _as_scipy(L):
         if torch.is_tensor(L):
@@ -238,7 +243,7 @@ class Pose2MeshEngine:
         pose2d = pose2d.float().contiguous()
         b = pose2d.shape[0]
         pose3d = self.posenet(pose2d.reshape(b, -1)).reshape(b, self.num_joint, 3)
-        if self.fused:
+        if self.fused and b <= self.FUSED_MAX_BATCH:
             return self.meshnet_fused(ops.lifter_combine(pose2d, pose3d, fpad=self.cl[0][1])), pose3d
         comb = torch.cat((pose2d, pose3d / 1000), dim=2)          # pose2mesh_net.py:20 (glue, 105 floats per sample)
         return self.meshnet(comb), pose3d
