@@ -116,8 +116,9 @@ int grid_for(long total) { return (int)((total + 255) / 256 < 8192 ? (total + 25
 //            dependent gather over 7 x 7): the same polynomial as cheby_graph_conv.py:28-31, rounded once per coefficient.
 //   phase 2  [16 x K] x [K x Fout] on the f16 MFMA in the split form (lo*hi + hi*lo + hi*hi per k tile, fp32 accumulate), the
 //            filter fragments read straight from global memory, eight k tiles requested at a time (<= 768 x 256 values,
-//            L2-resident), A fragments from LDS.  The sixteen waves are (column tile, k slice) pairs: 16 column tiles x 1
-//            slice at 256 outputs, 4 x 4 at 64, 1 x 16 for the 3-channel output layer; slices are added in slice order.
+//            L2-resident), A fragments from LDS.  A workgroup owns at most four 16-column tiles (blockIdx.y = column group);
+//            its sixteen waves are (column tile, k slice) pairs: 4 x 4 from 64 outputs on, 1 x 16 for the 3-channel output
+//            layer; slices are added in slice order.
 //   epilogue bias, ReLU, optional residual = linear interpolation of the block input along the FEATURE axis
 //            (meshnet.py:105-113, ATen's align_corners = False source index), `up` copies of the row (nearest vertex
 //            up-sampling), fp32 or S32 stores.
@@ -126,7 +127,6 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr int kGcRows = 16;      // rows per workgroup (one 16-row MFMA tile)
 constexpr int kGcPad = 8;        // halves of padding per LDS row: consecutive rows start 16 bytes further along the banks
 constexpr int kGcWaves = 16;     // 1024 threads: one basis item per thread at Fin = 256, one (column tile, k slice) per wave
-constexpr int kGcChunk = 16;     // neighbours gathered per batch of independent loads
 constexpr int kGcKBatch = 8;     // k tiles whose filter fragments are requested before the first of them is used
 
 struct GraphConvParams {
@@ -138,36 +138,60 @@ struct GraphConvParams {
   const float* xin;        // [rows][Fi] block input for the residual, or null
   void* y;                 // fp32 [rows * up][Fout], or S32 [rows * up][Fout / 32][2][32]
   int rows, V, Fin, Fout, K, Fi, relu, up, out_split;
-  int nt_pow2;             // column tiles rounded up to a power of two (<= 16); k slices = 16 / nt_pow2
+  int nt_pow2;             // column tiles of ONE workgroup (a power of two <= 4; blockIdx.y = column group); k slices = 16 / nt_pow2
   int* range_flag;
 };
 
-// sum_e val[e] * x[idx[e]][c4 .. c4 + 4) over one CSR row, in CSR order; the loads of kGcChunk neighbours are issued together
-// (written as load -> use per neighbour, every one of the ~26 gathers of a row waited for its own trip to the L2)
-__device__ __forceinline__ f32x4 gather_row(const int* __restrict__ ptr, const int* __restrict__ idx, const float* __restrict__ val,
-                                            int v, const float* __restrict__ xb, int fin) {
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  const int e1 = ptr[v + 1];
-  for (int e = ptr[v]; e < e1; e += kGcChunk) {
-    int id[kGcChunk];
-    float w[kGcChunk];
+// One round of the gathers of a basis row: NL neighbours of L from entry le and NQ neighbours of 2 L L - I from entry qe, all
+// their loads issued together (first every index / coefficient, then every x row), then accumulated in CSR order -- a1 += over
+// the L entries, a2 += over the others.  Written as load -> use per neighbour, every one of the ~26 gathers of a row waited
+// for its own trip to the L2 (the first version of this kernel: 110 us per layer, whatever the graph size).
+template <int NL, int NQ>
+__device__ __forceinline__ void gather_round(const GraphConvParams& p, int le, int le1, int qe, int qe1, const float* __restrict__ xb,
+                                             f32x4& a1, f32x4& a2) {
+  int id[NL + NQ];
+  float w[NL + NQ];
 #pragma unroll
-    for (int u = 0; u < kGcChunk; ++u) {
-      const bool in = e + u < e1;
-      id[u] = in ? idx[e + u] : v;
-      w[u] = in ? val[e + u] : 0.f;
-    }
-    f32x4 xv[kGcChunk];
-#pragma unroll
-    for (int u = 0; u < kGcChunk; ++u) xv[u] = *reinterpret_cast<const f32x4*>(xb + (long)id[u] * fin);
-#pragma unroll
-    for (int u = 0; u < kGcChunk; ++u)
-      if (e + u < e1) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] += w[u] * xv[u][q];
-      }
+  for (int u = 0; u < NL; ++u) {
+    const bool in = le + u < le1;
+    id[u] = in ? p.l_idx[le + u] : 0;
+    w[u] = in ? p.l_val[le + u] : 0.f;
   }
-  return acc;
+#pragma unroll
+  for (int u = 0; u < NQ; ++u) {
+    const bool in = qe + u < qe1;
+    id[NL + u] = in ? p.q_idx[qe + u] : 0;
+    w[NL + u] = in ? p.q_val[qe + u] : 0.f;
+  }
+  f32x4 xv[NL + NQ];
+#pragma unroll
+  for (int u = 0; u < NL + NQ; ++u) xv[u] = *reinterpret_cast<const f32x4*>(xb + (long)id[u] * p.Fin);
+#pragma unroll
+  for (int u = 0; u < NL; ++u)
+    if (le + u < le1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a1[q] += w[u] * xv[u][q];
+    }
+#pragma unroll
+  for (int u = 0; u < NQ; ++u)
+    if (qe + u < qe1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a2[q] += w[NL + u] * xv[NL + u][q];
+    }
+}
+
+// a1 = (L x)[v], a2 = ((2 L L - I) x)[v] for the 4 features at xb: the four row pointers in one trip, then rounds of 8 + 8
+// neighbours where the metadata is wave-uniform (scalar registers), 4 + 8 where every lane holds its own (a mesh vertex has ~7
+// entries in L and ~19 in 2 L L - I: two or three rounds)
+template <int NL, int NQ>
+__device__ __forceinline__ void gather_basis(const GraphConvParams& p, int v, const float* __restrict__ xb, f32x4& a1, f32x4& a2) {
+  int le = p.l_ptr[v], qe = p.q_ptr[v];
+  const int le1 = p.l_ptr[v + 1], qe1 = p.q_ptr[v + 1];
+  while (le < le1 || qe < qe1) {
+    gather_round<NL, NQ>(p, le, le1, qe, qe1, xb, a1, a2);
+    le += NL;
+    qe += NQ;
+  }
 }
 
 __global__ __launch_bounds__(kGcWaves * 64) void graph_conv_fused_kernel(const GraphConvParams p) {
@@ -179,6 +203,34 @@ __global__ __launch_bounds__(kGcWaves * 64) void graph_conv_fused_kernel(const G
   float* red = reinterpret_cast<float*>(gc_lds + 2 * kGcRows * ldk);   // [16 waves][64 lanes][4]: k-slice partial tiles
   const int row0 = blockIdx.x * kGcRows;
 
+  // the epilogue's operands depend on nothing the kernel computes: requested now, they arrive under phase 1 (fetched in the
+  // epilogue they were two more dependent trips to memory at the end of every launch)
+  const int nt_all = (p.Fout + 15) >> 4;
+  const int nt = blockIdx.y * p.nt_pow2 + (wave & (p.nt_pow2 - 1)), ks = wave / p.nt_pow2;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int col = nt * 16 + lr;
+  const bool live = nt < nt_all && col < p.Fout;
+  float bias = 0.f, res[4] = {0.f, 0.f, 0.f, 0.f};
+  if (live && ks == 0) {
+    if (p.bias) bias = p.bias[col];
+    if (p.xin) {   // ATen area_pixel_compute_source_index, align_corners = False (as feat_interp_add_kernel)
+      const float scale = (float)p.Fi / (float)p.Fout;
+      float src = fmaf(scale, (float)col + 0.5f, -0.5f);
+      src = src < 0.f ? 0.f : src;
+      const int i0 = (int)src;
+      const int i1 = i0 + (i0 < p.Fi - 1 ? 1 : 0);
+      const float w1 = src - (float)i0, w0 = 1.f - w1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + lg * 4 + r;
+        if (row < p.rows) {
+          const float* xr = p.xin + (long)row * p.Fi;
+          res[r] = w0 * xr[i0] + w1 * xr[i1];
+        }
+      }
+    }
+  }
+
   // ---- phase 1: the basis rows of this tile ----
   const int F4 = p.Fin >> 2;
   for (int i = tid; i < kGcRows * F4; i += kGcWaves * 64) {
@@ -186,11 +238,19 @@ __global__ __launch_bounds__(kGcWaves * 64) void graph_conv_fused_kernel(const G
     const int row = row0 + r;
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
     if (row < p.rows) {
-      const int b = row / p.V, v = row - b * p.V;
+      const int b = row / p.V;
+      int v = row - b * p.V;
+      // 256 features: a wave's 64 items are ONE row, so its CSR metadata is wave-uniform -- said to the compiler, which then
+      // fetches it with scalar loads (no vector registers, sixteen indices per instruction)
       const float* xb = p.x + (long)b * p.V * p.Fin + c * 4;
-      a0 = *reinterpret_cast<const f32x4*>(xb + (long)v * p.Fin);
-      a1 = gather_row(p.l_ptr, p.l_idx, p.l_val, v, xb, p.Fin);
-      a2 = gather_row(p.q_ptr, p.q_idx, p.q_val, v, xb, p.Fin);
+      if (F4 == 64) {
+        v = __builtin_amdgcn_readfirstlane(v);
+        a0 = *reinterpret_cast<const f32x4*>(xb + (long)v * p.Fin);
+        gather_basis<8, 8>(p, v, xb, a1, a2);
+      } else {
+        a0 = *reinterpret_cast<const f32x4*>(xb + (long)v * p.Fin);
+        gather_basis<4, 8>(p, v, xb, a1, a2);
+      }
     }
     const f32x4* parts[3] = {&a0, &a1, &a2};
 #pragma unroll
@@ -217,16 +277,11 @@ __global__ __launch_bounds__(kGcWaves * 64) void graph_conv_fused_kernel(const G
   __syncthreads();
 
   // ---- phase 2: [16 x K] x [K x Fout]; wave = (column tile nt, k slice ks) ----
-  const int nt_all = (p.Fout + 15) >> 4;
   const int slices = kGcWaves / p.nt_pow2;
-  const int nt = wave & (p.nt_pow2 - 1), ks = wave / p.nt_pow2;
-  const int lr = lane & 15, lg = lane >> 4;
   const int ktiles = p.K >> 5;
   const int per = (ktiles + slices - 1) / slices;
   const int kt0 = ks * per, kt1 = min(ktiles, kt0 + per);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  const int col = nt * 16 + lr;
-  const bool live = nt < nt_all && col < p.Fout;
   const f16x8 zero8 = {(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0};
   if (nt < nt_all) {
     const _Float16* wq = p.w16 + ((long)(live ? col : 0) * ktiles * 2) * 32 + lg * 8;
@@ -256,7 +311,7 @@ __global__ __launch_bounds__(kGcWaves * 64) void graph_conv_fused_kernel(const G
     __syncthreads();
     if (ks == 0)
       for (int s2 = 1; s2 < slices; ++s2) {
-        const f32x4 o = *reinterpret_cast<const f32x4*>(red + ((long)(s2 * p.nt_pow2 + nt) * 64 + lane) * 4);
+        const f32x4 o = *reinterpret_cast<const f32x4*>(red + ((long)(s2 * p.nt_pow2 + (wave & (p.nt_pow2 - 1))) * 64 + lane) * 4);
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[q] += o[q];
       }
@@ -264,18 +319,6 @@ __global__ __launch_bounds__(kGcWaves * 64) void graph_conv_fused_kernel(const G
   if (ks != 0 || !live) return;
 
   // ---- epilogue: D[row = lg * 4 + r][col] ----
-  const float bias = p.bias ? p.bias[col] : 0.f;
-  int i0 = 0, i1 = 0;
-  float w0 = 0.f, w1 = 0.f;
-  if (p.xin) {   // ATen area_pixel_compute_source_index, align_corners = False (as feat_interp_add_kernel)
-    const float scale = (float)p.Fi / (float)p.Fout;
-    float src = fmaf(scale, (float)col + 0.5f, -0.5f);
-    src = src < 0.f ? 0.f : src;
-    i0 = (int)src;
-    i1 = i0 + (i0 < p.Fi - 1 ? 1 : 0);
-    w1 = src - (float)i0;
-    w0 = 1.f - w1;
-  }
   bool bad = false;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -283,10 +326,7 @@ __global__ __launch_bounds__(kGcWaves * 64) void graph_conv_fused_kernel(const G
     if (row >= p.rows) continue;
     float v = acc[r] + bias;
     if (p.relu) v = hn::relu(v);
-    if (p.xin) {
-      const float* xr = p.xin + (long)row * p.Fi;
-      v = v + (w0 * xr[i0] + w1 * xr[i1]);
-    }
+    if (p.xin) v = v + res[r];
     for (int u = 0; u < p.up; ++u) {
       const long orow = (long)row * p.up + u;
       if (p.out_split) {
@@ -323,15 +363,21 @@ extern "C" int hn_graph_conv_cheby3_f16x3(const hn_graph_csr* L, const hn_graph_
   p.rows = batch * L->v; p.V = L->v; p.Fin = fin; p.Fout = fout; p.K = (3 * fin + 31) / 32 * 32; p.Fi = fi;
   p.relu = relu ? 1 : 0; p.up = up; p.out_split = out_split ? 1 : 0;
   p.range_flag = out_split ? hn::range_flag_ptr() : nullptr;
+  // column tiles per workgroup: at most 4 (a CU pulls its workgroup's share of the filter bank through ONE 64 B/clk vector
+  // memory path: the whole 768 x 256 bank per workgroup was 17 of a layer's 25 us; with four column groups every workgroup
+  // repeats the basis gather -- 3.5 us, in parallel on other CUs -- and reads a quarter of the bank, its sixteen waves
+  // sharing the k loop four ways)
   p.nt_pow2 = 1;
-  while (p.nt_pow2 * 16 < fout) p.nt_pow2 *= 2;
+  while (p.nt_pow2 * 16 < fout && p.nt_pow2 < 4) p.nt_pow2 *= 2;
+  const int col_groups = (fout + 16 * p.nt_pow2 - 1) / (16 * p.nt_pow2);
   const size_t lds = (size_t)2 * kGcRows * (p.K + kGcPad) * sizeof(_Float16) + (size_t)kGcWaves * 64 * 4 * sizeof(float);
   static bool attr_set = false;    // (> 64 KB of dynamic LDS needs the attribute once per process)
   if (!attr_set) {
     HN_CHECK_HIP(hipFuncSetAttribute((const void*)graph_conv_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(graph_conv_fused_kernel, dim3((p.rows + kGcRows - 1) / kGcRows), dim3(kGcWaves * 64), lds, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(graph_conv_fused_kernel, dim3((p.rows + kGcRows - 1) / kGcRows, col_groups), dim3(kGcWaves * 64), lds,
+                     (hipStream_t)stream, p);
   HN_CHECK_LAUNCH("graph_conv_fused_kernel");
   return HN_OK;
 }
