@@ -401,12 +401,14 @@ __global__ __launch_bounds__(256) void pad_split_rows_kernel(const float* __rest
 // pose_combine of pose2mesh_net.py:20: [pose2d | pose3d / 1000 | 0-pad] per joint, fp32 [rows][fpad] (fpad = 8: the padded
 // input of the first graph convolution)
 __global__ __launch_bounds__(256) void lifter_combine_kernel(const float* __restrict__ pose2d, const float* __restrict__ pose3d,
-                                                             float* __restrict__ out, long rows, int fpad) {
+                                                             float* __restrict__ out, long rows, int fpad, int joints,
+                                                             int p3_stride) {
   const long total = rows * fpad;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % fpad);
     const long r = i / fpad;
-    out[i] = c < 2 ? pose2d[r * 2 + c] : (c < 5 ? pose3d[r * 3 + (c - 2)] / 1000.f : 0.f);
+    const long b = r / joints, j = r - b * joints;
+    out[i] = c < 2 ? pose2d[r * 2 + c] : (c < 5 ? pose3d[b * p3_stride + j * 3 + (c - 2)] / 1000.f : 0.f);
   }
 }
 }  // namespace
@@ -420,11 +422,13 @@ extern "C" int hn_pad_split_rows_f32(const float* x, int64_t rows, int f, int cp
   return HN_OK;
 }
 
-extern "C" int hn_lifter_combine_f32(const float* pose2d, const float* pose3d, int64_t rows, int fpad, float* out, void* stream) {
+extern "C" int hn_lifter_combine_f32(const float* pose2d, const float* pose3d, int batch, int joints, int pose3d_stride, int fpad,
+                                     float* out, void* stream) {
   HN_CHECK_ARG(pose2d && pose3d && out, "hn_lifter_combine_f32: null pointer");
-  HN_CHECK_ARG(rows > 0 && fpad >= 5, "bad dims");
+  HN_CHECK_ARG(batch > 0 && joints > 0 && fpad >= 5 && pose3d_stride >= 3 * joints, "bad dims");
+  const long rows = (long)batch * joints;
   hipLaunchKernelGGL(lifter_combine_kernel, dim3(grid_for(rows * fpad)), dim3(256), 0, (hipStream_t)stream, pose2d, pose3d, out,
-                     (long)rows, fpad);
+                     rows, fpad, joints, pose3d_stride);
   HN_CHECK_LAUNCH("lifter_combine_kernel");
   return HN_OK;
 }

@@ -145,7 +145,7 @@ SIGNATURES = {
     "hn_graph_conv_cheby3_f16x3": (C.c_int, [C.POINTER(GraphCsr), C.POINTER(GraphCsr), VP, C.c_int, C.c_int, VP, VP, C.c_int,
                                              C.c_int, VP, C.c_int, C.c_int, VP, C.c_int, VP]),
     "hn_pad_split_rows_f32": (C.c_int, [VP, C.c_int64, C.c_int, C.c_int, VP, VP]),
-    "hn_lifter_combine_f32": (C.c_int, [VP, VP, C.c_int64, C.c_int, VP, VP]),
+    "hn_lifter_combine_f32": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP]),
     "hn_cheby3_basis_split": (C.c_int, [VP, VP, VP, C.c_int, VP, VP, VP, C.c_int, C.c_int, C.c_int, VP]),
     "hn_feat_interp_add_f32": (C.c_int, [VP, VP, VP, C.c_int64, C.c_int, C.c_int, C.c_int, VP]),
     "hn_fcos_preprocess_split": (C.c_int, [VP, VP] + [C.c_int] * 8 + [c_f32p, c_f32p, VP]),

@@ -1479,11 +1479,16 @@ def pad_split_rows(x, cpad):
 
 
 def lifter_combine(pose2d, pose3d, fpad=8):
-    """pose2d [B,J,2], pose3d [B,J,3] (or [B,3J]) fp32 -> [B,J,fpad] = [pose2d | pose3d / 1000 | 0] (pose2mesh_net.py:20)."""
-    _req(pose2d, name="pose2d"); _req(pose3d, name="pose3d")
+    """pose2d [B,J,2], pose3d [B,J,3] (a view of padded [B,S >= 3J] rows is fine) fp32 -> [B,J,fpad] = [pose2d | pose3d / 1000 | 0]
+    (pose2mesh_net.py:20)."""
+    _req(pose2d, name="pose2d")
     b, j, _ = pose2d.shape
+    if (not pose3d.is_cuda or pose3d.dtype != torch.float32 or tuple(pose3d.shape) != (b, j, 3) or pose3d.stride(2) != 1
+            or pose3d.stride(1) != 3 or pose3d.stride(0) < 3 * j):
+        raise ValueError("pose3d must be fp32 GPU [B,J,3] with dense joints (rows may be padded)")
     out = torch.empty((b, j, fpad), device=pose2d.device, dtype=torch.float32)
-    check(_lib.load().hn_lifter_combine_f32(ptr(pose2d), ptr(pose3d), b * j, fpad, ptr(out), _stream()), "hn_lifter_combine_f32")
+    check(_lib.load().hn_lifter_combine_f32(ptr(pose2d), ptr(pose3d), b, j, pose3d.stride(0), fpad, ptr(out), _stream()),
+          "hn_lifter_combine_f32")
     return out
 
 

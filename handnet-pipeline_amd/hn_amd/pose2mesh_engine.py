@@ -79,7 +79,16 @@ class Pose2MeshEngine:
                 "bn1": self._bn_table(sd, q + "batch_norm1", dev), "w1": _dense(sd[q + "w1.weight"], sd[q + "w1.bias"], dev),
                 "w1_bn2": _dense(sd[q + "w1.weight"] * s2.view(-1, 1), sd[q + "w1.bias"] * s2 + t2, dev),
                 "bn2": self._bn_table(sd, q + "batch_norm2", dev), "w2": _dense(sd[q + "w2.weight"], sd[q + "w2.bias"], dev)})
-        self.p_w2 = _dense(sd[p + "w2.weight"], sd[p + "w2.bias"], dev)
+        # the output Linear with its rows zero-padded to a multiple of 8 (63 -> 64): the convolution kernel's vectorised
+        # epilogue, and with it split-K, needs Cout % 8 == 0 -- unsplit, this one launch walked 128 k tiles in a row (40 us of
+        # the 0.37 ms forward at batch 1)
+        w2, b2 = sd[p + "w2.weight"], sd[p + "w2.bias"]
+        self.p_out = w2.shape[0]
+        padr = (-w2.shape[0]) % 8
+        if padr:
+            w2 = torch.cat([w2, torch.zeros((padr, w2.shape[1]), dtype=w2.dtype)])
+            b2 = torch.cat([b2, torch.zeros((padr,), dtype=b2.dtype)])
+        self.p_w2 = _dense(w2, b2, dev)
         m = "pose2mesh."
         self.fc = _dense(sd[m + "fc.weight"], sd[m + "fc.bias"], dev)
         self.cl = []
@@ -147,7 +156,7 @@ class Pose2MeshEngine:
                 z = ops.conv2d_nhwc(a, cw.w, cw.bias, relu=True, w16=cw.w16, out_split=True)
                 cw = st["w2"]
                 y = ops.conv2d_nhwc(z, cw.w, cw.bias, residual=y, w16=cw.w16, out_split=i == last)
-            return self._linear(y, self.p_w2).reshape(b, -1)
+            return self._linear(y, self.p_w2).reshape(b, -1)[:, : self.p_out]
         xin = torch.zeros((b, 1, 1, self.p_w1.cin), device=self.device, dtype=torch.float32)
         xin[:, 0, 0, : x2d.shape[1]] = x2d
         y = self._linear(xin, self.p_w1)
@@ -156,7 +165,7 @@ class Pose2MeshEngine:
             z = self._linear(ops.to_split(y, s1, t1, relu=True), st["w1"])
             s2, t2 = (t.expand(b, -1).contiguous() for t in st["bn2"])
             y = self._linear(ops.to_split(z, s2, t2, relu=True), st["w2"], residual=y)
-        return self._linear(y, self.p_w2).reshape(b, -1)
+        return self._linear(y, self.p_w2).reshape(b, -1)[:, : self.p_out]
 
     def _graph_conv(self, x, layer, g):
         cw, fin_pad, relu = layer
@@ -242,7 +251,7 @@ class Pose2MeshEngine:
             raise RuntimeError("Pose2MeshEngine needs GPU tensors (no CPU fallback)")
         pose2d = pose2d.float().contiguous()
         b = pose2d.shape[0]
-        pose3d = self.posenet(pose2d.reshape(b, -1)).reshape(b, self.num_joint, 3)
+        pose3d = self.posenet(pose2d.reshape(b, -1)).view(b, self.num_joint, 3)    # (a view of the padded [B, 64] rows)
         if self.fused and b <= self.FUSED_MAX_BATCH:
             return self.meshnet_fused(ops.lifter_combine(pose2d, pose3d, fpad=self.cl[0][1])), pose3d
         comb = torch.cat((pose2d, pose3d / 1000), dim=2)          # pose2mesh_net.py:20 (glue, 105 floats per sample)

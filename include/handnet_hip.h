@@ -607,9 +607,11 @@ int hn_graph_conv_cheby3_f16x3(const hn_graph_csr* L, const hn_graph_csr* L2, co
                                void* y, int out_split, void* stream);
 /* Glue of the lifter as single launches: fp32 rows [rows][f] -> S32 rows of cpad channels, zero padded (the operand of
  * PoseNet's first Linear from the [batch][2J] joints); pose_combine (pose2mesh_net.py:20) = [pose2d | pose3d / 1000 | 0] per
- * joint as fp32 [rows = batch*J][fpad] (the padded input of the first graph convolution). */
+ * joint as fp32 [batch*J][fpad] (the padded input of the first graph convolution; pose3d rows may be padded: PoseNet's last
+ * Linear is run with 64 output columns so that it takes the vectorised / split-K form of the convolution kernel). */
 int hn_pad_split_rows_f32(const float* x, int64_t rows, int f, int cpad, void* out16, void* stream);
-int hn_lifter_combine_f32(const float* pose2d, const float* pose3d, int64_t rows, int fpad, float* out, void* stream);
+int hn_lifter_combine_f32(const float* pose2d /* [batch][joints][2] */, const float* pose3d /* [batch][pose3d_stride], 3*joints used */,
+                          int batch, int joints, int pose3d_stride, int fpad, float* out, void* stream);
 int hn_cheby3_basis_split(const int32_t* indptr, const int32_t* indices, const float* values, int v,
                           const float* x0, const float* x1, void* out16, int batch, int f, int cpad,
                           void* stream);
