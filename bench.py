@@ -85,7 +85,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None, help="frames (or crops) per GPU; default 32 (a2j: 64)")
-    ap.add_argument("--workload", choices=["pipeline", "a2j", "fcos", "pose2mesh"], default="pipeline")
+    ap.add_argument("--workload", choices=["pipeline", "a2j", "fcos", "pose2mesh", "live"], default="pipeline",
+                    help="live: the live caller's chain (HandNet + convert_joints + Pose2Mesh lifter, one copy) as one step")
     ap.add_argument("--precision", choices=["f16x3", "f32", "f16x1"], default="f16x3",
                     help="f16x3: split-fp16 operands on the f16 MFMA (fp32-grade results; the headline); f32: exact f32 MFMA; "
                          "f16x1: hi*hi term only = plain fp16 operands, 1 MFMA per MAC -- the THROUGHPUT mode SURVEY D6 plans "
@@ -125,7 +126,7 @@ def build_workload(args, dev, rank):
     from hn_amd.pipeline import HandNetEngine
 
     wl = args.workload
-    batch = args.batch or (64 if wl == "a2j" else 32 if wl in ("pipeline", "pose2mesh") else 16)
+    batch = args.batch or (64 if wl == "a2j" else 32 if wl in ("pipeline", "pose2mesh") else 1 if wl == "live" else 16)
     if wl == "pose2mesh":   # the lifter that follows the path in the live demo
         import numpy as np
         import scipy.sparse as sp
@@ -160,6 +161,29 @@ def build_workload(args, dev, rank):
     a2j_sd = synth.make_a2j_state_dict(0)
     fcos_sd = synth.make_fcos_state_dict(0, 3)
     info = {"batch_per_gpu": batch}
+    if wl == "live":   # ros_demo.py:270-290,329-337 as one step (hn_amd/live.py); profiling workload of tools/collect_profiles.sh
+        import numpy as np
+        import scipy.sparse as sp
+        from hn_amd.live import LiveHandEngine
+        from hn_amd.pose2mesh_engine import Pose2MeshEngine
+        g = np.load(REPO / "tests" / "golden" / "pose2mesh_forward.npz")
+        graphs = [sp.csr_matrix((g[f"L{i}_data"], g[f"L{i}_indices"], g[f"L{i}_indptr"]),
+                                shape=tuple(int(v) for v in g[f"L{i}_shape"])) for i in range(int(g["num_levels"]))]
+        lifter = Pose2MeshEngine(synth.make_pose2mesh_state_dict(0, graph_sizes=[m.shape[0] for m in graphs]), graphs, device=dev)
+        hand = HandNetEngine(FCOSEngine(fcos_sd, 3, device=dev, precision=args.precision),
+                             A2JEngine(a2j_sd, device=dev, precision=args.precision), 3)
+        live = LiveHandEngine(hand, lifter, LIVE_PARAS, clamp=True)
+        rgb, depth = synth.make_rgb(batch, seed=1000 + rank).to(dev), synth.make_depth(batch, seed=2000 + rank).to(dev)
+        info.update(unit="frames/s", gflop_per_unit=2 * (hand.fcos.macs_per_frame() + hand.a2j.macs_per_crop()) / 1e9,
+                    name="the live caller's chain: HandNet -> convert_joints -> Pose2Mesh lifter -> one copy (ros_demo.py:270-337)")
+        if args.graph:
+            run, _, _, out = live.graphed(rgb, depth)
+
+            def step():
+                run()
+                return out.hand
+            return step, info, None
+        return (lambda: live.forward_device(rgb, depth).hand), info, None
     if wl == "a2j":
         eng = A2JEngine(a2j_sd, device=dev, precision=args.precision)
         x = synth.make_crops(batch, 176, seed=3000 + rank).to(dev)

@@ -427,3 +427,5 @@ extern "C" int hn_conv_stem_pool_f16x3_terms(const void* x16, int n, int ph, int
   HN_CHECK_ARG(terms == 0 || terms == 1 || terms == 3, "terms must be 0 / 3 or 1");
   return stem16_run(x16, n, ph, pw, pad, r, stride, cout, w16, bias, 1, y, 1, true, stream, terms);
 }
+
+int hn::tickets_nonzero_main(int64_t* count) { return tickets_nonzero_here(count); }

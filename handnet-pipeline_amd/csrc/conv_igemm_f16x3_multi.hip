@@ -129,3 +129,5 @@ extern "C" int hn_conv2d_f16x3_multi_fuses(const hn_conv_multi* mm, int64_t work
   return tile == HN_TILE_128x128 || tile == HN_TILE_128x64 || tile == HN_TILE_64x64 || tile == HN_TILE_64x128 || tile == HN_TILE_32x64 ||
          tile == HN_TILE_64x64_K2;
 }
+
+int hn::tickets_nonzero_multi(int64_t* count) { return tickets_nonzero_here(count); }

@@ -90,6 +90,19 @@ static int split_ticket_slot(const void* workspace) {
   keys[used] = workspace;
   return used++;
 }
+// hn_debug_tickets_nonzero: counters of THIS translation unit's g_split_tickets that are not zero (synchronises the device).
+// "Zero at rest" is the invariant the in-kernel reduction rests on: a launch that died between drawing and putting back would
+// leave a counter behind and the next launch on that slot would never see "last".
+static int tickets_nonzero_here(int64_t* count) {
+  static int host[kTicketSlots * kTicketsPerSlot];
+  HN_CHECK_HIP(hipDeviceSynchronize());
+  HN_CHECK_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_split_tickets), sizeof(host)));
+  int64_t c = 0;
+  for (int i = 0; i < kTicketSlots * kTicketsPerSlot; ++i) c += host[i] != 0;
+  *count += c;
+  return HN_OK;
+}
+
 // After plan_splits: the split launch reduces in its own last workgroups when it can have counters -- `taken` of the slot's
 // counters already belong to earlier members of the same launch (heterogeneous launches; 0 otherwise).
 static void assign_tickets(ConvParams16& p, int bm, int bn, int waves, const void* workspace, int& taken) {

@@ -371,10 +371,12 @@ extern "C" int hn_graph_conv_cheby3_f16x3(const hn_graph_csr* L, const hn_graph_
   while (p.nt_pow2 * 16 < fout && p.nt_pow2 < 4) p.nt_pow2 *= 2;
   const int col_groups = (fout + 16 * p.nt_pow2 - 1) / (16 * p.nt_pow2);
   const size_t lds = (size_t)2 * kGcRows * (p.K + kGcPad) * sizeof(_Float16) + (size_t)kGcWaves * 64 * 4 * sizeof(float);
-  static bool attr_set = false;    // (> 64 KB of dynamic LDS needs the attribute once per process)
-  if (!attr_set) {
+  static bool attr_set[64] = {};    // (> 64 KB of dynamic LDS needs the attribute once per device)
+  int dev = 0;
+  HN_CHECK_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
     HN_CHECK_HIP(hipFuncSetAttribute((const void*)graph_conv_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
   hipLaunchKernelGGL(graph_conv_fused_kernel, dim3((p.rows + kGcRows - 1) / kGcRows, col_groups), dim3(kGcWaves * 64), lds,
                      (hipStream_t)stream, p);

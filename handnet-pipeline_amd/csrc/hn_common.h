@@ -40,6 +40,10 @@ bool conv1x1_stream_operands_ok(const hn_conv_desc* d, const void* x16, const vo
 int conv1x1_stream(const hn_conv_desc* d, const void* x16, const void* w16, const float* bias, const void* residual, void* y,
                    hipStream_t st);
 
+// hn_debug_tickets_nonzero: the split-K ticket arrays of the two translation units that hold one
+int tickets_nonzero_main(int64_t* count);
+int tickets_nonzero_multi(int64_t* count);
+
 #define HN_CHECK_ARG(cond, ...)                          \
   do {                                                   \
     if (!(cond)) return hn::fail(HN_ERR_ARG, __VA_ARGS__); \

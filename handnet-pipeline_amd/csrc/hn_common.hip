@@ -56,6 +56,13 @@ int fail(int code, const char* fmt, ...) {
 
 extern "C" int hn_abi_version(void) { return HN_ABI_VERSION; }
 
+extern "C" int hn_debug_tickets_nonzero(int64_t* count) {
+  HN_CHECK_ARG(count, "hn_debug_tickets_nonzero: null pointer");
+  *count = 0;
+  if (int rc = hn::tickets_nonzero_main(count)) return rc;
+  return hn::tickets_nonzero_multi(count);
+}
+
 namespace hn {
 // Kernel-form switches: older forms of some kernels stay in the library as bit-identity references for the tests and for
 // same-box A/B timing.  The library never reads them from the environment: a development host sets them by name

@@ -183,6 +183,7 @@ SIGNATURES = {
     "hn_groupnorm_finalize_rows32_levels": (C.c_int, [C.POINTER(GnLevels), VP, VP, C.c_int, C.c_int, C.c_int, C.c_float, VP]),
     "hn_affine_split_f32_levels": (C.c_int, [C.POINTER(SplitLevels)] + [C.c_int] * 6 + [VP]),
     "hn_pack_records": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP]),
+    "hn_debug_tickets_nonzero": (C.c_int, [c_i64p]),
     "hn_pack_records_ex": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP]),
     "hn_unpack_records": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, VP]),
     "hn_nonfinite_count_f32": (C.c_int, [VP, C.c_int64, VP, VP]),

@@ -1303,6 +1303,14 @@ def nonfinite_count(x, flag=None):
     return flag
 
 
+def tickets_nonzero() -> int:
+    """Split-K ticket counters of the current device that are not zero (hn_debug_tickets_nonzero; synchronises).  0 after any
+    sequence of completed launches: the counters are zero at rest."""
+    c = C.c_int64(0)
+    check(_lib.load().hn_debug_tickets_nonzero(C.byref(c)), "hn_debug_tickets_nonzero")
+    return int(c.value)
+
+
 def set_form(name: str, on=True):
     """Kernel-form switch of the library (hn_set_form; names in include/handnet_hip.h): an older form of a kernel as a
     bit-identity reference or for A/B timing.  Process-wide; the product never sets one (hn_amd/forms.py)."""

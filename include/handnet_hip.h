@@ -93,6 +93,11 @@ int hn_range_check_collect(int32_t* block /* or NULL */, int32_t* dst /* device,
  * unless a test says otherwise).  The library NEVER reads them from the environment: a development host sets them by name
  * (bench.py and tools/ translate their HN_* variables through hn_amd/forms.py); a product process leaves them alone. */
 int hn_set_form(const char* name, int value);
+/* Debug / test: the number of split-K ticket counters of the CURRENT device that are not zero.  SYNCHRONISES the device.  The
+ * in-kernel split-K reduction (hn_conv2d_nhwc_f16x3_ws, _multi) draws tickets from library-owned counters that are zero at rest:
+ * after any sequence of completed launches the answer is 0; anything else means a launch died between drawing a ticket and
+ * putting it back (the next split launch on that workspace would then never elect a reducing workgroup). */
+int hn_debug_tickets_nonzero(int64_t* count /* host */);
 /* Development: scale factor (default 1.0) of a constant of the split-K cost model -- "splitk_fix", "splitk_tk", "splitk_red0",
  * "splitk_plane" (csrc/conv_igemm_f16x3.hip: plan_splits) -- for in-frame scans of the model; never set by the product. */
 int hn_set_tuning(const char* name, double value);
