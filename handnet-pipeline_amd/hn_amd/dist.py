@@ -312,9 +312,18 @@ class ShardedHandNet:
                         for _ in range(2):
                             self._step(s_img, s_dep, per_rank, bufs)
                     torch.cuda.current_stream().wait_stream(side)
+                    torch.cuda.current_stream().synchronize()
+                    eager = bufs["host"].clone()             # what the last eager step gathered for these inputs
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, capture_error_mode="thread_local"):
                         self._step(s_img, s_dep, per_rank, bufs)
+                # a captured collective must deliver what the eager one did: one replay on the same inputs, compared byte for
+                # byte (a backend that captures but replays something else -- or nothing -- is treated like one that refuses)
+                bufs["host"].zero_()
+                g.replay()
+                torch.cuda.current_stream().synchronize()
+                if not torch.equal(bufs["host"], eager):
+                    raise RuntimeError("the replayed step + all-gather returned other records than the eager one")
             except Exception as e:  # noqa: BLE001 -- the backend (or a capture-unsafe call elsewhere in the process) refused
                 torch.cuda.synchronize()
                 self.gather_captured = False

@@ -139,3 +139,23 @@ class NativeModel:
             check(self.lib.hn_handnet_forward(self._h, ptr(rgb), ptr(depth), n, h, w, ptr(kp), ptr(box), ptr(has), _stream()),
                   "hn_handnet_forward")
         return kp, box, has
+
+    def handnet_xyz(self, rgb, depth, paras=None, clamp=False):
+        """hn_handnet_forward_xyz: handnet() + the aggregation epilogue's image (u,v,d) and -- with paras = (fx, fy, cx, cy) --
+        camera xyz in mm -> (keypoints, image_uvd, xyz_mm or None, crop_box, has_hand); clamp: the live caller's clamps
+        (ros_demo.py:279-283) on what is converted."""
+        from . import _lib
+        rgb, depth = rgb.float().contiguous(), depth.float().contiguous()
+        n, _, h, w = rgb.shape
+        with on_device(self.device):
+            kp = torch.empty((n, self.num_joints, 3), device=self.device)
+            img = torch.empty((n, self.num_joints, 3), device=self.device)
+            xyz = torch.empty((n, self.num_joints, 3), device=self.device) if paras is not None else None
+            box = torch.empty((n, 4), device=self.device, dtype=torch.int64)
+            has = torch.empty((n,), device=self.device, dtype=torch.int32)
+            pp = (C.c_float * 4)(*[float(v) for v in paras]) if paras is not None else None
+            opts = _lib.ConvertOpts(1, h, w) if clamp else None
+            check(self.lib.hn_handnet_forward_xyz(self._h, ptr(rgb), ptr(depth), n, h, w, pp, C.byref(opts) if opts is not None else None,
+                                                  ptr(kp), ptr(img), ptr(xyz), ptr(box), ptr(has), _stream()), "hn_handnet_forward_xyz")
+        return kp, img, xyz, box, has
+

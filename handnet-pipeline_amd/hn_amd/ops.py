@@ -233,7 +233,7 @@ def clear_plan_caches():
 # split-K workspace: one fp32 buffer per (device, stream) -- a convolution only uses it between its own two
 # launches, and launches on one stream are ordered
 CONV_WORKSPACE_BYTES = 32 << 20
-SPLITK = True  # development switch (forms.apply_env: HN_SPLITK=0; tools/probes/exp/splitk.sh)
+SPLITK = True  # development switch (forms.apply_env: HN_SPLITK=0)
 # split short k loops too (desc.splitk = 1).  It used to pay only under graph replay; since the host path got
 # cheaper (raw stream handle, cached descriptors) it also wins in eager mode (batch 1: 294 -> 301 frames/s)
 SPLITK_EAGER = True

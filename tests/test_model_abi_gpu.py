@@ -277,3 +277,25 @@ def test_model_config_image_mean_std(fcos_sd):
             m.close()
     with pytest.raises(RuntimeError, match="image_std"):
         NativeModel(fcos_sd, None, num_classes=3, image_mean=mean, image_std=[0.2, 0.0, 0.3])
+
+
+def test_handnet_forward_xyz_carries_the_converted_joints(native):
+    """hn_handnet_forward_xyz: the same launches as hn_handnet_forward (keypoints / boxes / flags identical), plus image (u,v,d)
+    and camera xyz written by the aggregation's epilogue -- bit-identical to hn_convert_joints_f32 on its results, with and
+    without the live caller's clamps; a batch above the multi-launch threshold too (another A2J graph)."""
+    from hn_amd import ops, synth
+    paras = (617.343, 617.343, 312.42, 241.42)
+    for n in (2, 6):
+        rgb, depth = synth.make_rgb(n, seed=1000).cuda(), synth.make_depth(n, seed=2000).cuda()
+        kp0, box0, has0 = native.handnet(rgb, depth)
+        kp, img, xyz, box, has = native.handnet_xyz(rgb, depth, paras)
+        assert torch.equal(kp, kp0) and torch.equal(box, box0) and torch.equal(has, has0) and int((has == 1).sum()) == n
+        assert torch.equal(img, ops.convert_joints(kp, box, has, None)) and torch.equal(xyz, ops.convert_joints(kp, box, has, paras))
+        kp2, img2, xyz2, _b, _h = native.handnet_xyz(rgb, depth, None, clamp=True)
+        assert xyz2 is None and torch.equal(kp2, kp0)
+        assert torch.equal(img2, ops.convert_joints(torch.clamp(kp0, 0.0, 176.0), box, has, None))   # (boxes lie inside the frame)
+    with pytest.raises(RuntimeError, match="no converted output|null"):
+        from hn_amd._lib import check
+        check(native.lib.hn_handnet_forward_xyz(native._h, rgb.data_ptr(), depth.data_ptr(), n, 480, 640, None, None, kp.data_ptr(),
+                                                None, None, box.data_ptr(), has.data_ptr(), None), "hn_handnet_forward_xyz")
+
