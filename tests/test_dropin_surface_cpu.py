@@ -136,3 +136,30 @@ def test_weight_range_contract_is_checked_at_load():
     w[2, 1, 1, 5] = float("nan")
     with pytest.raises(ValueError, match="fp16 range"):
         split_f16x3(w)
+
+
+def test_wide_host_record_layout():
+    """hn_amd.pipeline.read_host_record on a record buffer packed by hand: the 296-byte record of the step (crop box 4 x int64,
+    has_hand, row flag, keypoints) and the WIDE record of a converting step (image uvd and camera xyz behind the keypoints), row
+    N = the range words -- the layout hn_pack_records_ex writes and the live step's one copy carries."""
+    import numpy as np
+    from hn_amd.pipeline import RECORD_BYTES, read_host_record, record_bytes
+    assert record_bytes(1) == RECORD_BYTES == 296 and record_bytes(2) == 544 and record_bytes(3) == 800
+    n = 3
+    rng = np.random.default_rng(0)
+    kp, img, xyz = (rng.normal(size=(n, 21, 3)).astype(np.float32) for _ in range(3))
+    box = rng.integers(0, 640, size=(n, 4)).astype(np.int64)
+    has = np.array([1, 0, 2], dtype=np.int32)
+    for fields, extras in ((1, ()), (3, (img, xyz))):
+        rec = np.zeros((n + 1, record_bytes(fields)), dtype=np.uint8)
+        rec[:n, :32] = box.view(np.uint8).reshape(n, 32)
+        rec[:n, 32:36] = has.view(np.uint8).reshape(n, 4)
+        rec[:n, 36:40] = np.ones(n, dtype=np.int32).view(np.uint8).reshape(n, 4)
+        for f, t in enumerate((kp,) + tuple(extras)):
+            rec[:n, 40 + 252 * f: 40 + 252 * (f + 1)] = t.reshape(n, 63).view(np.uint8)
+        rec[n, :16] = np.array([0, 1, 0, 0], dtype=np.int32).view(np.uint8)
+        out = read_host_record(torch.from_numpy(rec), n, extras=bool(extras))
+        assert np.array_equal(out[0].numpy(), kp) and out[1].tolist() == [1, 0, 2] and np.array_equal(out[2].numpy(), box)
+        assert out[3] == [0, 1, 0, 0]
+        if extras:
+            assert len(out[4]) == 2 and np.array_equal(out[4][0].numpy(), img) and np.array_equal(out[4][1].numpy(), xyz)
