@@ -219,7 +219,7 @@ class ShardedHandNet:
         dist.all_gather_into_tensor(recv, send, group=self.group)
 
     # -- one step on this rank's shard + the collectives (static launch sequence: capturable) ---------------------------------
-    def _step(self, images, depth, per_rank, bufs):
+    def _step(self, images, depth, per_rank, bufs, total):
         eng = self._engine()
         out = eng.forward_device(images, depth)
         b = out.keypoints.shape[0]
@@ -248,11 +248,11 @@ class ShardedHandNet:
                 sd[b:].zero_()
             self._all_gather(bufs["recv_d"], sd)
         bufs["host"].copy_(recv, non_blocking=True)
-        return out
+        return self._gathered(total, per_rank, bufs)      # (unpack + row selection: part of the step, so part of its capture)
 
     def forward_device(self, images, depth_images, global_batch: int | None = None) -> ShardedOutput:
         """The sync-free form: runs the step + the collectives and returns ShardedOutput (device tensors over the global batch;
-        its host_record is valid after the stream is synchronised)."""
+        its host_record is valid after the stream is synchronised).  Replayed steps return the capture's static tensors."""
         n_in = len(images)
         if global_batch is None:
             total = n_in
@@ -272,21 +272,20 @@ class ShardedHandNet:
         dev = batch.device
         channels = 4 if self.rgbd else 1
         bufs = self._buffers(per_rank, channels, dev)
-        key = (tuple(batch.shape), tuple(depth_images.shape), per_rank)
+        key = (tuple(batch.shape), tuple(depth_images.shape), per_rank, total)
         if dev.type == "cuda" and self.use_graph and not self._stage_through_host(batch):
             hit = self._graphs.get(key)
             if hit is None:
                 self._seen[key] = self._seen.get(key, 0) + 1
                 if self._seen[key] > self.GRAPH_AFTER and self.gather_captured is not False:
-                    hit = self._capture(key, batch, depth_images, per_rank, bufs)
+                    hit = self._capture(key, batch, depth_images, per_rank, bufs, total)
             if hit is not None:
-                g, s_img, s_dep = hit
+                g, s_img, s_dep, out = hit
                 s_img.copy_(batch)
                 s_dep.copy_(depth_images)
                 g.replay()
-                return self._gathered(total, per_rank, bufs)
-        self._step(batch, depth_images, per_rank, bufs)
-        return self._gathered(total, per_rank, bufs)
+                return out          # (static tensors of the capture: overwritten by the next replay)
+        return self._step(batch, depth_images, per_rank, bufs, total)
 
     def prepare(self, images, depth_images, global_batch: int | None = None):
         """Capture the step + collectives for these shapes NOW (instead of after GRAPH_AFTER eager steps): a caller that
@@ -295,7 +294,7 @@ class ShardedHandNet:
             self.forward_device(images, depth_images, global_batch)
         return self.gather_captured
 
-    def _capture(self, key, batch, depth, per_rank, bufs):
+    def _capture(self, key, batch, depth, per_rank, bufs, total):
         """The step and its collectives as ONE hipGraph.  The warm-up steps run the collectives eagerly first (communicator
         and buffers exist before the capture starts).  A backend that refuses to be captured leaves gather_captured = False:
         forward_device then stays eager for the collectives (the engine's own captured step still serves the launches)."""
@@ -310,13 +309,13 @@ class ShardedHandNet:
                 with ops.launch_cost_hidden():
                     with torch.cuda.stream(side):
                         for _ in range(2):
-                            self._step(s_img, s_dep, per_rank, bufs)
+                            self._step(s_img, s_dep, per_rank, bufs, total)
                     torch.cuda.current_stream().wait_stream(side)
                     torch.cuda.current_stream().synchronize()
                     eager = bufs["host"].clone()             # what the last eager step gathered for these inputs
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                        self._step(s_img, s_dep, per_rank, bufs)
+                        out = self._step(s_img, s_dep, per_rank, bufs, total)
                 # a captured collective must deliver what the eager one did: one replay on the same inputs, compared byte for
                 # byte (a backend that captures but replays something else -- or nothing -- is treated like one that refuses)
                 bufs["host"].zero_()
@@ -333,7 +332,7 @@ class ShardedHandNet:
         self.gather_captured = True
         self.capture_note = ("step + all-gather" + (" + depth all-gather" if self.gather_depth else "")
                              + " + record copy to the host captured in ONE hipGraph")
-        self._graphs[key] = (g, s_img, s_dep)
+        self._graphs[key] = (g, s_img, s_dep, out)
         return self._graphs[key]
 
     def _gathered(self, total, per_rank, bufs) -> ShardedOutput:
