@@ -68,18 +68,21 @@ class LiveHandEngine:
     @ops.device_guarded
     def forward_device(self, images, depth, _buffers=None) -> LiveOutput:
         """images [N,3,H,W] 0..1 (or a list), depth [N,1,H,W] metres on the GPU -> LiveOutput (no sync)."""
-        out = self.hand.forward_device(images, depth)
-        n = out.keypoints.shape[0]
-        p2d = ops.joints2d_standardize(out.image_uvd, valid=out.has_hand)
-        mesh, pose3d = self.lifter.forward(p2d)
-        v0 = mesh.shape[1]
+        n = len(images)
+        v0 = self.lifter.graphs[0].v
         dev, host = _buffers if _buffers is not None else self._out_buffers(n, v0)
         rb = record_bytes(3)
         rec = dev[: (n + 1) * rb].view(n + 1, rb)
-        ops.pack_records(out.keypoints, out.crop_box, out.has_hand, n + 1, rb, out=rec, extras=(out.image_uvd, out.xyz_mm))
-        if out.range_flags is not None:
-            rec[n, :16].view(torch.int32).copy_(out.range_flags)
-        dev[(n + 1) * rb:].view(torch.float32).view(n, v0, 3).copy_(mesh)
+        mesh_buf = dev[(n + 1) * rb:].view(torch.float32).view(n, v0, 3)
+
+        def lift(_kp, image_uvd, _xyz, has_hand):
+            # (inside the step's range scope: the lifter's split producers note into the step's flag words, which the step's one
+            # collect launch hands over -- an overflowing activation of the lifter raises like one of the pose network)
+            p2d = ops.joints2d_standardize(image_uvd, valid=has_hand)
+            return (p2d,) + tuple(self.lifter.forward(p2d, mesh_out=mesh_buf))     # the last layer writes into the copy buffer
+        # the step packs its wide records and its range words straight into `rec`; ONE copy moves records + mesh
+        out = self.hand.forward_device(images, depth, _record=(None, rec), _tail=lift)
+        p2d, mesh, pose3d = out.tail
         host.copy_(dev, non_blocking=True)
         return LiveOutput(out, p2d, mesh, pose3d, host, n)
 

@@ -1453,7 +1453,7 @@ def _csr_struct(g: CsrGraph):
     return _lib.GraphCsr(g.indptr.data_ptr(), g.indices.data_ptr(), g.values.data_ptr(), g.v)
 
 
-def graph_conv_cheby3(g: CsrGraph, g2: CsrGraph, x, cw, relu=True, xin=None, up=1, out_split=False):
+def graph_conv_cheby3(g: CsrGraph, g2: CsrGraph, x, cw, relu=True, xin=None, up=1, out_split=False, out=None):
     """One Chebyshev graph convolution (K = 3) as ONE launch (hn_graph_conv_cheby3_f16x3): x fp32 [B,V,Fin] ->
     act(Linear([x0 | L x0 | (2 L L - I) x0]) + bias) (+ feature-axis interpolation of xin [B,V,Fi], rows repeated `up` times);
     cw: ConvW-like with .w [Fout,1,1,K], .w16, .bias over K = pad32(3 Fin) k-major channels.  -> fp32 [B,V*up,Fout] or, with
@@ -1467,7 +1467,11 @@ def graph_conv_cheby3(g: CsrGraph, g2: CsrGraph, x, cw, relu=True, xin=None, up=
         _req(xin, name="xin")
         if tuple(xin.shape[:2]) != (b, v):
             raise ValueError("xin must be [B,V,Fi]")
-    if out_split:
+    if out is not None:
+        y = _req(out, torch.float16 if out_split else torch.float32, "out")
+        if y.numel() != b * v * up * fout * (2 if out_split else 1):
+            raise ValueError("out has the wrong size")
+    elif out_split:
         y = torch.empty((b, v * up, 1, fout // 32, 2, 32), device=x.device, dtype=torch.float16)
     else:
         y = torch.empty((b, v * up, fout), device=x.device, dtype=torch.float32)

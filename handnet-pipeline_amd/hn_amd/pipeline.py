@@ -33,6 +33,7 @@ class HandNetOutput:
     range_flags: torch.Tensor = None   # [4] int32 device: the step's f16x3 range-contract words (ops.range_bits), or None
     image_uvd: torch.Tensor = None     # [N,21,3] fp32 device, after HandNetEngine.set_convert(): image (u,v,d) per joint
     xyz_mm: torch.Tensor = None        # [N,21,3] fp32 device, set_convert(paras=...): camera xyz in millimetres
+    tail: object = None                # what forward_device's `_tail` callable returned (the live step: the lifter's mesh, pose3d)
     host_record: torch.Tensor = None   # to_host steps: PINNED uint8 [N+1, 296] the step copies its results into (device -> host
     #                                    copy enqueued by the step itself; valid after the stream is synchronised): rows 0..N-1 =
     #                                    hn_pack_records rows (crop box 32 B | has_hand | 1 | keypoints), row N = the range words
@@ -176,11 +177,14 @@ class HandNetEngine:
         return 1 if c is None else (3 if c["paras"] is not None else 2)
 
     @ops.device_guarded
-    def forward_device(self, images, depth: torch.Tensor, to_host: bool = False, _record=None) -> HandNetOutput:
+    def forward_device(self, images, depth: torch.Tensor, to_host: bool = False, _record=None, _tail=None) -> HandNetOutput:
         """images [N,3,H,W] 0..1 (or a list of [3,h_i,w_i] tensors of different sizes), depth [N,1,H,W] metres
         (RGBD model: [N,4,H,W] = RGB + depth), fp32 on the GPU.  to_host: the step also packs its per-frame results and the
         range words into one record buffer and enqueues ONE device -> host copy of it into pinned memory
-        (HandNetOutput.host_record; the reference returns its keypoints on the CPU, a2j/a2j.py:229) -- no sync here."""
+        (HandNetOutput.host_record; the reference returns its keypoints on the CPU, a2j/a2j.py:229) -- no sync here.
+        _tail(keypoints, image_uvd, xyz_mm, has_hand): more launches of the SAME step, issued inside its range scope -- before
+        the flag words are collected, so their split producers are covered by the step's range contract (the live step's
+        lifter, hn_amd/live.py); its return value is HandNetOutput.tail."""
         want_c = 4 if self.a2j.rgbd else 1
         if depth.dim() != 4 or depth.shape[1] != want_c or depth.shape[0] != len(images):
             raise ValueError(f"depth_images must be [N,{want_c},H,W] matching images"
@@ -200,13 +204,15 @@ class HandNetEngine:
             img_uvd = xyz = None
             if conv is not None:
                 kp, img_uvd, xyz = kp
+            tail = _tail(kp, img_uvd, xyz, has_hand) if _tail is not None else None
             host_rec = None
             if to_host or _record is not None:
                 n = len(images)
                 host_rec, dev_rec = _record if _record is not None else self._host_record_buffers(n)
                 ops.pack_records(kp, crop_box, has_hand, n + 1, dev_rec.shape[1], out=dev_rec, extras=(img_uvd, xyz))   # (row n: zeros)
                 flags = ops.range_check_collect(self._range_block, out=dev_rec[n, :16].view(torch.int32)) if noting else None
-                host_rec.copy_(dev_rec, non_blocking=True)
+                if host_rec is not None:      # (None: the caller copies a larger buffer that holds the records -- the live step)
+                    host_rec.copy_(dev_rec, non_blocking=True)
             else:
                 flags = ops.range_check_collect(self._range_block) if noting else None
         self._note_hand_count(has_hand, len(images))
@@ -214,7 +220,7 @@ class HandNetEngine:
             bits = ops.range_bits(flags.cpu().tolist())
             if bits:
                 raise ops.RangeError(range_message(bits))
-        return HandNetOutput(kp, crops, crop_box, has_hand, det, cand, flags, img_uvd, xyz, host_rec)
+        return HandNetOutput(kp, crops, crop_box, has_hand, det, cand, flags, img_uvd, xyz, tail, host_rec)
 
     # -------------------------------------------------------------------------------
     # sparse streams: A2J on the frames with a hand only

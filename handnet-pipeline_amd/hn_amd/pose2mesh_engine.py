@@ -178,8 +178,9 @@ class Pose2MeshEngine:
         basis = ops.cheby3_basis_split(g, x, ops.spmm_csr(g, x))
         return ops.conv2d_nhwc(basis, cw.w, cw.bias, relu=relu, w16=cw.w16).view(b, v, -1)
 
-    def meshnet_fused(self, x):
-        """[B, J, 8] (pose_combine, zero padded) -> [B, V0, 3]: one launch per graph convolution (+ fc)"""
+    def meshnet_fused(self, x, mesh_out=None):
+        """[B, J, 8] (pose_combine, zero padded) -> [B, V0, 3]: one launch per graph convolution (+ fc); mesh_out: a
+        preallocated fp32 [B, V0, 3] the last layer writes (the live step's copy buffer)"""
         b = x.shape[0]
         nblk = len(CL_F)
         li = 0
@@ -198,7 +199,8 @@ class Pose2MeshEngine:
                 elif last and 0 < i < nblk - 1:    # block residual (+ nearest x2 vertex up-sampling) in the epilogue
                     x = ops.graph_conv_cheby3(g, g2, x, cw, relu=relu, xin=xin, up=2 if i < nblk - 2 else 1)
                 else:
-                    x = ops.graph_conv_cheby3(g, g2, x, cw, relu=relu)
+                    final = i == nblk - 1 and last
+                    x = ops.graph_conv_cheby3(g, g2, x, cw, relu=relu, out=mesh_out if final else None)
         return x
 
     def meshnet(self, x):
@@ -243,8 +245,9 @@ class Pose2MeshEngine:
         return g.replay, s_in, out
 
     @ops.device_guarded
-    def forward(self, pose2d):
-        """pose2d [B,J,2] fp32 on the GPU -> (cam_mesh [B,V0,3], pose3d [B,J,3]), both on the GPU."""
+    def forward(self, pose2d, mesh_out=None):
+        """pose2d [B,J,2] fp32 on the GPU -> (cam_mesh [B,V0,3], pose3d [B,J,3]), both on the GPU.  mesh_out: optional
+        contiguous fp32 [B,V0,3] the mesh is written into (and returned)."""
         if pose2d.dim() != 3 or pose2d.shape[1:] != (self.num_joint, 2):
             raise ValueError(f"expected [B,{self.num_joint},2]")
         if not pose2d.is_cuda:
@@ -253,6 +256,10 @@ class Pose2MeshEngine:
         b = pose2d.shape[0]
         pose3d = self.posenet(pose2d.reshape(b, -1)).view(b, self.num_joint, 3)    # (a view of the padded [B, 64] rows)
         if self.fused and b <= self.FUSED_MAX_BATCH:
-            return self.meshnet_fused(ops.lifter_combine(pose2d, pose3d, fpad=self.cl[0][1])), pose3d
+            return self.meshnet_fused(ops.lifter_combine(pose2d, pose3d, fpad=self.cl[0][1]), mesh_out), pose3d
         comb = torch.cat((pose2d, pose3d / 1000), dim=2)          # pose2mesh_net.py:20 (glue, 105 floats per sample)
-        return self.meshnet(comb), pose3d
+        mesh = self.meshnet(comb)
+        if mesh_out is not None:
+            mesh_out.copy_(mesh.view(mesh_out.shape))
+            mesh = mesh_out
+        return mesh, pose3d
