@@ -215,3 +215,15 @@ def test_dropin_set_convert_carries_the_joints_in_the_same_record(fcos_sd, a2j_s
                 want3d = convert_joints(kp[i].numpy(), None, crops[i].cpu().numpy(), np.asarray(PARAS), 176, 176)
                 assert np.abs(conv["image_uvd"][i].numpy() - want2d).max() < 1e-3
                 assert np.abs(conv["xyz_mm"][i].numpy() - want3d).max() < 2e-2
+
+
+def test_live_demo_example_runs():
+    """examples/live_demo.py: the reference's live loop (ros_demo.py:260-337) on the drop-in tree, three ways."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    repo = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(repo / "examples" / "live_demo.py"), "3"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "1. HandNet.forward: (1, 21, 3) cpu" in r.stdout and "2. set_convert" in r.stdout and "3. live step: 3 frames" in r.stdout
+    assert "(778, 3) camera-frame vertices; has_hand = [1]" in r.stdout
