@@ -798,7 +798,7 @@ def other_configs_leg(args, info, dev, sds=None, hip=None):
     rec.update(unit="crops/s", hipgraph=True, workload="A2J-only inference, batch 64 176x176 depth crops (BASELINE config 2)",
                gflop_per_unit=round(2 * eng.a2j.macs_per_crop() / 1e9, 3), **roof_of(lambda: eng.a2j.forward(crops), rec["ms_per_step"]))
     out["a2j_b64"] = rec
-    # rows 0..15 of the timed batch-64 step's own output: compared with the oracle by parity_legs() AFTER every timed region
+    # rows 0..15 of the timed batch-64 step's own output: compared with the oracle by cpu_baseline() AFTER every timed region
     hip["a2j_b64"] = (keep[:PARITY_CROPS].cpu(), crops[:PARITY_CROPS].cpu())
     del crops, g, keep
     rgb16 = synth.make_rgb(16, seed=1000).to(dev)

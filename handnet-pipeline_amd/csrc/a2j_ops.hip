@@ -349,7 +349,7 @@ extern "C" int hn_a2j_aggregate_convert_f32(const float* cls, const float* reg, 
 // ---------------------------------------------------------------------------------------
 // The lifter's input (include/handnet_hip.h): per frame and axis (x - mean) / std over the J joints, population std.
 // One wave per frame; sums in fp64 in joint order (numpy's pairwise fp32 / fp64 summation differs from ANY fixed order by
-// rounding only; the oracle restates the caller's whole chain in fp64).
+// rounding only; the tests compare with a function-by-function fp64 restatement of the caller's chain).
 // ---------------------------------------------------------------------------------------
 namespace {
 __global__ __launch_bounds__(64) void joints2d_standardize_kernel(const float* __restrict__ uvd, const int* __restrict__ valid,
