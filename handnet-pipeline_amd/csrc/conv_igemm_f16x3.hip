@@ -152,6 +152,10 @@ static int pick_tile_base(const hn_conv_desc* d) {
   const int64_t want = 256;
   // the largest tile wins as soon as it yields one workgroup per CU
   if (d->cout > 64 && nblocks16(d, 128, 128) >= want) return HN_TILE_128x128;
+  // ... and a little earlier for very long k loops (round 6, tools/tile_sweep.py at batch 64 = BASELINE config 2): A2J's 2048 ->
+  // 512 3 x 3 head layer on 64 crops is 61 x 4 = 244 tiles of 128 x 128 with 576 k tiles each -- 328 us against 360 us on the
+  // 484 64 x 128 tiles the next rule picks; no shape of batch 1 or 32 comes near this corner
+  if (d->cout > 64 && d->r * d->s * d->cin / 32 >= 288 && nblocks16(d, 128, 128) >= 224) return HN_TILE_128x128;
   // Cout <= 64 with many rows: four waves stacked along M keep the 64x64 wave tile of the big kernel (+3 %)
   if (d->cout <= 64 && nblocks16(d, 256, 64) >= 2 * want) return HN_TILE_256x64;
   // mid-size grids: 128 columns per workgroup when there are that many (fewer weight re-reads), else 128 rows
