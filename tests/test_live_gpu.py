@@ -227,3 +227,53 @@ def test_live_demo_example_runs():
     assert r.returncode == 0, r.stdout + r.stderr
     assert "1. HandNet.forward: (1, 21, 3) cpu" in r.stdout and "2. set_convert" in r.stdout and "3. live step: 3 frames" in r.stdout
     assert "(778, 3) camera-frame vertices; has_hand = [1]" in r.stdout
+
+
+def test_converting_step_on_the_sparse_path_and_in_wide_records(fcos_sd, a2j_sd, monkeypatch):
+    """set_convert on a SPARSE batch (A2J compacted to the frames with a hand): image uvd / camera xyz of the frames with a hand
+    equal hn_convert_joints_f32 on the step's keypoints bit for bit, rows of frames without a hand are zeros in all three
+    fields; and a to_host step carries all of it in ONE wide record (800 bytes per frame), row N = the range words."""
+    from hn_amd import ops, pipeline, synth
+    from hn_amd.a2j_engine import A2JEngine
+    from hn_amd.fcos_engine import FCOSEngine
+    eng = pipeline.HandNetEngine(FCOSEngine(fcos_sd, 3, device="cuda"), A2JEngine(a2j_sd, device="cuda"), 3)
+    eng.set_convert(PARAS, clamp=False)
+    n = 16
+    rgb, depth = synth.make_rgb(n, seed=1000).cuda(), synth.make_depth(n, seed=2000).cuda()
+    keep = torch.zeros((n,), dtype=torch.int32, device="cuda")
+    keep[[2, 7, 12]] = 1
+    real_crop, calls = ops.crop_resize, []
+
+    def sparse_crop(*a, **k):
+        box, has, crops = real_crop(*a, **k)
+        return box * keep[:, None].to(box.dtype), has * keep, crops * keep[:, None, None, None].to(crops.dtype)
+    monkeypatch.setattr(pipeline.ops, "crop_resize", sparse_crop)
+    real_fwd = eng.a2j.forward_nhwc
+
+    def spy(x, valid=None, **k):
+        calls.append(x.shape[0])
+        return real_fwd(x, valid=valid, **k)
+    monkeypatch.setattr(eng.a2j, "forward_nhwc", spy)
+    first = eng.forward_device(rgb, depth)                    # masked full batch; arms the hint
+    torch.cuda.synchronize()
+    second = eng.forward_device(rgb, depth, to_host=True)     # compacted, wide record
+    torch.cuda.synchronize()
+    assert calls == [n, 3], calls
+    sel = keep.bool()
+    for out in (first, second):
+        assert torch.equal(out.image_uvd, ops.convert_joints(out.keypoints, out.crop_box, out.has_hand, None))
+        assert torch.equal(out.xyz_mm, ops.convert_joints(out.keypoints, out.crop_box, out.has_hand, PARAS))
+        for t in (out.keypoints, out.image_uvd, out.xyz_mm):
+            assert float(t[~sel].abs().max()) == 0.0 and float(t[sel].abs().min()) > 0.0
+    assert (second.keypoints[sel] - first.keypoints[sel]).abs().max().item() < 1e-4
+    rec = second.host_record
+    assert tuple(rec.shape) == (n + 1, 800)
+    kp, has, box, words, more = pipeline.read_host_record(rec, n, extras=True)
+    assert torch.equal(kp, second.keypoints.cpu()) and torch.equal(has, second.has_hand.cpu()) and torch.equal(box, second.crop_box.cpu())
+    assert torch.equal(more[0], second.image_uvd.cpu()) and torch.equal(more[1], second.xyz_mm.cpu()) and not any(words[:3])
+    # image uvd only (no intrinsics): 544-byte records
+    eng.set_convert(None)
+    third = eng.forward_device(rgb, depth, to_host=True)
+    torch.cuda.synchronize()
+    assert third.xyz_mm is None and tuple(third.host_record.shape) == (n + 1, 544)
+    assert torch.equal(pipeline.read_host_record(third.host_record, n, extras=True)[4][0], third.image_uvd.cpu())
