@@ -334,3 +334,27 @@ def test_sharded_handnet_rccl_single_rank_with_the_gather_in_the_graph(tmp_path,
     eng = HandNetEngine(FCOSEngine(fcos_sd, 3, device="cuda"), A2JEngine(a2j_sd, device="cuda"), 3)
     kp, depth_batch, crops = _reference_tuple(eng, total)
     assert torch.equal(g_crops, crops) and torch.equal(g_depth, depth_batch) and torch.equal(g_kp, kp)
+
+
+def test_sharded_handnet_rgbd_engine_without_a_group_equals_the_engine_step(fcos_sd, a2j_rgbd_sd):
+    """The RGB-D model (4-channel crops, [2,1,0,3] order) through ShardedHandNet without a process group (world 1: the records
+    take the same pack -> "gather" -> unpack path): the tuple is the engine step's own -- keypoints and crop boxes bit for
+    bit, depth_batch = the four-channel crops -- eager and replayed (the third call captures)."""
+    from hn_amd import dist as hdist
+    from hn_amd import synth
+    from hn_amd.a2j_engine import A2JEngine
+    from hn_amd.fcos_engine import FCOSEngine
+    from hn_amd.pipeline import HandNetEngine
+    eng = HandNetEngine(FCOSEngine(fcos_sd, 3, device="cuda"), A2JEngine(a2j_rgbd_sd, rgbd=True, device="cuda"), 3)
+    n = 4
+    rgb = synth.make_rgb(n, seed=1000).cuda()
+    rgbd = torch.cat([rgb, synth.make_depth(n, seed=2000).cuda()], dim=1)
+    ref = eng.forward_device(rgb, rgbd)
+    mask = ref.has_hand != 0
+    assert int(mask.sum()) == n
+    net = hdist.ShardedHandNet(eng, gather_depth=True, rgbd=True)
+    for call in range(5):
+        kp, depth_batch, crops = net([rgb[i] for i in range(n)], depth_images=rgbd)
+        assert kp.device.type == "cpu" and torch.equal(kp, ref.keypoints.cpu()) and torch.equal(crops, ref.crop_box)
+        assert tuple(depth_batch.shape) == (n, 4, 176, 176) and torch.equal(depth_batch, ref.crops_nhwc.permute(0, 3, 1, 2))
+    assert net.gather_captured is True and "ONE hipGraph" in net.capture_note
