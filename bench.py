@@ -93,6 +93,10 @@ def parse():
                          "beside the parity mode: misses the 1e-3 contract, reported with its error figures, never the headline")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (the default for --gpus > 1)")
     ap.add_argument("--eager", action="store_true", help="--gpus > 1: issue the step's launches from Python instead of replaying a graph")
+    ap.add_argument("--capture-gather", action="store_true",
+                    help="--gpus > 1: ALSO capture the all-gather into the step's hipGraph (ShardedHandNet's own default; verified on a "
+                         "single-rank RCCL group, never yet on a multi-rank one: the default here keeps the gather eager behind the "
+                         "replayed step, the form rehearsed since round 3)")
     ap.add_argument("--init-timeout", type=float, default=180.0,
                     help="--gpus > 1: seconds the process group may take to start (rendezvous + first collective) per attempt")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -926,7 +930,7 @@ def worker(args):
             sharded = hdist.ShardedHandNet(_StubNet(step), use_graph=False)
             shard_in = (torch.zeros((batch, 3, 2, 2)), torch.zeros((batch, 1, 2, 2)))
         elif not args.native:
-            sharded = hdist.ShardedHandNet(info["engine"], use_graph=bool(args.graph))
+            sharded = hdist.ShardedHandNet(info["engine"], use_graph=(True if args.capture_gather else "step") if args.graph else False)
             shard_in = info["inputs"]
             if args.graph:
                 sharded.prepare(*shard_in, global_batch=world * batch)

@@ -169,8 +169,12 @@ class ShardedHandNet:
 
     GRAPH_AFTER = 2     # eager steps with one input shape before the step + gather is captured
 
-    def __init__(self, net, group=None, gather_depth: bool = False, use_graph: bool = True, rgbd: bool | None = None):
-        self.net, self.group, self.gather_depth, self.use_graph = net, group, bool(gather_depth), bool(use_graph)
+    def __init__(self, net, group=None, gather_depth: bool = False, use_graph=True, rgbd: bool | None = None):
+        """use_graph: True -- step + collectives in ONE hipGraph once the shapes repeat; "step" -- the engine's own captured
+        step is replayed and the collectives are issued eagerly behind it (what bench.py --gpus N times by default: the form
+        rehearsed on real RCCL since round 3); False -- everything eager."""
+        self.net, self.group, self.gather_depth = net, group, bool(gather_depth)
+        self.use_graph = "step" if use_graph == "step" else bool(use_graph)
         self.rgbd = bool(getattr(net, "RGBD", False)) if rgbd is None else bool(rgbd)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -221,7 +225,14 @@ class ShardedHandNet:
     # -- one step on this rank's shard + the collectives (static launch sequence: capturable) ---------------------------------
     def _step(self, images, depth, per_rank, bufs, total):
         eng = self._engine()
-        out = eng.forward_device(images, depth)
+        if self.use_graph == "step" and images.is_cuda and hasattr(eng, "graphed") and not torch.cuda.is_current_stream_capturing():
+            run, s_img, s_dep, out = eng.graphed(images, depth)       # (captured at the first call with these shapes)
+            s_img.copy_(images)
+            s_dep.copy_(depth)
+            run()
+            self.capture_note = "the engine's captured step is replayed; all-gather issued eagerly behind it"
+        else:
+            out = eng.forward_device(images, depth)
         b = out.keypoints.shape[0]
         send, recv = bufs["send"], bufs["recv"]
         if send.is_cuda:
@@ -273,7 +284,7 @@ class ShardedHandNet:
         channels = 4 if self.rgbd else 1
         bufs = self._buffers(per_rank, channels, dev)
         key = (tuple(batch.shape), tuple(depth_images.shape), per_rank, total)
-        if dev.type == "cuda" and self.use_graph and not self._stage_through_host(batch):
+        if dev.type == "cuda" and self.use_graph is True and not self._stage_through_host(batch):
             hit = self._graphs.get(key)
             if hit is None:
                 self._seen[key] = self._seen.get(key, 0) + 1

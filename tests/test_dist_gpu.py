@@ -358,3 +358,10 @@ def test_sharded_handnet_rgbd_engine_without_a_group_equals_the_engine_step(fcos
         assert kp.device.type == "cpu" and torch.equal(kp, ref.keypoints.cpu()) and torch.equal(crops, ref.crop_box)
         assert tuple(depth_batch.shape) == (n, 4, 176, 176) and torch.equal(depth_batch, ref.crops_nhwc.permute(0, 3, 1, 2))
     assert net.gather_captured is True and "ONE hipGraph" in net.capture_note
+    # use_graph="step" (what bench.py --gpus N times by default): the engine's own captured step, the gather eager behind it
+    step = hdist.ShardedHandNet(eng, gather_depth=True, rgbd=True, use_graph="step")
+    for call in range(3):
+        kp, depth_batch, crops = step([rgb[i] for i in range(n)], depth_images=rgbd)
+        assert torch.equal(kp, ref.keypoints.cpu()) and torch.equal(crops, ref.crop_box)
+        assert torch.equal(depth_batch, ref.crops_nhwc.permute(0, 3, 1, 2))
+    assert step.gather_captured is None and "eagerly" in step.capture_note and eng.graph_count() >= 1
