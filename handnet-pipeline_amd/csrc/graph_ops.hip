@@ -133,11 +133,12 @@ struct GraphConvParams {
   const int* l_ptr; const int* l_idx; const float* l_val;       // L            (CSR, V rows)
   const int* q_ptr; const int* q_idx; const float* q_val;       // 2 L L - I    (CSR, V rows)
   const float* x;          // [rows][Fin] fp32
-  const _Float16* w16;     // [Fout][K / 32][2][32]
+  const _Float16* w16;     // [Fout][K / 32][2][32], or in fragment order [ceil(Fout / 16)][K / 32][2][64 lanes][8] (w_frag)
   const float* bias;       // [Fout] or null
   const float* xin;        // [rows][Fi] block input for the residual, or null
   void* y;                 // fp32 [rows * up][Fout], or S32 [rows * up][Fout / 32][2][32]
   int rows, V, Fin, Fout, K, Fi, relu, up, out_split;
+  int w_frag;              // 1: the filter bank is stored in MFMA fragment order (a wave's load is one contiguous KB)
   int nt_pow2;             // column tiles of ONE workgroup (a power of two <= 4; blockIdx.y = column group); k slices = 16 / nt_pow2
   int* range_flag;
 };
@@ -284,14 +285,19 @@ __global__ __launch_bounds__(kGcWaves * 64) void graph_conv_fused_kernel(const G
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const f16x8 zero8 = {(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0};
   if (nt < nt_all) {
-    const _Float16* wq = p.w16 + ((long)(live ? col : 0) * ktiles * 2) * 32 + lg * 8;
+    // standard layout: lane (column lr, k chunk lg) reads 16 bytes of its column's 64-byte run -- 16 runs of 64 bytes per wave
+    // load; fragment order: the wave's 64 x 16 bytes are one contiguous KB (half the cache lines through the CU's 64 B/clk path)
+    const _Float16* wq = p.w_frag ? p.w16 + ((long)nt * ktiles * 2 * 64 + lane) * 8
+                                  : p.w16 + ((long)(live ? col : 0) * ktiles * 2) * 32 + lg * 8;
+    const long kstep = p.w_frag ? 2 * 64 * 8 : 64, lo_off = p.w_frag ? 64 * 8 : 32;
+    const bool have = p.w_frag ? true : live;        // (fragment order holds zero columns behind Fout)
     for (int kb = kt0; kb < kt1; kb += kGcKBatch) {
       f16x8 bh[kGcKBatch], bl[kGcKBatch];
 #pragma unroll
       for (int u = 0; u < kGcKBatch; ++u) {
-        const bool in = live && kb + u < kt1;
-        bh[u] = in ? *reinterpret_cast<const f16x8*>(wq + (long)(kb + u) * 64) : zero8;
-        bl[u] = in ? *reinterpret_cast<const f16x8*>(wq + (long)(kb + u) * 64 + 32) : zero8;
+        const bool in = have && kb + u < kt1;
+        bh[u] = in ? *reinterpret_cast<const f16x8*>(wq + (long)(kb + u) * kstep) : zero8;
+        bl[u] = in ? *reinterpret_cast<const f16x8*>(wq + (long)(kb + u) * kstep + lo_off) : zero8;
       }
 #pragma unroll
       for (int u = 0; u < kGcKBatch; ++u) {
@@ -346,8 +352,8 @@ __global__ __launch_bounds__(kGcWaves * 64) void graph_conv_fused_kernel(const G
 }  // namespace
 
 extern "C" int hn_graph_conv_cheby3_f16x3(const hn_graph_csr* L, const hn_graph_csr* L2, const float* x, int batch, int fin,
-                                          const void* w16, const float* bias, int fout, int relu, const float* xin, int fi,
-                                          int up, void* y, int out_split, void* stream) {
+                                          const void* w16, int w_frag, const float* bias, int fout, int relu, const float* xin,
+                                          int fi, int up, void* y, int out_split, void* stream) {
   HN_CHECK_ARG(L && L2 && x && w16 && y, "hn_graph_conv_cheby3_f16x3: null pointer");
   HN_CHECK_ARG(L->indptr && L->indices && L->values && L2->indptr && L2->indices && L2->values, "null CSR arrays");
   HN_CHECK_ARG(L->v > 0 && L2->v == L->v && batch > 0, "bad graph / batch");
@@ -361,7 +367,7 @@ extern "C" int hn_graph_conv_cheby3_f16x3(const hn_graph_csr* L, const hn_graph_
   p.q_ptr = L2->indptr; p.q_idx = L2->indices; p.q_val = L2->values;
   p.x = x; p.w16 = (const _Float16*)w16; p.bias = bias; p.xin = xin; p.y = y;
   p.rows = batch * L->v; p.V = L->v; p.Fin = fin; p.Fout = fout; p.K = (3 * fin + 31) / 32 * 32; p.Fi = fi;
-  p.relu = relu ? 1 : 0; p.up = up; p.out_split = out_split ? 1 : 0;
+  p.relu = relu ? 1 : 0; p.up = up; p.out_split = out_split ? 1 : 0; p.w_frag = w_frag ? 1 : 0;
   p.range_flag = out_split ? hn::range_flag_ptr() : nullptr;
   // column tiles per workgroup: at most 4 (a CU pulls its workgroup's share of the filter bank through ONE 64 B/clk vector
   // memory path: the whole 768 x 256 bank per workgroup was 17 of a layer's 25 us; with four column groups every workgroup

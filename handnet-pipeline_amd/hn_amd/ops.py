@@ -1475,10 +1475,24 @@ def graph_conv_cheby3(g: CsrGraph, g2: CsrGraph, x, cw, relu=True, xin=None, up=
         y = torch.empty((b, v * up, 1, fout // 32, 2, 32), device=x.device, dtype=torch.float16)
     else:
         y = torch.empty((b, v * up, fout), device=x.device, dtype=torch.float32)
-    check(_lib.load().hn_graph_conv_cheby3_f16x3(C.byref(_csr_struct(g)), C.byref(_csr_struct(g2)), ptr(x), b, fin, ptr(cw.w16),
+    wf = getattr(cw, "w_frag", None)       # (the filter bank in MFMA fragment order, ops.fragment_order(cw.w16): optional)
+    check(_lib.load().hn_graph_conv_cheby3_f16x3(C.byref(_csr_struct(g)), C.byref(_csr_struct(g2)), ptr(x), b, fin,
+                                                 ptr(wf if wf is not None else cw.w16), 1 if wf is not None else 0,
                                                  ptr(cw.bias), fout, 1 if relu else 0, ptr(xin), xin.shape[2] if xin is not None else 0,
                                                  up, ptr(y), 1 if out_split else 0, _stream()), "hn_graph_conv_cheby3_f16x3")
     return y
+
+
+def fragment_order(w16):
+    """Split filter bank [Fout, K/32, 2, 32] fp16 -> the same values in MFMA fragment order [ceil(Fout/16), K/32, 2, 64, 8]
+    (hn_graph_conv_cheby3_f16x3 with w_frag = 1): element i of lane l = column 16 nt + (l & 15), channel 32 kt + 8 (l >> 4) + i,
+    zero rows behind Fout."""
+    fout, kt, _, _ = w16.shape
+    nt = (fout + 15) // 16
+    w = torch.zeros((nt * 16, kt, 2, 32), dtype=w16.dtype, device=w16.device)
+    w[:fout] = w16
+    # [nt, col 16, kt, pl, chunk 4, i 8] -> [nt, kt, pl, chunk, col, i]: lane = chunk * 16 + col
+    return w.view(nt, 16, kt, 2, 4, 8).permute(0, 2, 3, 4, 1, 5).contiguous().view(nt, kt, 2, 64, 8)
 
 
 def pad_split_rows(x, cpad):

@@ -107,7 +107,9 @@ class Pose2MeshEngine:
                     b = (b - sd[f"{m}bn.{idx}.running_mean"]) * s + sd[f"{m}bn.{idx}.bias"]
                 wk = torch.zeros((fout, CL_K, fin_pad), dtype=torch.float64)  # k-major, features zero-padded
                 wk[:, :, :fin] = w.permute(0, 2, 1)
-                self.cl.append((_dense(wk.reshape(fout, CL_K * fin_pad), b, dev), fin_pad, not last))
+                cw = _dense(wk.reshape(fout, CL_K * fin_pad), b, dev)
+                cw.w_frag = ops.fragment_order(cw.w16)          # (the fused graph convolution's contiguous fragment loads)
+                self.cl.append((cw, fin_pad, not last))
                 idx += 1
 
     # The one-launch graph convolution is a LATENCY design (16 rows per 1024-thread workgroup, every workgroup gathers its own

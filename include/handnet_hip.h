@@ -599,7 +599,9 @@ int hn_spmm_csr_f32(const int32_t* indptr, const int32_t* indices, const float* 
  *   y[r*up + u][:] = act(W [x0 | L x0 | L2 x0 | 0][r] + bias) (+ interp_linear(xin[r][:], fi -> fout)),  u < up
  * L2 = 2 L L - I, precomputed by the host (the same second-order Chebyshev polynomial, one rounding per coefficient instead of
  * a second dependent sparse product); x fp32 [batch][v][fin] (fin % 4 == 0, <= 256); w16 = the split filter bank
- * [fout][K/32][2][32] over K = pad32(3*fin) k-major channels (as hn_cheby3_basis_split's operand); xin fp32 [batch][v][fi]
+ * [fout][K/32][2][32] over K = pad32(3*fin) k-major channels (as hn_cheby3_basis_split's operand) -- or, with w_frag = 1, the
+ * same values in MFMA fragment order [ceil(fout/16)][K/32][2 (hi, lo)][64 lanes][8]: element i of lane l = column 16*nt +
+ * (l & 15), channel 32*kt + 8*(l >> 4) + i, zero behind fout (a wave's load is then one contiguous KB); xin fp32 [batch][v][fi]
  * or NULL; y fp32 [batch][v*up][fout], or S32 rows when out_split (fout % 32 == 0).  fout <= 256. */
 typedef struct hn_graph_csr {
   const int32_t* indptr;   /* [v + 1] */
@@ -608,8 +610,8 @@ typedef struct hn_graph_csr {
   int32_t v;
 } hn_graph_csr;
 int hn_graph_conv_cheby3_f16x3(const hn_graph_csr* L, const hn_graph_csr* L2, const float* x, int batch, int fin,
-                               const void* w16, const float* bias, int fout, int relu, const float* xin, int fi, int up,
-                               void* y, int out_split, void* stream);
+                               const void* w16, int w_frag, const float* bias, int fout, int relu, const float* xin, int fi,
+                               int up, void* y, int out_split, void* stream);
 /* Glue of the lifter as single launches: fp32 rows [rows][f] -> S32 rows of cpad channels, zero padded (the operand of
  * PoseNet's first Linear from the [batch][2J] joints); pose_combine (pose2mesh_net.py:20) = [pose2d | pose3d / 1000 | 0] per
  * joint as fp32 [batch*J][fpad] (the padded input of the first graph convolution; pose3d rows may be padded: PoseNet's last

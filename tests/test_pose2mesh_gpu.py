@@ -112,6 +112,11 @@ def test_fused_graph_conv_matches_the_layer_by_layer_form(p2m):
             if split:
                 got = ops.from_split(got).view(b, g.v * up, -1)
             assert got.shape == want.shape, (li, got.shape, want.shape)
+            # the filter bank in the standard layout (no w_frag) takes the same values in the same order: bit-identical
+            import types
+            plain = types.SimpleNamespace(w=cw.w, bias=cw.bias, w16=cw.w16)
+            again = ops.graph_conv_cheby3(g, g2, x, plain, relu=relu, xin=xin, up=up, out_split=split)
+            assert torch.equal(ops.from_split(again).view(b, g.v * up, -1) if split else again, got)
             scale = max(1.0, want.abs().max().item())
             assert (got - want).abs().max().item() <= 3e-6 * scale, (b, li, (got - want).abs().max().item(), scale)
 
