@@ -421,6 +421,123 @@ __global__ __launch_bounds__(256) void lifter_combine_kernel(const float* __rest
 }
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// A Linear layer on 1..4 rows (PoseNet at the live caller's batch: 42 -> 4096 -> 4096 x 4 -> 63): a matrix-VECTOR product, i.e.
+// 67 MB of filter bank streamed once for 17 M MACs -- HBM-bound by three orders of magnitude, so the vector ALU does it: every
+// wave streams whole rows of the bank (1 KB per load = 8 blocks of hi[32] | lo[32]; a lane holds eight hi OR eight lo halves and
+// multiplies them with the matching fp32 activations from LDS; hi and lo partial sums meet in the wave reduction: w = hi + lo
+// exactly, the activations stay fp32 -- MORE precise than the three-term MFMA form, which drops lo * lo).  The activations are
+// staged in LDS once per workgroup, optionally through the pre-activation BatchNorm + ReLU of posenet.py:24-26 (scale / shift),
+// so a PoseNet stage is two launches and no split pass.  Bias, fp32 residual, ReLU in the epilogue; fp32 in, fp32 out.
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int kLinRowsPerWave = 2, kLinMaxBatch = 4, kLinKLoads = 16;   // 16 loads x 256 channels = 4096 channels per pass
+
+struct LinearParams {
+  const float* x; int xs;            // [M][xs] fp32, k_real columns used
+  const float* scale; const float* shift;   // [K] pre-activation affine (+ ReLU) applied while staging x, or null
+  const _Float16* w16;               // [N][K / 32][2][32]
+  const float* bias; const float* residual; int rs;   // [N] or null; [M][rs] fp32 or null
+  float* y; int ys;                  // [M][ys]
+  int M, K, k_real, N, relu;
+};
+
+__global__ __launch_bounds__(256, 2) void linear_rows_kernel(const LinearParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lin_x[];   // [M][K]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int blk = lane >> 3, chunk = lane & 3;   // 32-channel block of a load (lanes 4..7 of a block hold its lo halves), 8-channel chunk
+  const int ktiles = p.K >> 5;
+  const int n0 = (blockIdx.x * 4 + wave) * kLinRowsPerWave;
+  // The filter rows do not depend on the activations: a 4096-channel pass of BOTH rows of this wave is requested first (32 loads
+  // of 1 KB), the activations are staged under their latency.  (Staging first, then one row after the other: 22 us per
+  // 4096 x 4096 layer, slower than the convolution kernel's 18.5 us; the bank must be in flight before anything waits.)
+  f16x8 wv[kLinRowsPerWave][kLinKLoads];
+  auto request = [&](int k0) {
+#pragma unroll
+    for (int rr = 0; rr < kLinRowsPerWave; ++rr) {
+      const int n = n0 + rr;
+      const _Float16* wrow = p.w16 + (long)(n < p.N ? n : 0) * ktiles * 64 + lane * 8;
+#pragma unroll
+      for (int u = 0; u < kLinKLoads; ++u) {
+        const int kt = k0 + u * 8;             // first of the 8 blocks this load covers
+        wv[rr][u] = (n < p.N && kt + blk < ktiles) ? *reinterpret_cast<const f16x8*>(wrow + (long)kt * 64) : f16x8{};
+      }
+    }
+  };
+  request(0);
+  for (int i = tid; i < p.M * p.K; i += 256) {
+    const int m = i / p.K, k = i - m * p.K;
+    float v = k < p.k_real ? p.x[(long)m * p.xs + k] : 0.f;
+    if (p.scale && k < p.k_real) v = hn::relu(v * p.scale[k] + p.shift[k]);
+    lin_x[i] = v;
+  }
+  __syncthreads();
+  float acc[kLinRowsPerWave][kLinMaxBatch];
+#pragma unroll
+  for (int rr = 0; rr < kLinRowsPerWave; ++rr)
+#pragma unroll
+    for (int m = 0; m < kLinMaxBatch; ++m) acc[rr][m] = 0.f;
+  for (int k0 = 0; k0 < ktiles; k0 += 8 * kLinKLoads) {
+    if (k0) request(k0);                       // (banks deeper than 4096 channels: further passes)
+#pragma unroll
+    for (int u = 0; u < kLinKLoads; ++u) {
+      const int kt = k0 + u * 8 + blk;
+      if (kt < ktiles) {
+        const float* xk = lin_x + kt * 32 + chunk * 8;
+#pragma unroll
+        for (int m = 0; m < kLinMaxBatch; ++m)
+          if (m < p.M) {
+            float xv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xv[i] = xk[m * p.K + i];
+#pragma unroll
+            for (int rr = 0; rr < kLinRowsPerWave; ++rr)
+#pragma unroll
+              for (int i = 0; i < 8; ++i) acc[rr][m] += (float)wv[rr][u][i] * xv[i];
+          }
+      }
+    }
+  }
+#pragma unroll
+  for (int rr = 0; rr < kLinRowsPerWave; ++rr) {
+    const int n = n0 + rr;
+    if (n >= p.N) break;                       // (wave-uniform)
+#pragma unroll
+    for (int m = 0; m < kLinMaxBatch; ++m) {
+      if (m >= p.M) break;
+      float v = acc[rr][m];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if (lane == 0) {
+        if (p.bias) v += p.bias[n];
+        if (p.residual) v += p.residual[(long)m * p.rs + n];
+        if (p.relu) v = hn::relu(v);
+        p.y[(long)m * p.ys + n] = v;
+      }
+    }
+  }
+}
+}  // namespace
+
+extern "C" int hn_linear_rows_f16x3(const float* x, int batch, int x_stride, int k_real, const float* scale, const float* shift,
+                                    const void* w16, int k, int n, const float* bias, const float* residual, int res_stride,
+                                    int relu, float* y, int y_stride, void* stream) {
+  HN_CHECK_ARG(x && w16 && y, "hn_linear_rows_f16x3: null pointer");
+  HN_CHECK_ARG(batch >= 1 && batch <= kLinMaxBatch, "hn_linear_rows_f16x3 takes 1..4 rows (larger batches: the convolution kernel)");
+  HN_CHECK_ARG(k > 0 && k % 32 == 0 && k_real > 0 && k_real <= k && x_stride >= k_real && n > 0 && y_stride >= n, "bad dims");
+  HN_CHECK_ARG((scale == nullptr) == (shift == nullptr) && (!residual || res_stride >= n), "bad affine / residual arguments");
+  HN_CHECK_ARG((size_t)batch * k * 4 <= 64 * 1024 && (uintptr_t)w16 % 16 == 0, "activations must fit 64 KB of LDS; aligned bank");
+  LinearParams p;
+  p.x = x; p.xs = x_stride; p.scale = scale; p.shift = shift; p.w16 = (const _Float16*)w16; p.bias = bias;
+  p.residual = residual; p.rs = res_stride; p.y = y; p.ys = y_stride; p.M = batch; p.K = k; p.k_real = k_real; p.N = n;
+  p.relu = relu ? 1 : 0;
+  const int rows_per_wg = 4 * kLinRowsPerWave;
+  hipLaunchKernelGGL(linear_rows_kernel, dim3((n + rows_per_wg - 1) / rows_per_wg), dim3(256), (size_t)batch * k * 4,
+                     (hipStream_t)stream, p);
+  HN_CHECK_LAUNCH("linear_rows_kernel");
+  return HN_OK;
+}
+
 extern "C" int hn_pad_split_rows_f32(const float* x, int64_t rows, int f, int cpad, void* out16, void* stream) {
   HN_CHECK_ARG(x && out16, "hn_pad_split_rows_f32: null pointer");
   HN_CHECK_ARG(rows > 0 && f > 0 && cpad >= f && cpad % 32 == 0, "bad dims (cpad: a multiple of 32 >= f)");

@@ -29,7 +29,8 @@ ARCH = "gfx950"
 # process had work on the same card (tests/test_dist_gpu.py, tools/diag/preprocess_pattern.py, profiles/NOTEBOOK.md round 4);
 # alone on the card the same binary is bit-exact.  No other kernel of the library holds such an instruction, and the build
 # refuses one (_check_packed_opsel).
-EXTRA_FLAGS = {"fcos_post.hip": ["-ffp-contract=off", "-fno-slp-vectorize"]}
+# graph_ops.hip: the matrix-vector Linear's eight-wide fp32 FMA chains were packed the same way (round 6; the build refused it).
+EXTRA_FLAGS = {"fcos_post.hip": ["-ffp-contract=off", "-fno-slp-vectorize"], "graph_ops.hip": ["-fno-slp-vectorize"]}
 
 # Kernels that request operands with `asm volatile` loads / LDS-DMA and retire them with hand-counted s_waitcnt: the
 # compiler cannot see that such a register is still in flight, so a SPILL of it stores garbage (profiles/NOTEBOOK.md, round

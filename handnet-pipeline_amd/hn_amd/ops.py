@@ -1495,6 +1495,22 @@ def fragment_order(w16):
     return w.view(nt, 16, kt, 2, 4, 8).permute(0, 2, 3, 4, 1, 5).contiguous().view(nt, kt, 2, 64, 8)
 
 
+def linear_rows(x, cw, scale=None, shift=None, residual=None, relu=False, n_out=None):
+    """x fp32 [M <= 4, Kx] -> fp32 [M, N]: act(W pre(x) + bias (+ residual)) as a matrix-vector product (hn_linear_rows_f16x3);
+    cw: ConvW-like 1x1 bank (.w [N,1,1,K], .w16, .bias), K >= Kx zero padded; scale / shift [Kx]: pre-activation affine + ReLU."""
+    _req(x, name="x")
+    m, kx = x.shape
+    n, _, _, k = cw.w.shape
+    y = torch.empty((m, n), device=x.device, dtype=torch.float32)
+    for t, nm in ((scale, "scale"), (shift, "shift"), (residual, "residual")):
+        if t is not None:
+            _req(t, name=nm)
+    check(_lib.load().hn_linear_rows_f16x3(ptr(x), m, x.stride(0), kx, ptr(scale), ptr(shift), ptr(cw.w16), k, n, ptr(cw.bias),
+                                           ptr(residual), residual.stride(0) if residual is not None else 0, 1 if relu else 0,
+                                           ptr(y), n, _stream()), "hn_linear_rows_f16x3")
+    return y
+
+
 def pad_split_rows(x, cpad):
     """fp32 [rows, f] -> S32 [rows,1,1,cpad/32,2,32], channels f.. zero (hn_pad_split_rows_f32)."""
     _req(x, name="x")

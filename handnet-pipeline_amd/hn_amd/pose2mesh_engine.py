@@ -15,10 +15,11 @@ Everything stays on the device.  Graph Laplacians are host-side preprocessing (g
 passed in as scipy / torch sparse matrices, finest level first, joint graph last.
 
 Launch structure (round 6; the forward is launch-bound at the live caller's batch): `fused=True` (default) runs the forward as
-26 launches instead of 76 --
-  PoseNet   hn_pad_split_rows_f32 (the input operand), then per stage: the pre-activation BatchNorm + ReLU + split pass,
-            Linear 1 with batch_norm2 FOLDED into it (BatchNorm directly behind a Linear) + ReLU + split in its epilogue,
-            Linear 2 with the residual in its epilogue (the last stage writes the final Linear's operand directly)  = 9
+23 launches instead of 76 at 1..4 samples (26 above) --
+  PoseNet   1..4 samples: six matrix-vector launches (hn_linear_rows_f16x3: pre-activation BatchNorm + ReLU applied while the
+            activations are staged, batch_norm2 FOLDED into the Linear in front of it, residual in the epilogue)     = 6
+            larger batches: hn_pad_split_rows_f32 (the input operand), then per stage the pre-activation BatchNorm + ReLU +
+            split pass, Linear 1 (+ folded batch_norm2) + ReLU + split, Linear 2 + residual on the convolution kernel = 9
   glue      hn_lifter_combine_f32 (pose_combine, zero padded to the first graph convolution's 8 input features)       = 1
   mesh net  ONE launch per graph convolution (hn_graph_conv_cheby3_f16x3: basis gather -> MFMA -> bias / ReLU -> the
             block's residual + vertex up-sampling in the epilogue of its last layer; the layer in front of `fc` writes
@@ -149,6 +150,14 @@ class Pose2MeshEngine:
     def posenet(self, x2d):
         """[B, 2J] fp32 -> [B, 3J] (LinearModel.forward, eval)"""
         b = x2d.shape[0]
+        if self.fused and b <= self.FUSED_MAX_BATCH:
+            # 1..4 rows: every Linear is a matrix-vector product on the vector ALU (hn_linear_rows_f16x3: the 67 MB bank streamed
+            # once, fp32 activations staged in LDS through the pre-activation BatchNorm + ReLU) -- 6 launches, no split passes
+            y = ops.linear_rows(x2d.contiguous(), self.p_w1)
+            for st in self.p_stages:
+                z = ops.linear_rows(y, st["w1_bn2"], scale=st["bn1"][0], shift=st["bn1"][1], relu=True)
+                y = ops.linear_rows(z, st["w2"], residual=y)
+            return ops.linear_rows(y, self.p_w2)[:, : self.p_out]
         if self.fused:
             y = self._linear(ops.pad_split_rows(x2d.contiguous(), self.p_w1.cin), self.p_w1)
             last = len(self.p_stages) - 1

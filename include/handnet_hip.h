@@ -617,6 +617,14 @@ int hn_graph_conv_cheby3_f16x3(const hn_graph_csr* L, const hn_graph_csr* L2, co
  * joint as fp32 [batch*J][fpad] (the padded input of the first graph convolution; pose3d rows may be padded: PoseNet's last
  * Linear is run with 64 output columns so that it takes the vectorised / split-K form of the convolution kernel). */
 int hn_pad_split_rows_f32(const float* x, int64_t rows, int f, int cpad, void* out16, void* stream);
+/* A Linear layer on 1..4 rows as a matrix-vector product on the vector ALU (PoseNet at the live caller's batch, posenet.py:24-41,
+ * 78-88: 67 MB of filter bank per 17 M MACs): y[m][:] = act(W (pre(x[m])) + bias (+ residual[m])), pre = relu(x * scale + shift)
+ * when scale / shift ([k_real] fp32: the pre-activation BatchNorm) are given.  x fp32 [batch][x_stride] (k_real columns used), w16 =
+ * the split bank [n][k/32][2][32] (k % 32 == 0, columns >= k_real zero), y / residual fp32.  w = hi + lo exactly and fp32
+ * activations: at least as precise as the three-term MFMA form. */
+int hn_linear_rows_f16x3(const float* x, int batch, int x_stride, int k_real, const float* scale, const float* shift,
+                         const void* w16, int k, int n, const float* bias, const float* residual, int res_stride, int relu,
+                         float* y, int y_stride, void* stream);
 int hn_lifter_combine_f32(const float* pose2d /* [batch][joints][2] */, const float* pose3d /* [batch][pose3d_stride], 3*joints used */,
                           int batch, int joints, int pose3d_stride, int fpad, float* out, void* stream);
 int hn_cheby3_basis_split(const int32_t* indptr, const int32_t* indices, const float* values, int v,

@@ -134,3 +134,26 @@ def test_fused_lifter_matches_the_layer_by_layer_lifter(p2m):
         m1, p1 = a.forward(pose2d)
         m2, p2 = b.forward(pose2d)
         assert (p1 - p2).abs().max().item() < 5e-3 and (m1 - m2).abs().max().item() < 2e-4
+
+
+def test_linear_rows_matches_fp64(p2m):
+    """hn_linear_rows_f16x3 (a Linear on 1..4 rows as a matrix-vector product) vs fp64: plain, with the pre-activation affine +
+    ReLU on the input, with residual and output ReLU, a padded bank (42 real of 64 columns) and 63 / 64 / 4096 outputs."""
+    from hn_amd import ops
+    from hn_amd.pose2mesh_engine import _dense
+    gen = torch.Generator().manual_seed(41)
+    for m, kx, n in ((1, 42, 4096), (3, 4096, 4096), (4, 4096, 63), (2, 4096, 64), (1, 96, 40)):
+        w = torch.randn((n, kx), generator=gen, dtype=torch.float64) * (2.0 / kx) ** 0.5
+        b = torch.randn((n,), generator=gen, dtype=torch.float64)
+        cw = _dense(w, b, "cuda")
+        x = torch.randn((m, kx), generator=gen)
+        sc, sh = torch.rand((kx,), generator=gen) + 0.5, torch.randn((kx,), generator=gen) * 0.3
+        res = torch.randn((m, n), generator=gen)
+        y0 = ops.linear_rows(x.cuda(), cw).cpu().double()
+        want0 = x.double() @ w.T + b
+        y1 = ops.linear_rows(x.cuda(), cw, scale=sc.cuda(), shift=sh.cuda(), residual=res.cuda(), relu=True).cpu().double()
+        want1 = torch.relu(torch.relu(x.double() * sc.double() + sh.double()) @ w.T + b + res.double())
+        tol = 2e-6 * max(1.0, want0.abs().max().item()) * max(1.0, (kx / 64) ** 0.5)
+        assert (y0 - want0).abs().max().item() < tol and (y1 - want1).abs().max().item() < tol, (m, kx, n)
+    with pytest.raises(RuntimeError, match="1..4 rows"):
+        ops.linear_rows(torch.zeros((5, 64)).cuda(), cw)
