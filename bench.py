@@ -699,7 +699,7 @@ LIVE_PARAS = (617.343, 617.343, 312.42, 241.42)   # SURVEY 8d's intrinsics
 
 def lifter_legs(eng, dev, timed):
     """SURVEY 8f #4 and the live caller's chain (ros_demo.py:270-290,329-337): the Pose2Mesh lifter alone at batch 1 and 32
-    (hipGraph replay; 26 launches per forward), and `live_b1`: HandNet -> clamp + convert_joints in the aggregation's epilogue
+    (hipGraph replay; 23 launches per forward at batch 1), and `live_b1`: HandNet -> clamp + convert_joints in the aggregation's epilogue
     -> lifter input -> Pose2Mesh -> ONE device -> host copy, all of it one captured step on one frame.  The graph hierarchy
     is the data fixture of the lifter's golden test (synthetic topology with the reference's level sizes; the MANO files do
     not travel), weights seeded like every other leg."""
@@ -721,7 +721,10 @@ def lifter_legs(eng, dev, timed):
         x = torch.randn((b, 21, 2), generator=torch.Generator().manual_seed(5000)).to(dev)
         run, _, _ = lifter.graphed(x)
         rec = timed(run, b, per_group=per, warm=5)
-        rec.update(unit="meshes/s", hipgraph=True, launches_per_step=26,
+        rec.update(unit="meshes/s", hipgraph=True,
+                   launch_structure=("23 launches (6 matrix-vector Linear + 1 glue + 15 fused graph convolutions + fc; "
+                                     "profiles/r06b_p2m_kernel_stats.csv)" if b <= Pose2MeshEngine.FUSED_MAX_BATCH else
+                                     "layer by layer above 4 samples (throughput-bound)"),
                    workload=f"Pose2Mesh lifter alone, batch {b} (PoseNet MLP + 15 Chebyshev graph convolutions + fc; SURVEY 8f #4)")
         out[f"pose2mesh_b{b}"] = rec
     live = LiveHandEngine(eng, lifter, LIVE_PARAS, clamp=True)
