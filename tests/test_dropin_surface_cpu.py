@@ -163,3 +163,23 @@ def test_wide_host_record_layout():
         assert out[3] == [0, 1, 0, 0]
         if extras:
             assert len(out[4]) == 2 and np.array_equal(out[4][0].numpy(), img) and np.array_equal(out[4][1].numpy(), xyz)
+
+
+def test_fragment_order_layout():
+    """ops.fragment_order: the split filter bank [Fout, K/32, 2, 32] re-ordered so that an MFMA B fragment of 16 columns x 32
+    channels is 64 lanes x 8 halves of contiguous memory -- element i of lane l = column 16 nt + (l & 15), channel 32 kt +
+    8 (l >> 4) + i; columns behind Fout are zero (hn_graph_conv_cheby3_f16x3 with w_frag = 1 reads it without a bounds test)."""
+    from hn_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for fout, kt in ((3, 1), (40, 3), (256, 24)):
+        w16 = torch.randn((fout, kt, 2, 32), generator=g).half()
+        f = ops.fragment_order(w16)
+        nt = (fout + 15) // 16
+        assert tuple(f.shape) == (nt, kt, 2, 64, 8) and f.is_contiguous()
+        for t in range(nt):
+            for lane in (0, 1, 15, 16, 37, 63):
+                col, chunk = t * 16 + (lane & 15), lane >> 4
+                for k in range(kt):
+                    for pl in (0, 1):
+                        want = w16[col, k, pl, chunk * 8: chunk * 8 + 8] if col < fout else torch.zeros(8, dtype=torch.float16)
+                        assert torch.equal(f[t, k, pl, lane], want)
