@@ -87,6 +87,25 @@ class LiveHandEngine:
         return LiveOutput(out, p2d, mesh, pose3d, host, n)
 
     @ops.device_guarded
+    def forward_raw(self, bgr_u8, depth_raw) -> LiveOutput:
+        """The camera's buffers in, the mesh out: bgr_u8 uint8 [N,H,W,3] (cv_bridge 'bgr8'), depth_raw [N,H,W] uint16 millimetres
+        (16UC1) or float32 metres (32FC1), on the GPU or on the host (pinned: read in place; pageable: staged) -- ONE ingest
+        kernel writes the captured step's input buffers (ros_demo.py:227-231,266-269) and the live step replays (captured at
+        the first call with these shapes).  Returns the capture's static LiveOutput (overwritten by the next call); no sync."""
+        staged = []
+        bgr, dep = self.hand._device_readable(bgr_u8, staged), self.hand._device_readable(depth_raw, staged)
+        n, h, w, _ = bgr.shape
+        key = ((n, 3, h, w), (n, 1, h, w))
+        if key not in self._graphs:
+            rgb, d1, _ = ops.ingest_raw(bgr, dep, device=self.device)
+            self.graphed(rgb, d1)
+        g, s_img, s_dep, out = self._graphs[key]
+        ops.ingest_raw(bgr, dep, out_rgb=s_img, out_depth=s_dep)
+        self.hand._staged_done(staged)
+        g.replay()
+        return out
+
+    @ops.device_guarded
     def graphed(self, images: torch.Tensor, depth: torch.Tensor):
         """(run, static images, static depth, static LiveOutput): copy new frames into the static inputs and call run()."""
         key = (tuple(images.shape), tuple(depth.shape))

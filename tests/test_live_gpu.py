@@ -277,3 +277,30 @@ def test_converting_step_on_the_sparse_path_and_in_wide_records(fcos_sd, a2j_sd,
     torch.cuda.synchronize()
     assert third.xyz_mm is None and tuple(third.host_record.shape) == (n + 1, 544)
     assert torch.equal(pipeline.read_host_record(third.host_record, n, extras=True)[4][0], third.image_uvd.cpu())
+
+
+def test_live_forward_raw_equals_the_converted_feed(live):
+    """LiveHandEngine.forward_raw (cv_bridge 'bgr8' + 16UC1 buffers from pageable host memory -> ingest kernel -> captured live
+    step) against the same frames converted on the host as ros_demo.py:227-231,266-267 does and fed through graphed():
+    identical records and mesh; two calls in a row with different frames (rotating staging buffers) stay apart."""
+    eng, _, _ = live
+    rng = np.random.default_rng(7)
+    outs = []
+    for i in range(2):
+        bgr = rng.integers(0, 256, size=(1, 480, 640, 3), dtype=np.uint8)
+        mm = rng.integers(300, 1500, size=(1, 480, 640)).astype(np.uint16)
+        out = eng.forward_raw(torch.from_numpy(bgr), torch.from_numpy(mm))
+        torch.cuda.synchronize()
+        got = out.read()
+        rgb = torch.from_numpy(bgr[..., ::-1].transpose(0, 3, 1, 2).astype(np.float32) / 255.0).cuda()
+        dep = torch.from_numpy(mm.astype(np.float32) / 1000.0).unsqueeze(1).cuda()
+        run, s_img, s_dep, ref = eng.graphed(rgb, dep)
+        s_img.copy_(rgb)
+        s_dep.copy_(dep)
+        run()
+        torch.cuda.synchronize()
+        want = ref.read()
+        assert torch.equal(got[0], want[0]) and torch.equal(got[2], want[2]) and torch.equal(got[5], want[5])
+        assert torch.equal(got[4][0], want[4][0]) and torch.equal(got[4][1], want[4][1])
+        outs.append(got)
+    assert not torch.equal(outs[0][0], outs[1][0])      # (different frames: different keypoints)
