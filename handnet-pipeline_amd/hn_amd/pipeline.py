@@ -55,16 +55,18 @@ def read_host_record(rec: torch.Tensor, n: int, joints: int = 21, extras: bool =
     import numpy as np
     a = rec.numpy()
     j3 = joints * 3
-    kp = torch.from_numpy(np.ascontiguousarray(a[:n, 40:40 + 4 * j3]).view(np.float32).reshape(n, joints, 3))
-    has = torch.from_numpy(np.ascontiguousarray(a[:n, 32:36]).view(np.int32).reshape(n))
-    box = torch.from_numpy(np.ascontiguousarray(a[:n, :32]).view(np.int64).reshape(n, 4))
+    # (.copy(), not np.ascontiguousarray: a ONE-row slice is already contiguous and would come back as a VIEW of the pinned
+    # buffer -- at batch 1, the live caller's batch, the "fresh" keypoints of round 5 aliased the record the next call overwrites)
+    kp = torch.from_numpy(a[:n, 40:40 + 4 * j3].copy().view(np.float32).reshape(n, joints, 3))
+    has = torch.from_numpy(a[:n, 32:36].copy().view(np.int32).reshape(n))
+    box = torch.from_numpy(a[:n, :32].copy().view(np.int64).reshape(n, 4))
     words = a[n, :16].view(np.int32).tolist()
     if not extras:
         return kp, has, box, words
     more = []
     for f in range(1, (a.shape[1] - 40) // (4 * j3)):
         lo = 40 + 4 * j3 * f
-        more.append(torch.from_numpy(np.ascontiguousarray(a[:n, lo:lo + 4 * j3]).view(np.float32).reshape(n, joints, 3)))
+        more.append(torch.from_numpy(a[:n, lo:lo + 4 * j3].copy().view(np.float32).reshape(n, joints, 3)))
     return kp, has, box, words, more
 
 

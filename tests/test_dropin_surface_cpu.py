@@ -163,6 +163,18 @@ def test_wide_host_record_layout():
         assert out[3] == [0, 1, 0, 0]
         if extras:
             assert len(out[4]) == 2 and np.array_equal(out[4][0].numpy(), img) and np.array_equal(out[4][1].numpy(), xyz)
+    # the results are COPIES, also for ONE frame (a one-row slice of the record is contiguous as it stands: numpy would hand
+    # back a view of the pinned buffer, which the engine's next step overwrites)
+    for fields in (1, 3):
+        rec = np.zeros((2, record_bytes(fields)), dtype=np.uint8)
+        rec[0, 40:292] = kp[0].reshape(63).view(np.uint8)
+        rec[0, :32] = box[0].view(np.uint8)
+        buf = torch.from_numpy(rec)
+        out = read_host_record(buf, 1, extras=fields == 3)
+        rec[:] = 0xFF
+        assert np.array_equal(out[0].numpy()[0], kp[0]) and np.array_equal(out[2].numpy()[0], box[0])
+        if fields == 3:
+            assert not out[4][0].numpy().any() and not out[4][1].numpy().any()
 
 
 def test_fragment_order_layout():

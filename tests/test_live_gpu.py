@@ -304,3 +304,27 @@ def test_live_forward_raw_equals_the_converted_feed(live):
         assert torch.equal(got[4][0], want[4][0]) and torch.equal(got[4][1], want[4][1])
         outs.append(got)
     assert not torch.equal(outs[0][0], outs[1][0])      # (different frames: different keypoints)
+
+
+def test_dropin_results_at_batch_1_do_not_alias_the_step_record(fcos_sd, a2j_sd):
+    """The keypoints HandNet.forward returns are the caller's to keep (handnet_pipeline.py:113-116 builds fresh tensors): the
+    next call -- eager or replayed -- must not change them.  At ONE frame per call (ros_demo.py:270) a one-row slice of the
+    pinned record is contiguous as it stands, and round 5's reader handed it back as a view: found by
+    test_live_forward_raw_equals_the_converted_feed."""
+    import types
+    from handnet_pipeline.handnet_pipeline import HandNet
+    from hn_amd import synth
+    net = HandNet(types.SimpleNamespace(pretrained_fcos="-", pretrained_a2j="-"), num_classes=3)
+    net.detector.load_state_dict(fcos_sd, strict=False)
+    net.a2j.load_state_dict(a2j_sd, strict=False)
+    net = net.cuda().eval()
+    frames = [(synth.make_rgb(1, seed=1000 + i).cuda(), synth.make_depth(1, seed=2000 + i).cuda()) for i in range(8)]
+    kept = []
+    with torch.inference_mode():
+        for rgb, dep in frames:                      # (calls 5.. replay a captured step)
+            kp, depth_batch, crops = net([rgb[0]], depth_images=dep)
+            kept.append((kp, kp.clone(), depth_batch, depth_batch.clone(), crops, crops.clone()))
+    assert net.engine().graph_count() == 1
+    for kp, kp0, db, db0, cr, cr0 in kept:
+        assert torch.equal(kp, kp0) and torch.equal(db, db0) and torch.equal(cr, cr0)
+    assert not torch.equal(kept[0][0], kept[1][0]) and not torch.equal(kept[5][0], kept[6][0])
