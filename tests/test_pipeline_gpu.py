@@ -813,3 +813,28 @@ def test_nonfinite_rgb_pixels_raise_instead_of_giving_undefined_detections(fcos_
         rgb[1, 0, 200, 300] = 0.5
         kp, _, _ = net([r.cuda() for r in rgb], depth_images=depth.cuda())       # the flags are per step
         assert torch.isfinite(kp).all()
+
+
+def test_engine_forward_raw_back_to_back_from_pageable_memory(fcos_sd, a2j_sd):
+    """HandNetEngine.forward_raw is sync-free, and pageable inputs travel through a pinned staging buffer that the
+    ingest kernel reads ASYNCHRONOUSLY.  Five calls in a row with five different frame pairs and NO synchronisation in between
+    (a pipelined caller): every step's results must be those of its own frames -- the staging buffers rotate and a buffer is
+    only rewritten once the ingest launch that read it has passed its event."""
+    from hn_amd.a2j_engine import A2JEngine
+    from hn_amd.fcos_engine import FCOSEngine
+    from hn_amd.pipeline import HandNetEngine
+    eng = HandNetEngine(FCOSEngine(fcos_sd, 3, device="cuda"), A2JEngine(a2j_sd, device="cuda"), 3)
+    frames = [_raw_frames(2, seed=31 + i) for i in range(5)]
+    refs = []
+    for bgr, mm in frames:
+        rgb, depth = _host_ingest(bgr, mm)
+        o = eng.forward_device(rgb.cuda(), depth.cuda())
+        torch.cuda.synchronize()
+        refs.append((o.keypoints.clone(), o.crop_box.clone()))
+    outs = [eng.forward_raw(torch.from_numpy(bgr), torch.from_numpy(mm)) for bgr, mm in frames]     # no sync in between
+    torch.cuda.synchronize()
+    for o, (kp, box) in zip(outs, refs):
+        assert torch.equal(o.crop_box, box) and torch.equal(o.keypoints, kp)
+    assert len({tuple(r[1].flatten().tolist()) for r in refs}) > 1          # (the frames really differ in their results)
+    ring = next(iter(eng._raw_staging.values()))
+    assert len(ring["slots"]) == 2
