@@ -277,8 +277,8 @@ class ShardedHandNet:
                 raise ValueError(f"rank {self.rank} of {self.world} holds frames [{lo}, {hi}) of a {total}-frame batch, "
                                  f"got {n_in} frames")
         per_rank = -(-total // self.world)
-        if hi == lo:
-            raise ValueError(f"a {total}-frame batch leaves rank {self.rank} of {self.world} without a frame")
+        if total < self.world:      # (decided from numbers every rank knows: ALL ranks raise, none is left waiting in the collective)
+            raise ValueError(f"a {total}-frame batch leaves ranks of a {self.world}-rank group without a frame")
         batch = images if torch.is_tensor(images) else torch.stack([i.float() for i in images])
         dev = batch.device
         channels = 4 if self.rgbd else 1

@@ -378,3 +378,9 @@ def test_sharded_handnet_single_process_and_collective_count(monkeypatch):
         assert torch.equal(got[0], want[0]) and torch.equal(got[2], want[2])
     with pytest.raises(ValueError, match="holds frames"):
         hdist.ShardedHandNet(_StubNet())(images, depth_images=depth, global_batch=9)
+    # fewer frames than ranks: refused on EVERY rank from numbers all of them know (no rank is left in the collective)
+    monkeypatch.setattr(dist, "get_world_size", lambda group=None: 8)
+    for rank in (0, 7):
+        monkeypatch.setattr(dist, "get_rank", lambda group=None, r=rank: r)
+        with pytest.raises(ValueError, match="without a frame"):
+            hdist.ShardedHandNet(_StubNet())(images, depth_images=depth)
