@@ -299,3 +299,28 @@ def test_lifter_input_chain_is_a_per_axis_standardisation():
     # the affine map really is isotropic scale + translation (three-point solve, as cv2.getAffineTransform)
     t = pose2mesh_ref._affine_transform_rot0(np.array([100.0, 50.0], np.float32), np.array([40.0, 30.0], np.float32), (288, 384))
     assert abs(t[0, 1]) < 1e-9 and abs(t[1, 0]) < 1e-9 and abs(t[0, 0] - t[1, 1]) < 1e-9 and t[0, 0] > 0
+
+
+def test_lifter_input_pieces_match_the_imported_reference(golden_dir):
+    """oracle.pose2mesh_ref.get_bbox / process_bbox / the centre-scale step / the affine point map against outputs of the
+    reference's own coord_utils.py and aug_utils.py (tests/golden/make_golden_lifter_input.py IMPORTS them): everything of
+    ros_demo.py:148-157 except the one cv2.getAffineTransform call (OpenCV is absent: restated as the three-point solve)."""
+    import numpy as np
+    from oracle import pose2mesh_ref as r
+    g = np.load(golden_dir / "lifter_input.npz")
+    assert tuple(g["input_shape"]) == r.INPUT_SHAPE
+    for i in range(g["joints"].shape[0]):
+        b = r.get_bbox(g["joints"][i])
+        assert np.array_equal(b, g["bbox"][i])
+        b2 = r.process_bbox(b.copy())
+        assert (b2 is not None) == bool(g["ok"][i])
+        if b2 is None:
+            assert r.lifter_input(g["joints"][i]) is None
+            continue
+        assert np.array_equal(np.asarray(b2, dtype=np.float64), g["bbox2"][i])
+        center = np.array([b2[0] + b2[2] * 0.5, b2[1] + b2[3] * 0.5], dtype=np.float32)
+        scale = np.array([b2[2] * 1.0, b2[3] * 1.0], dtype=np.float32)
+        assert np.array_equal(center, g["center"][i]) and np.array_equal(scale, g["scale"][i])
+    for t, ps, ws in zip(g["t"], g["pts"], g["warped"]):
+        for p, w in zip(ps, ws):
+            assert np.array_equal(np.dot(t, np.array([p[0], p[1], 1.]).T)[:2], w)       # affine_transform, aug_utils.py:176-179
