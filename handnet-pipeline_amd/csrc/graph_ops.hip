@@ -538,6 +538,40 @@ extern "C" int hn_linear_rows_f16x3(const float* x, int batch, int x_stride, int
   return HN_OK;
 }
 
+namespace {
+// out['mesh'] of ros_demo.py:162,332-337: the vertices of the real mesh in original order (pred_mesh[:, graph_perm_reverse[:V]]),
+// moved to the camera frame of the depth sensor -- (mesh * 1000 + joints3d[0]) / 1000 -- with y and z negated; numpy float32
+// arithmetic, one rounding per operation: the intrinsics keep the compiler from contracting mul + add into an fma
+__global__ __launch_bounds__(256) void mesh_finish_kernel(const float* __restrict__ mesh, const long long* __restrict__ perm,
+                                                          const float* __restrict__ xyz_mm, const int* __restrict__ valid,
+                                                          float* __restrict__ out, int n, int v0, int v, int joints) {
+  const long total = (long)n * v * 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % 3);
+    const long r = i / 3;
+    const int vv = (int)(r % v), img = (int)(r / v);
+    float val = 0.f;
+    if (!valid || valid[img] == 1) {
+      const float m = mesh[((long)img * v0 + perm[vv]) * 3 + c];
+      const float root = xyz_mm[(long)img * joints * 3 + c];               // joints3d[0]: the first joint
+      val = __fdiv_rn(__fadd_rn(__fmul_rn(m, 1000.f), root), 1000.f);
+      if (c) val = -val;
+    }
+    out[i] = val;
+  }
+}
+}  // namespace
+
+extern "C" int hn_mesh_finish_f32(const float* mesh, const int64_t* perm, const float* xyz_mm, const int32_t* valid, int n, int v0,
+                                  int v, int joints, float* out, void* stream) {
+  HN_CHECK_ARG(mesh && perm && xyz_mm && out, "hn_mesh_finish_f32: null pointer");
+  HN_CHECK_ARG(n > 0 && v0 > 0 && v > 0 && joints > 0, "bad dims");
+  hipLaunchKernelGGL(mesh_finish_kernel, dim3(grid_for((long)n * v * 3)), dim3(256), 0, (hipStream_t)stream, mesh,
+                     (const long long*)perm, xyz_mm, valid, out, n, v0, v, joints);
+  HN_CHECK_LAUNCH("mesh_finish_kernel");
+  return HN_OK;
+}
+
 extern "C" int hn_pad_split_rows_f32(const float* x, int64_t rows, int f, int cpad, void* out16, void* stream) {
   HN_CHECK_ARG(x && out16, "hn_pad_split_rows_f32: null pointer");
   HN_CHECK_ARG(rows > 0 && f > 0 && cpad >= f && cpad % 32 == 0, "bad dims (cpad: a multiple of 32 >= f)");

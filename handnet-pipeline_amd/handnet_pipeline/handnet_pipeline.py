@@ -97,15 +97,16 @@ class HandNet(EngineOwner):
         self.last_converted = None
         return self
 
-    def live(self, lifter, paras, clamp: bool = True):
+    def live(self, lifter, paras, clamp: bool = True, perm_reverse=None):
         """The live caller's chain as ONE step (hn_amd.live.LiveHandEngine; ros_demo.py:270-290,329-337): this network, the
         caller's clamp + convert_joints (in the aggregation's epilogue), the lifter's input, Pose2Mesh, one device -> host copy.
         lifter: the drop-in `models.pose2mesh_net.get_model(...)` module (on the GPU) or a Pose2MeshEngine; paras = (fx, fy,
-        cx, cy).  The returned engine owns this network's step from then on (forward() of this module keeps working and
+        cx, cy); perm_reverse = graph_perm_reverse[:V]: the step then also does ros_demo.py:162,332-337 and hands over out['mesh'].
+        The returned engine owns this network's step from then on (forward() of this module keeps working and
         carries the converted joints: set_convert)."""
         from hn_amd.live import LiveHandEngine
         self._convert_cfg = (tuple(paras), bool(clamp))
-        return LiveHandEngine(self.engine(), lifter.engine() if hasattr(lifter, "engine") else lifter, paras, clamp)
+        return LiveHandEngine(self.engine(), lifter.engine() if hasattr(lifter, "engine") else lifter, paras, clamp, perm_reverse)
 
     # forward() switches ITSELF to hipGraph replay once the same input shapes have come in a few times in a row -- the live
     # caller's case (ros_demo.py:270-273: one 640x480 frame per call, ~150 dependent launches whose host cost is 8 % of the

@@ -146,6 +146,7 @@ SIGNATURES = {
                                              C.c_int, C.c_int, VP, C.c_int, C.c_int, VP, C.c_int, VP]),
     "hn_linear_rows_f16x3": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, C.c_int, C.c_int, VP, VP, C.c_int, C.c_int, VP,
                                        C.c_int, VP]),
+    "hn_mesh_finish_f32": (C.c_int, [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP]),
     "hn_pad_split_rows_f32": (C.c_int, [VP, C.c_int64, C.c_int, C.c_int, VP, VP]),
     "hn_lifter_combine_f32": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP]),
     "hn_cheby3_basis_split": (C.c_int, [VP, VP, VP, C.c_int, VP, VP, VP, C.c_int, C.c_int, C.c_int, VP]),

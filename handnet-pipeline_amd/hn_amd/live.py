@@ -27,7 +27,8 @@ from .pose2mesh_engine import Pose2MeshEngine
 class LiveOutput:
     hand: HandNetOutput          # the step's detector / pose results (image_uvd and xyz_mm included), on the device
     pose2d: torch.Tensor         # [N,21,2] the lifter's standardised input
-    mesh: torch.Tensor           # [N,V0,3] Pose2Mesh vertices (finest level of the graph hierarchy, coarsening order)
+    mesh: torch.Tensor           # [N,V0,3] Pose2Mesh vertices (finest level of the graph hierarchy, coarsening order), or --
+    #                              with perm_reverse -- [N,V,3] = out['mesh'] of ros_demo.py:337 (camera frame, original order)
     pose3d: torch.Tensor         # [N,21,3] PoseNet's lifted joints (millimetre scale of the lifter's training set)
     host: torch.Tensor           # pinned uint8: (N + 1) wide records, then the mesh as fp32 -- ONE copy, enqueued by the step
     n: int = 0
@@ -44,13 +45,22 @@ class LiveOutput:
 
 
 class LiveHandEngine:
-    def __init__(self, hand: HandNetEngine, lifter: Pose2MeshEngine, paras, clamp: bool = True):
+    def __init__(self, hand: HandNetEngine, lifter: Pose2MeshEngine, paras, clamp: bool = True, perm_reverse=None):
         """paras = (fx, fy, cx, cy) of the depth camera (ros_demo.py:191-196); clamp: the caller's clamps before the
-        conversion (ros_demo.py:279-283)."""
+        conversion (ros_demo.py:279-283).  perm_reverse: graph_perm_reverse[:V] (int64, V = vertices of the real mesh,
+        ros_demo.py:162) -- given, the step also does the caller's last three lines (vertex order, camera offset by the first
+        joint, y / z negated: ros_demo.py:332-337) and `mesh` of the outputs IS out['mesh'], [N,V,3]; else the lifter's raw
+        [N,V0,3] vertices in coarsening order."""
         if hand.device != lifter.device:
             raise ValueError(f"HandNet on {hand.device} but the lifter on {lifter.device}")
         self.hand, self.lifter, self.device = hand, lifter, hand.device
         hand.set_convert(paras=paras, clamp=clamp)
+        self.perm = None
+        if perm_reverse is not None:
+            self.perm = torch.as_tensor(perm_reverse).to(torch.int64).to(self.device).contiguous()
+            if int(self.perm.max()) >= lifter.graphs[0].v or int(self.perm.min()) < 0:
+                raise ValueError("perm_reverse points outside the lifter's finest graph")
+        self.vertices = lifter.graphs[0].v if self.perm is None else int(self.perm.shape[0])
         self._graphs = {}
         self._buffers = {}
 
@@ -69,17 +79,20 @@ class LiveHandEngine:
     def forward_device(self, images, depth, _buffers=None) -> LiveOutput:
         """images [N,3,H,W] 0..1 (or a list), depth [N,1,H,W] metres on the GPU -> LiveOutput (no sync)."""
         n = len(images)
-        v0 = self.lifter.graphs[0].v
+        v0 = self.vertices
         dev, host = _buffers if _buffers is not None else self._out_buffers(n, v0)
         rb = record_bytes(3)
         rec = dev[: (n + 1) * rb].view(n + 1, rb)
         mesh_buf = dev[(n + 1) * rb:].view(torch.float32).view(n, v0, 3)
 
-        def lift(_kp, image_uvd, _xyz, has_hand):
+        def lift(_kp, image_uvd, xyz, has_hand):
             # (inside the step's range scope: the lifter's split producers note into the step's flag words, which the step's one
             # collect launch hands over -- an overflowing activation of the lifter raises like one of the pose network)
             p2d = ops.joints2d_standardize(image_uvd, valid=has_hand)
-            return (p2d,) + tuple(self.lifter.forward(p2d, mesh_out=mesh_buf))     # the last layer writes into the copy buffer
+            if self.perm is None:
+                return (p2d,) + tuple(self.lifter.forward(p2d, mesh_out=mesh_buf))  # the last layer writes into the copy buffer
+            raw, pose3d = self.lifter.forward(p2d)
+            return p2d, ops.mesh_finish(raw, self.perm, xyz, valid=has_hand, out=mesh_buf), pose3d
         # the step packs its wide records and its range words straight into `rec`; ONE copy moves records + mesh
         out = self.hand.forward_device(images, depth, _record=(None, rec), _tail=lift)
         p2d, mesh, pose3d = out.tail
@@ -116,7 +129,7 @@ class LiveHandEngine:
                 s_img.copy_(images)
                 s_dep.copy_(depth)
                 n = images.shape[0]
-                v0 = self.lifter.graphs[0].v
+                v0 = self.vertices
                 nbytes = (n + 1) * record_bytes(3) + n * v0 * 12
                 bufs = (torch.zeros((nbytes,), dtype=torch.uint8, device=self.device),
                         torch.zeros((nbytes,), dtype=torch.uint8, pin_memory=True))

@@ -1511,6 +1511,21 @@ def linear_rows(x, cw, scale=None, shift=None, residual=None, relu=False, n_out=
     return y
 
 
+def mesh_finish(mesh, perm, xyz_mm, valid=None, out=None):
+    """mesh [N,V0,3], perm int64 [V] (graph_perm_reverse[:V]), xyz_mm [N,J,3] -> [N,V,3] = ((mesh[:, perm] * 1000 + xyz_mm[:, 0])
+    / 1000) * (1, -1, -1): out['mesh'] of ros_demo.py:162,332-337, bit-identical to the numpy float32 arithmetic."""
+    _req(mesh, name="mesh"); _req(perm, torch.int64, "perm"); _req(xyz_mm, name="xyz_mm")
+    n, v0, _ = mesh.shape
+    v = perm.shape[0]
+    if out is None:
+        out = torch.empty((n, v, 3), device=mesh.device, dtype=torch.float32)
+    if valid is not None:
+        _req(valid, torch.int32, "valid")
+    check(_lib.load().hn_mesh_finish_f32(ptr(mesh), ptr(perm), ptr(xyz_mm), ptr(valid), n, v0, v, xyz_mm.shape[1], ptr(out), _stream()),
+          "hn_mesh_finish_f32")
+    return out
+
+
 def pad_split_rows(x, cpad):
     """fp32 [rows, f] -> S32 [rows,1,1,cpad/32,2,32], channels f.. zero (hn_pad_split_rows_f32)."""
     _req(x, name="x")

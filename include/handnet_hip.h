@@ -617,6 +617,12 @@ int hn_graph_conv_cheby3_f16x3(const hn_graph_csr* L, const hn_graph_csr* L2, co
  * joint as fp32 [batch*J][fpad] (the padded input of the first graph convolution; pose3d rows may be padded: PoseNet's last
  * Linear is run with 64 output columns so that it takes the vectorised / split-K form of the convolution kernel). */
 int hn_pad_split_rows_f32(const float* x, int64_t rows, int f, int cpad, void* out16, void* stream);
+/* The last lines of the live caller's mesh path (ros_demo.py:162,332-337): out[i][k][:] = ((mesh[i][perm[k]][:] * 1000 +
+ * xyz_mm[i][0][:]) / 1000) * (1, -1, -1) -- the real mesh's vertices in original order (perm = graph_perm_reverse[:v], int64
+ * on the device, entries < v0), moved by the first joint's camera position, y and z negated; numpy's float32 arithmetic, one
+ * rounding per operation (bit-identical).  mesh [n][v0][3], xyz_mm [n][joints][3], out [n][v][3]; rows with valid != 1 are zeros. */
+int hn_mesh_finish_f32(const float* mesh, const int64_t* perm, const float* xyz_mm, const int32_t* valid /* or NULL */, int n,
+                       int v0, int v, int joints, float* out, void* stream);
 /* A Linear layer on 1..4 rows as a matrix-vector product on the vector ALU (PoseNet at the live caller's batch, posenet.py:24-41,
  * 78-88: 67 MB of filter bank per 17 M MACs): y[m][:] = act(W (pre(x[m])) + bias (+ residual[m])), pre = relu(x * scale + shift)
  * when scale / shift ([k_real] fp32: the pre-activation BatchNorm) are given.  x fp32 [batch][x_stride] (k_real columns used), w16 =

@@ -328,3 +328,34 @@ def test_dropin_results_at_batch_1_do_not_alias_the_step_record(fcos_sd, a2j_sd)
     for kp, kp0, db, db0, cr, cr0 in kept:
         assert torch.equal(kp, kp0) and torch.equal(db, db0) and torch.equal(cr, cr0)
     assert not torch.equal(kept[0][0], kept[1][0]) and not torch.equal(kept[5][0], kept[6][0])
+
+
+def test_live_step_hands_over_the_callers_final_mesh(live, golden_dir):
+    """perm_reverse given, the live step also runs the caller's last lines (ros_demo.py:162,332-337): `mesh` of its outputs is
+    out['mesh'] -- numpy float32 arithmetic on the raw vertices and the step's own joints3d, bit for bit."""
+    from hn_amd import synth
+    from hn_amd.live import LiveHandEngine
+    eng, _, _ = live
+    g = np.load(golden_dir / "pose2mesh_forward.npz")
+    perm = g["perm_reverse"][:778]
+    rgb, depth = synth.make_rgb(2, seed=1000).cuda(), synth.make_depth(2, seed=2000).cuda()
+    raw = eng.forward_device(rgb, depth)
+    torch.cuda.synchronize()
+    raw_mesh, xyz = raw.mesh.cpu().numpy(), raw.hand.xyz_mm.cpu().numpy()
+    fin = LiveHandEngine(eng.hand, eng.lifter, PARAS, clamp=True, perm_reverse=perm)
+    for graphed in (False, True):
+        if graphed:
+            run, s_img, s_dep, out = fin.graphed(rgb, depth)
+            run()
+        else:
+            out = fin.forward_device(rgb, depth)
+        torch.cuda.synchronize()
+        kp, has, box, words, (img, xyz_rec), mesh = out.read()
+        assert tuple(mesh.shape) == (2, 778, 3) and torch.equal(xyz_rec, raw.hand.xyz_mm.cpu())
+        for i in range(2):
+            want = raw_mesh[i][perm, :]                              # pred_mesh[:, graph_perm_reverse[:V]]      (:162)
+            want = want * 1000. + xyz[i][0]                          # out['mesh'] * 1000. + joints3d[0]         (:332)
+            want /= 1000.                                            #                                           (:333)
+            want[:, 1] *= -1                                         #                                           (:334)
+            want[:, 2] *= -1                                         #                                           (:335)
+            assert want.dtype == np.float32 and np.array_equal(mesh[i].numpy(), want)
