@@ -32,6 +32,7 @@ class LiveOutput:
     pose3d: torch.Tensor         # [N,21,3] PoseNet's lifted joints (millimetre scale of the lifter's training set)
     host: torch.Tensor           # pinned uint8: (N + 1) wide records, then the mesh as fp32 -- ONE copy, enqueued by the step
     n: int = 0
+    raw_mesh: torch.Tensor = None   # [N,V0,3] the lifter's own output on the device (= mesh without perm_reverse)
 
     def read(self):
         """After the stream is synchronised: (keypoints, has_hand, crop_box, range words, [image_uvd, xyz_mm], mesh) as fresh CPU
@@ -90,14 +91,15 @@ class LiveHandEngine:
             # collect launch hands over -- an overflowing activation of the lifter raises like one of the pose network)
             p2d = ops.joints2d_standardize(image_uvd, valid=has_hand)
             if self.perm is None:
-                return (p2d,) + tuple(self.lifter.forward(p2d, mesh_out=mesh_buf))  # the last layer writes into the copy buffer
+                mesh, pose3d = self.lifter.forward(p2d, mesh_out=mesh_buf)          # the last layer writes into the copy buffer
+                return p2d, mesh, pose3d, mesh
             raw, pose3d = self.lifter.forward(p2d)
-            return p2d, ops.mesh_finish(raw, self.perm, xyz, valid=has_hand, out=mesh_buf), pose3d
+            return p2d, ops.mesh_finish(raw, self.perm, xyz, valid=has_hand, out=mesh_buf), pose3d, raw
         # the step packs its wide records and its range words straight into `rec`; ONE copy moves records + mesh
         out = self.hand.forward_device(images, depth, _record=(None, rec), _tail=lift)
-        p2d, mesh, pose3d = out.tail
+        p2d, mesh, pose3d, raw = out.tail
         host.copy_(dev, non_blocking=True)
-        return LiveOutput(out, p2d, mesh, pose3d, host, n)
+        return LiveOutput(out, p2d, mesh, pose3d, host, n, raw)
 
     @ops.device_guarded
     def forward_raw(self, bgr_u8, depth_raw) -> LiveOutput:
