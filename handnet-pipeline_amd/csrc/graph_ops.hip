@@ -541,10 +541,11 @@ extern "C" int hn_linear_rows_f16x3(const float* x, int batch, int x_stride, int
 namespace {
 // out['mesh'] of ros_demo.py:162,332-337: the vertices of the real mesh in original order (pred_mesh[:, graph_perm_reverse[:V]]),
 // moved to the camera frame of the depth sensor -- (mesh * 1000 + joints3d[0]) / 1000 -- with y and z negated; numpy float32
-// arithmetic, one rounding per operation: the intrinsics keep the compiler from contracting mul + add into an fma
+// arithmetic, one rounding per operation (contraction is switched off inside the kernel)
 __global__ __launch_bounds__(256) void mesh_finish_kernel(const float* __restrict__ mesh, const long long* __restrict__ perm,
                                                           const float* __restrict__ xyz_mm, const int* __restrict__ valid,
                                                           float* __restrict__ out, int n, int v0, int v, int joints) {
+#pragma clang fp contract(off)   // (HIP's __fmul_rn / __fadd_rn are plain operators: without this the pair becomes one fma)
   const long total = (long)n * v * 3;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % 3);
@@ -554,7 +555,9 @@ __global__ __launch_bounds__(256) void mesh_finish_kernel(const float* __restric
     if (!valid || valid[img] == 1) {
       const float m = mesh[((long)img * v0 + perm[vv]) * 3 + c];
       const float root = xyz_mm[(long)img * joints * 3 + c];               // joints3d[0]: the first joint
-      val = __fdiv_rn(__fadd_rn(__fmul_rn(m, 1000.f), root), 1000.f);
+      const float scaled = m * 1000.f;
+      const float moved = scaled + root;
+      val = moved / 1000.f;
       if (c) val = -val;
     }
     out[i] = val;
