@@ -53,7 +53,8 @@ def main():
         conv = net.last_converted
         print("2. set_convert: joints2d[0] =", conv["image_uvd"][0, 0, :2].tolist(), " joints3d[0] (mm) =", conv["xyz_mm"][0, 0].tolist())
         # 3. the live chain as one captured step
-        live = net.live(model, PARAS, clamp=True)
+        rev = torch.from_numpy(g["perm_reverse"][:778].astype(np.int64))                  # graph_perm_reverse[:V], ros_demo.py:162
+        live = net.live(model, PARAS, clamp=True, perm_reverse=rev)                      # -> the step hands over out['mesh']
         run, s_img, s_dep, out = live.graphed(rgb, depth)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -64,10 +65,9 @@ def main():
             torch.cuda.current_stream().synchronize()
             kp, has_hand, crop_box, _words, (image_uvd, xyz_mm), mesh = out.read()
         dt = time.perf_counter() - t0
-        rev = torch.from_numpy(g["perm_reverse"][:778].astype(np.int64))                  # ros_demo.py:162
-        cam_mesh = (mesh[0, rev] * 1000.0 + xyz_mm[0, 0]) / 1000.0                        # ros_demo.py:332-334
+        cam_mesh = mesh[0]                                                                # out['mesh'] of ros_demo.py:332-337
         print(f"3. live step: {frames} frames, {1e3 * dt / frames:.2f} ms per frame incl. synthetic frame generation; "
-              f"mesh {tuple(mesh.shape)} -> {tuple(cam_mesh.shape)} camera-frame vertices; has_hand = {has_hand.tolist()}")
+              f"mesh {tuple(out.raw_mesh.shape)} -> {tuple(cam_mesh.shape)} camera-frame vertices; has_hand = {has_hand.tolist()}")
 
 
 if __name__ == "__main__":

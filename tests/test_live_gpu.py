@@ -226,7 +226,7 @@ def test_live_demo_example_runs():
     r = subprocess.run([sys.executable, str(repo / "examples" / "live_demo.py"), "3"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "1. HandNet.forward: (1, 21, 3) cpu" in r.stdout and "2. set_convert" in r.stdout and "3. live step: 3 frames" in r.stdout
-    assert "(778, 3) camera-frame vertices; has_hand = [1]" in r.stdout
+    assert "mesh (1, 1152, 3) -> (778, 3) camera-frame vertices; has_hand = [1]" in r.stdout
 
 
 def test_converting_step_on_the_sparse_path_and_in_wide_records(fcos_sd, a2j_sd, monkeypatch):
