@@ -358,3 +358,54 @@ def test_live_step_hands_over_the_callers_final_mesh(live, golden_dir):
             want[:, 1] *= -1                                         #                                           (:334)
             want[:, 2] *= -1                                         #                                           (:335)
             assert want.dtype == np.float32 and np.array_equal(mesh[i].numpy(), want)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_live_chain_parity_on_other_weight_draws(golden_dir, seed):
+    """The live chain against the oracle's chain (handnet_ref -> the caller's numpy glue -> pose2mesh_ref) AWAY from the seed-0
+    weights: other draws of the detector, the pose network AND the lifter, structured frames beside noise -- crop boxes
+    identical, joints within the pipeline's tolerance, final camera-frame mesh (out['mesh'], ros_demo.py:332-337) within 3e-3."""
+    from hn_amd import synth
+    from hn_amd.a2j_engine import A2JEngine
+    from hn_amd.fcos_engine import FCOSEngine
+    from hn_amd.live import LiveHandEngine
+    from hn_amd.pipeline import HandNetEngine
+    from hn_amd.pose2mesh_engine import Pose2MeshEngine
+    from oracle import a2j_ref, handnet_ref, pose2mesh_ref
+    g = np.load(golden_dir / "pose2mesh_forward.npz")
+    graphs = pose2mesh_ref.load_graphs(g)
+    perm = g["perm_reverse"][:778]
+    fcos_sd, a2j_sd = synth.make_fcos_state_dict(seed, 3), synth.make_a2j_state_dict(seed)
+    p2m_sd = synth.make_pose2mesh_state_dict(seed=seed + 10, graph_sizes=[m.shape[0] for m in graphs])
+    eng = LiveHandEngine(HandNetEngine(FCOSEngine(fcos_sd, 3, device="cuda"), A2JEngine(a2j_sd, device="cuda"), 3),
+                         Pose2MeshEngine(p2m_sd, graphs, device="cuda"), PARAS, clamp=True, perm_reverse=perm)
+    rgb, depth = synth.make_rgb(2, seed=1200 + seed), synth.make_depth(2, seed=2200 + seed)
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, 480), torch.linspace(0, 1, 640), indexing="ij")
+    rgb[1] = torch.stack([xx, yy, 0.5 * (xx + yy)])                      # a ramp frame beside the noise frame
+    out = eng.forward_device(rgb.cuda(), depth.cuda())
+    torch.cuda.synchronize()
+    kp, has, box, words, (img, xyz), mesh = out.read()
+    assert not any(words[:3])
+    o_kp, _o_depth, o_crops = handnet_ref.handnet_forward([rgb[i] for i in range(2)], depth, fcos_sd, a2j_sd, 3)
+    hands = [i for i in range(2) if int(has[i]) == 1]
+    assert hands, "no frame with a hand in this case"
+    if len(hands) == 2:
+        assert torch.equal(o_crops, box)
+    row = 0
+    for i in hands:
+        det = o_crops[row].clone()
+        assert torch.equal(det, box[i])
+        det[:2] = torch.clamp(det[:2], 0, 480)
+        det[2:] = torch.clamp(det[2:], 0, 640)
+        k = torch.clamp(o_kp[i], min=0.0, max=176.0).numpy()
+        assert np.abs(k - torch.clamp(kp[i], 0.0, 176.0).numpy()).max() < 1e-3
+        j2d = a2j_ref.convert_joints(k, det.numpy(), None)[:, :2]
+        j3d = a2j_ref.convert_joints(k, det.numpy(), PARAS)
+        x = pose2mesh_ref.lifter_input(j2d)
+        o_mesh, _ = pose2mesh_ref.pose2mesh_forward(torch.from_numpy(x)[None], p2m_sd, graphs)
+        want = o_mesh[0].numpy()[perm, :] * 1000. + j3d[0]
+        want /= 1000.
+        want[:, 1] *= -1
+        want[:, 2] *= -1
+        assert np.abs(mesh[i].numpy() - want).max() < 3e-3, (seed, i, np.abs(mesh[i].numpy() - want).max())
+        row += 1
