@@ -493,6 +493,16 @@ def cpu_baseline(args, sds, engine=None, dev=None, others=None, hip_outputs=None
             others["a2j_b64"]["parity"], a2j_s = parity.a2j_parity(hip_kp, crops, a2j_sd)
             res["a2j_only"] = {"value": round(crops.shape[0] / a2j_s, 2), "unit": "crops/s",
                                "sample": f"ONE batch-{crops.shape[0]} oracle.a2j_ref.a2j_forward (the parity run of other_configs.a2j_b64)"}
+        if "live_b1" in hip_outputs:
+            # frame 0 of the sample IS the live step's frame (seeds 1000/2000); the lifter's weights / graphs are the step's own
+            hip_live, p2m_sd, graphs = hip_outputs["live_b1"]
+            others["live_b1"]["parity"], live_s, lift_s = parity.live_parity(hip_live, rgb[:1], depth[:1], fcos_sd, a2j_sd, p2m_sd,
+                                                                             graphs, LIVE_PARAS, 3)
+            res["live_batch1"] = {"value": round(1.0 / live_s, 3), "unit": "frames/s", "ms_per_frame": round(1e3 * live_s, 1),
+                                  "lifter_ms": round(1e3 * lift_s, 1),
+                                  "sample": "median of 5 single-frame oracle chains after one warm-up: full-pipeline oracle forward + the "
+                                            "caller's numpy glue + oracle.pose2mesh_ref (the parity run of other_configs.live_b1); "
+                                            "lifter_ms = lifter_input + pose2mesh_forward alone"}
     return res
 
 
@@ -697,7 +707,7 @@ PARITY_CROPS = 16    # crops of the batch-64 A2J step compared with the oracle (
 LIVE_PARAS = (617.343, 617.343, 312.42, 241.42)   # SURVEY 8d's intrinsics
 
 
-def lifter_legs(eng, dev, timed):
+def lifter_legs(eng, dev, timed, hip=None):
     """SURVEY 8f #4 and the live caller's chain (ros_demo.py:270-290,329-337): the Pose2Mesh lifter alone at batch 1 and 32
     (hipGraph replay; 23 launches per forward at batch 1), and `live_b1`: HandNet -> clamp + convert_joints in the aggregation's epilogue
     -> lifter input -> Pose2Mesh -> ONE device -> host copy, all of it one captured step on one frame.  The graph hierarchy
@@ -733,7 +743,9 @@ def lifter_legs(eng, dev, timed):
         run, _, _, lo = live.graphed(rgb1, dep1)
         rec = timed(run, 1, per_group=10, warm=5)
         torch.cuda.synchronize()
-        kp, has, _box, _words, _more, mesh = lo.read()
+        kp, has, box, _words, (img, xyz), mesh = lo.read()
+        if hip is not None:      # what the TIMED captured step copied to the host, for cpu_baseline's oracle chain (live_parity)
+            hip["live_b1"] = ((kp, box, img, xyz, mesh), sd, graphs)
         rec.update(unit="frames/s", hipgraph=True,
                    workload="the live caller's chain on one frame (ros_demo.py:270-290,329-337): HandNet -> clamp + convert_joints "
                             "(aggregation epilogue) -> lifter input -> Pose2Mesh -> one device -> host copy, ONE captured step",
@@ -827,7 +839,7 @@ def other_configs_leg(args, info, dev, sds=None, hip=None):
                **roof_of(lambda: eng.forward_device(rgb1, dep1), rec["ms_per_step"]))
     out["pipeline_b1"] = rec
     if args.precision == "f16x3":
-        out.update(lifter_legs(eng, dev, timed))
+        out.update(lifter_legs(eng, dev, timed, hip))
     if args.precision == "f16x3" and sds is not None:
         # the reference's own arithmetic -- IEEE fp32 operands on the f32 MFMA -- driver-timed beside the split-fp16 headline:
         # the same step on engines built with precision="f32", eager, 3 timed steps; roofline against the f32-MFMA peak

@@ -169,3 +169,58 @@ def a2j_parity(hip_kp, crops, a2j_sd, box=(224, 152, 400, 328), paras=(617.343, 
             "mm_epe": float(np.mean(epe)), "max_crop_mm_epe": float(np.max(epe)), "tolerance": tolerance,
             "keypoints_within_tolerance": bool(float(d.max()) < tolerance), "crop_box_for_mm": list(box), "paras": list(paras),
             "what": "HIP A2J (rows of the batch-64 step) vs oracle.a2j_ref.a2j_forward (torch CPU fp32) on the same crops"}, oracle_s
+
+
+def live_parity(hip, rgb, depth, fcos_sd, a2j_sd, p2m_sd, graphs, paras, num_classes=3, reps=5):
+    """The live caller's chain on the frames of bench.py's `live_b1` step (ros_demo.py:270-290,329-337,148-161) through the
+    oracle: handnet_ref -> the caller's clamps -> a2j_ref.convert_joints (twice: image uv, camera xyz) -> pose2mesh_ref.lifter_input
+    -> pose2mesh_ref.pose2mesh_forward, against what the captured HIP step copied to the host:
+      hip = (keypoints [n,21,3], crop_box [n,4], image_uvd [n,21,3], xyz_mm [n,21,3], mesh [n,V0,3]) CPU tensors.
+    Returns (stats, median seconds of `reps` timed oracle chains per frame after one warm-up, median seconds of the lifter part
+    alone).  The mesh figure is on frames whose integer crop box is identical (else the keypoints differ by O(1 px), see above)."""
+    import numpy as np
+    from . import pose2mesh_ref
+    h_kp, h_box, h_img, h_xyz, h_mesh = hip
+    n = h_kp.shape[0]
+    H, W = depth.shape[-2:]
+
+    def chain(i):
+        t0 = time.time()
+        o_kp, _d, o_crops = handnet_ref.handnet_forward([rgb[i]], depth[i:i + 1], fcos_sd, a2j_sd, num_classes)
+        det = o_crops[0].clone()
+        det[:2] = torch.clamp(det[:2], 0, H)              # ros_demo.py:281-283
+        det[2:] = torch.clamp(det[2:], 0, W)
+        k = torch.clamp(o_kp[0], min=0.0, max=176.0).numpy()
+        j2d = a2j_ref.convert_joints(k, det.numpy(), None)
+        j3d = a2j_ref.convert_joints(k, det.numpy(), paras)
+        t1 = time.time()
+        x = pose2mesh_ref.lifter_input(j2d[:, :2])
+        mesh = None
+        if x is not None:
+            mesh, _pose3d = pose2mesh_ref.pose2mesh_forward(torch.from_numpy(x)[None], p2m_sd, graphs)
+        t2 = time.time()
+        return (o_kp[0], o_crops[0], j2d, j3d, mesh), t2 - t0, t2 - t1
+
+    chain(0)
+    whole, lift = [], []
+    same_box, d_kp, d_img, d_xyz, d_mesh = 0, 0.0, 0.0, 0.0, 0.0
+    for i in range(n):
+        for r in range(reps if i == 0 else 1):
+            (o_kp, o_box, j2d, j3d, o_mesh), s, sl = chain(i)
+            if i == 0:
+                whole.append(s)
+                lift.append(sl)
+        if not torch.equal(o_box, h_box[i]) or o_mesh is None:
+            continue
+        same_box += 1
+        d_kp = max(d_kp, float((o_kp - h_kp[i]).abs().max()))
+        d_img = max(d_img, float(np.abs(h_img[i].numpy()[:, :2] - j2d[:, :2]).max()))
+        d_xyz = max(d_xyz, float(np.abs(h_xyz[i].numpy() - j3d).max()))
+        d_mesh = max(d_mesh, float((o_mesh[0] - h_mesh[i]).abs().max()))
+    stats = {"frames": int(n), "crop_box_identical": int(same_box), "max_abs_keypoint_diff": d_kp, "max_abs_image_uv_diff_px": d_img,
+             "max_abs_xyz_diff_mm": d_xyz, "max_abs_mesh_vertex_diff": d_mesh, "mesh_tolerance": 2e-3,
+             "mesh_within_tolerance": bool(same_box > 0 and d_mesh < 2e-3),
+             "what": "the captured live step's host record (keypoints, image uv, camera xyz, Pose2Mesh vertices) vs the oracle's "
+                     "chain on the same frame: handnet_ref -> clamps -> a2j_ref.convert_joints -> pose2mesh_ref.lifter_input -> "
+                     "pose2mesh_ref.pose2mesh_forward (torch CPU fp32 + numpy glue)"}
+    return stats, sorted(whole)[len(whole) // 2], sorted(lift)[len(lift) // 2]

@@ -143,6 +143,10 @@ def test_bench_line_contract():
     pf = oc["fcos_b16"]["parity"]
     assert pf["frames"] == 2 and pf["matched_survivors"] > 0 and pf["label_equality_rate"] == 1.0
     assert pf["survivor_index_set_equal_frames"] == 2 and pf["min_box_iou"] > 0.999
+    # the live chain's own parity: the captured step's host record against the oracle's chain on the same frame
+    pl = live["parity"]
+    assert pl["frames"] == 1 and pl["crop_box_identical"] == 1 and pl["mesh_within_tolerance"] is True
+    assert pl["max_abs_keypoint_diff"] < 1e-3 and pl["max_abs_xyz_diff_mm"] < 2e-2 and pl["max_abs_mesh_vertex_diff"] < 2e-3
     dr = d["dropin"]
     assert dr["batch1"]["frames_per_s"] > 0 and dr["batch2"]["frames_per_s"] > 0 and "HandNet.forward" in dr["call"]
     cpu = d["cpu_baseline"]
@@ -151,6 +155,7 @@ def test_bench_line_contract():
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["parity"]["frames"] == 2
     assert "ONE pass" in cpu["sample"] and cpu["batch1"]["value"] > 0 and "median of 5" in cpu["batch1"]["sample"]
     assert cpu["parity"]["keypoints_within_tolerance"] is True
+    assert cpu["live_batch1"]["value"] > 0 and 0 < cpu["live_batch1"]["lifter_ms"] < cpu["live_batch1"]["ms_per_frame"]
 
 
 def test_four_ranks_equal_single_process_batch(tmp_path, fcos_sd, a2j_sd):

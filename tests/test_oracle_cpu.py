@@ -324,3 +324,32 @@ def test_lifter_input_pieces_match_the_imported_reference(golden_dir):
     for t, ps, ws in zip(g["t"], g["pts"], g["warped"]):
         for p, w in zip(ps, ws):
             assert np.array_equal(np.dot(t, np.array([p[0], p[1], 1.]).T)[:2], w)       # affine_transform, aug_utils.py:176-179
+
+
+def test_live_parity_harness_on_the_oracles_own_chain(golden_dir, fcos_sd, a2j_sd):
+    """oracle.parity.live_parity (bench.py's other_configs.live_b1.parity): fed the oracle chain's own outputs as "the HIP
+    step's record" it reports zero differences on an identical crop box; with the box moved by one pixel the frame is not
+    compared (a different integer crop is a different input); a mesh moved by 1e-2 is outside the tolerance."""
+    from oracle import parity, pose2mesh_ref
+    g = np.load(golden_dir / "pose2mesh_forward.npz")
+    graphs = pose2mesh_ref.load_graphs(g)
+    p2m_sd = synth.make_pose2mesh_state_dict(0, graph_sizes=[m.shape[0] for m in graphs])
+    paras = (617.343, 617.343, 312.42, 241.42)
+    rgb, depth = synth.make_rgb(1, seed=1000), synth.make_depth(1, seed=2000)
+    kp, _d, crops = handnet_ref.handnet_forward([rgb[0]], depth, fcos_sd, a2j_sd, 3)
+    det = crops[0].clone()
+    det[:2], det[2:] = torch.clamp(det[:2], 0, 480), torch.clamp(det[2:], 0, 640)
+    k = torch.clamp(kp[0], 0.0, 176.0).numpy()
+    j2d, j3d = a2j_ref.convert_joints(k, det.numpy(), None), a2j_ref.convert_joints(k, det.numpy(), paras)
+    mesh, _ = pose2mesh_ref.pose2mesh_forward(torch.from_numpy(pose2mesh_ref.lifter_input(j2d[:, :2]))[None], p2m_sd, graphs)
+    hip = (kp, crops, torch.from_numpy(j2d)[None], torch.from_numpy(j3d)[None], mesh)
+    stats, whole_s, lift_s = parity.live_parity(hip, rgb, depth, fcos_sd, a2j_sd, p2m_sd, graphs, paras, reps=1)
+    assert stats["frames"] == 1 and stats["crop_box_identical"] == 1 and stats["mesh_within_tolerance"] is True
+    assert stats["max_abs_keypoint_diff"] == 0 and stats["max_abs_xyz_diff_mm"] == 0 and stats["max_abs_mesh_vertex_diff"] == 0
+    assert 0 < lift_s < whole_s
+    moved = (kp, crops + 1, hip[2], hip[3], mesh)
+    stats, _, _ = parity.live_parity(moved, rgb, depth, fcos_sd, a2j_sd, p2m_sd, graphs, paras, reps=1)
+    assert stats["crop_box_identical"] == 0 and stats["mesh_within_tolerance"] is False
+    off = (kp, crops, hip[2], hip[3], mesh + 1e-2)
+    stats, _, _ = parity.live_parity(off, rgb, depth, fcos_sd, a2j_sd, p2m_sd, graphs, paras, reps=1)
+    assert stats["mesh_within_tolerance"] is False and abs(stats["max_abs_mesh_vertex_diff"] - 1e-2) < 1e-6
