@@ -11,7 +11,9 @@ the CPU (the reference ends with `.data.cpu()`, a2j/a2j.py:229).  Callers keep w
 `A2JModelLightning` (a2j/a2j.py:252-366) is provided for what the callers use it for -- `load_from_checkpoint(path)`
 of a Lightning `.ckpt` (handnet_pipeline.py:28-29; commented alternative in a2j_infer.py:26, a2j_mesh.py:30) and
 `forward` -- so that `from a2j.a2j import A2JModelLightning` (a2j_infer.py:12, a2j_mesh.py:15,
-handnet_pipeline/handnet_pipeline.py:8) resolves; its training / test hooks raise.
+handnet_pipeline/handnet_pipeline.py:8) resolves -- and its evaluation hook `test_step` (a2j/a2j.py:333-359: forward ->
+convert_joints on prediction and ground truth -> RMSE in mm -> the HPE evaluator's text file), the second caller SURVEY 8f #1
+names, with the conversion in the aggregation's epilogue.  The training-side hooks raise.
 Training (`gt is not None`) is out of scope and raises.
 """
 from __future__ import annotations
@@ -79,6 +81,43 @@ class A2JModel(EngineOwner):
         return out
 
 
+    def forward_xyz(self, x, box, paras=None):
+        """The forward of the callers that convert right away -- the evaluation loop (`test_step`, a2j/a2j.py:333-346) and the
+        stand-alone demos (a2j_infer.py) -- with convert_joints + uvd2xyz in the aggregation's epilogue:
+          x      [K,C,176,176] crops
+          box    [K,4] the boxes the crops were cut with: float32 as the dataset hands them (fractional corners,
+                 a2jdataset.py:293 -- every operation then stays in fp32, bit-identical to numpy on those operands) or int64 as
+                 the detector path does (handnet_pipeline.py:88)
+          paras  None, one camera (fx, fy, cx, cy), or [K,4] float32 per sample (a2jdataset.py:279)
+        -> (crop uvd [K,J,3], image uvd [K,J,3], camera xyz in mm [K,J,3] or None): CPU tensors from ONE device -> host copy,
+        under the same range contract as forward()."""
+        eng = self.engine()
+        dev = eng.device
+        x = x.to(dev)
+        k = x.shape[0]
+        box = torch.as_tensor(box)
+        conv = {}
+        if box.dtype == torch.int64:
+            conv["crop_box"] = box.reshape(k, 4).to(dev).contiguous()
+        else:
+            conv["sample_box"] = box.reshape(k, 4).to(torch.float32).to(dev).contiguous()
+        if paras is not None:
+            p = torch.as_tensor(paras, dtype=torch.float32)
+            if p.numel() == 4 and (k != 1 or p.dim() == 1):
+                conv["paras"] = [float(v) for v in p.reshape(4)]
+            else:
+                conv["sample_paras"] = p.reshape(k, 4).to(dev).contiguous()
+        (kp, img, xyz), flags = eng.forward_flags(x, convert=conv)
+        parts = [t.contiguous().reshape(-1).view(torch.int32) for t in (kp, img) + ((xyz,) if xyz is not None else ())]
+        if flags is not None:
+            parts.append(flags[:3])
+        flat = torch.cat(parts).cpu()
+        n = kp.numel()
+        outs = [flat[i * n:(i + 1) * n].contiguous().view(torch.float32).reshape(kp.shape) for i in range(len(parts) - (flags is not None))]
+        check_range_contract(outs[0], flat[-3:].tolist() if flags is not None else None, x)
+        return outs[0], outs[1], (outs[2] if xyz is not None else None)
+
+
 class A2JModelLightning(EngineOwner):
     """Inference-side stand-in for the reference's LightningModule (a2j/a2j.py:252-366): same constructor
     arguments, `.a2j` = the HIP-backed A2JModel, state_dict keys `a2j.*` (the layout of a Lightning checkpoint's
@@ -135,11 +174,62 @@ class A2JModelLightning(EngineOwner):
     def forward_device(self, x, valid=None):
         return self.a2j.forward_device(x, valid)
 
-    def _no_training(self, *a, **k):
-        raise NotImplementedError("training / evaluation hooks of A2JModelLightning (a2j/a2j.py:283-366) are outside "
-                                  "the inference hot path")
+    current_epoch = 0      # (Lightning's trainer sets it; `test_step` names its output file after it, a2j/a2j.py:356)
 
-    training_step = test_step = test_epoch_end = configure_optimizers = _no_training
+    def log(self, name, value):
+        """Lightning's self.log, reduced to what the evaluation loop needs: values per name, in call order (`logged`)."""
+        self.__dict__.setdefault("logged", {}).setdefault(name, []).append(float(value))
+
+    def test_step(self, batch, batch_idx):
+        """a2j/a2j.py:333-359, the evaluation caller of the path: forward -> convert_joints (prediction AND ground truth, the
+        dataset's float32 box and the sample's intrinsics) -> RMSE in mm -> one text line per sample for the HPE evaluator.
+        The prediction's conversion rides in the aggregation's epilogue (it comes back in the forward's one copy), the ground
+        truth's is one small launch; the RMSE and the text are numpy on those values exactly as the reference writes them.
+        The reference's convert_joints reshapes the whole batch against ONE box (batch size 1 only); here every sample is
+        converted with its own box and intrinsics and gets its own line."""
+        from hn_amd import ops
+        im, jt_uvd_gt, dexycb_id, _color_im, box, paras, combined_im = batch
+        x = combined_im if self.rgbd else im
+        k = x.shape[0]
+        _kp, _img, pred_xyz = self.a2j.forward_xyz(x, torch.as_tensor(box, dtype=torch.float32), torch.as_tensor(paras, dtype=torch.float32).reshape(k, 4))
+        dev = self.a2j.engine().device
+        gt = torch.as_tensor(jt_uvd_gt, dtype=torch.float32).reshape(k, -1, 3).to(dev).contiguous()
+        _, gt_xyz = ops.convert_joints_samples(gt, torch.as_tensor(box, dtype=torch.float32).reshape(k, 4).to(dev).contiguous(),
+                                               torch.as_tensor(paras, dtype=torch.float32).reshape(k, 4).to(dev).contiguous(),
+                                               want_image=False)
+        jt_xyz_pred, jt_xyz_gt = pred_xyz.numpy().reshape(-1, 3), gt_xyz.cpu().numpy().reshape(-1, 3)
+        rmse = np.sqrt(np.mean(np.square(jt_xyz_gt - jt_xyz_pred)))
+        self.log("test_rmse", rmse)
+        os.makedirs(os.path.join(self.output_dir, "a2j_test_metrics"), exist_ok=True)
+        epoch_output = os.path.join(self.output_dir, f"a2j_test_metrics/s0_test_{self.current_epoch}.txt")
+        j = jt_xyz_pred.shape[0] // k
+        with open(epoch_output, "a") as output:
+            for i in range(k):
+                # "x,y,z,x,y,z,..." in the digits numpy 1.x prints for a float32 inside a list (= str() of the scalar: shortest
+                # round trip), no spaces, no trailing comma (a2j/a2j.py:351-354)
+                j_text = ",".join(str(v) for v in jt_xyz_pred[i * j:(i + 1) * j].reshape(-1))
+                ident = dexycb_id[i]
+                ident = ident.cpu().numpy() if torch.is_tensor(ident) else np.asarray(ident)
+                print(str(ident)[1:-1] + "," + j_text, file=output)
+        return rmse
+
+    def test_epoch_end(self, outputs):
+        """a2j/a2j.py:361-363: hands the epoch's file to dex_ycb_toolkit's HPEEvaluator (not part of this image: raises a clear
+        ImportError when the toolkit is absent; the file `test_step` wrote is complete either way)."""
+        try:
+            from dex_ycb_toolkit.hpe_eval import HPEEvaluator
+        except ImportError as e:
+            raise ImportError("test_epoch_end needs dex_ycb_toolkit (HPEEvaluator); the predictions are in "
+                              f"{os.path.join(self.output_dir, 'a2j_test_metrics')}") from e
+        hpe_eval = HPEEvaluator("s0_test")
+        hpe_eval.evaluate(self.current_epoch, os.path.join(self.output_dir, f"a2j_test_metrics/s0_test_{self.current_epoch}.txt"),
+                          os.path.join(self.output_dir, "dexycb_metrics/"))
+
+    def _no_training(self, *a, **k):
+        raise NotImplementedError("the training-side hooks of A2JModelLightning (training_step / validation_step need the A2J "
+                                  "loss, a2j/a2j.py:283-331; configure_optimizers) are outside the inference hot path")
+
+    training_step = validation_step = configure_optimizers = _no_training
 
 
 def convert_joints(jt_uvd_pred, jt_uvd_gt, box, paras, cropWidth, cropHeight):

@@ -61,7 +61,9 @@ __global__ __launch_bounds__(256) void pack_depth_kernel(const float* __restrict
 // bit-identical by construction.  (Every operation is a single rounding in the reference's order; nothing here can contract
 // into an fma: each product feeds a division.)
 struct ConvertSpec {
-  const long long* box;   // [n,4] padded crop boxes (x1,y1,x2,y2), or nullptr: no conversion
+  const long long* box;   // [n,4] padded crop boxes (x1,y1,x2,y2), or nullptr: no conversion (unless box_f32)
+  const float* box_f32;   // [n,4] the DATASET's float boxes (the evaluation caller, a2j/a2j.py:339-346; a2jdataset.py:293): used instead
+  const float* sample_paras;   // [n,4] per-sample (fx, fy, cx, cy) on the device (a2jdataset.py:279,293): used instead of fx..cy
   float crop_w, crop_h;
   int has_paras;          // camera intrinsics given: xyz_mm is written
   float fx, fy, cx, cy;
@@ -72,8 +74,12 @@ struct ConvertSpec {
 };
 
 __device__ __forceinline__ void convert_one(const ConvertSpec& cs, int img, long joint_row, float ku, float kv, float kd) {
-  float x0 = (float)cs.box[img * 4 + 0], y0 = (float)cs.box[img * 4 + 1];
-  float x1 = (float)cs.box[img * 4 + 2], y1 = (float)cs.box[img * 4 + 3];
+  float x0, y0, x1, y1;
+  if (cs.box_f32) {
+    x0 = cs.box_f32[img * 4 + 0], y0 = cs.box_f32[img * 4 + 1], x1 = cs.box_f32[img * 4 + 2], y1 = cs.box_f32[img * 4 + 3];
+  } else {
+    x0 = (float)cs.box[img * 4 + 0], y0 = (float)cs.box[img * 4 + 1], x1 = (float)cs.box[img * 4 + 2], y1 = (float)cs.box[img * 4 + 3];
+  }
   if (cs.clamp_h > 0) {
     x0 = fminf(fmaxf(x0, 0.f), (float)cs.clamp_h);
     y0 = fminf(fmaxf(y0, 0.f), (float)cs.clamp_h);
@@ -95,8 +101,10 @@ __device__ __forceinline__ void convert_one(const ConvertSpec& cs, int img, long
   }
   if (cs.xyz_mm && cs.has_paras) {
     float* o = cs.xyz_mm + joint_row * 3;
-    o[0] = (u - cs.cx) * kd / cs.fx * 1000.f;
-    o[1] = (v - cs.cy) * kd / cs.fy * 1000.f;
+    float fx = cs.fx, fy = cs.fy, cx = cs.cx, cy = cs.cy;
+    if (cs.sample_paras) fx = cs.sample_paras[img * 4 + 0], fy = cs.sample_paras[img * 4 + 1], cx = cs.sample_paras[img * 4 + 2], cy = cs.sample_paras[img * 4 + 3];
+    o[0] = (u - cx) * kd / fx * 1000.f;
+    o[1] = (v - cy) * kd / fy * 1000.f;
     o[2] = kd * 1000.f;
   }
 }
@@ -227,7 +235,7 @@ __global__ __launch_bounds__(1024) void a2j_aggregate_kernel(const float* __rest
     o[2] = kd;
     // convert_joints + uvd2xyz in the aggregation's epilogue (what every caller does next: ros_demo.py:289,
     // 329-330, a2j/a2j.py:341-348) -- from the registers that hold the joint, no second launch
-    if (cs.box) convert_one(cs, k, (long)k * J + j0 + jj, ku, kv, kd);
+    if (cs.box || cs.box_f32) convert_one(cs, k, (long)k * J + j0 + jj, ku, kv, kd);
   }
 }
 
@@ -239,8 +247,8 @@ __global__ __launch_bounds__(256) void convert_joints_kernel(const float* __rest
   if (i >= n * J) return;
   const int img = i / J;
   if (valid && valid[img] == 0) {
-    float* o = (cs.has_paras ? cs.xyz_mm : cs.image_uvd) + (long)i * 3;
-    o[0] = o[1] = o[2] = 0.f;
+    if (cs.image_uvd) cs.image_uvd[(long)i * 3 + 0] = cs.image_uvd[(long)i * 3 + 1] = cs.image_uvd[(long)i * 3 + 2] = 0.f;
+    if (cs.xyz_mm && cs.has_paras) cs.xyz_mm[(long)i * 3 + 0] = cs.xyz_mm[(long)i * 3 + 1] = cs.xyz_mm[(long)i * 3 + 2] = 0.f;
     return;
   }
   convert_one(cs, img, i, kp[(long)i * 3 + 0], kp[(long)i * 3 + 1], kp[(long)i * 3 + 2]);
@@ -265,6 +273,29 @@ extern "C" int hn_convert_joints_f32(const float* kp, const int64_t* crop_box, c
   cs.cy = paras ? paras[3] : 0.f;
   cs.image_uvd = paras ? nullptr : out;
   cs.xyz_mm = paras ? out : nullptr;
+  hipLaunchKernelGGL(convert_joints_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, kp, valid, n, joints, cs);
+  HN_CHECK_LAUNCH("convert_joints_kernel");
+  return HN_OK;
+}
+
+extern "C" int hn_convert_joints_samples_f32(const float* kp, const float* box_f32, const float* sample_paras, const int32_t* valid,
+                                             int n, int joints, float crop_w, float crop_h, float* out_image_uvd, float* out_xyz_mm,
+                                             void* stream) {
+  HN_CHECK_ARG(kp && box_f32, "hn_convert_joints_samples_f32: null pointer");
+  HN_CHECK_ARG(out_image_uvd || out_xyz_mm, "hn_convert_joints_samples_f32: no output requested");
+  HN_CHECK_ARG(!out_xyz_mm || sample_paras, "hn_convert_joints_samples_f32: camera xyz needs the samples' intrinsics");
+  HN_CHECK_ARG(n >= 0 && joints > 0 && crop_w > 0.f && crop_h > 0.f, "bad dims");
+  if (n == 0) return HN_OK;
+  const int total = n * joints;
+  ConvertSpec cs{};
+  cs.box_f32 = box_f32;
+  cs.sample_paras = sample_paras;
+  cs.crop_w = crop_w;
+  cs.crop_h = crop_h;
+  cs.has_paras = sample_paras ? 1 : 0;
+  cs.fx = cs.fy = 1.f;
+  cs.image_uvd = out_image_uvd;
+  cs.xyz_mm = out_xyz_mm;
   hipLaunchKernelGGL(convert_joints_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, kp, valid, n, joints, cs);
   HN_CHECK_LAUNCH("convert_joints_kernel");
   return HN_OK;
@@ -322,9 +353,11 @@ extern "C" int hn_a2j_aggregate_convert_f32(const float* cls, const float* reg, 
                                             int fh, int fw, int joints, int stride, const int64_t* crop_box, float crop_w,
                                             float crop_h, const float* paras, const hn_convert_opts* opts, float* out_uvd,
                                             float* out_image_uvd, float* out_xyz_mm, void* stream) {
-  HN_CHECK_ARG(cls && reg && dep && out_uvd && crop_box, "hn_a2j_aggregate_convert_f32: null pointer");
+  HN_CHECK_ARG(cls && reg && dep && out_uvd, "hn_a2j_aggregate_convert_f32: null pointer");
+  HN_CHECK_ARG(crop_box || (opts && opts->sample_box), "hn_a2j_aggregate_convert_f32: no boxes (crop_box or opts->sample_box)");
   HN_CHECK_ARG(out_image_uvd || out_xyz_mm, "hn_a2j_aggregate_convert_f32: no converted output requested");
-  HN_CHECK_ARG(!out_xyz_mm || paras, "hn_a2j_aggregate_convert_f32: camera xyz needs the intrinsics (fx, fy, cx, cy)");
+  HN_CHECK_ARG(!out_xyz_mm || paras || (opts && opts->sample_paras),
+               "hn_a2j_aggregate_convert_f32: camera xyz needs the intrinsics (fx, fy, cx, cy)");
   HN_CHECK_ARG(k >= 0 && fh > 0 && fw > 0 && stride > 0 && crop_w > 0.f && crop_h > 0.f, "bad dims");
   HN_CHECK_ARG(joints > 0 && joints * kAnchorsPerCell <= 1024, "joints must be in [1, 64]");
   if (k == 0) return HN_OK;
@@ -332,7 +365,9 @@ extern "C" int hn_a2j_aggregate_convert_f32(const float* cls, const float* reg, 
   cs.box = (const long long*)crop_box;
   cs.crop_w = crop_w;
   cs.crop_h = crop_h;
-  cs.has_paras = paras ? 1 : 0;
+  cs.box_f32 = opts ? opts->sample_box : nullptr;
+  cs.sample_paras = opts ? opts->sample_paras : nullptr;
+  cs.has_paras = (paras || cs.sample_paras) ? 1 : 0;
   cs.fx = paras ? paras[0] : 1.f;
   cs.fy = paras ? paras[1] : 1.f;
   cs.cx = paras ? paras[2] : 0.f;

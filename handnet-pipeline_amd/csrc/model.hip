@@ -1441,7 +1441,8 @@ extern "C" int hn_handnet_forward_xyz(hn_model* m, const float* rgb, const float
                                       const hn_convert_opts* opts, float* keypoints, float* image_uvd, float* xyz_mm,
                                       int64_t* crop_box, int32_t* has_hand, void* stream) {
   HN_CHECK_ARG(image_uvd || xyz_mm, "hn_handnet_forward_xyz: no converted output requested (use hn_handnet_forward)");
-  HN_CHECK_ARG(!xyz_mm || paras, "hn_handnet_forward_xyz: camera xyz needs the intrinsics (fx, fy, cx, cy)");
+  HN_CHECK_ARG(!xyz_mm || paras || (opts && opts->sample_paras), "hn_handnet_forward_xyz: camera xyz needs the intrinsics (fx, fy, cx, cy)");
+  HN_CHECK_ARG(!opts || !opts->sample_box, "hn_handnet_forward_xyz: the boxes are the detector's (opts->sample_box must be NULL)");
   const ConvertReq req{crop_box, paras, opts, image_uvd, xyz_mm};
   t_convert = &req;     // (this host thread's forward; the aggregation's launch reads it)
   const int rc = hn_handnet_forward(m, rgb, depth, n, h, w, keypoints, crop_box, has_hand, stream);

@@ -12,7 +12,7 @@ from pathlib import Path
 
 from . import build as _build
 
-ABI_VERSION = 33
+ABI_VERSION = 34
 
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, _TILE_RETIRED_5, TILE_64x128 = range(7)
 HN_FCOS_MAX_LEVELS = 5
@@ -53,7 +53,8 @@ class GraphCsr(C.Structure):  # == struct hn_graph_csr
 
 
 class ConvertOpts(C.Structure):  # == struct hn_convert_opts
-    _fields_ = [("clamp_keypoints", C.c_int32), ("clamp_box_h", C.c_int32), ("clamp_box_w", C.c_int32)]
+    _fields_ = [("clamp_keypoints", C.c_int32), ("clamp_box_h", C.c_int32), ("clamp_box_w", C.c_int32), ("reserved", C.c_int32),
+                ("sample_box", C.c_void_p), ("sample_paras", C.c_void_p)]
 
 
 class ModelConfig(C.Structure):  # == struct hn_model_config
@@ -196,6 +197,7 @@ SIGNATURES = {
                                                       VP, VP, C.c_int, VP]),
     "hn_conv3x3_thin_uses_flat": (C.c_int, [C.POINTER(ThinLevels), C.c_int, C.c_int, C.c_int]),
     "hn_convert_joints_f32": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_float, C.c_float, c_f32p, VP, VP]),
+    "hn_convert_joints_samples_f32": (C.c_int, [VP, VP, VP, VP, C.c_int, C.c_int, C.c_float, C.c_float, VP, VP, VP]),
     "hn_a2j_aggregate_convert_f32": (C.c_int, [VP, VP, VP, VP] + [C.c_int] * 5 + [VP, C.c_float, C.c_float, c_f32p,
                                                C.POINTER(ConvertOpts), VP, VP, VP, VP]),
     "hn_joints2d_standardize_f32": (C.c_int, [VP, VP, C.c_int, C.c_int, VP, VP]),

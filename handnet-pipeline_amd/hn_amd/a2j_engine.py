@@ -245,21 +245,23 @@ class A2JEngine:
         return out
 
     @ops.device_guarded
-    def forward_flags(self, depth):
+    def forward_flags(self, depth, convert=None):
         """The A2J-only entry with the f16x3 range contract: -> (keypoints [K,J,3] on the GPU, flag words [4] int32 on the GPU
-        or None in the f32 mode / with HN_CHECK_RANGE=0).  No sync; the drop-in reads the words with the keypoints."""
+        or None in the f32 mode / with HN_CHECK_RANGE=0).  No sync; the drop-in reads the words with the keypoints.
+        convert: as forward()."""
         if self.precision != "f16x3" or not self.note_range:
-            return self.forward(depth), None
+            return self.forward(depth, convert=convert), None
         if getattr(self, "_range_block", None) is None:
             self._range_block = torch.zeros((4,), device=self.device, dtype=torch.int32)
         with ops.range_scope(self._range_block):
-            kp = self.forward(depth)
+            kp = self.forward(depth, convert=convert)
             flags = ops.range_check_collect(self._range_block)
         return kp, flags
 
     @ops.device_guarded
-    def forward(self, depth, valid=None):
-        """depth [K,1,H,W] (or [K,4,H,W] for RGBD) fp32 on the GPU -> [K,J,3] on the GPU."""
+    def forward(self, depth, valid=None, convert=None):
+        """depth [K,1,H,W] (or [K,4,H,W] for RGBD) fp32 on the GPU -> [K,J,3] on the GPU; with convert (forward_nhwc) the
+        triple (crop uvd, image uvd, camera xyz in mm or None)."""
         if depth.dim() != 4:
             raise ValueError("expected [K,C,H,W]")
         if not depth.is_cuda:
@@ -273,7 +275,7 @@ class A2JEngine:
             # (the A2J-only entry: flags of its own, so that a crop with NaN / inf pixels gives NaN keypoints like
             # a2j/a2j.py:243-250 does)
             valid = torch.ones((depth.shape[0],), device=depth.device, dtype=torch.int32)
-        return self.forward_nhwc(x, valid)
+        return self.forward_nhwc(x, valid, convert=convert)
 
     # -----------------------------------------------------------------------------------
     def macs_per_crop(self, h=176, w=176) -> int:

@@ -1198,21 +1198,29 @@ def a2j_aggregate(cls, reg, dep, joints=21, stride=16, valid=None, out=None, con
     if valid is not None:
         _req(valid, torch.int32, "valid")
     if convert is not None:
-        box = _req(convert["crop_box"], torch.int64, "crop_box")
-        if tuple(box.shape) != (k, 4):
-            raise ValueError("crop_box must be [K,4]")
+        # the evaluation caller's operands (a2j/a2j.py:339-346): the dataset's fp32 boxes / per-sample intrinsics on the device
+        sbox, sparas = convert.get("sample_box"), convert.get("sample_paras")
+        box = convert.get("crop_box")
+        if (box is None) == (sbox is None):
+            raise ValueError("convert needs crop_box (int64, the detector's) or sample_box (fp32, the dataset's), one of them")
+        for t, dt, nm in ((box, torch.int64, "crop_box"), (sbox, torch.float32, "sample_box"), (sparas, torch.float32, "sample_paras")):
+            if t is not None and tuple(_req(t, dt, nm).shape) != (k, 4):
+                raise ValueError(f"{nm} must be [K,4]")
         paras = convert.get("paras")
+        if paras is not None and sparas is not None:
+            raise ValueError("convert: paras (one camera) or sample_paras (one per sample), not both")
         img = convert.get("image_uvd")
         xyz = convert.get("xyz_mm")
         if img is None:
             img = torch.empty((k, joints, 3), device=cls.device, dtype=torch.float32)
-        if xyz is None and paras is not None:
+        if xyz is None and (paras is not None or sparas is not None):
             xyz = torch.empty((k, joints, 3), device=cls.device, dtype=torch.float32)
         pp = (C.c_float * 4)(*[float(v) for v in paras]) if paras is not None else None
         opts = None
         cb = convert.get("clamp_box")
-        if convert.get("clamp_keypoints") or cb:
-            opts = _lib.ConvertOpts(1 if convert.get("clamp_keypoints") else 0, int(cb[0]) if cb else 0, int(cb[1]) if cb else 0)
+        if convert.get("clamp_keypoints") or cb or sbox is not None or sparas is not None:
+            opts = _lib.ConvertOpts(1 if convert.get("clamp_keypoints") else 0, int(cb[0]) if cb else 0, int(cb[1]) if cb else 0, 0,
+                                    ptr(sbox), ptr(sparas))
         crop = float(convert.get("crop", 176))
         check(lib.hn_a2j_aggregate_convert_f32(ptr(cls), ptr(reg), ptr(dep), ptr(valid), k, fh, fw, joints, stride, ptr(box),
                                                crop, crop, pp, C.byref(opts) if opts is not None else None, ptr(out), ptr(img),
@@ -1255,6 +1263,27 @@ def convert_joints(kp, crop_box, valid=None, paras=None, crop=176, out=None):
     check(lib.hn_convert_joints_f32(ptr(kp), ptr(crop_box), ptr(valid), n, j, float(crop), float(crop), pp, ptr(out),
                                     _stream()), "hn_convert_joints_f32")
     return out
+
+
+def convert_joints_samples(kp, box_f32, sample_paras=None, valid=None, crop=176, want_image=True):
+    """The evaluation caller's conversion (A2JModelLightning.test_step, a2j/a2j.py:339-346): kp [N,J,3] crop-(u,v,d), box_f32
+    [N,4] fp32 = the dataset's boxes (fractional corners), sample_paras [N,4] fp32 = each sample's (fx, fy, cx, cy), all on the
+    device -> (image (u,v,d) or None, camera xyz in mm or None); fp32 in the reference's order (bit-identical to numpy)."""
+    _req(kp, name="kp")
+    n, j, _ = kp.shape
+    if tuple(_req(box_f32, torch.float32, "box_f32").shape) != (n, 4):
+        raise ValueError("box_f32 must be [N,4]")
+    if sample_paras is not None and tuple(_req(sample_paras, torch.float32, "sample_paras").shape) != (n, 4):
+        raise ValueError("sample_paras must be [N,4]")
+    if valid is not None:
+        _req(valid, torch.int32, "valid")
+    if not want_image and sample_paras is None:
+        raise ValueError("nothing to compute: no image (u,v,d) wanted and no intrinsics given")
+    img = torch.empty_like(kp) if want_image else None
+    xyz = torch.empty_like(kp) if sample_paras is not None else None
+    check(_lib.load().hn_convert_joints_samples_f32(ptr(kp), ptr(box_f32), ptr(sample_paras), ptr(valid), n, j, float(crop),
+                                                    float(crop), ptr(img), ptr(xyz), _stream()), "hn_convert_joints_samples_f32")
+    return img, xyz
 
 
 def pack_records(kp, crop_box, has_hand, rows, rec_bytes, out=None, extras=()):

@@ -33,7 +33,7 @@ extern "C" {
 #define HN_ERR_HIP 2
 
 /* ABI version; bumped whenever a struct below changes. */
-#define HN_ABI_VERSION 33
+#define HN_ABI_VERSION 34
 int hn_abi_version(void);
 const char* hn_last_error(void);
 
@@ -530,6 +530,15 @@ int hn_convert_joints_f32(const float* kp, const int64_t* crop_box, const int32_
                           int n, int joints, float crop_w, float crop_h,
                           const float* paras /* host, 4 floats, or NULL */, float* out, void* stream);
 
+/* The evaluation caller's form of the same conversion (A2JModelLightning.test_step, a2j/a2j.py:333-348 -- on the prediction
+ * and on the ground truth): box_f32 [n][4] fp32 = the dataset's crop box with fractional corners, sample_paras [n][4] fp32 =
+ * each sample's (fx, fy, cx, cy), both on the DEVICE (datasets3d/a2jdataset.py:262-265,279,293).  Writes the image (u,v,d)
+ * (out_image_uvd, or NULL) and / or the camera xyz in millimetres (out_xyz_mm, or NULL; needs sample_paras), [n][joints][3]
+ * each.  All fp32 in the reference's order: bit-identical to numpy on float32 operands.  valid as above. */
+int hn_convert_joints_samples_f32(const float* kp, const float* box_f32, const float* sample_paras /* or NULL */,
+                                  const int32_t* valid /* or NULL */, int n, int joints, float crop_w, float crop_h,
+                                  float* out_image_uvd, float* out_xyz_mm, void* stream);
+
 /* The aggregation with convert_joints + uvd2xyz in its EPILOGUE: what hn_a2j_aggregate_f32 writes to out_uvd,
  * plus -- from the registers that hold each joint, no second launch -- its image (u,v,d) (out_image_uvd, or NULL) and its
  * camera xyz in millimetres (out_xyz_mm, or NULL; needs paras = host array (fx, fy, cx, cy)), each [k][J][3]: bit-identical
@@ -543,6 +552,14 @@ int hn_convert_joints_f32(const float* kp, const int64_t* crop_box, const int32_
 typedef struct hn_convert_opts {
   int32_t clamp_keypoints;
   int32_t clamp_box_h, clamp_box_w;
+  int32_t reserved;           /* 0 */
+  /* The evaluation caller's operands (A2JModelLightning.test_step, a2j/a2j.py:333-348: the DATASET's box and intrinsics per
+   * sample, datasets3d/a2jdataset.py:262-265,279,293), device pointers or NULL:
+   *   sample_box    [k][4] fp32 (x1,y1,x2,y2), fractional corners: used INSTEAD of crop_box (which may then be NULL); every
+   *                 operation of the conversion stays in fp32 like numpy's on a float32 box (bit-identical to the reference)
+   *   sample_paras  [k][4] fp32 (fx, fy, cx, cy) per sample: used INSTEAD of `paras` */
+  const float* sample_box;
+  const float* sample_paras;
 } hn_convert_opts;
 int hn_a2j_aggregate_convert_f32(const float* cls, const float* reg, const float* dep, const int32_t* valid, int k, int fh,
                                  int fw, int joints, int stride, const int64_t* crop_box, float crop_w, float crop_h,

@@ -137,7 +137,21 @@ def to_dtype(sd, dtype):
 
 
 def convert_joints(jt_uvd, box, paras, crop_w=176, crop_h=176):
-    """a2j/a2j.py:17-34 + datasets3d/a2jdataset.py:31-38: crop-uvd -> camera xyz in mm."""
+    """a2j/a2j.py:17-34 + datasets3d/a2jdataset.py:31-38: crop-uvd -> camera xyz in mm.  With the detector's int64 box (the live
+    caller, ros_demo.py:289) numpy promotes the reference's arithmetic to float64; with the DATASET's float32 box and intrinsics
+    (the evaluation caller, a2j/a2j.py:339-346; a2jdataset.py:293) every operation stays in float32, in the reference's order."""
+    if np.asarray(box).dtype == np.float32:
+        jt = np.asarray(jt_uvd, dtype=np.float32).reshape(-1, 3)
+        b = np.asarray(box).reshape(4)
+        out = np.ones_like(jt)
+        out[:, 0] = jt[:, 0] * (b[2] - b[0]) / np.float32(crop_w) + b[0]
+        out[:, 1] = jt[:, 1] * (b[3] - b[1]) / np.float32(crop_h) + b[1]
+        out[:, 2] = jt[:, 2]
+        if paras is not None:
+            p = np.asarray(paras, dtype=np.float32).reshape(4)
+            out[:, :2] = (out[:, :2] - p[2:]) * out[:, 2:] / p[:2]
+            out = out * np.float32(1000.0)
+        return out
     jt = np.asarray(jt_uvd, dtype=np.float64).reshape(-1, 3)
     x0, y0, x1, y1 = [float(v) for v in np.asarray(box).reshape(4)]
     out = np.ones_like(jt)

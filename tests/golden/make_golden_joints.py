@@ -79,8 +79,23 @@ def main():
     p0 = np.array([617.343, 617.343, 312.42, 241.42], np.float32)
     uvd = xyz2uvd(pts, p0)
     back = uvd2xyz(uvd, p0)
+    # the evaluation caller's form (A2JModelLightning.test_step, a2j/a2j.py:333-348): the DATASET's box, float32 with fractional
+    # corners (a2jdataset.py:262-265,293), and the sample's own intrinsics (:279,293) -- every operation stays in float32.
+    # (Drawn after everything above: the earlier arrays of the file do not change.)
+    box_f32 = np.zeros((cases, 4), np.float32)
+    xyz_pred_f32 = np.zeros((cases, 21, 3), np.float32)
+    xyz_gt_f32 = np.zeros((cases, 21, 3), np.float32)
+    uvd_img_f32 = np.zeros((cases, 21, 3), np.float32)
+    for i in range(cases):
+        x1, y1 = rng.uniform(0, 400), rng.uniform(0, 300)
+        box_f32[i] = [x1, y1, x1 + rng.uniform(20, 639 - x1), y1 + rng.uniform(20, 479 - y1)]
+        a, b = convert_joints(pred[i].copy(), gt[i].copy(), box_f32[i].copy(), paras[i].copy(), 176, 176)
+        assert a.dtype == np.float32 and b.dtype == np.float32
+        xyz_pred_f32[i], xyz_gt_f32[i] = a, b
+        uvd_img_f32[i] = convert_joints(pred[i].copy(), None, box_f32[i].copy(), None, 176, 176)
     np.savez_compressed(HERE / "convert_joints.npz", pred=pred, gt=gt, box=box, paras=paras, xyz_pred=xyz_pred,
-                        xyz_gt=xyz_gt, uvd_img=uvd_img, pts=pts, p0=p0, uvd=uvd, back=back)
+                        xyz_gt=xyz_gt, uvd_img=uvd_img, pts=pts, p0=p0, uvd=uvd, back=back, box_f32=box_f32,
+                        xyz_pred_f32=xyz_pred_f32, xyz_gt_f32=xyz_gt_f32, uvd_img_f32=uvd_img_f32)
     print("wrote", HERE / "convert_joints.npz", "max |xyz|", float(np.abs(xyz_pred).max()))
 
 

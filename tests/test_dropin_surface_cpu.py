@@ -124,6 +124,14 @@ def test_convert_joints_dropin_matches_reference_golden(golden_dir):
         assert np.abs(convert_joints(g["pred"][i], None, g["box"][i], None, 176, 176) - g["uvd_img"][i]).max() < 1e-4
         assert np.abs(a2j_ref.convert_joints(g["pred"][i], g["box"][i], g["paras"][i]) - g["xyz_pred"][i]).max() < 2e-3
         assert np.abs(a2j_ref.convert_joints(g["pred"][i], g["box"][i], None) - g["uvd_img"][i]).max() < 1e-4
+        # the evaluation caller's operands (a2j/a2j.py:339-346: the dataset's float32 box, fractional corners): every operation
+        # stays in float32, so the drop-in and the oracle reproduce the reference BIT FOR BIT
+        a, b = convert_joints(g["pred"][i], g["gt"][i], g["box_f32"][i], g["paras"][i], 176, 176)
+        assert a.dtype == np.float32 and np.array_equal(a, g["xyz_pred_f32"][i]) and np.array_equal(b, g["xyz_gt_f32"][i])
+        assert np.array_equal(convert_joints(g["pred"][i], None, g["box_f32"][i], None, 176, 176), g["uvd_img_f32"][i])
+        assert np.array_equal(a2j_ref.convert_joints(g["pred"][i], g["box_f32"][i], g["paras"][i]), g["xyz_pred_f32"][i])
+        assert np.array_equal(a2j_ref.convert_joints(g["gt"][i], g["box_f32"][i], g["paras"][i]), g["xyz_gt_f32"][i])
+        assert np.array_equal(a2j_ref.convert_joints(g["pred"][i], g["box_f32"][i], None), g["uvd_img_f32"][i])
 
 
 def test_weight_range_contract_is_checked_at_load():
