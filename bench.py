@@ -753,6 +753,19 @@ def lifter_legs(eng, dev, timed, hip=None):
         out["live_b1"] = rec
     finally:
         eng.set_convert(on=False)     # (the run's engine goes back to the plain step: the later legs time that)
+    # the same chain without the detector: the stand-alone mesh demo's loop body on one dataset crop (a2j_mesh.py:58-80)
+    from hn_amd.live import CropMeshEngine
+    cm = CropMeshEngine(eng.a2j, lifter, clamp=True)
+    crop1 = synth.make_crops(1, 176, seed=3000).to(dev)
+    box1 = torch.tensor([[224.25, 152.5, 400.75, 328.5]], device=dev)
+    run, _, _, _, co = cm.graphed(crop1, box1, torch.tensor([LIVE_PARAS], device=dev))
+    rec = timed(run, 1, per_group=10, warm=5)
+    torch.cuda.synchronize()
+    rec.update(unit="crops/s", hipgraph=True, host_bytes_per_crop=int(co.host.numel() * 4),
+               workload="the mesh demo's loop body on one dataset crop (a2j_mesh.py:58-80): A2J -> clip + convert_joints with the "
+                        "dataset's float32 box and intrinsics (aggregation epilogue) -> lifter input -> Pose2Mesh -> one copy, ONE "
+                        "captured step")
+    out["crop_mesh_b1"] = rec
     return out
 
 

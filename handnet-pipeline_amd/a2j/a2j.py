@@ -118,6 +118,14 @@ class A2JModel(EngineOwner):
         return outs[0], outs[1], (outs[2] if xyz is not None else None)
 
 
+    def mesh(self, lifter, clamp: bool = True, perm_reverse=None):
+        """The stand-alone mesh demo's loop body as ONE step (hn_amd.live.CropMeshEngine; a2j_mesh.py:58-80): this network, np.clip
+        + convert_joints in the aggregation's epilogue, the lifter's input, Pose2Mesh, the caller's last lines, one copy.
+        lifter: the drop-in `models.pose2mesh_net.get_model(...)` module (on the GPU) or a Pose2MeshEngine."""
+        from hn_amd.live import CropMeshEngine
+        return CropMeshEngine(self.engine(), lifter.engine() if hasattr(lifter, "engine") else lifter, clamp, perm_reverse)
+
+
 class A2JModelLightning(EngineOwner):
     """Inference-side stand-in for the reference's LightningModule (a2j/a2j.py:252-366): same constructor
     arguments, `.a2j` = the HIP-backed A2JModel, state_dict keys `a2j.*` (the layout of a Lightning checkpoint's

@@ -138,8 +138,8 @@ __global__ __launch_bounds__(1024) void a2j_aggregate_kernel(const float* __rest
       const float fill = valid[k] == 0 ? 0.f : __builtin_nanf("");
       const long at = ((long)k * J + j0) * 3 + threadIdx.x;
       out[at] = fill;
-      if (cs.box && cs.image_uvd) cs.image_uvd[at] = fill;
-      if (cs.box && cs.xyz_mm && cs.has_paras) cs.xyz_mm[at] = fill;
+      if ((cs.box || cs.box_f32) && cs.image_uvd) cs.image_uvd[at] = fill;
+      if ((cs.box || cs.box_f32) && cs.xyz_mm && cs.has_paras) cs.xyz_mm[at] = fill;
     }
     return;
   }

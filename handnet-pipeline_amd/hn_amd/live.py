@@ -11,6 +11,9 @@ the pose network and the lifter (the reference copies the keypoints to the CPU, 
 normalised joints again, per frame).  What stays the caller's: the vertex permutation / camera offset of the final mesh
 (`pred_mesh[:, graph_perm_reverse[:V]]`, `mesh * 1000 + joints3d[0]`, ros_demo.py:162,332-337) -- the step hands over what
 `model(joint_img)` and `convert_joints` return.
+
+`CropMeshEngine` is the same chain without the detector, for the reference's stand-alone mesh demo (a2j_mesh.py:58-80): dataset
+crops + the dataset's float32 boxes + per-sample intrinsics -> A2J -> clip + convert -> lifter input -> Pose2Mesh -> final mesh.
 """
 from __future__ import annotations
 
@@ -21,6 +24,13 @@ import torch
 from . import ops
 from .pipeline import HandNetEngine, HandNetOutput, read_host_record, record_bytes
 from .pose2mesh_engine import Pose2MeshEngine
+
+
+def _same_device(a, b) -> bool:
+    """"cuda" and "cuda:<current device>" name the same card"""
+    a, b = torch.device(a), torch.device(b)
+    index = lambda d: d.index if d.index is not None else torch.cuda.current_device()
+    return a.type == b.type and (a.type != "cuda" or index(a) == index(b))
 
 
 @dataclass
@@ -52,7 +62,7 @@ class LiveHandEngine:
         ros_demo.py:162) -- given, the step also does the caller's last three lines (vertex order, camera offset by the first
         joint, y / z negated: ros_demo.py:332-337) and `mesh` of the outputs IS out['mesh'], [N,V,3]; else the lifter's raw
         [N,V0,3] vertices in coarsening order."""
-        if hand.device != lifter.device:
+        if not _same_device(hand.device, lifter.device):
             raise ValueError(f"HandNet on {hand.device} but the lifter on {lifter.device}")
         self.hand, self.lifter, self.device = hand, lifter, hand.device
         hand.set_convert(paras=paras, clamp=clamp)
@@ -148,3 +158,91 @@ class LiveHandEngine:
             hit = self._graphs[key] = (g, s_img, s_dep, out)
         g, s_img, s_dep, out = hit
         return g.replay, s_img, s_dep, out
+
+
+@dataclass
+class CropMeshOutput:
+    keypoints: torch.Tensor      # [K,21,3] crop (u,v,d) as the network returns it, on the device
+    image_uvd: torch.Tensor      # [K,21,3] image (u,v,d) of the (clipped) joints
+    xyz_mm: torch.Tensor         # [K,21,3] camera xyz in millimetres
+    pose2d: torch.Tensor         # [K,21,2] the lifter's input
+    mesh: torch.Tensor           # [K,V,3]: out['mesh'] of a2j_mesh.py:77-80 with perm_reverse, else the lifter's raw [K,V0,3]
+    pose3d: torch.Tensor         # [K,21,3]
+    raw_mesh: torch.Tensor       # [K,V0,3] the lifter's own output
+    host: torch.Tensor           # pinned fp32: keypoints | image_uvd | xyz_mm | mesh | 4 range words (as bits) -- ONE copy
+    k: int = 0
+
+    def read(self):
+        """After the stream is synchronised: (keypoints, image_uvd, xyz_mm, mesh, range words) as fresh CPU tensors."""
+        k, j3 = self.k, self.keypoints.shape[1] * 3
+        h = self.host
+        parts = [h[i * k * j3:(i + 1) * k * j3].reshape(k, -1, 3).clone() for i in range(3)]
+        mesh = h[3 * k * j3:-4].reshape(k, -1, 3).clone()
+        return parts[0], parts[1], parts[2], mesh, h[-4:].view(torch.int32).tolist()
+
+
+class CropMeshEngine:
+    """The stand-alone mesh demo's loop body (a2j_mesh.py:58-80) as one step on the device: dataset crops -> A2J -> np.clip to
+    [0, 176] + convert_joints twice (image uv; camera xyz with the sample's intrinsics -- the dataset's float32 box, fractional
+    corners: a2jdataset.py:293) in the aggregation's epilogue -> the lifter's input (predict_mesh, ros_demo.py:148-157) ->
+    Pose2Mesh -> the caller's last lines (vertex order, camera offset by the first joint, y / z negated: a2j_mesh.py:77-80) ->
+    ONE device -> host copy.  The reference goes to the CPU after A2J, converts in numpy and uploads the normalised joints."""
+
+    def __init__(self, a2j, lifter: Pose2MeshEngine, clamp: bool = True, perm_reverse=None):
+        if not _same_device(a2j.device, lifter.device):
+            raise ValueError(f"A2J on {a2j.device} but the lifter on {lifter.device}")
+        self.a2j, self.lifter, self.device, self.clamp = a2j, lifter, a2j.device, bool(clamp)
+        self.perm = None
+        if perm_reverse is not None:
+            self.perm = torch.as_tensor(perm_reverse).to(torch.int64).to(self.device).contiguous()
+            if int(self.perm.max()) >= lifter.graphs[0].v or int(self.perm.min()) < 0:
+                raise ValueError("perm_reverse points outside the lifter's finest graph")
+        self.vertices = lifter.graphs[0].v if self.perm is None else int(self.perm.shape[0])
+        self._block = None
+        self._graphs = {}
+
+    @ops.device_guarded
+    def forward_device(self, crops, box_f32, paras, _host=None) -> CropMeshOutput:
+        """crops [K,1,176,176] (or [K,4,..] for the RGB-D network), box_f32 [K,4] float32, paras [K,4] float32, on the GPU."""
+        k = crops.shape[0]
+        if self._block is None:
+            self._block = torch.zeros((4,), device=self.device, dtype=torch.int32)
+        conv = dict(sample_box=box_f32, sample_paras=paras, clamp_keypoints=self.clamp)
+        with ops.range_scope(self._block, on=self.a2j.precision == "f16x3" and self.a2j.note_range):
+            kp, img, xyz = self.a2j.forward(crops, convert=conv)
+            p2d = ops.joints2d_standardize(img)
+            raw, pose3d = self.lifter.forward(p2d)
+            mesh = raw if self.perm is None else ops.mesh_finish(raw, self.perm, xyz)
+            words = ops.range_check_collect(self._block)
+        dev = torch.cat([kp.reshape(-1), img.reshape(-1), xyz.reshape(-1), mesh.reshape(-1), words.view(torch.float32)])
+        if _host is None:
+            _host = torch.empty((dev.numel(),), dtype=torch.float32, pin_memory=True)
+        _host.copy_(dev, non_blocking=True)
+        return CropMeshOutput(kp, img, xyz, p2d, mesh, pose3d, raw, _host, k)
+
+    @ops.device_guarded
+    def graphed(self, crops, box_f32, paras):
+        """(run, static crops, static boxes, static intrinsics, static CropMeshOutput): copy a new batch into the static inputs and
+        call run() -- every launch of the step and its copy replay from one hipGraph."""
+        key = (tuple(crops.shape),)
+        hit = self._graphs.get(key)
+        if hit is None:
+            with torch.inference_mode(False), torch.no_grad():
+                s = [torch.empty_like(t) for t in (crops, box_f32, paras)]
+                for a, b in zip(s, (crops, box_f32, paras)):
+                    a.copy_(b)
+                k = crops.shape[0]
+                host = torch.zeros((3 * k * self.a2j.joints * 3 + k * self.vertices * 3 + 4,), dtype=torch.float32, pin_memory=True)
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with ops.launch_cost_hidden():
+                    with torch.cuda.stream(side):
+                        for _ in range(2):
+                            self.forward_device(*s, _host=host)
+                    torch.cuda.current_stream().wait_stream(side)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        out = self.forward_device(*s, _host=host)
+            hit = self._graphs[key] = (g, s[0], s[1], s[2], out)
+        g, s_crops, s_box, s_paras, out = hit
+        return g.replay, s_crops, s_box, s_paras, out

@@ -122,11 +122,12 @@ def test_bench_line_contract():
                                            ("launches/step", "another revision", "dominant kernel"))
     assert set(roof["stages"]) >= {"resnet34_body", "fpn", "towers", "head_outputs", "a2j_trunk", "a2j_heads"}
     oc = d["other_configs"]
-    assert set(oc) == {"a2j_b64", "fcos_b16", "pipeline_b1", "pipeline_b32_f32", "pose2mesh_b1", "pose2mesh_b32", "live_b1"}
+    assert set(oc) == {"a2j_b64", "fcos_b16", "pipeline_b1", "pipeline_b32_f32", "pose2mesh_b1", "pose2mesh_b32", "live_b1", "crop_mesh_b1"}
     assert oc["pose2mesh_b1"]["unit"] == "meshes/s" and oc["pose2mesh_b32"]["value"] > oc["pose2mesh_b1"]["value"] > 0
     live = oc["live_b1"]
+    assert 0 < oc["crop_mesh_b1"]["ms_per_step"] < live["ms_per_step"] and oc["crop_mesh_b1"]["unit"] == "crops/s"
     assert live["frames_with_hand"] == 1 and live["mesh_vertices"] > 700 and live["ms_per_step"] > oc["pipeline_b1"]["ms_per_step"]
-    oc = {k: v for k, v in oc.items() if k not in ("pose2mesh_b1", "pose2mesh_b32", "live_b1")}
+    oc = {k: v for k, v in oc.items() if k not in ("pose2mesh_b1", "pose2mesh_b32", "live_b1", "crop_mesh_b1")}
     for name, unit in (("a2j_b64", "crops/s"), ("fcos_b16", "frames/s"), ("pipeline_b1", "frames/s"), ("pipeline_b32_f32", "frames/s")):
         assert oc[name]["unit"] == unit and oc[name]["value"] > 0 and oc[name]["ms_per_step"] > 0
         assert 0 < oc[name]["frac"] < 1 and "conv_igemm" in oc[name]["kernel"]
