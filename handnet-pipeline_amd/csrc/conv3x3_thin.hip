@@ -43,19 +43,20 @@ struct ThinParams {
 
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 
-__global__ __launch_bounds__(kNT, 2) void conv3x3_thin_kernel(const ThinParams p) {
+// one workgroup of the tap kernel: workgroup `block` of the launch described by p
+__device__ __forceinline__ void thin_tap_body(const ThinParams p, const int block) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, px = lane & 15;
   // level of this workgroup: constant-index selects (a dynamic index into the by-value table would go through scratch)
   int li = 0;
 #pragma unroll
   for (int l = 1; l < HN_FCOS_MAX_LEVELS; ++l)
-    if (l < p.levels && (int)blockIdx.x >= p.lv[l].first_block) li = l;
+    if (l < p.levels && block >= p.lv[l].first_block) li = l;
   ThinLevel L = p.lv[0];
 #pragma unroll
   for (int l = 1; l < HN_FCOS_MAX_LEVELS; ++l)
     if (l == li) L = p.lv[l];
-  const int lid = (int)blockIdx.x - L.first_block;
+  const int lid = block - L.first_block;
   const int per_img = L.ty * L.tx;
   const int img = lid / per_img;
   const int rem = lid - img * per_img;
@@ -158,6 +159,23 @@ __global__ __launch_bounds__(kNT, 2) void conv3x3_thin_kernel(const ThinParams p
       dst[n] = v;
     }
   }
+}
+
+__global__ __launch_bounds__(kNT, 2) void conv3x3_thin_kernel(const ThinParams p) { thin_tap_body(p, (int)blockIdx.x); }
+
+// Up to three independent launches of the tap kernel as ONE grid (the FCOS head outputs of a single frame: cls + lr, ext, reg +
+// ctr -- 89 workgroups each on 256 CUs, latency-bound: 17-18 us per launch alone).  Member m owns the workgroups
+// [first[m], first[m + 1]); each workgroup runs exactly what its own launch would have run (bit-identical outputs).
+constexpr int kThinGroupMax = 3;
+struct ThinGroup {
+  ThinParams m[kThinGroupMax];
+  int first1, first2;   // first workgroup of members 1 and 2 (0x7fffffff: absent)
+};
+__global__ __launch_bounds__(kNT, 2) void conv3x3_thin_group_kernel(const ThinGroup g) {
+  const int b = (int)blockIdx.x;
+  if (b < g.first1) thin_tap_body(g.m[0], b);
+  else if (b < g.first2) thin_tap_body(g.m[1], b - g.first1);
+  else thin_tap_body(g.m[2], b - g.first2);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -528,13 +546,19 @@ extern "C" int hn_conv3x3_thin_affine_f16x3_levels(const hn_thin_levels* lv, con
   return thin_flat_run(lv, aff, n, cin, cout, w16, bias, relu_cols, aff->in_pix_stride, (hipStream_t)stream);
 }
 
-extern "C" int hn_conv3x3_thin_f16x3_levels(const hn_thin_levels* lv, int n, int cin, int cout, const void* w16, const float* bias,
-                                            int relu_cols, int in_pix_stride, void* stream) {
+#define HN_TRY_THIN(expr)       \
+  do {                          \
+    const int st_ = (expr);     \
+    if (st_ != HN_OK) return st_; \
+  } while (0)
+
+// the tap kernel's launch description: scalars (checked), then the level table and the workgroup count
+static int thin_tap_scalars(const hn_thin_levels* lv, int n, int cin, int cout, const void* w16, const float* bias, int relu_cols,
+                            int in_pix_stride, ThinParams& p) {
   HN_CHECK_ARG(lv && w16, "hn_conv3x3_thin_f16x3_levels: null pointer");
   HN_CHECK_ARG(lv->count >= 1 && lv->count <= HN_FCOS_MAX_LEVELS, "level count must be 1..%d", HN_FCOS_MAX_LEVELS);
   HN_CHECK_ARG(n > 0 && cin > 0 && cin % 32 == 0 && cout >= 1 && cout <= 16, "need cin %% 32 == 0 and 1 <= cout <= 16");
   HN_CHECK_ARG(relu_cols >= 0 && relu_cols <= cout, "bad relu_cols");
-  ThinParams p;
   p.levels = lv->count; p.n = n; p.cbs = cin / 32; p.cout = cout;
   p.xs = in_pix_stride ? in_pix_stride : 2 * cin;
   p.ys = cout; p.relu_cols = relu_cols;
@@ -547,26 +571,31 @@ extern "C" int hn_conv3x3_thin_f16x3_levels(const hn_thin_levels* lv, int n, int
     HN_CHECK_ARG(lv->x16[l] && lv->y[l] && lv->h[l] > 0 && lv->w[l] > 0, "level %d: null pointer or empty map", l);
     HN_CHECK_ARG((uintptr_t)lv->x16[l] % 16 == 0, "level %d: unaligned input", l);
   }
-  if (hn_conv3x3_thin_uses_flat(lv, n, cin, cout))
-    return thin_flat_run(lv, nullptr, n, cin, cout, w16, bias, relu_cols, p.xs, (hipStream_t)stream);
+  return HN_OK;
+}
+
+static int thin_tap_levels(const hn_thin_levels* lv, int n, ThinParams& p, int* nblocks) {
   int blocks = 0;
   for (int l = 0; l < HN_FCOS_MAX_LEVELS; ++l) {
     ThinLevel& t = p.lv[l];
     if (l < lv->count) {
-      HN_CHECK_ARG(lv->x16[l] && lv->y[l] && lv->h[l] > 0 && lv->w[l] > 0, "level %d: null pointer or empty map", l);
-      HN_CHECK_ARG((uintptr_t)lv->x16[l] % 16 == 0, "level %d: unaligned input", l);
       const int64_t xbytes = (int64_t)n * lv->h[l] * lv->w[l] * p.xs * 2;
       HN_CHECK_ARG(xbytes < ((int64_t)1 << 31), "level %d: input too large for 32-bit offsets", l);
       t.x = (const _Float16*)lv->x16[l]; t.y = lv->y[l]; t.h = lv->h[l]; t.w = lv->w[l];
       t.ty = hn::cdiv(t.h, kT); t.tx = hn::cdiv(t.w, kT);
       t.first_block = blocks;
       t.x_records = (unsigned)xbytes;
-      HN_CHECK_ARG((int64_t)blocks + (int64_t)n * t.ty * t.tx < (int64_t)1 << 31, "too many tiles");
+      HN_CHECK_ARG((int64_t)blocks + (int64_t)n * t.ty * t.tx < (int64_t)1 << 30, "too many tiles");
       blocks += n * t.ty * t.tx;
     } else {
       t.x = nullptr; t.y = nullptr; t.h = t.w = t.ty = t.tx = 1; t.first_block = 0x7fffffff; t.x_records = 0;
     }
   }
+  *nblocks = blocks;
+  return HN_OK;
+}
+
+static int thin_tap_prepare() {
   constexpr int LDS_BYTES = 2 * kStageBytes;
   static_assert(LDS_BYTES <= 160 * 1024 - 2048, "one 8-wave workgroup per CU");
   static bool attr_set[64] = {};
@@ -574,9 +603,57 @@ extern "C" int hn_conv3x3_thin_f16x3_levels(const hn_thin_levels* lv, int n, int
   HN_CHECK_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64 || !attr_set[dev]) {
     HN_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_thin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    HN_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_thin_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
-  hipLaunchKernelGGL(conv3x3_thin_kernel, dim3(blocks), dim3(kNT), LDS_BYTES, (hipStream_t)stream, p);
+  return HN_OK;
+}
+
+extern "C" int hn_conv3x3_thin_f16x3_levels(const hn_thin_levels* lv, int n, int cin, int cout, const void* w16, const float* bias,
+                                            int relu_cols, int in_pix_stride, void* stream) {
+  ThinParams p;
+  HN_TRY_THIN(thin_tap_scalars(lv, n, cin, cout, w16, bias, relu_cols, in_pix_stride, p));
+  if (hn_conv3x3_thin_uses_flat(lv, n, cin, cout))
+    return thin_flat_run(lv, nullptr, n, cin, cout, w16, bias, relu_cols, p.xs, (hipStream_t)stream);
+  int blocks = 0;
+  HN_TRY_THIN(thin_tap_levels(lv, n, p, &blocks));
+  HN_TRY_THIN(thin_tap_prepare());
+  hipLaunchKernelGGL(conv3x3_thin_kernel, dim3(blocks), dim3(kNT), 2 * kStageBytes, (hipStream_t)stream, p);
   HN_CHECK_LAUNCH("conv3x3_thin_kernel");
+  return HN_OK;
+}
+
+extern "C" int hn_conv3x3_thin_f16x3_levels_group(const hn_thin_member* members, int count, int n, int cin, int in_pix_stride,
+                                                  void* stream) {
+  HN_CHECK_ARG(members && count >= 1 && count <= kThinGroupMax, "hn_conv3x3_thin_f16x3_levels_group: 1..%d members", kThinGroupMax);
+  // the P form (large pixel counts: HBM-bound streams, nothing to gain from sharing a grid) and single members: member by member
+  bool flat = false;
+  for (int m = 0; m < count; ++m)
+    flat = flat || hn_conv3x3_thin_uses_flat(&members[m].lv, n, cin, members[m].cout);
+  if (flat || count == 1 || hn::env_flags().thin_nogroup) {
+    for (int m = 0; m < count; ++m)
+      HN_TRY_THIN(hn_conv3x3_thin_f16x3_levels(&members[m].lv, n, cin, members[m].cout, members[m].w16, members[m].bias,
+                                               members[m].relu_cols, in_pix_stride, stream));
+    return HN_OK;
+  }
+  ThinGroup g;
+  int first[kThinGroupMax + 1] = {0, 0x7fffffff, 0x7fffffff, 0};
+  int total = 0;
+  for (int m = 0; m < kThinGroupMax; ++m) {
+    const hn_thin_member& mm = members[m < count ? m : 0];   // (absent members repeat member 0: never selected)
+    int blocks = 0;
+    HN_TRY_THIN(thin_tap_scalars(&mm.lv, n, cin, mm.cout, mm.w16, mm.bias, mm.relu_cols, in_pix_stride, g.m[m]));
+    HN_TRY_THIN(thin_tap_levels(&mm.lv, n, g.m[m], &blocks));
+    if (m < count) {
+      first[m] = total;
+      total += blocks;
+      HN_CHECK_ARG(total < (1 << 30), "too many tiles");
+    }
+  }
+  g.first1 = count > 1 ? first[1] : 0x7fffffff;
+  g.first2 = count > 2 ? first[2] : 0x7fffffff;
+  HN_TRY_THIN(thin_tap_prepare());
+  hipLaunchKernelGGL(conv3x3_thin_group_kernel, dim3(total), dim3(kNT), 2 * kStageBytes, (hipStream_t)stream, g);
+  HN_CHECK_LAUNCH("conv3x3_thin_group_kernel");
   return HN_OK;
 }

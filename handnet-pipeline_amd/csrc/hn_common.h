@@ -17,7 +17,7 @@ int* range_flag_ptr();
 // Kernel-form switches (hn_set_form; all false in a product process: the library never reads the environment)
 struct EnvFlags {
   bool no_rs, no_rs32, split_generic, no_halo, no_thin, thin_tap, thin_flat, no_fuse_last_gn, pre_generic, no_multi,
-      halo_stamps, splitk_fill512, no_stream, no_mixed, no_deepk, no_fused_reduce;
+      halo_stamps, splitk_fill512, no_stream, no_mixed, no_deepk, no_fused_reduce, thin_nogroup;
 };
 const EnvFlags& env_flags();
 // development: scale factors of planning constants (hn_set_tuning; 1.0 in a product process)

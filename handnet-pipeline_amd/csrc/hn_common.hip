@@ -100,6 +100,7 @@ extern "C" int hn_set_form(const char* name, int value) {
       {"no_thin_outputs", &hn::EnvFlags::no_thin},          // model.hip: grouped implicit GEMM for the head outputs
       {"thin_form_tap", &hn::EnvFlags::thin_tap},           // thin kernel: never the P form
       {"thin_form_flat", &hn::EnvFlags::thin_flat},         // ... the P form at any size
+      {"thin_no_group", &hn::EnvFlags::thin_nogroup},       // hn_conv3x3_thin_f16x3_levels_group: members one after the other
       {"halo_stamps", &hn::EnvFlags::halo_stamps},          // diagnostics: s_memtime stamps of the halo kernel
       {"splitk_fill512", &hn::EnvFlags::splitk_fill512},    // split-K plan of rounds 1-3 (fill 512 slots below 256 workgroups)
       {"conv_no_stream", &hn::EnvFlags::no_stream},         // implicit-GEMM form of the short-k 1x1 layers (conv1x1_stream.hip)

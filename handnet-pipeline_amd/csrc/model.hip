@@ -469,6 +469,29 @@ int conv_thin_levels(Ctx& cx, const GroupSpec& g, int relu_cols) {
                                       cx.stream);
 }
 
+// ops.conv3x3_thin_levels_group: up to three of them as one launch where they run the tap kernel
+int conv_thin_levels_group(Ctx& cx, const GroupSpec* const* gs, const int* relu_cols, int count) {
+  bool thin = !hn::env_flags().no_thin && t_terms != 1 && gs[0]->count <= HN_FCOS_MAX_LEVELS;
+  for (int m = 0; m < count; ++m) thin = thin && gs[m]->w[0]->cout <= 16;
+  if (!thin) {
+    for (int m = 0; m < count; ++m) HN_TRY(conv_thin_levels(cx, *gs[m], relu_cols[m]));
+    return HN_OK;
+  }
+  hn_thin_member mem[3];
+  memset(mem, 0, sizeof(mem));
+  for (int m = 0; m < count; ++m) {
+    const GroupSpec& g = *gs[m];
+    mem[m].lv.count = g.count;
+    for (int i = 0; i < g.count; ++i) {
+      mem[m].lv.x16[i] = g.x[i].p; mem[m].lv.y[i] = (float*)g.y[i]; mem[m].lv.h[i] = g.x[i].h; mem[m].lv.w[i] = g.x[i].w;
+    }
+    mem[m].cout = g.w[0]->cout; mem[m].relu_cols = relu_cols[m]; mem[m].w16 = g.w[0]->w16; mem[m].bias = g.w[0]->bias;
+  }
+  if (cx.dry) return HN_OK;
+  const T& x0 = gs[0]->x[0];
+  return hn_conv3x3_thin_f16x3_levels_group(mem, count, x0.n, x0.c, x0.ps == 2 * x0.c ? 0 : x0.ps, cx.stream);
+}
+
 // one exact-f32 convolution (ops.conv2d_nhwc without w16 -> hn_conv2d_nhwc_f32): fp32 NHWC in and out; in_scale / in_shift =
 // the GroupNorm of the PREVIOUS layer applied (with its ReLU) while the input is staged
 int conv32(Ctx& cx, const T& x, const ConvW& cw, int relu_cols, const T* res, bool res_up, const float* in_scale,
@@ -1008,17 +1031,18 @@ int fcos_net_f16(Ctx& cx, const float* rgb, int n, int h, int w, const Geometry&
       lv.h[l] = a[l].h; lv.w[l] = a[l].w; lv.stride[l] = g.ph / a[l].h;
       lv.cls_lr[l] = (const float*)cls_lr[l].p; lv.reg_ctr[l] = (const float*)reg_ctr[l].p;
     }
-    HN_TRY(conv_thin_levels(cx, gc, 0));
+    GroupSpec ge;
     if (want_ext) {  // ext heads: relu(hand_dydx_layer)[3] | hand_contact_state_layer[5] from the cls tower (fcos.py:255-264)
-      GroupSpec ge;
       ge.count = L;
       for (int l = 0; l < L; ++l) {
         ext_lv[l] = alloc(cx, n, a[l].h, a[l].w, 8, false);
         ge.x[l] = slice_blocks(a[l], 0, 8); ge.w[l] = &m->f_ext_out; ge.y[l] = ext_lv[l].p; ge.gn[l] = nullptr;
       }
-      HN_TRY(conv_thin_levels(cx, ge, 3));
     }
-    HN_TRY(conv_thin_levels(cx, gr, 4));
+    // one launch for the two (ext: three) filter banks where they run the tap kernel (a single frame); else one each
+    const GroupSpec* members[3] = {&gc, want_ext ? &ge : &gr, &gr};
+    const int relus[3] = {0, want_ext ? 3 : 4, 4};
+    HN_TRY(conv_thin_levels_group(cx, members, relus, want_ext ? 3 : 2));
   }
   return HN_OK;
 }

@@ -12,7 +12,7 @@ from pathlib import Path
 
 from . import build as _build
 
-ABI_VERSION = 34
+ABI_VERSION = 35
 
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, _TILE_RETIRED_5, TILE_64x128 = range(7)
 HN_FCOS_MAX_LEVELS = 5
@@ -91,6 +91,10 @@ class SplitLevels(C.Structure):  # == struct hn_split_levels
 class ThinLevels(C.Structure):  # == struct hn_thin_levels
     _fields_ = [("count", C.c_int32), ("x16", C.c_void_p * HN_FCOS_MAX_LEVELS), ("y", C.c_void_p * HN_FCOS_MAX_LEVELS),
                 ("h", C.c_int32 * HN_FCOS_MAX_LEVELS), ("w", C.c_int32 * HN_FCOS_MAX_LEVELS)]
+
+
+class ThinMember(C.Structure):  # == struct hn_thin_member
+    _fields_ = [("lv", ThinLevels), ("cout", C.c_int32), ("relu_cols", C.c_int32), ("w16", C.c_void_p), ("bias", C.c_void_p)]
 
 
 class ThinAffine(C.Structure):  # == struct hn_thin_affine
@@ -192,6 +196,7 @@ SIGNATURES = {
     "hn_unpack_records": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, VP]),
     "hn_nonfinite_count_f32": (C.c_int, [VP, C.c_int64, VP, VP]),
     "hn_conv3x3_thin_f16x3_levels": (C.c_int, [C.POINTER(ThinLevels), C.c_int, C.c_int, C.c_int, VP, VP, C.c_int, C.c_int, VP]),
+    "hn_conv3x3_thin_f16x3_levels_group": (C.c_int, [C.POINTER(ThinMember), C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "hn_conv3x3_thin_affine_applies": (C.c_int, [C.POINTER(ThinLevels), C.c_int, C.c_int, C.c_int]),
     "hn_conv3x3_thin_affine_f16x3_levels": (C.c_int, [C.POINTER(ThinLevels), C.POINTER(ThinAffine), C.c_int, C.c_int, C.c_int,
                                                       VP, VP, C.c_int, VP]),

@@ -65,6 +65,11 @@ def _check_resources(src: Path, remarks: str, objdir: Path) -> None:
         if any(k in name for k in NO_SPILL_KERNELS) and (res.get("VGPRs Spill", "0") != "0" or not sgpr_ok):
             raise RuntimeError(f"{src.name}: {name} spills registers ({res.get('VGPRs Spill')} VGPR, {res.get('SGPRs Spill')} SGPR): "
                                "its asm loads / counted waits are only correct without spills")
+        # (scratch without a spill: a by-value kernel argument whose address escaped -- e.g. handed to a device function by
+        # reference -- is copied to private memory and every use becomes a scratch load; seen once, on the thin kernel)
+        if any(k in name for k in NO_SPILL_KERNELS) and res.get("ScratchSize [bytes/lane]", "0") != "0":
+            raise RuntimeError(f"{src.name}: {name} uses {res.get('ScratchSize [bytes/lane]')} bytes of scratch per lane "
+                               "(a kernel argument copied to private memory?): these kernels are written to run from registers")
     (objdir / (src.stem + ".resources.txt")).write_text("\n".join(out) + "\n")
 
 

@@ -313,9 +313,11 @@ class FCOSEngine:
         ac, ar = [x[:, :, :, :8] for x in a], [x[:, :, :, 8:] for x in a]
         ops.PROFILE_STAGE = "head_outputs"
         if self.thin_outputs and self.terms == 3:   # <= 16 output channels: the thin-N kernels (csrc/conv3x3_thin.hip)
-            cls_lr = ops.conv3x3_thin_levels(ac, self.cls_out)
-            ext = ops.conv3x3_thin_levels(ac, self.ext_out, relu_cols=3) if self.ext else [None] * L
-            reg_ctr = ops.conv3x3_thin_levels(ar, self.reg_out, relu_cols=4)
+            # one launch for the two (ext: three) filter banks where they run the tap kernel (a single frame); else one each
+            members = [(ac, self.cls_out, 0)] + ([(ac, self.ext_out, 3)] if self.ext else []) + [(ar, self.reg_out, 4)]
+            outs = ops.conv3x3_thin_levels_group(members)
+            cls_lr, reg_ctr = outs[0], outs[-1]
+            ext = outs[1] if self.ext else [None] * L
         else:
             cls_lr = ops.conv2d_nhwc_grouped(ac, [self.cls_out] * L, pad=1)
             ext = ops.conv2d_nhwc_grouped(ac, [self.ext_out] * L, pad=1, relu_cols=3) if self.ext else [None] * L

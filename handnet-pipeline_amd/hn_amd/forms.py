@@ -32,7 +32,7 @@ _LIB_ENV = {
     "HN_CONV_NO_MULTI": ("conv_no_multi", None), "HN_HALO_STAMPS": ("halo_stamps", None),
     "HN_SPLITK_FILL512": ("splitk_fill512", None), "HN_CONV_NO_STREAM": ("conv_no_stream", None),
     "HN_CONV_NO_MIXED": ("conv_no_mixed", None), "HN_CONV_NO_DEEPK": ("conv_no_deepk", None),
-    "HN_CONV_NO_FUSED_REDUCE": ("conv_no_fused_reduce", None),
+    "HN_CONV_NO_FUSED_REDUCE": ("conv_no_fused_reduce", None), "HN_THIN_NO_GROUP": ("thin_no_group", None),
 }
 
 

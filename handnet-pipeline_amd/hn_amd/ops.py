@@ -628,6 +628,52 @@ def conv3x3_thin_levels(xs, cw, relu_cols=0):
     return outs
 
 
+def conv3x3_thin_levels_group(members):
+    """Up to three conv3x3_thin_levels calls as ONE launch where they run the tap kernel (hn_conv3x3_thin_f16x3_levels_group; the
+    FCOS head outputs of a single frame: 89 workgroups each, latency-bound): members = [(xs, cw, relu_cols), ...] with one batch
+    size, channel count and pixel stride -> [outs of member 0, outs of member 1, ...], bit-identical to the separate calls (which
+    is what runs where a member takes the P form)."""
+    lib = _lib.load()
+    if not 1 <= len(members) <= 3:
+        raise ValueError("1..3 members")
+    n = members[0][0][0].shape[0]
+    cin = members[0][1].w.shape[3]
+    xstride = _pixel_stride(members[0][0][0], "x")
+    arr = (_lib.ThinMember * len(members))()
+    results = []
+    rows = 0
+    for m, (xs, cw, relu_cols) in enumerate(members):
+        cout, r, s_, c = cw.w.shape
+        if (r, s_) != (3, 3) or cout > 16 or cw.w16 is None or len(xs) > _lib.HN_FCOS_MAX_LEVELS or c != cin:
+            raise ValueError("members need 3x3 filter banks with <= 16 output channels, a split bank and one input channel count")
+        mm = arr[m]
+        mm.lv.count = len(xs)
+        outs = []
+        for i, x in enumerate(xs):
+            if not is_split(x) or x.shape[0] != n or channels(x) != cin or _pixel_stride(x, "x") != xstride:
+                raise ValueError("levels must be S32 tensors of one batch size, channel count and pixel stride")
+            y = torch.empty((n, x.shape[1], x.shape[2], cout), device=x.device, dtype=torch.float32)
+            mm.lv.x16[i], mm.lv.y[i], mm.lv.h[i], mm.lv.w[i] = x.data_ptr(), y.data_ptr(), x.shape[1], x.shape[2]
+            outs.append(y)
+        mm.cout, mm.relu_cols, mm.w16, mm.bias = cout, int(relu_cols), ptr(cw.w16), ptr(cw.bias)
+        results.append(outs)
+        rows += sum(n * x.shape[1] * x.shape[2] for x in xs) * cout
+    prof = CONV_PROFILE
+    if prof is not None:
+        timer = HipTimer()
+        timer.start()
+    check(lib.hn_conv3x3_thin_f16x3_levels_group(arr, len(members), n, cin, 0 if xstride == 2 * cin else xstride, _stream()),
+          "hn_conv3x3_thin_f16x3_levels_group")
+    if prof is not None:
+        timer.stop()
+        flat = any(lib.hn_conv3x3_thin_uses_flat(C.byref(arr[m].lv), n, cin, arr[m].cout) for m in range(len(members)))
+        px = sum(n * x.shape[1] * x.shape[2] for x in members[0][0])
+        couts = sum(mm[1].w.shape[0] for mm in members)
+        prof.append((("f16x3", "thin-P" if flat else f"thin16x16x{len(members)}"), rows * 9 * cin, timer,
+                     (1, px, 1, cin, couts, 3, 1, 1), PROFILE_STAGE))
+    return results
+
+
 def _thin_levels_of(shapes):
     lv = _lib.ThinLevels()
     lv.count = len(shapes)

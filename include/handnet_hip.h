@@ -33,7 +33,7 @@ extern "C" {
 #define HN_ERR_HIP 2
 
 /* ABI version; bumped whenever a struct below changes. */
-#define HN_ABI_VERSION 34
+#define HN_ABI_VERSION 35
 int hn_abi_version(void);
 const char* hn_last_error(void);
 
@@ -338,6 +338,20 @@ typedef struct hn_thin_levels {
 int hn_conv3x3_thin_f16x3_levels(const hn_thin_levels* lv, int n, int cin, int cout, const void* w16, const float* bias,
                                  int relu_cols, int in_pix_stride, void* stream);
 int hn_conv3x3_thin_uses_flat(const hn_thin_levels* lv, int n, int cin, int cout);   /* only count, h[] and w[] are read */
+
+/* Up to three such convolutions -- different filter banks on their own inputs: the FCOS head outputs cls_logits + hand_lr, the
+ * ext heads, bbox_reg + ctrness (fcos.py:255-264,299-320) -- in ONE launch where they run the tap kernel (a single frame: 89
+ * workgroups each on 256 CUs, latency-bound at 17-18 us per launch; together one round of the chip).  Every workgroup runs
+ * exactly what its member's own launch would have run: bit-identical to `count` calls of hn_conv3x3_thin_f16x3_levels, which is
+ * also what happens where a member takes the P form (large pixel counts: HBM-bound streams) or for count == 1. */
+typedef struct hn_thin_member {
+  hn_thin_levels lv;
+  int32_t cout, relu_cols;
+  const void* w16;
+  const float* bias;
+} hn_thin_member;
+int hn_conv3x3_thin_f16x3_levels_group(const hn_thin_member* members, int count /* 1..3 */, int n, int cin, int in_pix_stride,
+                                       void* stream);
 
 /* The P form with the LAST GroupNorm apply pass of the towers fused in (fcos.py:232-239 conv -> GroupNorm -> ReLU, then the
  * output conv): x[l] = RAW fp32 conv output [n][h_l][w_l][in_pix_stride] at the head's first channel, scale[l] / shift[l] =

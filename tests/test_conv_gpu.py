@@ -811,6 +811,41 @@ def test_thin_output_conv_matches_the_grouped_kernel(n, cout, relu_cols, sizes, 
         ops.set_form("thin_form_flat", False)
 
 
+@pytest.mark.parametrize("n,sizes", [
+    (1, [(100, 136), (50, 68), (25, 34)]),          # a single frame's pyramid: the tap kernel, ONE launch for the members
+    (2, [(13, 17), (1, 2), (7, 300)]),              # odd maps, a level wider than the P form takes
+    (8, [(100, 136), (50, 68), (25, 34)]),          # > 64 k pixels: the 5-channel members take the P form -> member by member
+])
+def test_thin_output_group_equals_its_members(n, sizes):
+    """hn_conv3x3_thin_f16x3_levels_group (the FCOS head outputs -- cls + lr, ext, reg + ctr -- as one launch where they run the
+    tap kernel): two and three members with their own filter banks, output widths, ReLU columns and inputs (channel slices of
+    one 512-channel stack, as heads_grouped hands them over) == the same calls one after the other, bit for bit; also with the
+    grouping switched off (form "thin_no_group")."""
+    from hn_amd import ops
+    from hn_amd.weights import ConvW
+    g = torch.Generator().manual_seed(4321 + n)
+    cin = 256
+    banks = [ConvW(torch.randn(c, 3, 3, cin, generator=g) * 0.05, torch.randn(c, generator=g), 1, 1, 1).to("cuda") for c in (5, 8, 5)]
+    stacks = [ops.to_split(torch.randn(n, h, wd, 2 * cin, generator=g).cuda()) for h, wd in sizes]
+    ac, ar = [s[:, :, :, :8] for s in stacks], [s[:, :, :, 8:] for s in stacks]
+    for members in ([(ac, banks[0], 0), (ar, banks[2], 4)], [(ac, banks[0], 0), (ac, banks[1], 3), (ar, banks[2], 4)],
+                    [(ar, banks[1], 8)]):
+        want = [ops.conv3x3_thin_levels(xs, cw, relu_cols=rc) for xs, cw, rc in members]
+        for no_group in (False, True):
+            ops.set_form("thin_no_group", no_group)
+            try:
+                got = ops.conv3x3_thin_levels_group(members)
+            finally:
+                ops.set_form("thin_no_group", False)
+            assert len(got) == len(want)
+            for gm, wm in zip(got, want):
+                assert len(gm) == len(wm) and all(torch.equal(a, b) for a, b in zip(gm, wm))
+    with pytest.raises(ValueError):
+        ops.conv3x3_thin_levels_group([])
+    with pytest.raises(ValueError):
+        ops.conv3x3_thin_levels_group([(ac, banks[0], 0)] * 4)
+
+
 def test_thin_output_conv_is_deterministic_at_full_size():
     """The P-form kernel hands P columns from 16 waves to the output threads through an LDS ring that it overwrites every
     step; a missing barrier would show as run-to-run differences.  Batch-32 pyramid (580 k pixels, 254 workgroup ranges
