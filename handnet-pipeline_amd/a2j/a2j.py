@@ -129,7 +129,8 @@ class A2JModel(EngineOwner):
 class A2JModelLightning(EngineOwner):
     """Inference-side stand-in for the reference's LightningModule (a2j/a2j.py:252-366): same constructor
     arguments, `.a2j` = the HIP-backed A2JModel, state_dict keys `a2j.*` (the layout of a Lightning checkpoint's
-    `state_dict`), `load_from_checkpoint`, `forward`.  pytorch-lightning is not needed (and not installed here)."""
+    `state_dict`), `load_from_checkpoint`, `forward`, and the evaluation hooks `test_step` / `test_epoch_end` / `log`.
+    pytorch-lightning is not needed (and not installed here); the training-side hooks raise."""
 
     def __init__(self, num_classes: int = 21, crop_height: int = 176, crop_width: int = 176, is_3D: bool = True,
                  is_RGBD: bool = False, spatial_factor: float = 0.5, display_freq: int = 5000,
