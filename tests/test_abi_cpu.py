@@ -42,6 +42,50 @@ def test_conv_desc_struct_matches_header():
     assert fields == [f for f, _ in _lib.ConvDesc._fields_]
 
 
+def test_every_struct_of_the_header_has_the_ctypes_layout(tmp_path):
+    """The by-value / by-pointer structs of include/handnet_hip.h against their ctypes mirrors in hn_amd/_lib.py: a C probe
+    compiled with gcc against the header prints sizeof and every field's offsetof; ctypes must agree field by field (a field
+    added on one side only -- hn_convert_opts grew two pointers in ABI v34, hn_thin_member is new in v35 -- shifts everything
+    behind it silently otherwise).  Every `typedef struct ... {` of the header must be in the table."""
+    import shutil
+    import subprocess
+    pairs = {"hn_conv_desc": _lib.ConvDesc, "hn_conv_group": _lib.ConvGroup, "hn_conv_multi": _lib.ConvMulti,
+             "hn_gn_levels": _lib.GnLevels, "hn_split_levels": _lib.SplitLevels, "hn_thin_levels": _lib.ThinLevels,
+             "hn_thin_member": _lib.ThinMember, "hn_thin_affine": _lib.ThinAffine, "hn_fcos_levels": _lib.FcosLevels,
+             "hn_convert_opts": _lib.ConvertOpts, "hn_graph_csr": _lib.GraphCsr, "hn_model_config": _lib.ModelConfig}
+    header = build.REPO_ROOT / "include" / "handnet_hip.h"
+    declared = set(re.findall(r"typedef struct (\w+) \{", header.read_text()))
+    assert declared == set(pairs), declared ^ set(pairs)
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc is part of the image"
+    lines = ["#include <stdio.h>", "#include <stddef.h>", f'#include "{header}"', "int main(void) {"]
+    for name, cls in pairs.items():
+        lines.append(f'  printf("{name} %zu\\n", sizeof({name}));')
+        for field, _ in cls._fields_:
+            lines.append(f'  printf("{name}.{field} %zu\\n", offsetof({name}, {field}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines) + "\n")
+    exe = tmp_path / "layout"
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-o", str(exe), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr     # (a field of the ctypes class that the header lacks fails HERE, by name)
+    got = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    for name, cls in pairs.items():
+        assert int(got[name]) == C_sizeof(cls), (name, got[name], C_sizeof(cls))
+        for field, _ in cls._fields_:
+            assert int(got[f"{name}.{field}"]) == getattr(cls, field).offset, (name, field)
+        # ... and a field the header has but ctypes lacks shows as a size difference above, unless it hides in tail padding:
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), header.read_text(), flags=re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        n_fields = sum(len(d.split(",")) for d in re.findall(r"([^;{}]+);", body))     # declarators per declaration
+        assert n_fields == len(cls._fields_), (name, n_fields, len(cls._fields_))
+
+
+def C_sizeof(cls):
+    import ctypes
+    return ctypes.sizeof(cls)
+
+
 def test_argument_errors_do_not_need_a_gpu():
     import ctypes as C
     lib = _lib.load()
