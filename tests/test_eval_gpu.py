@@ -210,3 +210,37 @@ def test_crop_mesh_step_is_the_mesh_demos_loop_body(golden_dir, a2j_sd):
     kp2, _img2, xyz2, mesh2, _ = o2.read()
     assert tuple(mesh2.shape) == (k, 1152, 3) and bool(torch.isnan(kp2[1]).all()) and bool(torch.isnan(xyz2[1]).all())
     assert torch.equal(kp2[0], kp[0]) and torch.equal(mesh2[0], out.raw_mesh.cpu()[0])
+
+
+def test_crop_mesh_step_at_batch_64_is_row_independent(golden_dir, a2j_sd):
+    """BASELINE config 2's batch (64 crops) through the mesh demo's step: a row's results depend on its own crop, box and
+    intrinsics only -- permuting the batch permutes every output bit for bit (A2J at 64 crops, the fused conversion, the
+    lifter's layer-by-layer form above 4 samples, the mesh finish) -- and the first rows agree with a batch of 3 (the
+    lifter's fused latency form) to the summation-order difference of the two lifter forms."""
+    from a2j.a2j import A2JModel
+    from hn_amd import synth
+    from hn_amd.pose2mesh_engine import Pose2MeshEngine
+    from oracle import pose2mesh_ref
+    g = np.load(golden_dir / "pose2mesh_forward.npz")
+    graphs = pose2mesh_ref.load_graphs(g)
+    p2m_sd = synth.make_pose2mesh_state_dict(seed=int(g["weight_seed"]), graph_sizes=[m.shape[0] for m in graphs])
+    net = A2JModel(21, 176, 176)
+    net.load_state_dict(a2j_sd, strict=False)
+    eng = net.cuda().eval().mesh(Pose2MeshEngine(p2m_sd, graphs, device="cuda"), clamp=True, perm_reverse=g["perm_reverse"][:778])
+    k = 64
+    im, _gt, _ids, _, box, paras, _ = _eval_batch(k, seed=31)
+    out = eng.forward_device(im.cuda(), box.cuda(), paras.cuda())
+    torch.cuda.synchronize()
+    kp, img, xyz, mesh, words = out.read()
+    assert not any(words[:3]) and tuple(mesh.shape) == (k, 778, 3) and bool(torch.isfinite(mesh).all())
+    perm = torch.randperm(k, generator=torch.Generator().manual_seed(5))
+    out_p = eng.forward_device(im[perm].cuda(), box[perm].cuda(), paras[perm].cuda())
+    torch.cuda.synchronize()
+    kp_p, img_p, xyz_p, mesh_p, _ = out_p.read()
+    assert torch.equal(kp_p, kp[perm]) and torch.equal(img_p, img[perm]) and torch.equal(xyz_p, xyz[perm])
+    assert torch.equal(mesh_p, mesh[perm])
+    small = eng.forward_device(im[:3].cuda(), box[:3].cuda(), paras[:3].cuda())
+    torch.cuda.synchronize()
+    kp_s, _img_s, xyz_s, mesh_s, _ = small.read()
+    assert (kp_s - kp[:3]).abs().max().item() < 2.5e-4 and (xyz_s - xyz[:3]).abs().max().item() < 5e-3
+    assert (mesh_s - mesh[:3]).abs().max().item() < 1e-3
