@@ -409,3 +409,29 @@ def test_live_chain_parity_on_other_weight_draws(golden_dir, seed):
         want[:, 2] *= -1
         assert np.abs(mesh[i].numpy() - want).max() < 3e-3, (seed, i, np.abs(mesh[i].numpy() - want).max())
         row += 1
+
+
+def test_live_step_at_batch_32_is_frame_independent(live):
+    """BASELINE config 4's batch through the live step: permuting the 32 frames permutes every output (crop boxes, flags,
+    keypoints, converted joints, mesh vertices) bit for bit -- the detector, the crop, A2J, the fused conversion and the
+    lifter's layer-by-layer form above 4 samples keep frames apart -- and frame 0 agrees with the single-frame step (the
+    lifter's fused latency form, other split-K plans) to the summation-order tolerance."""
+    from hn_amd import synth
+    eng, _, _ = live
+    n = 32
+    rgb, depth = synth.make_rgb(n, seed=1000), synth.make_depth(n, seed=2000)
+    out = eng.forward_device(rgb.cuda(), depth.cuda())
+    torch.cuda.synchronize()
+    kp, has, box, words, (img, xyz), mesh = out.read()
+    assert not any(words[:3]) and int((has == 1).sum()) == n and bool(torch.isfinite(mesh).all())
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(9))
+    out_p = eng.forward_device(rgb[perm].cuda(), depth[perm].cuda())
+    torch.cuda.synchronize()
+    kp_p, has_p, box_p, _w, (img_p, xyz_p), mesh_p = out_p.read()
+    assert torch.equal(box_p, box[perm]) and torch.equal(has_p, has[perm]) and torch.equal(kp_p, kp[perm])
+    assert torch.equal(img_p, img[perm]) and torch.equal(xyz_p, xyz[perm]) and torch.equal(mesh_p, mesh[perm])
+    one = eng.forward_device(rgb[:1].cuda(), depth[:1].cuda())
+    torch.cuda.synchronize()
+    kp1, _h1, box1, _w1, (_img1, xyz1), mesh1 = one.read()
+    assert torch.equal(box1[0], box[0]) and (kp1[0] - kp[0]).abs().max().item() < 2.5e-4
+    assert (xyz1[0] - xyz[0]).abs().max().item() < 5e-3 and (mesh1[0] - mesh[0]).abs().max().item() < 1e-3
