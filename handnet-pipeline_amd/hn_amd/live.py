@@ -169,7 +169,8 @@ class CropMeshOutput:
     mesh: torch.Tensor           # [K,V,3]: out['mesh'] of a2j_mesh.py:77-80 with perm_reverse, else the lifter's raw [K,V0,3]
     pose3d: torch.Tensor         # [K,21,3]
     raw_mesh: torch.Tensor       # [K,V0,3] the lifter's own output
-    host: torch.Tensor           # pinned fp32: keypoints | image_uvd | xyz_mm | mesh | 4 range words (as bits) -- ONE copy
+    host: torch.Tensor           # pinned fp32: keypoints | image_uvd | xyz_mm | mesh | 4 range words (as bits) -- ONE copy; the
+    #                              engine's buffer for this batch size: the next call overwrites it (read() returns copies)
     k: int = 0
 
     def read(self):
@@ -200,6 +201,7 @@ class CropMeshEngine:
         self.vertices = lifter.graphs[0].v if self.perm is None else int(self.perm.shape[0])
         self._block = None
         self._graphs = {}
+        self._hosts = {}
 
     @ops.device_guarded
     def forward_device(self, crops, box_f32, paras, _host=None) -> CropMeshOutput:
@@ -215,8 +217,11 @@ class CropMeshEngine:
             mesh = raw if self.perm is None else ops.mesh_finish(raw, self.perm, xyz)
             words = ops.range_check_collect(self._block)
         dev = torch.cat([kp.reshape(-1), img.reshape(-1), xyz.reshape(-1), mesh.reshape(-1), words.view(torch.float32)])
-        if _host is None:
-            _host = torch.empty((dev.numel(),), dtype=torch.float32, pin_memory=True)
+        if _host is None:     # one pinned buffer per batch size, like the live step's: the NEXT eager call with this batch size
+            _host = self._hosts.get(dev.numel())      # overwrites it (read() hands out copies)
+            if _host is None:
+                with torch.inference_mode(False):
+                    _host = self._hosts[dev.numel()] = torch.empty((dev.numel(),), dtype=torch.float32, pin_memory=True)
         _host.copy_(dev, non_blocking=True)
         return CropMeshOutput(kp, img, xyz, p2d, mesh, pose3d, raw, _host, k)
 
