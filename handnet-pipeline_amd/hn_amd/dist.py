@@ -305,41 +305,67 @@ class ShardedHandNet:
             self.forward_device(images, depth_images, global_batch)
         return self.gather_captured
 
+    def _agree(self, ok: bool) -> bool:
+        """True iff EVERY rank says ok (one tiny eager all-reduce over host memory on ranks > 1): a capture that works on some
+        ranks only must be dropped by all of them -- a rank that replays a captured collective beside a rank that issues it
+        eagerly is fine, but the ranks must go through the same NUMBER of collectives, and only a common decision keeps the
+        validation replay below from being issued by some ranks and not by others."""
+        if not dist.is_initialized() or self.world == 1:
+            return ok
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        if dist.get_backend(self.group) != "gloo":
+            flag = flag.to(self._engine().device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(flag.item()) == 1)
+
     def _capture(self, key, batch, depth, per_rank, bufs, total):
         """The step and its collectives as ONE hipGraph.  The warm-up steps run the collectives eagerly first (communicator
         and buffers exist before the capture starts).  A backend that refuses to be captured leaves gather_captured = False:
-        forward_device then stays eager for the collectives (the engine's own captured step still serves the launches)."""
+        forward_device then stays eager for the collectives (the engine's own captured step still serves the launches).
+        Every rank goes through the same collectives whatever happens on it: two eager warm-up steps, an agreement on "captured"
+        (`_agree`), then -- only if all ranks captured -- ONE validation replay and an agreement on "replay == eager"."""
         from . import ops
+
+        def refused(why):
+            torch.cuda.synchronize()
+            self.gather_captured = False
+            self.capture_note = f"capture of step + all-gather refused ({why}); the gather is issued eagerly behind the step"
+            return None
+
         with torch.inference_mode(False), torch.no_grad():
             s_img, s_dep = torch.empty_like(batch), torch.empty_like(depth)
             s_img.copy_(batch)
             s_dep.copy_(depth)
-            try:
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with ops.launch_cost_hidden():
-                    with torch.cuda.stream(side):
-                        for _ in range(2):
-                            self._step(s_img, s_dep, per_rank, bufs, total)
-                    torch.cuda.current_stream().wait_stream(side)
-                    torch.cuda.current_stream().synchronize()
-                    eager = bufs["host"].clone()             # what the last eager step gathered for these inputs
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with ops.launch_cost_hidden():
+                with torch.cuda.stream(side):
+                    for _ in range(2):     # (a failure HERE is a failure of the eager path: it propagates, like any step's)
+                        self._step(s_img, s_dep, per_rank, bufs, total)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.current_stream().synchronize()
+                eager = bufs["host"].clone()             # what the last eager step gathered for these inputs
+                why, g, out = None, None, None
+                try:
+                    if os.environ.get("HN_TEST_REFUSE_CAPTURE_RANK") == str(self.rank):     # (tests: a one-rank refusal)
+                        raise RuntimeError("refused on this rank for the test")
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, capture_error_mode="thread_local"):
                         out = self._step(s_img, s_dep, per_rank, bufs, total)
-                # a captured collective must deliver what the eager one did: one replay on the same inputs, compared byte for
-                # byte (a backend that captures but replays something else -- or nothing -- is treated like one that refuses)
-                bufs["host"].zero_()
-                g.replay()
-                torch.cuda.current_stream().synchronize()
-                if not torch.equal(bufs["host"], eager):
-                    raise RuntimeError("the replayed step + all-gather returned other records than the eager one")
-            except Exception as e:  # noqa: BLE001 -- the backend (or a capture-unsafe call elsewhere in the process) refused
-                torch.cuda.synchronize()
-                self.gather_captured = False
-                self.capture_note = (f"capture of step + all-gather refused ({type(e).__name__}: {str(e)[:200]}); the gather is "
-                                     "issued eagerly behind the step")
-                return None
+                except Exception as e:  # noqa: BLE001 -- the backend (or a capture-unsafe call elsewhere in the process) refused
+                    torch.cuda.synchronize()
+                    why = f"{type(e).__name__}: {str(e)[:200]}"
+            if not self._agree(why is None):
+                return refused(why or "another rank could not capture it")
+            # a captured collective must deliver what the eager one did: one replay on the same inputs, compared byte for
+            # byte (a backend that captures but replays something else -- or nothing -- is treated like one that refuses)
+            bufs["host"].zero_()
+            g.replay()
+            torch.cuda.current_stream().synchronize()
+            same = torch.equal(bufs["host"], eager)
+            if not self._agree(same):
+                return refused("the replayed step + all-gather returned other records than the eager one" if not same
+                               else "on another rank the replay returned other records than the eager step")
         self.gather_captured = True
         self.capture_note = ("step + all-gather" + (" + depth all-gather" if self.gather_depth else "")
                              + " + record copy to the host captured in ONE hipGraph")

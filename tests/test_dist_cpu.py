@@ -306,6 +306,8 @@ def _sharded_worker(rank, world, port, total, out_dir, gather_depth, local_shard
         else:
             outs.append(net(images, depth_images=depth))
     assert all(torch.equal(a, b) for a, b in zip(*outs))
+    # the vote that keeps a one-rank capture refusal from splitting the ranks (ShardedHandNet._capture): unanimous or nothing
+    assert net._agree(True) is True and net._agree(rank != world - 1) is False and net._agree(False) is False
     torch.save(outs[-1], os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
